@@ -1,0 +1,180 @@
+"""Synthetic ISO-14443A captures (host side, numpy) for tests and bench.py.
+
+The reference ships no recordings (``.MISSING_LARGE_BLOBS``), so inputs are
+rebuilt from the byte content of its example traces (``outputs/ultralight.out``)
+with the pulse timing its encoders use:
+
+* frame bits: LSB first + odd parity per byte (utilities.py:51-62); REQA is a
+  7-bit short frame without parity (report section 3.3);
+* Modified Miller pulse lists as miller.py:200-233 builds them, Manchester as
+  manchester.py:64-79;
+* ``int(dur_us * rate_msps)`` samples per pulse (binary_src.py:83).
+
+SURVEY.md section 8(d) fixes the waveform: carrier amplitude A=0.5 at phase
+0.3 rad, reader pauses are 100 % ASK (m=0), tag load modulation lifts the
+envelope by ``depth``, white noise sigma=0.002 on I and Q, idle lead-in that
+covers the averaging window, idle gaps between frames.
+"""
+
+import numpy as np
+
+SEED = 0x14443A
+
+T_FULL = 9.44
+T_ZERO = 3.00
+T_HALF = T_FULL / 2
+T_ZERO_REM = T_FULL - T_ZERO
+T_ONE_REM = T_HALF - T_ZERO
+
+READER, TAG = 1, 0   # packet types (packets.py:19-20)
+
+# (direction, name, bytes, short_frame_bits) -- outputs/ultralight.out, in order.
+ULTRALIGHT_TXN = [
+    (READER, 'REQA',   [0x26], 7),
+    (TAG,    'ATQAUL', [0x44, 0x00], 0),
+    (READER, 'ANTI1R', [0x93, 0x20], 0),
+    (TAG,    'ANTI1U', [0x88, 0x04, 0xBE, 0x6F, 0x5D], 0),
+    (READER, 'SEL1R',  [0x93, 0x70, 0x88, 0x04, 0xBE, 0x6F, 0x5D, 0xA1, 0x8E], 0),
+    (TAG,    'SEL1U',  [0x04, 0xDA, 0x17], 0),
+    (READER, 'ANTI2R', [0x95, 0x20], 0),
+    (TAG,    'ANTI2T', [0x22, 0x09, 0x29, 0x80, 0x82], 0),
+    (READER, 'SEL2R',  [0x95, 0x70, 0x22, 0x09, 0x29, 0x80, 0x82, 0xD8, 0xBA], 0),
+    (TAG,    'SEL2T',  [0x00, 0xFE, 0x51], 0),
+    (READER, 'READR',  [0x30, 0x00, 0x02, 0xA8], 0),
+    (TAG,    'READT',  [0x04, 0xBE, 0x6F, 0x5D, 0x22, 0x09, 0x29, 0x80, 0x82, 0x48, 0x00, 0x00,
+                        0xE1, 0x10, 0x12, 0x00, 0xF8, 0x99], 0),
+    (READER, 'READR',  [0x30, 0x04, 0x26, 0xEE], 0),
+    (TAG,    'READT',  [0x01, 0x03, 0xA0, 0x10, 0x44, 0x03, 0x00, 0xFE, 0x00, 0x00, 0x00, 0x00,
+                        0x00, 0x00, 0x00, 0x00, 0x81, 0x3B], 0),
+    (READER, 'READR',  [0x30, 0x08, 0x4A, 0x24], 0),
+    (TAG,    'READT',  [0x00] * 16 + [0x37, 0x49], 0),
+    (READER, 'READR',  [0x30, 0x0C, 0x6E, 0x62], 0),
+    (TAG,    'READT',  [0x00] * 16 + [0x37, 0x49], 0),
+    (READER, 'HALT',   [0x50, 0x00, 0x57, 0xCD], 0),
+]
+
+
+def frame_bits(data, short_bits=0):
+    """Bytes -> on-air data bits (no start/end bit)."""
+    if short_bits:
+        return [(data[0] >> i) & 1 for i in range(short_bits)]
+    out = []
+    for b in data:
+        ones = 0
+        for i in range(8):
+            bit = (b >> i) & 1
+            ones += bit
+            out.append(bit)
+        out.append(1 - (ones & 1))
+    return out
+
+
+def miller_pulses(bits):
+    """Modified Miller (level, us) list: start-of-frame zero, the bits, end zero."""
+    one = [(1, T_HALF), (0, T_ZERO), (1, T_ONE_REM)]
+    zero_after_zero = [(0, T_ZERO), (1, T_ZERO_REM)]
+    zero_after_one = [(1, T_FULL)]
+    seq = list(zero_after_zero)
+    prev_bit = 0
+    for bit in list(bits) + [0]:
+        piece = one if bit else (zero_after_zero if prev_bit == 0 else zero_after_one)
+        prev_bit = bit
+        lvl, dur = seq[-1]
+        if piece[0][0] == lvl:
+            seq[-1] = (lvl, piece[0][1] + dur)
+            seq.extend(piece[1:])
+        else:
+            seq.extend(piece)
+    return seq
+
+
+def manchester_pulses(bits):
+    """Manchester (level, us) list: start bit 1, then the bits; level 1 = loaded."""
+    halves = [1, 0]
+    for b in bits:
+        halves += [b, 1 - b]
+    seq = []
+    for h in halves:
+        if seq and seq[-1][0] == h:
+            seq[-1] = (h, T_FULL)
+        else:
+            seq.append((h, T_HALF))
+    return seq
+
+
+def pulses_to_levels(pulses, rate_msps):
+    """(level, us) list -> per-sample level array (int8)."""
+    parts = [np.full(int(d * rate_msps), lvl, dtype=np.int8) for lvl, d in pulses]
+    return np.concatenate(parts) if parts else np.zeros(0, np.int8)
+
+
+def modulation_profile(frames, rate_msps=2.0, gap_us=150.0, lead_in=3000, tail=400, depth=0.08):
+    """Amplitude multiplier m[n] (float32) for a list of (direction, bits).
+
+    Reader frames: m = level (pause -> 0).  Tag frames: m = 1 + depth*level.
+    """
+    gap = np.ones(int(gap_us * rate_msps), np.float32)
+    parts = [np.ones(lead_in, np.float32)]
+    for direction, bits in frames:
+        if direction == READER:
+            lv = pulses_to_levels(miller_pulses(bits), rate_msps).astype(np.float32)
+        else:
+            lv = 1.0 + np.float32(depth) * pulses_to_levels(manchester_pulses(bits), rate_msps).astype(np.float32)
+        parts.append(lv.astype(np.float32))
+        parts.append(gap)
+    parts.append(np.ones(tail, np.float32))
+    return np.concatenate(parts)
+
+
+def txn_frames(txn=ULTRALIGHT_TXN, directions=(READER, TAG)):
+    return [(d, frame_bits(data, sb)) for d, _, data, sb in txn if d in directions]
+
+
+def iq_from_profile(m, amp=0.5, phase=0.3, sigma=0.002, seed=SEED):
+    """m[n] -> interleaved float32 I,Q (len 2N)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = len(m)
+    iq = rng.standard_normal(2 * n, dtype=np.float32)
+    iq *= np.float32(sigma)
+    iq[0::2] += (np.float32(amp * np.cos(phase)) * m).astype(np.float32)
+    iq[1::2] += (np.float32(amp * np.sin(phase)) * m).astype(np.float32)
+    return iq
+
+
+def tiled_profile(period, n, lead_in=3000):
+    """Idle lead-in then ``period`` repeated to exactly n samples."""
+    out = np.ones(n, np.float32)
+    body = n - lead_in
+    if body > 0:
+        reps = -(-body // len(period))
+        out[lead_in:] = np.tile(period, reps)[:body]
+    return out
+
+
+def workload(name, n, rate_msps=2.0, seed=SEED, sigma=0.002):
+    """Named bench/test workloads (BASELINE.json configs 2-4).
+
+    'miller'      reader frames only (REQA, ANTI1R, SEL1R, READR), 150 us gaps
+    'manchester'  tag frames only (ATQA, ANTI1U, SEL1U, READT), 150 us gaps
+    'all'         the whole Ultralight transaction, both directions
+    Returns interleaved float32 IQ of n samples.
+    """
+    if name == 'miller':
+        picks = [ULTRALIGHT_TXN[i] for i in (0, 2, 4, 10)]
+    elif name == 'manchester':
+        picks = [ULTRALIGHT_TXN[i] for i in (1, 3, 5, 11)]
+    elif name == 'all':
+        picks = ULTRALIGHT_TXN
+    else:
+        raise ValueError('unknown workload %r' % (name,))
+    frames = [(d, frame_bits(data, sb)) for d, _, data, sb in picks]
+    period = modulation_profile(frames, rate_msps=rate_msps, lead_in=0, tail=0)
+    m = tiled_profile(period, n)
+    return iq_from_profile(m, seed=seed, sigma=sigma)
+
+
+def envelope_f32(iq):
+    """fp32 |IQ|^2 with one rounding per product and per sum (numpy does not fuse)."""
+    i = iq[0::2]
+    q = iq[1::2]
+    return (i * i) + (q * q)
