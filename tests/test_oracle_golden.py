@@ -74,3 +74,58 @@ def test_envelope_of_iq_fixture():
     iq = load_npz('fx_ultralight_iq.npz')['iq']
     c = Case('fx_ultralight_txn')
     assert np.array_equal(po.envelope_iq(iq), c.x)
+
+
+# ---------------------------------------------------------------------------
+# the C restatement (oracle/nfc_oracle.c) against the same vectors
+# ---------------------------------------------------------------------------
+from oracle import c_oracle as co
+
+
+@pytest.mark.parametrize('name', PATH_CASES)
+@pytest.mark.parametrize('chunk', [0, 777])
+def test_c_oracle_matches_reference(name, chunk):
+    c = Case(name)
+    o = co.COracle(**c.params)
+    if chunk:
+        for i in range(0, len(c.x), chunk):
+            o.push_env(c.x[i:i + chunk])
+    else:
+        o.push_env(c.x)
+    assert o.transitions() == c.transitions
+    assert o.symbols(0).tolist() == c.sym_tag.tolist()
+    assert o.symbols(1).tolist() == c.sym_reader.tolist()
+    assert o.packets() == c.packets
+
+
+def test_c_oracle_iq_envelope():
+    iq = load_npz('fx_ultralight_iq.npz')['iq']
+    c = Case('fx_ultralight_txn')
+    o = co.COracle(**c.params)
+    o.push_iq(iq)
+    assert o.transitions() == c.transitions
+    assert o.packets() == c.packets
+
+
+def test_c_oracle_equals_python_oracle_on_random_streams():
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        n = int(rng.integers(2500, 9000))
+        base = rng.uniform(0.05, 2.0)
+        x = (base * (1 + 0.05 * rng.standard_normal(n))).astype(np.float32)
+        # bursts of low / high samples
+        for _ in range(int(rng.integers(3, 30))):
+            s = int(rng.integers(0, n - 80))
+            k = int(rng.integers(1, 80))
+            x[s:s + k] *= np.float32(rng.choice([0.0, 0.05, 0.09, 0.11, 1.09, 1.1, 1.12, 1.5]))
+        x = np.abs(x)
+        kw = dict(samp_rate=float(rng.choice([1e6, 2e6, 4e6, 1e7])), hi_val=float(rng.choice([1.05, 1.09, 1.1])),
+                  av_window=int(rng.choice([100, 777, 2000])), max_len=int(rng.choice([7, 30, 50])))
+        r = po.run_path(x, chunk=1000, want_trace=True, **kw)
+        o = co.COracle(trace=True, **kw)
+        o.push_env(x)
+        assert o.transitions() == r['transitions']
+        assert o.trace().tolist() == r['trace']
+        assert o.symbols(0).tolist() == r['symbols_tag']
+        assert o.symbols(1).tolist() == r['symbols_reader']
+        assert o.packets() == r['packets']
