@@ -1,0 +1,173 @@
+/*
+ * nfc_amd.h -- C-ABI of the MI355X-native ISO-14443A IQ -> bit eavesdrop path.
+ *
+ * This is the drop-in boundary for the one hot path of giech/usrp_nfc:
+ *
+ *   envelope (gnuradio complex_to_mag_squared, decoder.py:27 / usrp_src.py:31)
+ *   -> transition_sink   (transition_sink.py:10-125: gated running mean, lo/hi
+ *                         ratio threshold with hysteresis, run-length timing)
+ *   -> background router (background.py:30-52)
+ *   -> miller_decoder / manchester_decoder (miller.py:13-197, manchester.py:13-61)
+ *   -> PacketProcessor   (packets.py:57-98)
+ *
+ * The reference has no FFI of its own (it is pure Python on GNU Radio); the
+ * functions below are what a ctypes binding placed inside the reference's
+ * transition_sink.work()/background.append() would call.  INTEGRATION.md shows
+ * that binding.  Plain C types only; every buffer is caller-allocated; every
+ * function returns 0 on success or a negative nfc_status and leaves a message
+ * for nfc_last_error().  A context is one stream; it is not thread-safe.  All
+ * compute runs in hand-written HIP kernels on the selected device: there is no
+ * CPU fallback, and nfc_create fails if no GPU is usable.
+ */
+#ifndef NFC_AMD_H
+#define NFC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFC_AMD_ABI_VERSION 1
+
+typedef enum {
+    NFC_OK = 0,
+    NFC_ERR_ARG = -1,      /* bad parameter */
+    NFC_ERR_DEVICE = -2,   /* HIP runtime error / no device */
+    NFC_ERR_NOMEM = -3,
+    NFC_ERR_STATE = -4,    /* call sequence error */
+    NFC_ERR_INTERNAL = -5  /* a kernel reported an impossible condition */
+} nfc_status;
+
+/* What one input sample is (replaces the source side of decoder.py:21-29). */
+typedef enum {
+    NFC_IN_IQ_F32 = 0,      /* interleaved float32 I,Q; x = fl(fl(I*I)+fl(Q*Q))  (uhd branch, usrp_src.py:31) */
+    NFC_IN_ENV_F32 = 1,     /* float32 envelope already computed; x = sample                                    */
+    NFC_IN_REAL_F32_SQ = 2, /* float32 real sample, Q = 0; x = fl(s*s)              (wav branch, decoder.py:25-28) */
+    NFC_IN_I16_SQ = 3       /* int16 PCM; s = fl((float)pcm * i16_scale); x = fl(s*s)  (wavfile_source + wav branch) */
+} nfc_input_kind;
+
+/* nfc_params.flags */
+#define NFC_FLAG_FORCE_SEQUENTIAL 1u /* run the exact one-lane sequential kernel for the threshold stage (slow; testing) */
+#define NFC_FLAG_NO_EDGES 2u         /* stop after the threshold stage (val codes only; profiling)                      */
+
+/* Constructor arguments of transition_sink (transition_sink.py:12) and background (background.py:17). */
+typedef struct {
+    double samp_rate;      /* samples per second; durations are reported as d * 1e6 / samp_rate microseconds */
+    double lo_val;         /* 0.1  */
+    double hi_val;         /* 1.1 for IQ input (decoder.py:23), 1.09 for the WAV branch (decoder.py:29) */
+    int32_t av_window;     /* 2000 */
+    int32_t max_len;       /* 50   */
+    int32_t enable_reader; /* Modified-Miller decoder present (background.py:20) */
+    int32_t enable_tag;    /* Manchester decoder present      (background.py:21) */
+    int32_t input_kind;    /* nfc_input_kind */
+    int32_t device;        /* HIP device ordinal */
+    float i16_scale;       /* NFC_IN_I16_SQ only; 0 -> 1/32768 */
+    uint32_t flags;
+    int32_t chunk_samples; /* samples per time chunk of the threshold kernel; 0 -> default */
+    int32_t reserved;
+} nfc_params;
+
+/* One entry of the list transition_sink hands to its callback
+ * (transition_sink.py:89-90,97): ((v, d*factor), t) plus the sample index at
+ * which the reference appended it. 16 bytes. */
+typedef struct {
+    uint64_t idx; /* 0-based sample index in the whole stream */
+    int32_t d;    /* duration in samples, 1..max_len */
+    int8_t v;     /* -1, 0, 1, 2 */
+    int8_t t;     /* cur_state - 1: -1 idle, 0 tag->reader, 1 reader->tag */
+    int16_t pad;
+} nfc_edge;
+
+/* A packet as PacketProcessor.append_bit returns it (packets.py:67-79). */
+typedef struct {
+    uint64_t idx;     /* sample index of the edge whose symbol closed the packet */
+    uint64_t bit_off; /* offset of its first bit in the per-type packet bit array of this batch */
+    uint32_t n_bits;
+    int32_t type;     /* 0 TAG_TO_READER, 1 READER_TO_TAG (packets.py:19-20) */
+} nfc_packet;
+
+typedef struct {
+    uint64_t n_samples;    /* samples in the last batch */
+    uint64_t n_edges;      /* transitions produced by the last batch */
+    uint64_t n_symbols[2]; /* symbols handed to append_bit per packet type (0 tag, 1 reader) */
+    uint64_t n_packets[2]; /* closed, non-empty packets per type */
+    uint64_t n_packet_bits[2];
+} nfc_counts;
+
+typedef struct {
+    double ms_total;          /* device time of the last batch, all kernels (hipEvent) */
+    double ms_threshold;      /* envelope + threshold kernel launches of the last batch */
+    double ms_edges;          /* run-length / edge extraction */
+    double ms_decode;         /* Miller / Manchester / framing */
+    uint32_t threshold_passes; /* launches of the threshold kernel (2 = speculate + verify) */
+    uint32_t chunks_rerun;    /* chunks re-evaluated after the verify pass */
+    uint32_t used_sequential; /* 1 if the exact sequential kernel ran */
+    uint32_t n_chunks;
+    uint64_t bytes_in;        /* input bytes of the last batch */
+} nfc_stats;
+
+/* Everything a successor time chunk needs from its predecessor:
+ * fixed header; the ring (av_window float32) follows in the caller's buffer. */
+typedef struct {
+    uint64_t n_seen;       /* samples consumed so far */
+    double ss;             /* transition_sink._sum */
+    int64_t last_low;      /* index of the last LOW sample, or -1 */
+    int32_t filled;        /* transition_sink._filled */
+    int32_t stable;        /* work has been rebound to work_stable */
+    int32_t cur_state;     /* transition_sink._current_state */
+    int32_t last_bit;      /* transition_sink._last_bit */
+    int32_t dur;           /* transition_sink._dur */
+    int32_t miller_state;  /* (stage, has_started, prev) packed: stage | started<<2 | prev<<3 */
+    int32_t manch_state;   /* prev_set | (prev+1)<<1 */
+    int32_t pkt_started[2];
+    uint32_t n_pending_bits[2]; /* PacketProcessor._cur lengths (bits stay on the device) */
+    int32_t av_window;
+    int32_t reserved;
+} nfc_state_header;
+
+int nfc_abi_version(void);
+int nfc_device_count(void);
+
+typedef struct nfc_ctx nfc_ctx; /* opaque; one per stream */
+
+int nfc_create(const nfc_params *params, nfc_ctx **out);
+void nfc_destroy(nfc_ctx *ctx);
+const char *nfc_last_error(const nfc_ctx *ctx); /* ctx may be NULL: message of the last failed nfc_create */
+
+/* transition_sink.work(): consume n samples (any n >= 0, any chunking gives the
+ * same concatenated outputs).  Host buffer: staged to the device first. */
+int nfc_push(nfc_ctx *ctx, const void *host_samples, size_t n);
+/* Same, input already in device memory (16-byte aligned). */
+int nfc_push_device(nfc_ctx *ctx, const void *dev_samples, size_t n);
+/* Wait for the device; outputs of the last push are complete after it. */
+int nfc_sync(nfc_ctx *ctx);
+
+/* Outputs of the LAST push (valid until the next push). */
+int nfc_get_counts(nfc_ctx *ctx, nfc_counts *out);
+int nfc_read_edges(nfc_ctx *ctx, size_t first, nfc_edge *out, size_t cap, size_t *n_out);
+/* symbols handed to CombinedPacketProcessor.append_bit(bit, type): 0/1 or an ErrorCode (utilities.py:7-14) */
+int nfc_read_symbols(nfc_ctx *ctx, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out);
+/* closed packets of one type in stream order, and their bits (one byte per bit) */
+int nfc_read_packets(nfc_ctx *ctx, int type, nfc_packet *out, size_t cap, size_t *n_out);
+int nfc_read_packet_bits(nfc_ctx *ctx, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out);
+/* per-sample classification of the last batch (-1 LOW, 0 accepted, +1 HIGH); debugging tap */
+int nfc_read_val(nfc_ctx *ctx, size_t first, int8_t *out, size_t cap, size_t *n_out);
+
+/* Boundary state for multi-GPU time sharding / restart. ring must hold av_window floats. */
+int nfc_get_state(nfc_ctx *ctx, nfc_state_header *hdr, float *ring, size_t ring_cap);
+int nfc_set_state(nfc_ctx *ctx, const nfc_state_header *hdr, const float *ring, size_t ring_len);
+
+int nfc_get_stats(nfc_ctx *ctx, nfc_stats *out);
+
+/* Host-only helpers (no GPU needed): the duration LUTs the decode kernels use,
+ * driven sequentially.  Used by the CPU test-suite to pin the tables to the
+ * reference decoders' golden vectors.  type: 0 Manchester, 1 Miller. */
+int nfc_host_decode_lut(const nfc_params *params, int type, const int8_t *cur, const int32_t *d, size_t n,
+                        uint8_t *sym_out, size_t cap, size_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFC_AMD_H */

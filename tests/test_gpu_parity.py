@@ -1,0 +1,150 @@
+"""Parity of the HIP path (through the C-ABI) with the reference: golden vectors produced by the
+unmodified reference, and the pinned C oracle on seeded inputs.  Bit-exact: integer / index work."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from tests.golden_util import PATH_CASES, Case, load_npz
+from usrp_nfc_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return i, a[i], b[i]
+    return (n, None, None) if len(a) != len(b) else None
+
+
+def run_gpu(x, params, kind=api.NFC_IN_ENV_F32, pushes=None, flags=0, chunk_samples=0):
+    """Feed x in pieces; concatenate what each push produced."""
+    ctx = api.NfcContext(input_kind=kind, flags=flags, chunk_samples=chunk_samples, **params)
+    per = 2 if kind == api.NFC_IN_IQ_F32 else 1
+    n = len(x) // per
+    cuts = [0, n] if pushes is None else pushes
+    tr, sym0, sym1, pk, val = [], [], [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ctx.push(x[a * per:b * per])
+        tr += ctx.transitions()
+        sym0 += ctx.symbols(0).tolist()
+        sym1 += ctx.symbols(1).tolist()
+        pk += ctx.packets()
+        val += ctx.val().tolist()
+    st = ctx.stats()
+    ctx.close()
+    return dict(transitions=tr, sym_tag=sym0, sym_reader=sym1, packets=pk, val=val, stats=st)
+
+
+def check_case(c, r):
+    d = first_diff(r['transitions'], c.transitions)
+    assert d is None, 'transition %s' % (d,)
+    assert r['sym_tag'] == c.sym_tag.tolist()
+    assert r['sym_reader'] == c.sym_reader.tolist()
+    assert r['packets'] == c.packets
+
+
+@pytest.mark.parametrize('name', PATH_CASES)
+def test_golden_single_push(name):
+    c = Case(name)
+    check_case(c, run_gpu(c.x, c.params))
+
+
+@pytest.mark.parametrize('name', PATH_CASES)
+def test_golden_many_chunks(name):
+    # smallest legal time chunk: exercises speculate / verify / look-back on the small fixtures
+    c = Case(name)
+    check_case(c, run_gpu(c.x, c.params, chunk_samples=256))
+
+
+@pytest.mark.parametrize('name', PATH_CASES)
+@pytest.mark.parametrize('step', [777, 8192])
+def test_golden_streamed(name, step):
+    # transition_sink.work() chunk invariance: any split of the stream gives the same outputs
+    c = Case(name)
+    cuts = list(range(0, len(c.x), step)) + [len(c.x)]
+    check_case(c, run_gpu(c.x, c.params, pushes=cuts))
+
+
+@pytest.mark.parametrize('name', PATH_CASES)
+def test_golden_sequential_kernel(name):
+    c = Case(name)
+    check_case(c, run_gpu(c.x, c.params, flags=api.NFC_FLAG_FORCE_SEQUENTIAL))
+
+
+def test_golden_iq_input():
+    iq = load_npz('fx_ultralight_iq.npz')['iq']
+    c = Case('fx_ultralight_txn')
+    check_case(c, run_gpu(iq, c.params, kind=api.NFC_IN_IQ_F32))
+    check_case(c, run_gpu(iq, c.params, kind=api.NFC_IN_IQ_F32, chunk_samples=256,
+                          pushes=[0, 1001, 2000, 2001, 7001, len(iq) // 2]))
+
+
+def oracle_run(x, params, kind):
+    o = co.COracle(trace=True, **params)
+    {api.NFC_IN_ENV_F32: o.push_env, api.NFC_IN_IQ_F32: o.push_iq, api.NFC_IN_REAL_F32_SQ: o.push_real_sq}[kind](x)
+    return o
+
+
+def check_vs_oracle(x, params, kind=api.NFC_IN_ENV_F32, **kw):
+    o = oracle_run(x, params, kind)
+    r = run_gpu(x, params, kind=kind, **kw)
+    L = params.get('av_window', 2000)
+    d = first_diff(r['val'][L:], o.trace().tolist())
+    assert d is None, 'val %s' % (d,)
+    e = o.edges()
+    d = first_diff(r['transitions'], o.transitions())
+    assert d is None, 'transition %s (of %d)' % (d, len(e))
+    assert r['sym_tag'] == o.symbols(0).tolist()
+    assert r['sym_reader'] == o.symbols(1).tolist()
+    assert r['packets'] == o.packets()
+    return r
+
+
+def test_real_squared_input():
+    c = Case('fx_ultralight_txn')
+    s = np.sqrt(c.x.astype(np.float64)).astype(np.float32)
+    check_vs_oracle(s, c.params, kind=api.NFC_IN_REAL_F32_SQ)
+
+
+def test_low_run_ending_on_a_timeout():
+    # a LOW run of exactly max_len+1 (and 2*max_len+1) samples resets the state at its last sample
+    # (transition_sink.py:95-99); a HIGH sample right after it must be classified HIGH, not ignored
+    rng = np.random.default_rng(3)
+    x = (0.25 * (1 + 0.004 * rng.standard_normal(12000))).astype(np.float32)
+    for start, ln in ((3000, 51), (4000, 101), (5000, 50), (6000, 52), (7000, 151), (8000, 1), (9000, 500)):
+        x[start:start + ln] = 1e-6
+        x[start + ln:start + ln + 3] = 0.25 * 1.3
+    for kw in (dict(), dict(chunk_samples=256), dict(pushes=[0, 3050, 3051, 4101, 7151, 12000])):
+        check_vs_oracle(x, dict(hi_val=1.1), **kw)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_streams(seed):
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(6000, 60000))
+    base = rng.uniform(0.05, 2.0)
+    x = (base * (1 + 0.01 * rng.standard_normal(n))).astype(np.float32)
+    for _ in range(int(rng.integers(5, 200))):
+        s = int(rng.integers(0, n - 200))
+        k = int(rng.integers(1, 200))
+        x[s:s + k] *= np.float32(rng.choice([0.0, 0.05, 0.09, 0.1, 0.11, 0.5, 1.09, 1.1, 1.105, 1.12, 1.5, 3.0]))
+    x = np.abs(x)
+    params = dict(samp_rate=float(rng.choice([2e6, 4e6, 1e7])), hi_val=float(rng.choice([1.05, 1.09, 1.1])),
+                  av_window=int(rng.choice([128, 777, 2000])), max_len=int(rng.choice([7, 30, 50])))
+    check_vs_oracle(x, params)
+    check_vs_oracle(x, params, chunk_samples=256)
+    cuts = sorted(set([0, n] + rng.integers(0, n, 5).tolist()))
+    check_vs_oracle(x, params, pushes=cuts)
+
+
+@pytest.mark.parametrize('name,kw', [('miller', dict(tag=False)), ('manchester', dict(reader=False)), ('all', dict())])
+def test_synthetic_workloads_2M(name, kw):
+    # BASELINE.json configs 2-4 at a size the oracle finishes in a blink; 122 time chunks
+    iq = synth.workload(name, 2_000_000)
+    r = check_vs_oracle(iq, dict(hi_val=1.1, **kw), kind=api.NFC_IN_IQ_F32)
+    st = r['stats']
+    assert st.used_sequential == 0
+    assert st.threshold_passes == 2, 'speculation missed: %d passes, %d chunks rerun' % (st.threshold_passes, st.chunks_rerun)
+    assert len(r['packets']) > 100

@@ -1,0 +1,67 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol of
+include/nfc_amd.h, and the host-built decoder LUTs reproduce the reference decoders'
+golden vectors (no GPU calls here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.golden_util import load_json, load_npz
+from usrp_nfc_amd import _lib, api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    hdr = open(os.path.join(ROOT, 'include', 'nfc_amd.h')).read()
+    declared = set(re.findall(r'\b(nfc_[a-z_0-9]+)\s*\(', hdr)) - {'nfc_ctx'}
+    assert declared == set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.nfc_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    assert _lib.EDGE_DTYPE.itemsize == 16
+    assert _lib.PACKET_DTYPE.itemsize == 24
+    assert C.sizeof(_lib.Params) == 64
+    assert C.sizeof(_lib.Counts) == 64
+
+
+def test_lut_report_example_and_reqa():
+    fx = load_json('fx_report_miller.json')
+    # report section 4.3: durations in microseconds at 1 Msps are integer sample counts
+    p = fx['report_example']['pulses']
+    got = api.host_decode_lut(1, [c for c, _ in p], [d for _, d in p], samp_rate=1e6, max_len=50)
+    assert got.tolist() == fx['report_example']['symbols'] == [0, 1, 0, 1]
+
+
+@pytest.mark.parametrize('key,factor', [('1', 1.0), ('0p5', 0.5), ('0p25', 0.25), ('0p1', 0.1)])
+def test_lut_random_vectors(key, factor):
+    z = load_npz('fx_decoder_vectors.npz')
+    rate = 1e6 / factor
+    got = api.host_decode_lut(1, z['curm_' + key], z['d_' + key], samp_rate=rate)
+    assert got.tolist() == z['symm_' + key].tolist()
+    got = api.host_decode_lut(0, z['curt_' + key], z['d_' + key], samp_rate=rate)
+    assert got.tolist() == z['symt_' + key].tolist()
+
+
+@pytest.mark.parametrize('key,factor', [('frames_0p5', 0.5), ('frames_0p25', 0.25)])
+def test_lut_frame_vectors(key, factor):
+    z = load_npz('fx_decoder_vectors.npz')
+    rate = 1e6 / factor
+    got = api.host_decode_lut(1, z['curm_' + key], z['dm_' + key], samp_rate=rate)
+    assert got.tolist() == z['symm_' + key].tolist()
+    got = api.host_decode_lut(0, z['curt_' + key], z['dt_' + key], samp_rate=rate)
+    assert got.tolist() == z['symt_' + key].tolist()
+
+
+def test_no_gpu_means_loud_failure():
+    L = _lib.load()
+    if L.nfc_device_count() > 0:
+        pytest.skip('a GPU is present')
+    with pytest.raises(api.NfcError):
+        api.NfcContext()

@@ -1,0 +1,90 @@
+"""ctypes loader for libnfc_amd.so -- the C-ABI of include/nfc_amd.h.
+
+There is no CPU implementation behind this package: if the shared library is
+missing it is built with hipcc (usrp_nfc_amd/build.py); if that fails, or no GPU
+is usable when a context is created, the caller gets an exception."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+NFC_IN_IQ_F32, NFC_IN_ENV_F32, NFC_IN_REAL_F32_SQ, NFC_IN_I16_SQ = 0, 1, 2, 3
+NFC_FLAG_FORCE_SEQUENTIAL, NFC_FLAG_NO_EDGES = 1, 2
+
+
+class Params(C.Structure):
+    _fields_ = [('samp_rate', C.c_double), ('lo_val', C.c_double), ('hi_val', C.c_double),
+                ('av_window', C.c_int32), ('max_len', C.c_int32), ('enable_reader', C.c_int32),
+                ('enable_tag', C.c_int32), ('input_kind', C.c_int32), ('device', C.c_int32),
+                ('i16_scale', C.c_float), ('flags', C.c_uint32), ('chunk_samples', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class Counts(C.Structure):
+    _fields_ = [('n_samples', C.c_uint64), ('n_edges', C.c_uint64), ('n_symbols', C.c_uint64 * 2),
+                ('n_packets', C.c_uint64 * 2), ('n_packet_bits', C.c_uint64 * 2)]
+
+
+class Stats(C.Structure):
+    _fields_ = [('ms_total', C.c_double), ('ms_threshold', C.c_double), ('ms_edges', C.c_double),
+                ('ms_decode', C.c_double), ('threshold_passes', C.c_uint32), ('chunks_rerun', C.c_uint32),
+                ('used_sequential', C.c_uint32), ('n_chunks', C.c_uint32), ('bytes_in', C.c_uint64)]
+
+
+class StateHeader(C.Structure):
+    _fields_ = [('n_seen', C.c_uint64), ('ss', C.c_double), ('last_low', C.c_int64), ('filled', C.c_int32),
+                ('stable', C.c_int32), ('cur_state', C.c_int32), ('last_bit', C.c_int32), ('dur', C.c_int32),
+                ('miller_state', C.c_int32), ('manch_state', C.c_int32), ('pkt_started', C.c_int32 * 2),
+                ('n_pending_bits', C.c_uint32 * 2), ('av_window', C.c_int32), ('reserved', C.c_int32)]
+
+
+EDGE_DTYPE = np.dtype([('idx', '<u8'), ('d', '<i4'), ('v', 'i1'), ('t', 'i1'), ('pad', '<i2')])
+PACKET_DTYPE = np.dtype([('idx', '<u8'), ('bit_off', '<u8'), ('n_bits', '<u4'), ('type', '<i4')])
+
+# every symbol include/nfc_amd.h declares
+SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', 'nfc_last_error', 'nfc_push',
+           'nfc_push_device', 'nfc_sync', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_symbols', 'nfc_read_packets',
+           'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_get_stats',
+           'nfc_host_decode_lut']
+
+_lib = None
+
+
+def lib_path():
+    return _build.SO
+
+
+def load():
+    """Load (building if needed) the shared library and declare its prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    L = C.CDLL(path)
+    vp, sz, psz = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)
+    L.nfc_abi_version.restype = C.c_int
+    L.nfc_device_count.restype = C.c_int
+    L.nfc_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.nfc_destroy.argtypes = [vp]
+    L.nfc_destroy.restype = None
+    L.nfc_last_error.argtypes = [vp]
+    L.nfc_last_error.restype = C.c_char_p
+    L.nfc_push.argtypes = [vp, vp, sz]
+    L.nfc_push_device.argtypes = [vp, vp, sz]
+    L.nfc_sync.argtypes = [vp]
+    L.nfc_get_counts.argtypes = [vp, C.POINTER(Counts)]
+    L.nfc_read_edges.argtypes = [vp, sz, vp, sz, psz]
+    L.nfc_read_symbols.argtypes = [vp, C.c_int, sz, vp, sz, psz]
+    L.nfc_read_packets.argtypes = [vp, C.c_int, vp, sz, psz]
+    L.nfc_read_packet_bits.argtypes = [vp, C.c_int, sz, vp, sz, psz]
+    L.nfc_read_val.argtypes = [vp, sz, vp, sz, psz]
+    L.nfc_get_state.argtypes = [vp, C.POINTER(StateHeader), vp, sz]
+    L.nfc_set_state.argtypes = [vp, C.POINTER(StateHeader), vp, sz]
+    L.nfc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.nfc_host_decode_lut.argtypes = [C.POINTER(Params), C.c_int, vp, vp, sz, vp, sz, psz]
+    for name in SYMBOLS:
+        getattr(L, name)
+    _lib = L
+    return L

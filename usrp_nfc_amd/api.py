@@ -1,0 +1,163 @@
+"""Python face of the C-ABI: one NfcContext = one stream (include/nfc_amd.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (EDGE_DTYPE, NFC_FLAG_FORCE_SEQUENTIAL, NFC_FLAG_NO_EDGES, NFC_IN_ENV_F32, NFC_IN_I16_SQ,
+                   NFC_IN_IQ_F32, NFC_IN_REAL_F32_SQ, PACKET_DTYPE)
+
+__all__ = ['NfcContext', 'NfcError', 'host_decode_lut', 'NFC_IN_IQ_F32', 'NFC_IN_ENV_F32', 'NFC_IN_REAL_F32_SQ',
+           'NFC_IN_I16_SQ', 'NFC_FLAG_FORCE_SEQUENTIAL', 'NFC_FLAG_NO_EDGES']
+
+_KIND_DTYPE = {NFC_IN_IQ_F32: (np.float32, 2), NFC_IN_ENV_F32: (np.float32, 1),
+               NFC_IN_REAL_F32_SQ: (np.float32, 1), NFC_IN_I16_SQ: (np.int16, 1)}
+
+
+class NfcError(RuntimeError):
+    pass
+
+
+def _params(samp_rate, lo_val, hi_val, av_window, max_len, reader, tag, input_kind, device, i16_scale, flags,
+            chunk_samples):
+    return _lib.Params(float(samp_rate), float(lo_val), float(hi_val), int(av_window), int(max_len), int(bool(reader)),
+                       int(bool(tag)), int(input_kind), int(device), float(i16_scale), int(flags), int(chunk_samples), 0)
+
+
+class NfcContext(object):
+    """Arguments mirror transition_sink.transition_sink (transition_sink.py:12) and
+    background.background (background.py:17) of the reference."""
+
+    def __init__(self, samp_rate=2e6, lo_val=0.1, hi_val=1.1, av_window=2000, max_len=50, reader=True, tag=True,
+                 input_kind=NFC_IN_IQ_F32, device=0, i16_scale=0.0, flags=0, chunk_samples=0):
+        self.L = _lib.load()
+        self.h = C.c_void_p()
+        self.input_kind = input_kind
+        self.factor = 1e6 / samp_rate
+        p = _params(samp_rate, lo_val, hi_val, av_window, max_len, reader, tag, input_kind, device, i16_scale, flags,
+                    chunk_samples)
+        rc = self.L.nfc_create(C.byref(p), C.byref(self.h))
+        if rc != 0:
+            raise NfcError('nfc_create: %s (status %d)' % (self.L.nfc_last_error(None).decode(), rc))
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.nfc_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise NfcError('%s: %s (status %d)' % (what, self.L.nfc_last_error(self.h).decode(), rc))
+
+    # -- input ---------------------------------------------------------------
+    def push(self, samples):
+        """Host array: float32 IQ interleaved / complex64, float32 envelope or real, or int16 PCM."""
+        dt, per = _KIND_DTYPE[self.input_kind]
+        a = np.asarray(samples)
+        if a.dtype == np.complex64 and per == 2:
+            a = a.view(np.float32)
+        a = np.ascontiguousarray(a, dtype=dt)
+        n = a.size // per
+        self._chk(self.L.nfc_push(self.h, a.ctypes.data, n), 'nfc_push')
+        return n
+
+    def push_device(self, dev_ptr, n):
+        """Device pointer (int), n samples, 16-byte aligned."""
+        self._chk(self.L.nfc_push_device(self.h, C.c_void_p(int(dev_ptr)), n), 'nfc_push_device')
+        return n
+
+    # -- outputs of the last push -----------------------------------------------
+    def counts(self):
+        c = _lib.Counts()
+        self._chk(self.L.nfc_get_counts(self.h, C.byref(c)), 'nfc_get_counts')
+        return c
+
+    def stats(self):
+        s = _lib.Stats()
+        self._chk(self.L.nfc_get_stats(self.h, C.byref(s)), 'nfc_get_stats')
+        return s
+
+    def _read(self, fn, total, dtype, *lead):
+        out = np.zeros(int(total), dtype)
+        got = C.c_size_t(0)
+        if total:
+            self._chk(fn(self.h, *lead, out.ctypes.data, out.size, C.byref(got)), fn.__name__)
+            assert got.value == out.size
+        return out
+
+    def edges(self):
+        return self._read(self.L.nfc_read_edges, self.counts().n_edges, EDGE_DTYPE, 0)
+
+    def transitions(self):
+        """The list transition_sink hands to its callback: [((v, d*factor), t), ...]."""
+        e = self.edges()
+        f = self.factor
+        return [((int(v), int(d) * f), int(t)) for v, d, t in zip(e['v'], e['d'], e['t'])]
+
+    def symbols(self, ptype):
+        return self._read(self.L.nfc_read_symbols, self.counts().n_symbols[ptype], np.uint8, ptype, 0)
+
+    def packet_table(self, ptype):
+        n = self.counts().n_packets[ptype]
+        out = np.zeros(int(n), PACKET_DTYPE)
+        got = C.c_size_t(0)
+        if n:
+            self._chk(self.L.nfc_read_packets(self.h, ptype, out.ctypes.data, out.size, C.byref(got)), 'nfc_read_packets')
+        return out
+
+    def packets(self):
+        """Closed packets of both types in stream order: [(type, [bits]), ...] -- what
+        CombinedPacketProcessor hands to fsm.process_bits (packets.py:96-98)."""
+        items = []
+        for t in (0, 1):
+            tab = self.packet_table(t)
+            if not len(tab):
+                continue
+            hi = int((tab['bit_off'] + tab['n_bits']).max())
+            bits = np.zeros(hi, np.uint8)
+            got = C.c_size_t(0)
+            self._chk(self.L.nfc_read_packet_bits(self.h, t, 0, bits.ctypes.data, bits.size, C.byref(got)),
+                      'nfc_read_packet_bits')
+            for p in tab:
+                o = int(p['bit_off'])
+                items.append((int(p['idx']), t, bits[o:o + int(p['n_bits'])].tolist()))
+        # one edge feeds one decoder, so closing indices of the two types never tie
+        items.sort(key=lambda r: r[0])
+        return [(t, b) for _, t, b in items]
+
+    def val(self):
+        return self._read(self.L.nfc_read_val, self.counts().n_samples, np.int8, 0)
+
+    def get_state(self):
+        h = _lib.StateHeader()
+        self._chk(self.L.nfc_get_state(self.h, C.byref(h), None, 0), 'nfc_get_state')
+        ring = np.zeros(h.av_window, np.float32)
+        self._chk(self.L.nfc_get_state(self.h, C.byref(h), ring.ctypes.data, ring.size), 'nfc_get_state')
+        return h, ring
+
+    def set_state(self, header, ring):
+        ring = np.ascontiguousarray(ring, np.float32)
+        self._chk(self.L.nfc_set_state(self.h, C.byref(header), ring.ctypes.data, ring.size), 'nfc_set_state')
+
+
+def host_decode_lut(ptype, cur, d, samp_rate=2e6, max_len=50):
+    """Drive the decode kernels' duration LUTs sequentially on the host (no GPU)."""
+    L = _lib.load()
+    p = _params(samp_rate, 0.1, 1.1, 2000, max_len, True, True, NFC_IN_IQ_F32, 0, 0.0, 0, 0)
+    cur = np.ascontiguousarray(cur, np.int8)
+    d = np.ascontiguousarray(d, np.int32)
+    out = np.zeros(2 * len(cur) + 1, np.uint8)
+    got = C.c_size_t(0)
+    rc = L.nfc_host_decode_lut(C.byref(p), ptype, cur.ctypes.data, d.ctypes.data, len(cur), out.ctypes.data, out.size,
+                               C.byref(got))
+    if rc != 0:
+        raise NfcError('nfc_host_decode_lut status %d' % rc)
+    return out[:got.value]

@@ -1,0 +1,37 @@
+"""Build libnfc_amd.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SO = os.path.join(HERE, 'libnfc_amd.so')
+SOURCES = ['nfc_amd.hip']
+DEPS = ['nfc_amd.hip', 'threshold.hip.h', 'edges.hip.h', 'decode.hip.h', 'scan.hip.h', 'decoder_tables.h',
+        os.path.join('..', '..', 'include', 'nfc_amd.h')]
+
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+         '-ffp-contract=off', '-fno-fast-math',      # envelope and fp64 sums must round like the reference
+         '-Wall', '-Wno-unused-function']
+
+
+def stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return SO
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', SO]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == '__main__':
+    build(force='-f' in sys.argv, verbose=True)

@@ -1,0 +1,910 @@
+// nfc_amd.hip -- context, batch orchestration and the C-ABI (include/nfc_amd.h) of the
+// MI355X-native ISO-14443A IQ -> bit path.  gfx950 only; no CPU fallback.
+//
+// One nfc_push = one batch:
+//   k_fill (first av_window samples only) -> k_prepare
+//   -> k_threshold pass 0 (speculate) -> pass 1 (verify) [-> re-evaluations | k_threshold_seq]
+//   -> k_finalize_state
+//   -> run starts (scan) -> emission counts (scan) -> k_write_edges -> k_edge_carry
+//   -> decoder state maps (scan) -> symbols (scan) -> k_dec_carry
+//   -> per type: framing maps (scan) -> packet bits / closes (scan) -> k_pkt_finish
+// Outputs stay in HBM until read through nfc_read_*.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nfc_amd.h"
+#include "decode.hip.h"
+#include "decoder_tables.h"
+#include "edges.hip.h"
+#include "scan.hip.h"
+#include "threshold.hip.h"
+
+using namespace nfc;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes, bool keep = false, hipStream_t st = nullptr) {
+        if (bytes <= cap) return hipSuccess;
+        size_t ncap = std::max(bytes, cap + cap / 2);
+        ncap = (ncap + 255) & ~(size_t)255;
+        void *np = nullptr;
+        hipError_t e = hipMalloc(&np, ncap);
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) {
+            e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { (void)hipFree(np); return e; }
+        }
+        if (p) (void)hipFree(p);
+        p = np;
+        cap = ncap;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct nfc_ctx {
+    nfc_params P;
+    int L, mx, C, Lpad, wpb, twords;
+    double factor;
+    double hi_plus, lo_a, lo_b, hi_a, hi_b;
+    int bands_ok;
+    float i16_scale;
+    size_t in_bytes_per_sample;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[8] = {};
+    std::string err;
+
+    // tables
+    DevBuf d_mil_map, d_man_map, d_mil_out, d_man_out;
+    DecTables T;
+
+    // carried state
+    DevBuf d_carry, d_ecarry, d_dcarry, d_ring[2];
+    int ring_cur = 0;
+    Carry h_carry;
+    EdgeCarry h_ecarry;
+    DecCarry h_dcarry;
+    uint64_t nseen = 0;
+
+    // batch buffers
+    DevBuf d_in, d_val, d_ringout[2], d_touched[2], d_info[2], d_ver, d_changed, d_gmin, d_gmax, d_gflags, d_list;
+    DevBuf d_starts, d_offs, d_edges, d_states, d_sym[2], d_src[2], d_started, d_bits[2], d_pending[2], d_close_end[2],
+        d_close_idx[2];
+    DevBuf d_partials, d_totals;  // scan scratch; totals: small device scalars
+    std::vector<uint8_t> h_ver, h_changed, h_gmin, h_gmax, h_gflags;
+    std::vector<uint32_t> h_list;
+
+    // last batch
+    const void *last_in = nullptr;
+    uint32_t last_n = 0, last_skip = 0;
+    uint64_t last_g0 = 0;
+    uint32_t n_runs = 0, n_edges = 0;
+    uint32_t n_sym[2] = {0, 0}, n_close[2] = {0, 0}, n_bits[2] = {0, 0};
+    bool have_outputs = false;
+    nfc_stats stats;
+    // lazily built packet lists
+    std::vector<nfc_packet> pk[2];
+    bool pk_ready[2] = {false, false};
+};
+
+namespace {
+
+int fail(nfc_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess)                                                                       \
+            return fail((c), NFC_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+// totals layout (device scalars in d_totals)
+enum : int {
+    TOT_RUNS = 0,       // u32
+    TOT_EDGES = 8,      // u32
+    TOT_DECMAP = 16,    // DecMaps (16 bytes)
+    TOT_SYMS = 32,      // u64: miller | manchester << 32
+    TOT_PKTMAP0 = 40,   // u32
+    TOT_PKTMAP1 = 48,   // u32
+    TOT_PKT0 = 56,      // u64: bits | closes << 32
+    TOT_PKT1 = 64,
+    TOT_BYTES = 128
+};
+
+template <int KIND>
+void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
+    const uint32_t blocks = (nwork + c->wpb - 1) / c->wpb;
+    const size_t lds = (size_t)c->wpb * c->Lpad * 5;
+    hipLaunchKernelGGL((k_threshold<KIND>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
+}
+void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
+    switch (c->P.input_kind) {
+    case NFC_IN_IQ_F32: launch_threshold<IN_IQ_F32>(c, A, nwork); break;
+    case NFC_IN_ENV_F32: launch_threshold<IN_ENV_F32>(c, A, nwork); break;
+    case NFC_IN_REAL_F32_SQ: launch_threshold<IN_REAL_F32_SQ>(c, A, nwork); break;
+    default: launch_threshold<IN_I16_SQ>(c, A, nwork); break;
+    }
+}
+void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n) {
+    float *ring = c->d_ring[c->ring_cur].as<float>();
+    Carry *cr = c->d_carry.as<Carry>();
+    switch (c->P.input_kind) {
+    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(64), 0, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
+    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(64), 0, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
+    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(64), 0, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
+    default: hipLaunchKernelGGL((k_fill<IN_I16_SQ>), dim3(1), dim3(64), 0, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
+    }
+}
+void launch_seq_kind(nfc_ctx *c, const SeqArgs &A) {
+    switch (c->P.input_kind) {
+    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_threshold_seq<IN_IQ_F32>), dim3(1), dim3(64), 0, c->st, A); break;
+    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_threshold_seq<IN_ENV_F32>), dim3(1), dim3(64), 0, c->st, A); break;
+    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_threshold_seq<IN_REAL_F32_SQ>), dim3(1), dim3(64), 0, c->st, A); break;
+    default: hipLaunchKernelGGL((k_threshold_seq<IN_I16_SQ>), dim3(1), dim3(64), 0, c->st, A); break;
+    }
+}
+
+int ceil_log2(int v) {
+    int b = 0;
+    while ((1 << b) < v) b++;
+    return b;
+}
+
+double elapsed_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+// ---------------------------------------------------------------------------
+// threshold stage
+// ---------------------------------------------------------------------------
+int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
+    const int L = c->L;
+    const uint32_t nch = (n + c->C - 1) / c->C;
+    c->stats.n_chunks = nch;
+    HIPCHK(c, c->d_val.ensure(((size_t)n / 16 + 2) * 4 + 64));
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(c, c->d_ringout[b].ensure((size_t)nch * L * sizeof(float)));
+        HIPCHK(c, c->d_touched[b].ensure((size_t)nch * c->twords * sizeof(uint32_t)));
+        HIPCHK(c, c->d_info[b].ensure((size_t)nch * sizeof(ChunkInfo)));
+    }
+    HIPCHK(c, c->d_ver.ensure(nch));
+    HIPCHK(c, c->d_changed.ensure(nch));
+    HIPCHK(c, c->d_gmin.ensure(nch));
+    HIPCHK(c, c->d_gmax.ensure(nch));
+    HIPCHK(c, c->d_gflags.ensure(nch));
+    HIPCHK(c, c->d_list.ensure((size_t)nch * 4));
+    c->h_ver.assign(nch, 0);
+    c->h_changed.assign(nch, 0);
+    c->h_gmin.assign(nch, 255);
+    c->h_gmax.assign(nch, 0);
+    c->h_gflags.assign(nch, 0);
+    HIPCHK(c, hipMemsetAsync(c->d_ver.p, 0, nch, c->st));
+
+    // carried "HIGH ignored" bookkeeping from (_current_state, _last_bit, _dur) at the first stable sample
+    const int s0 = (int)skip;
+    int nl0, kl0;
+    if (c->h_ecarry.last_bit == -1) {
+        nl0 = s0 - c->h_ecarry.dur - 1;
+        kl0 = 2 * (s0 - 1) + (c->h_ecarry.state == 2 ? 1 : 0);
+    } else if (c->h_ecarry.state == 2) {
+        nl0 = s0 - 1;
+        kl0 = 2 * (s0 - c->h_ecarry.dur - 1) + 1;
+    } else {
+        nl0 = s0 - 1;
+        kl0 = KEY_NONE;
+    }
+
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(64), 0, c->st, c->d_ring[c->ring_cur].as<float>(), L, c->d_carry.as<Carry>());
+
+    const bool force_seq = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0;
+    bool need_seq = force_seq;
+    c->stats.threshold_passes = 0;
+    c->stats.chunks_rerun = 0;
+    c->stats.used_sequential = 0;
+
+    if (!force_seq) {
+        ThrArgs A;
+        memset(&A, 0, sizeof A);
+        A.in = d_in;
+        A.n = n;
+        A.skip = skip;
+        A.g0modL = (uint32_t)(c->nseen % (uint64_t)L);
+        A.L = L;
+        A.Lpad = c->Lpad;
+        A.mx = c->mx;
+        A.C = c->C;
+        A.nchunks = (int)nch;
+        A.lo = c->P.lo_val;
+        A.hi = c->P.hi_val;
+        A.hi_plus = c->hi_plus;
+        A.lo_a = c->lo_a;
+        A.lo_b = c->lo_b;
+        A.hi_a = c->hi_a;
+        A.hi_b = c->hi_b;
+        A.bands_ok = c->bands_ok;
+        A.i16_scale = c->i16_scale;
+        A.ring_carry = c->d_ring[c->ring_cur].as<float>();
+        A.carry = c->d_carry.as<Carry>();
+        A.nl0 = nl0;
+        A.kl0 = kl0;
+        for (int b = 0; b < 2; b++) {
+            A.ring_out[b] = c->d_ringout[b].as<float>();
+            A.touched[b] = c->d_touched[b].as<uint32_t>();
+            A.info[b] = c->d_info[b].as<ChunkInfo>();
+        }
+        A.ver = c->d_ver.as<uint8_t>();
+        A.changed = c->d_changed.as<uint8_t>();
+        A.gmin = c->d_gmin.as<uint8_t>();
+        A.gmax = c->d_gmax.as<uint8_t>();
+        A.gflags = c->d_gflags.as<uint8_t>();
+        A.val = c->d_val.as<uint8_t>();
+        A.twords = c->twords;
+
+        // pass 0: every chunk, speculative incoming state (chunk 0: the carried, exact one)
+        A.list = nullptr;
+        A.nlist = 0;
+        A.mode = 0;
+        launch_threshold_kind(c, A, nch);
+        c->stats.threshold_passes++;
+
+        // pass 1..: exact incoming state by look-back; repeat for chunks that can see a changed summary
+        c->h_list.clear();
+        for (uint32_t k = 1; k < nch; k++) c->h_list.push_back(k);
+        int guard_iter = 0;
+        while (!c->h_list.empty()) {
+            const uint32_t nl = (uint32_t)c->h_list.size();
+            HIPCHK(c, hipMemcpyAsync(c->d_list.p, c->h_list.data(), (size_t)nl * 4, hipMemcpyHostToDevice, c->st));
+            A.list = c->d_list.as<uint32_t>();
+            A.nlist = nl;
+            A.mode = 1;
+            launch_threshold_kind(c, A, nl);
+            c->stats.threshold_passes++;
+            if (c->stats.threshold_passes > 2) c->stats.chunks_rerun += nl;
+            HIPCHK(c, hipMemcpyAsync(c->h_changed.data(), c->d_changed.p, nch, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipMemcpyAsync(c->h_gflags.data(), c->d_gflags.p, nch, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            std::vector<uint8_t> ran(nch, 0);
+            for (uint32_t k : c->h_list) {
+                ran[k] = 1;
+                c->h_ver[k] ^= 1;
+            }
+            HIPCHK(c, hipMemcpyAsync(c->d_ver.p, c->h_ver.data(), nch, hipMemcpyHostToDevice, c->st));
+            c->h_list.clear();
+            bool vis = false;
+            for (uint32_t k = 0; k < nch; k++) {
+                if (vis) c->h_list.push_back(k);
+                const bool ch = ran[k] && c->h_changed[k];
+                const bool full = !(c->h_gflags[k] & 2);
+                vis = ch || (vis && !full);
+            }
+            if (++guard_iter > (int)nch + 2) return fail(c, NFC_ERR_INTERNAL, "threshold passes did not converge");
+        }
+
+        // can every fp64 sum of this batch be proven exact?  (otherwise the summation order matters)
+        HIPCHK(c, hipMemcpyAsync(c->h_gmin.data(), c->d_gmin.p, nch, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->h_gmax.data(), c->d_gmax.p, nch, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->h_gflags.data(), c->d_gflags.p, nch, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(&c->h_carry, c->d_carry.p, sizeof(Carry), hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        int emin = 255, emax = 0;
+        bool flagged = false;
+        for (uint32_t k = 0; k < nch; k++) {
+            emin = std::min(emin, (int)c->h_gmin[k]);
+            emax = std::max(emax, (int)c->h_gmax[k]);
+            if (c->h_gflags[k] & 1) flagged = true;
+        }
+        int low = emin - 23, high = emax + 2 + ceil_log2(L);
+        if (c->h_carry.ss_emin != 255) low = std::min(low, c->h_carry.ss_emin);
+        high = std::max(high, c->h_carry.ss_emax);
+        const bool exact = (emax < 255) && (high - low <= 52);
+        if (!exact || flagged) need_seq = true;
+    }
+
+    if (need_seq) {
+        SeqArgs S;
+        memset(&S, 0, sizeof S);
+        S.in = d_in;
+        S.n = n;
+        S.skip = skip;
+        S.g0modL = (uint32_t)(c->nseen % (uint64_t)L);
+        S.L = L;
+        S.mx = c->mx;
+        S.lo = c->P.lo_val;
+        S.hi = c->P.hi_val;
+        S.hi_plus = c->hi_plus;
+        S.i16_scale = c->i16_scale;
+        S.ring = c->d_ring[c->ring_cur].as<float>();
+        S.carry = c->d_carry.as<Carry>();
+        S.state = c->h_ecarry.state;
+        S.last_bit = c->h_ecarry.last_bit;
+        S.dur = c->h_ecarry.dur;
+        S.val = c->d_val.as<uint8_t>();
+        launch_seq_kind(c, S);
+        c->stats.used_sequential = 1;
+    } else {
+        FinArgs F;
+        memset(&F, 0, sizeof F);
+        F.L = L;
+        F.nchunks = (int)nch;
+        F.twords = c->twords;
+        F.ring_carry = c->d_ring[c->ring_cur].as<float>();
+        F.ring_next = c->d_ring[1 - c->ring_cur].as<float>();
+        for (int b = 0; b < 2; b++) {
+            F.ring_out[b] = c->d_ringout[b].as<float>();
+            F.touched[b] = c->d_touched[b].as<uint32_t>();
+        }
+        F.ver = c->d_ver.as<uint8_t>();
+        F.carry = c->d_carry.as<Carry>();
+        hipLaunchKernelGGL(k_finalize_state, dim3(1), dim3(64), 0, c->st, F);
+        c->ring_cur = 1 - c->ring_cur;
+    }
+    return NFC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// edge stage
+// ---------------------------------------------------------------------------
+int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
+    uint8_t *tot = c->d_totals.as<uint8_t>();
+    const size_t nwords = ((size_t)n + 15) / 16;
+    ChangeMask cm{c->d_val.as<uint32_t>(), n, skip, val_to_code(c->h_ecarry.last_bit)};
+    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<8>(nwords) + 1) * sizeof(uint32_t)));
+    scan_phase1<AddU32, 8>(c->st, nwords, LoadChangeCount{cm}, 0u, c->d_partials.as<uint32_t>(), (uint32_t *)(tot + TOT_RUNS));
+    uint32_t nruns = 0;
+    HIPCHK(c, hipMemcpyAsync(&nruns, tot + TOT_RUNS, 4, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->n_runs = nruns;
+    HIPCHK(c, c->d_starts.ensure(((size_t)nruns + 1) * 4));
+    scan_phase2<AddU32, 8>(c->st, nwords, LoadChangeCount{cm}, StoreRunStarts{cm, c->d_starts.as<uint32_t>()},
+                           c->d_partials.as<uint32_t>());
+
+    RunView rv;
+    rv.starts = c->d_starts.as<uint32_t>();
+    rv.val = c->d_val.as<uint8_t>();
+    rv.nruns = nruns;
+    rv.n = n;
+    rv.skip = (int32_t)skip;
+    rv.mx = c->mx;
+    rv.dur_in = c->h_ecarry.dur;
+    rv.last_bit_in = c->h_ecarry.last_bit;
+    rv.state_in = c->h_ecarry.state;
+
+    const size_t nitems = (size_t)nruns + 1;  // virtual run + real runs
+    HIPCHK(c, c->d_offs.ensure((nitems + 1) * 4));
+    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<4>(nitems) + 1) * sizeof(uint32_t)));
+    device_scan<AddU32, 4>(c->st, nitems, LoadEmissionCount{rv}, StoreEmissionOffset{c->d_offs.as<uint32_t>()}, 0u,
+                           c->d_partials.as<uint32_t>(), (uint32_t *)(tot + TOT_EDGES));
+    uint32_t nedges = 0;
+    HIPCHK(c, hipMemcpyAsync(&nedges, tot + TOT_EDGES, 4, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->n_edges = nedges;
+    HIPCHK(c, c->d_edges.ensure(((size_t)nedges + 1) * sizeof(nfc_edge)));
+    if (nedges) {
+        const uint32_t per = 256 * EDGE_ITEMS;
+        hipLaunchKernelGGL(k_write_edges, dim3((nedges + per - 1) / per), dim3(256), 0, c->st, rv, c->d_offs.as<uint32_t>(), nedges,
+                           g0, c->d_edges.as<nfc_edge>());
+    }
+    hipLaunchKernelGGL(k_edge_carry, dim3(1), dim3(64), 0, c->st, rv, c->d_ecarry.as<EdgeCarry>());
+    return NFC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// decode + framing
+// ---------------------------------------------------------------------------
+int run_decode(nfc_ctx *c) {
+    uint8_t *tot = c->d_totals.as<uint8_t>();
+    const uint32_t ne = c->n_edges;
+    const nfc_edge *edges = c->d_edges.as<nfc_edge>();
+    HIPCHK(c, c->d_states.ensure((size_t)ne + 16));
+    HIPCHK(c, c->d_sym[1].ensure((size_t)2 * ne + 16));
+    HIPCHK(c, c->d_src[1].ensure(((size_t)2 * ne + 16) * 4));
+    HIPCHK(c, c->d_sym[0].ensure((size_t)ne + 16));
+    HIPCHK(c, c->d_src[0].ensure(((size_t)ne + 16) * 4));
+    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<4>(ne) + 1) * sizeof(DecMaps)));
+
+    DecMaps idm{identity_map(16), (uint32_t)identity_map(8)};
+    device_scan<ComposeDec, 4>(c->st, ne, LoadEdgeMaps{edges, c->T},
+                               StoreEdgeStates{c->d_states.as<uint8_t>(), c->h_dcarry.mil_state, c->h_dcarry.man_state}, idm,
+                               c->d_partials.as<DecMaps>(), (DecMaps *)(tot + TOT_DECMAP));
+    StoreSymbols ss{edges, c->d_states.as<uint8_t>(), c->T, {c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()},
+                    {c->d_src[0].as<uint32_t>(), c->d_src[1].as<uint32_t>()}};
+    device_scan<AddU64, 4>(c->st, ne, LoadSymCounts{edges, c->d_states.as<uint8_t>(), c->T}, ss, 0ull,
+                           c->d_partials.as<uint64_t>(), (uint64_t *)(tot + TOT_SYMS));
+    hipLaunchKernelGGL(k_dec_carry, dim3(1), dim3(64), 0, c->st, (const DecMaps *)(tot + TOT_DECMAP), c->d_dcarry.as<DecCarry>());
+    uint64_t nsyms = 0;
+    HIPCHK(c, hipMemcpyAsync(&nsyms, tot + TOT_SYMS, 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->n_sym[1] = (uint32_t)nsyms;
+    c->n_sym[0] = (uint32_t)(nsyms >> 32);
+
+    for (int t = 0; t < 2; t++) {
+        const uint32_t ns = c->n_sym[t];
+        const uint32_t pend = c->h_dcarry.pending[t];
+        const int start_bit = (t == 0) ? 1 : 0;  // packets.py:24-28
+        HIPCHK(c, c->d_started.ensure((size_t)ns + 16));
+        HIPCHK(c, c->d_bits[t].ensure((size_t)pend + ns + 16));
+        HIPCHK(c, c->d_pending[t].ensure((size_t)pend + ns + 16, true, c->st));
+        HIPCHK(c, c->d_close_end[t].ensure(((size_t)ns + 4) * 4));
+        HIPCHK(c, c->d_close_idx[t].ensure(((size_t)ns + 4) * 8));
+        HIPCHK(c, c->d_partials.ensure((scan_num_tiles<8>(ns) + 1) * sizeof(uint64_t)));
+        if (pend) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t].p, pend, hipMemcpyDeviceToDevice, c->st));
+        const uint8_t *sym = c->d_sym[t].as<uint8_t>();
+        uint32_t *maptot = (uint32_t *)(tot + (t ? TOT_PKTMAP1 : TOT_PKTMAP0));
+        uint64_t *pktot = (uint64_t *)(tot + (t ? TOT_PKT1 : TOT_PKT0));
+        device_scan<ComposePkt, 8>(c->st, ns, LoadPktMaps{sym, start_bit},
+                                   StorePktStarted{c->d_started.as<uint8_t>(), c->h_dcarry.pkt_started[t]},
+                                   (uint32_t)identity_map(2), c->d_partials.as<uint32_t>(), maptot);
+        StorePkt sp{sym, c->d_started.as<uint8_t>(), c->d_src[t].as<uint32_t>(), edges, start_bit, c->d_bits[t].as<uint8_t>(),
+                    c->d_close_end[t].as<uint32_t>(), c->d_close_idx[t].as<uint64_t>()};
+        device_scan<AddU64, 8>(c->st, ns, LoadPktCounts{sym, c->d_started.as<uint8_t>(), start_bit}, sp, (uint64_t)pend,
+                               c->d_partials.as<uint64_t>(), pktot);
+        PktFinish F{c->d_bits[t].as<uint8_t>(), c->d_pending[t].as<uint8_t>(), c->d_close_end[t].as<uint32_t>(), pktot, maptot,
+                    c->d_dcarry.as<DecCarry>(), t, (uint32_t)std::min<size_t>(c->d_pending[t].cap, 0xFFFFFFFFu)};
+        hipLaunchKernelGGL(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
+    }
+    uint64_t pk[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(&pk[0], tot + TOT_PKT0, 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(&pk[1], tot + TOT_PKT1, 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(&c->h_dcarry, c->d_dcarry.p, sizeof(DecCarry), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    for (int t = 0; t < 2; t++) {
+        c->n_bits[t] = (uint32_t)pk[t];
+        c->n_close[t] = (uint32_t)(pk[t] >> 32);
+    }
+    return NFC_OK;
+}
+
+int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
+    c->have_outputs = false;
+    c->pk_ready[0] = c->pk_ready[1] = false;
+    c->n_runs = c->n_edges = 0;
+    for (int t = 0; t < 2; t++) c->n_sym[t] = c->n_close[t] = c->n_bits[t] = 0;
+    memset(&c->stats, 0, sizeof c->stats);
+    if (n64 > (1ull << 30)) return fail(c, NFC_ERR_ARG, "batch of %zu samples exceeds 2^30; push it in pieces", n64);
+    const uint32_t n = (uint32_t)n64;
+    c->last_n = n;
+    c->last_g0 = c->nseen;
+    c->last_skip = 0;
+    c->stats.bytes_in = (uint64_t)n * c->in_bytes_per_sample;
+    if (n == 0) {
+        c->have_outputs = true;
+        return NFC_OK;
+    }
+    if (((uintptr_t)d_in & 15u) != 0) return fail(c, NFC_ERR_ARG, "device input must be 16-byte aligned");
+    HIPCHK(c, hipEventRecord(c->ev[0], c->st));
+
+    uint32_t skip = 0;
+    if (!c->h_carry.stable) {
+        skip = (uint32_t)std::min<uint64_t>(n, (uint64_t)(c->L - c->h_carry.filled));
+        launch_fill_kind(c, d_in, n);
+        c->h_carry.filled += (int)skip;
+        if (c->h_carry.filled == c->L) {
+            c->h_carry.stable = 1;
+            c->h_ecarry.state = 0;
+            c->h_ecarry.last_bit = 0;
+            c->h_ecarry.dur = c->L % c->mx;  // transition_sink.py:123
+            HIPCHK(c, hipMemcpyAsync(c->d_ecarry.p, &c->h_ecarry, sizeof(EdgeCarry), hipMemcpyHostToDevice, c->st));
+        }
+    }
+    c->last_skip = skip;
+    if (!c->h_carry.stable || skip == n) {
+        // the whole batch went into the averaging window: no callback content (transition_sink.py:109-125)
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        c->nseen += n;
+        c->have_outputs = true;
+        return NFC_OK;
+    }
+
+    HIPCHK(c, hipEventRecord(c->ev[1], c->st));
+    int rc = run_threshold(c, d_in, n, skip);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[2], c->st));
+    if (!(c->P.flags & NFC_FLAG_NO_EDGES)) {
+        rc = run_edges(c, n, skip, c->nseen);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+        rc = run_decode(c);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(&c->h_ecarry, c->d_ecarry.p, sizeof(EdgeCarry), hipMemcpyDeviceToHost, c->st));
+    } else {
+        HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[4], c->st));
+    HIPCHK(c, hipMemcpyAsync(&c->h_carry, c->d_carry.p, sizeof(Carry), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->stats.ms_total = elapsed_ms(c->ev[0], c->ev[4]);
+    c->stats.ms_threshold = elapsed_ms(c->ev[1], c->ev[2]);
+    c->stats.ms_edges = elapsed_ms(c->ev[2], c->ev[3]);
+    c->stats.ms_decode = elapsed_ms(c->ev[3], c->ev[4]);
+    c->nseen += n;
+    c->last_in = d_in;
+    c->have_outputs = true;
+    return NFC_OK;
+}
+
+int build_packets(nfc_ctx *c, int t) {
+    if (c->pk_ready[t]) return NFC_OK;
+    c->pk[t].clear();
+    const uint32_t nc = c->n_close[t];
+    if (nc) {
+        std::vector<uint32_t> ends(nc);
+        std::vector<uint64_t> idx(nc);
+        HIPCHK(c, hipMemcpy(ends.data(), c->d_close_end[t].p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(idx.data(), c->d_close_idx[t].p, (size_t)nc * 8, hipMemcpyDeviceToHost));
+        uint32_t prev = 0;
+        for (uint32_t k = 0; k < nc; k++) {
+            if (ends[k] > prev) {  // packets.py:97 -- empty lists never reach the fsm
+                nfc_packet p;
+                p.idx = idx[k];
+                p.bit_off = prev;
+                p.n_bits = ends[k] - prev;
+                p.type = t;
+                c->pk[t].push_back(p);
+            }
+            prev = ends[k];
+        }
+    }
+    c->pk_ready[t] = true;
+    return NFC_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+extern "C" {
+
+int nfc_abi_version(void) { return NFC_AMD_ABI_VERSION; }
+
+int nfc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *nfc_last_error(const nfc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int nfc_create(const nfc_params *p, nfc_ctx **out) {
+    if (!p || !out) return fail(nullptr, NFC_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (!(p->samp_rate > 0)) return fail(nullptr, NFC_ERR_ARG, "samp_rate must be positive");
+    if (p->av_window < 1 || p->av_window > 30000) return fail(nullptr, NFC_ERR_ARG, "av_window must be in [1, 30000]");
+    if (p->max_len < 1 || p->max_len > 4000) return fail(nullptr, NFC_ERR_ARG, "max_len must be in [1, 4000]");
+    if (p->input_kind < 0 || p->input_kind > 3) return fail(nullptr, NFC_ERR_ARG, "unknown input_kind");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, NFC_ERR_DEVICE, "no HIP device: this library has no CPU fallback");
+    if (p->device < 0 || p->device >= ndev) return fail(nullptr, NFC_ERR_ARG, "device %d out of range (%d devices)", p->device, ndev);
+    if (hipSetDevice(p->device) != hipSuccess) return fail(nullptr, NFC_ERR_DEVICE, "hipSetDevice failed");
+
+    nfc_ctx *c = new nfc_ctx();
+    c->P = *p;
+    c->L = p->av_window;
+    c->mx = p->max_len;
+    c->factor = 1e6 / p->samp_rate;
+    c->Lpad = (c->L + 15) & ~15;
+    c->twords = (c->L + 31) / 32;
+    int C = p->chunk_samples > 0 ? p->chunk_samples : 16384;
+    C = std::max(C, 2 * c->L);
+    C = std::max(C, c->mx + 2);
+    C = (C + STEP - 1) / STEP * STEP;
+    c->C = C;
+    c->wpb = std::max(1, std::min(4, (int)(65536 / ((size_t)c->Lpad * 5))));
+    c->hi_plus = p->hi_val + 0.1;  // transition_sink.py:63
+    const double eps = std::ldexp(1.0, -48);
+    auto band = [&](double v, double &a, double &b) {
+        a = v - std::fabs(v) * eps;
+        b = v + std::fabs(v) * eps;
+    };
+    band(p->lo_val, c->lo_a, c->lo_b);
+    band(p->hi_val, c->hi_a, c->hi_b);
+    auto sane = [](double v) { return v == 0 || (std::fabs(v) > 1e-100 && std::fabs(v) < 1e100); };
+    c->bands_ok = sane(p->lo_val) && sane(p->hi_val) && std::isfinite(p->lo_val) && std::isfinite(p->hi_val);
+    c->i16_scale = p->i16_scale != 0.f ? p->i16_scale : 1.0f / 32768.0f;
+    static const size_t bps[4] = {8, 4, 4, 2};
+    c->in_bytes_per_sample = bps[p->input_kind];
+    memset(&c->h_carry, 0, sizeof c->h_carry);
+    c->h_carry.ss_emin = 255;
+    c->h_ecarry = EdgeCarry{0, 0, 1, 0};  // transition_sink.py:22-23,30
+    memset(&c->h_dcarry, 0, sizeof c->h_dcarry);
+    c->h_dcarry.mil_state = 0;             // stage BEGINNING, not started, prev 0 (miller.py:22,29)
+    c->h_dcarry.man_state = (0 + 1) << 1;  // prev_set False, prev 0 (manchester.py:22-25)
+    memset(&c->stats, 0, sizeof c->stats);
+
+#define CRT(call)                                                                                      \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            int rc__ = fail(nullptr, NFC_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e__));   \
+            nfc_destroy(c);                                                                            \
+            return rc__;                                                                               \
+        }                                                                                              \
+    } while (0)
+    CRT(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    for (auto &e : c->ev) CRT(hipEventCreate(&e));
+    const size_t lds = (size_t)c->wpb * c->Lpad * 5;
+    if (lds > 160 * 1024) {
+        nfc_destroy(c);
+        return fail(nullptr, NFC_ERR_ARG, "av_window too large for one wave's LDS ring");
+    }
+    if (lds > 64 * 1024) {
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_IQ_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    // decoder LUTs
+    DecoderTables t = build_tables(p->samp_rate, c->mx);
+    CRT(c->d_mil_map.ensure(t.miller_map.size() * 8));
+    CRT(c->d_man_map.ensure(t.manch_map.size() * 4));
+    CRT(c->d_mil_out.ensure(t.miller_out.size()));
+    CRT(c->d_man_out.ensure(t.manch_out.size()));
+    CRT(hipMemcpy(c->d_mil_map.p, t.miller_map.data(), t.miller_map.size() * 8, hipMemcpyHostToDevice));
+    CRT(hipMemcpy(c->d_man_map.p, t.manch_map.data(), t.manch_map.size() * 4, hipMemcpyHostToDevice));
+    CRT(hipMemcpy(c->d_mil_out.p, t.miller_out.data(), t.miller_out.size(), hipMemcpyHostToDevice));
+    CRT(hipMemcpy(c->d_man_out.p, t.manch_out.data(), t.manch_out.size(), hipMemcpyHostToDevice));
+    c->T.mil_map = c->d_mil_map.as<uint64_t>();
+    c->T.man_map = c->d_man_map.as<uint32_t>();
+    c->T.mil_out = c->d_mil_out.as<uint8_t>();
+    c->T.man_out = c->d_man_out.as<uint8_t>();
+    c->T.nd = c->mx + 1;
+    c->T.reader = p->enable_reader ? 1 : 0;
+    c->T.tag = p->enable_tag ? 1 : 0;
+    // carried state
+    CRT(c->d_carry.ensure(sizeof(Carry)));
+    CRT(c->d_ecarry.ensure(sizeof(EdgeCarry)));
+    CRT(c->d_dcarry.ensure(sizeof(DecCarry)));
+    CRT(c->d_totals.ensure(TOT_BYTES));
+    for (int b = 0; b < 2; b++) {
+        CRT(c->d_ring[b].ensure((size_t)c->Lpad * 4));
+        CRT(hipMemset(c->d_ring[b].p, 0, (size_t)c->Lpad * 4));
+        CRT(c->d_pending[b].ensure(1024));
+    }
+    CRT(hipMemcpy(c->d_carry.p, &c->h_carry, sizeof(Carry), hipMemcpyHostToDevice));
+    CRT(hipMemcpy(c->d_ecarry.p, &c->h_ecarry, sizeof(EdgeCarry), hipMemcpyHostToDevice));
+    CRT(hipMemcpy(c->d_dcarry.p, &c->h_dcarry, sizeof(DecCarry), hipMemcpyHostToDevice));
+    CRT(hipMemset(c->d_totals.p, 0, TOT_BYTES));
+#undef CRT
+    *out = c;
+    return NFC_OK;
+}
+
+void nfc_destroy(nfc_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->P.device);
+    if (c->st) (void)hipStreamSynchronize(c->st);
+    DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_carry, &c->d_ecarry, &c->d_dcarry,
+                     &c->d_ring[0], &c->d_ring[1], &c->d_in, &c->d_val, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
+                     &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_changed, &c->d_gmin, &c->d_gmax,
+                     &c->d_gflags, &c->d_list, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
+                     &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0],
+                     &c->d_pending[1], &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
+                     &c->d_partials, &c->d_totals};
+    for (DevBuf *b : all) b->release();
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    delete c;
+}
+
+int nfc_push_device(nfc_ctx *c, const void *dev_samples, size_t n) {
+    if (!c) return NFC_ERR_ARG;
+    if (n && !dev_samples) return fail(c, NFC_ERR_ARG, "null input");
+    if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
+    return process_batch(c, dev_samples, n);
+}
+
+int nfc_push(nfc_ctx *c, const void *host_samples, size_t n) {
+    if (!c) return NFC_ERR_ARG;
+    if (n && !host_samples) return fail(c, NFC_ERR_ARG, "null input");
+    if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
+    const size_t bytes = n * c->in_bytes_per_sample;
+    HIPCHK(c, c->d_in.ensure(bytes + 64));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(c->d_in.p, host_samples, bytes, hipMemcpyHostToDevice, c->st));
+    return process_batch(c, c->d_in.p, n);
+}
+
+int nfc_sync(nfc_ctx *c) {
+    if (!c) return NFC_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return NFC_OK;
+}
+
+int nfc_get_counts(nfc_ctx *c, nfc_counts *out) {
+    if (!c || !out) return NFC_ERR_ARG;
+    if (!c->have_outputs) return fail(c, NFC_ERR_STATE, "no completed batch");
+    memset(out, 0, sizeof *out);
+    out->n_samples = c->last_n;
+    out->n_edges = c->n_edges;
+    for (int t = 0; t < 2; t++) {
+        out->n_symbols[t] = c->n_sym[t];
+        int rc = build_packets(c, t);
+        if (rc) return rc;
+        out->n_packets[t] = c->pk[t].size();
+        uint64_t nb = 0;
+        for (auto &p : c->pk[t]) nb += p.n_bits;
+        out->n_packet_bits[t] = nb;
+    }
+    return NFC_OK;
+}
+
+static int read_range(nfc_ctx *c, const void *dev, size_t total, size_t esz, size_t first, void *out, size_t cap, size_t *n_out) {
+    if (!c->have_outputs) return fail(c, NFC_ERR_STATE, "no completed batch");
+    size_t n = 0;
+    if (first < total) n = std::min(cap, total - first);
+    if (n && !out) return fail(c, NFC_ERR_ARG, "null output");
+    if (n) HIPCHK(c, hipMemcpy(out, (const char *)dev + first * esz, n * esz, hipMemcpyDeviceToHost));
+    if (n_out) *n_out = n;
+    return NFC_OK;
+}
+
+int nfc_read_edges(nfc_ctx *c, size_t first, nfc_edge *out, size_t cap, size_t *n_out) {
+    if (!c) return NFC_ERR_ARG;
+    return read_range(c, c->d_edges.p, c->n_edges, sizeof(nfc_edge), first, out, cap, n_out);
+}
+
+int nfc_read_symbols(nfc_ctx *c, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out) {
+    if (!c || type < 0 || type > 1) return NFC_ERR_ARG;
+    return read_range(c, c->d_sym[type].p, c->n_sym[type], 1, first, out, cap, n_out);
+}
+
+int nfc_read_packets(nfc_ctx *c, int type, nfc_packet *out, size_t cap, size_t *n_out) {
+    if (!c || type < 0 || type > 1) return NFC_ERR_ARG;
+    if (!c->have_outputs) return fail(c, NFC_ERR_STATE, "no completed batch");
+    int rc = build_packets(c, type);
+    if (rc) return rc;
+    const size_t n = std::min(cap, c->pk[type].size());
+    if (n && !out) return fail(c, NFC_ERR_ARG, "null output");
+    if (n) memcpy(out, c->pk[type].data(), n * sizeof(nfc_packet));
+    if (n_out) *n_out = n;
+    return NFC_OK;
+}
+
+int nfc_read_packet_bits(nfc_ctx *c, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out) {
+    if (!c || type < 0 || type > 1) return NFC_ERR_ARG;
+    return read_range(c, c->d_bits[type].p, c->n_bits[type], 1, first, out, cap, n_out);
+}
+
+int nfc_read_val(nfc_ctx *c, size_t first, int8_t *out, size_t cap, size_t *n_out) {
+    if (!c) return NFC_ERR_ARG;
+    if (!c->have_outputs) return fail(c, NFC_ERR_STATE, "no completed batch");
+    size_t n = 0;
+    if (first < c->last_n) n = std::min(cap, (size_t)c->last_n - first);
+    if (n_out) *n_out = n;
+    if (!n) return NFC_OK;
+    if (c->last_skip >= c->last_n) {  // batch was all fill: nothing was classified
+        memset(out, 0, n);
+        return NFC_OK;
+    }
+    const size_t b0 = first / 4, b1 = (first + n + 3) / 4;
+    std::vector<uint8_t> tmp(b1 - b0);
+    HIPCHK(c, hipMemcpy(tmp.data(), c->d_val.as<uint8_t>() + b0, b1 - b0, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        const size_t m = first + i;
+        const uint32_t code = (tmp[m / 4 - b0] >> (2 * (m & 3))) & 3u;
+        out[i] = (int8_t)(code == 1 ? 1 : (code == 2 ? -1 : 0));
+    }
+    return NFC_OK;
+}
+
+int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap) {
+    if (!c || !h) return NFC_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    memset(h, 0, sizeof *h);
+    h->n_seen = c->nseen;
+    h->ss = c->h_carry.ss;
+    h->last_low = -1;
+    h->filled = c->h_carry.filled;
+    h->stable = c->h_carry.stable;
+    h->cur_state = c->h_ecarry.state;
+    h->last_bit = c->h_ecarry.last_bit;
+    h->dur = c->h_ecarry.dur;
+    h->miller_state = c->h_dcarry.mil_state;
+    h->manch_state = c->h_dcarry.man_state;
+    for (int t = 0; t < 2; t++) {
+        h->pkt_started[t] = c->h_dcarry.pkt_started[t];
+        h->n_pending_bits[t] = c->h_dcarry.pending[t];
+    }
+    h->av_window = c->L;
+    if (ring) {
+        if (ring_cap < (size_t)c->L) return fail(c, NFC_ERR_ARG, "ring buffer too small");
+        HIPCHK(c, hipMemcpy(ring, c->d_ring[c->ring_cur].p, (size_t)c->L * 4, hipMemcpyDeviceToHost));
+    }
+    return NFC_OK;
+}
+
+int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size_t ring_len) {
+    if (!c || !h || !ring) return NFC_ERR_ARG;
+    if (h->av_window != c->L || ring_len != (size_t)c->L) return fail(c, NFC_ERR_ARG, "state was taken with another av_window");
+    if (h->n_pending_bits[0] || h->n_pending_bits[1])
+        return fail(c, NFC_ERR_ARG, "a state with an open packet cannot be transplanted (its bits live on the source device)");
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->nseen = h->n_seen;
+    c->h_carry.ss = h->ss;
+    c->h_carry.delta = 0;
+    c->h_carry.filled = h->filled;
+    c->h_carry.stable = h->stable;
+    c->h_ecarry.state = h->cur_state;
+    c->h_ecarry.last_bit = h->last_bit;
+    c->h_ecarry.dur = h->dur;
+    c->h_dcarry.mil_state = h->miller_state;
+    c->h_dcarry.man_state = h->manch_state;
+    for (int t = 0; t < 2; t++) {
+        c->h_dcarry.pkt_started[t] = h->pkt_started[t];
+        c->h_dcarry.pending[t] = 0;
+    }
+    HIPCHK(c, hipMemcpy(c->d_ring[c->ring_cur].p, ring, (size_t)c->L * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_carry.p, &c->h_carry, sizeof(Carry), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_ecarry.p, &c->h_ecarry, sizeof(EdgeCarry), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_dcarry.p, &c->h_dcarry, sizeof(DecCarry), hipMemcpyHostToDevice));
+    c->have_outputs = false;
+    return NFC_OK;
+}
+
+int nfc_get_stats(nfc_ctx *c, nfc_stats *out) {
+    if (!c || !out) return NFC_ERR_ARG;
+    *out = c->stats;
+    return NFC_OK;
+}
+
+int nfc_host_decode_lut(const nfc_params *p, int type, const int8_t *cur, const int32_t *d, size_t n, uint8_t *sym_out,
+                        size_t cap, size_t *n_out) {
+    if (!p || !cur || !d || !n_out || type < 0 || type > 1) return NFC_ERR_ARG;
+    if (!(p->samp_rate > 0) || p->max_len < 1) return NFC_ERR_ARG;
+    const DecoderTables t = build_tables(p->samp_rate, p->max_len);
+    const int nd = p->max_len + 1;
+    int state = type ? 0 : ((0 + 1) << 1);
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (cur[i] < -1 || cur[i] > 2 || d[i] < 0 || d[i] > p->max_len) return NFC_ERR_ARG;
+        const int li = (cur[i] + 1) * nd + d[i];
+        uint8_t w;
+        if (type) {
+            w = t.miller_out[(size_t)li * kMillerStates + state];
+            state = (int)((t.miller_map[li] >> (4 * state)) & 15u);
+        } else {
+            w = t.manch_out[(size_t)li * kManchStates + state];
+            state = (int)((t.manch_map[li] >> (4 * state)) & 15u);
+        }
+        const int no = w & 3;
+        if (no >= 1) { if (k < cap) sym_out[k] = (w >> 2) & 7; k++; }
+        if (no >= 2) { if (k < cap) sym_out[k] = (w >> 5) & 7; k++; }
+    }
+    *n_out = k;
+    return NFC_OK;
+}
+
+}  // extern "C"
