@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ Msamples/s -> decoded bits on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--samples S] [--workload miller|manchester|all]
+
+One "step" = one pass of the whole hot path (envelope -> threshold -> edges -> Miller/Manchester ->
+framing) over the rank's batch of synthetic IQ, input already resident in HBM.  At N=1 the workload is
+BASELINE.json configs[1]: Miller-only decode of 1e8 synthetic IQ samples @ 2 Msps.  For N>1 (launched by
+torch.distributed.run, one rank per GPU) every rank holds one contiguous time chunk of a single N*1e8-sample
+capture plus an overlap prefix; it decodes its chunk from a speculated boundary state, the true boundary
+states travel over RCCL (all_gather), and a rank whose speculation was wrong re-decodes (weak scaling).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from usrp_nfc_amd import api, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+OVERLAP = 65536         # samples of the predecessor's chunk each rank > 0 also holds (>= window + longest frames)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--samples', type=float, default=1e8, help='samples per GPU')
+    ap.add_argument('--workload', default='miller', choices=['miller', 'manchester', 'all'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
+    return ap.parse_args()
+
+
+def decoder_flags(workload):
+    return dict(reader=workload in ('miller', 'all'), tag=workload in ('manchester', 'all'))
+
+
+def make_capture_slice(workload, n_per_rank, rank, world):
+    """Rank's time chunk of ONE capture of world*n_per_rank samples (plus OVERLAP samples before it).
+
+    The modulation profile is a pure function of the global sample index (a frame sequence tiled after a
+    3000-sample idle lead-in); the noise comes from a per-rank PCG64 stream, the overlap region from the
+    predecessor's stream, so neighbouring ranks agree on the samples they share."""
+    picks = {'miller': (0, 2, 4, 10), 'manchester': (1, 3, 5, 11), 'all': tuple(range(19))}[workload]
+    frames = [(d, synth.frame_bits(data, sb)) for d, _, data, sb in (synth.ULTRALIGHT_TXN[i] for i in picks)]
+    period = synth.modulation_profile(frames, rate_msps=2.0, lead_in=0, tail=0)
+    lead = 3000
+
+    def profile(g_lo, g_hi):
+        g = np.arange(g_lo, g_hi, dtype=np.int64)
+        m = np.ones(len(g), np.float32)
+        body = g >= lead
+        m[body] = period[(g[body] - lead) % len(period)]
+        return m
+
+    def noisy(g_lo, g_hi, owner):
+        # owner's stream covers [owner*n, (owner+1)*n); take the sub-range
+        rng = np.random.Generator(np.random.PCG64([synth.SEED, owner]))
+        base = owner * n_per_rank
+        iq = rng.standard_normal(2 * n_per_rank, dtype=np.float32)[2 * (g_lo - base):2 * (g_hi - base)]
+        iq *= np.float32(0.002)
+        m = profile(g_lo, g_hi)
+        iq[0::2] += (np.float32(0.5 * np.cos(0.3)) * m).astype(np.float32)
+        iq[1::2] += (np.float32(0.5 * np.sin(0.3)) * m).astype(np.float32)
+        return iq
+
+    lo = rank * n_per_rank
+    own = noisy(lo, lo + n_per_rank, rank)
+    if rank == 0:
+        return np.zeros(0, np.float32), own
+    ov = noisy(lo - OVERLAP, lo, rank - 1)
+    return ov, own
+
+
+def carrier_level(iq_head):
+    """Robust unloaded-carrier level of an IQ excerpt (same estimate the threshold kernel speculates with)."""
+    x = synth.envelope_f32(iq_head)
+    half = 0.5 * x.max()
+    ca = x[x >= half].mean()
+    sel = x[(x >= half) & (x <= ca)]
+    return float(sel.mean() if len(sel) else ca)
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    n = int(a.samples)
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dev = local if world > 1 else 0
+
+    ov, own = make_capture_slice(a.workload, n, rank, world)
+    flags = decoder_flags(a.workload)
+    d_own = api.DeviceBuffer(own, dev)
+    d_ov = api.DeviceBuffer(ov, dev) if len(ov) else None
+    ctx = api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32, device=dev, **flags)
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    redo_count = 0
+
+    level = carrier_level(ov[:2 * 4096]) if len(ov) else 0.0
+    g_lo = rank * n
+
+    def one_step():
+        nonlocal redo_count
+        if d_ov is None:
+            ctx.reset()
+        else:
+            # speculate the boundary state: start OVERLAP samples early from a primed (level-estimate) state
+            ctx.prime(g_lo - len(ov) // 2, level)
+            ctx.push_device(d_ov, len(ov) // 2)
+        spec_in = ctx.state_blob() if world > 1 else None
+        ctx.push_device(d_own, n)
+        if world > 1:
+            import torch
+            # boundary exchange: every rank's end state over RCCL; a rank whose speculated start state
+            # differs from its predecessor's true end state re-decodes its chunk from the true state
+            mine = ctx.state_blob()
+            ln = torch.tensor([len(mine)], device='cuda', dtype=torch.int64)
+            lens = [torch.zeros_like(ln) for _ in range(world)]
+            dist.all_gather(lens, ln)
+            cap = int(max(int(x) for x in lens))
+            buf = torch.zeros(cap, dtype=torch.uint8, device='cuda')
+            buf[:len(mine)] = torch.from_numpy(mine).cuda()
+            allb = [torch.zeros_like(buf) for _ in range(world)]
+            dist.all_gather(allb, buf)
+            if rank > 0:
+                prev = allb[rank - 1][:int(lens[rank - 1])].cpu().numpy()
+                if len(prev) != len(spec_in) or not np.array_equal(prev, spec_in):
+                    redo_count += 1
+                    ctx.set_state_blob(prev)
+                    ctx.push_device(d_own, n)
+        return ctx.stats()
+
+    for _ in range(a.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    n_pass = []
+    for _ in range(a.steps):
+        st = one_step()
+        kernel_ms += [st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed)]
+        n_pass.append(st.threshold_passes)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    cnt = ctx.counts()
+    st = ctx.stats()
+    n_edges = int(cnt.n_edges)
+    out = None
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        k_avg = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
+        alg_bytes = 8.0 * n + 16.0 * n_edges                       # 8 B/sample + 16 B/edge
+        achieved = alg_bytes / (k_avg * 1e-3) / 1e9
+        out = {
+            'metric': 'IQ Msamples/s -> decoded bits (2 Msps stream)',
+            'value': world * n * a.steps / dt / 1e6,
+            'unit': 'Msamples/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 envelope / f64 window sums / u8 symbols', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: Miller-only decode, synthetic IQ @2 Msps' if a.workload == 'miller'
+                       else 'workload=%s' % a.workload,
+                       'samples_per_gpu': n, 'time_chunk_samples': 16384, 'parallelism': 'time-chunk x%d' % world,
+                       'edges_per_gpu': n_edges, 'symbols_reader': int(cnt.n_symbols[1]),
+                       'symbols_tag': int(cnt.n_symbols[0]), 'packets': int(cnt.n_packets[0] + cnt.n_packets[1]),
+                       'boundary_redos': redo_count},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_threshold (fused envelope + gated-mean threshold)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'avg_launch_ms': k_avg,
+                         'launches_per_step': float(np.mean(n_pass)) if n_pass else None,
+                         'algorithmic_bytes_per_launch': alg_bytes},
+            'stage_ms_last_step': {'total_device': st.ms_total, 'threshold': st.ms_threshold, 'edges': st.ms_edges,
+                                   'decode': st.ms_decode, 'used_sequential': int(st.used_sequential)},
+        }
+        if not a.no_parity:
+            out['parity'] = parity_check(a, own, flags, n)
+        if not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(own, flags)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def parity_check(a, own, flags, n):
+    """Rank 0's chunk decoded from a fresh stream, GPU vs the pinned C oracle, full size."""
+    from oracle import c_oracle as co
+    ctx = api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32, **flags)
+    ctx.push(own)
+    o = co.COracle(samp_rate=2e6, hi_val=1.1, **flags)
+    o.push_iq(own)
+    ge, oe = ctx.edges(), o.edges()
+    ok_edges = len(ge) == len(oe) and np.array_equal(ge['idx'].astype(np.int64), oe['idx']) and \
+        np.array_equal(ge['d'], oe['d']) and np.array_equal(ge['v'], oe['v']) and np.array_equal(ge['t'], oe['t'])
+    ok_sym = all(np.array_equal(ctx.symbols(t), o.symbols(t)) for t in (0, 1))
+    gp = ctx.packets()
+    ok_pk = gp == o.packets()
+    ctx.close()
+    return {'vs': 'oracle/nfc_oracle.c on the same %d samples' % n, 'edges_equal': bool(ok_edges),
+            'symbols_equal': bool(ok_sym), 'packets_equal': bool(ok_pk), 'n_edges': int(len(oe)), 'n_packets': len(gp)}
+
+
+def cpu_baseline(own, flags):
+    """The reference's CPU path timed on this host: the pinned C port of the per-sample loop (1 core),
+    and -- for the reference's own language -- the line-for-line Python restatement on a prefix."""
+    from oracle import c_oracle as co, py_oracle as po
+    o = co.COracle(samp_rate=2e6, hi_val=1.1, **flags)
+    n = len(own) // 2
+    t0 = time.perf_counter()
+    o.push_iq(own)
+    tc = time.perf_counter() - t0
+    npy = min(n, 4_000_000)
+    x = synth.envelope_f32(own[:2 * npy])
+    t0 = time.perf_counter()
+    po.run_path(x, samp_rate=2e6, hi_val=1.1, chunk=8192, **flags)
+    tp = time.perf_counter() - t0
+    return {'value': n / tc / 1e6, 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
+            'sample': 'oracle/nfc_oracle.c (C restatement of transition_sink+decoders), whole %d-sample workload, '
+                      '1 thread; the reference itself is a single-threaded Python loop' % n,
+            'python_restatement_msamples_s': npy / tp / 1e6,
+            'python_sample': 'oracle/py_oracle.py on the first %d samples in 8192-sample work() calls '
+                             '(GNU Radio is not installed: envelope by numpy)' % npy,
+            'host_cpus': os.cpu_count()}
+
+
+if __name__ == '__main__':
+    main()

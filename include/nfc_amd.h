@@ -106,6 +106,9 @@ typedef struct {
     uint32_t used_sequential; /* 1 if the exact sequential kernel ran */
     uint32_t n_chunks;
     uint64_t bytes_in;        /* input bytes of the last batch */
+    double ms_threshold_kernel[6]; /* hipEvent duration of each k_threshold launch of the last batch (first 6) */
+    uint32_t n_threshold_timed;
+    uint32_t reserved;
 } nfc_stats;
 
 /* Everything a successor time chunk needs from its predecessor:
@@ -155,11 +158,24 @@ int nfc_read_packet_bits(nfc_ctx *ctx, int type, size_t first, uint8_t *out, siz
 /* per-sample classification of the last batch (-1 LOW, 0 accepted, +1 HIGH); debugging tap */
 int nfc_read_val(nfc_ctx *ctx, size_t first, int8_t *out, size_t cap, size_t *n_out);
 
-/* Boundary state for multi-GPU time sharding / restart. ring must hold av_window floats. */
-int nfc_get_state(nfc_ctx *ctx, nfc_state_header *hdr, float *ring, size_t ring_cap);
-int nfc_set_state(nfc_ctx *ctx, const nfc_state_header *hdr, const float *ring, size_t ring_len);
+/* Boundary state for multi-GPU time sharding / restart.  ring holds av_window floats; pending_bits holds the
+ * open packets' bits (PacketProcessor._cur), type 0 first, hdr->n_pending_bits[0] + [1] bytes.  ring and
+ * pending_bits may be NULL in nfc_get_state to query the header (and the sizes) only. */
+int nfc_get_state(nfc_ctx *ctx, nfc_state_header *hdr, float *ring, size_t ring_cap, uint8_t *pending_bits,
+                  size_t pending_cap);
+int nfc_set_state(nfc_ctx *ctx, const nfc_state_header *hdr, const float *ring, size_t ring_len,
+                  const uint8_t *pending_bits, size_t pending_len);
+/* Back to the state of a freshly created context (a new stream), keeping the device buffers. */
+int nfc_reset(nfc_ctx *ctx);
 
 int nfc_get_stats(nfc_ctx *ctx, nfc_stats *out);
+
+/* Device memory helpers so that a caller without HIP bindings (ctypes) can keep its input
+ * resident in HBM and use nfc_push_device. */
+int nfc_device_alloc(int device, size_t bytes, void **out);
+int nfc_device_free(int device, void *p);
+int nfc_device_upload(int device, void *dst, const void *src_host, size_t bytes);
+int nfc_device_download(int device, void *dst_host, const void *src, size_t bytes);
 
 /* Host-only helpers (no GPU needed): the duration LUTs the decode kernels use,
  * driven sequentially.  Used by the CPU test-suite to pin the tables to the

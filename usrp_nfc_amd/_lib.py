@@ -30,7 +30,8 @@ class Counts(C.Structure):
 class Stats(C.Structure):
     _fields_ = [('ms_total', C.c_double), ('ms_threshold', C.c_double), ('ms_edges', C.c_double),
                 ('ms_decode', C.c_double), ('threshold_passes', C.c_uint32), ('chunks_rerun', C.c_uint32),
-                ('used_sequential', C.c_uint32), ('n_chunks', C.c_uint32), ('bytes_in', C.c_uint64)]
+                ('used_sequential', C.c_uint32), ('n_chunks', C.c_uint32), ('bytes_in', C.c_uint64),
+                ('ms_threshold_kernel', C.c_double * 6), ('n_threshold_timed', C.c_uint32), ('reserved', C.c_uint32)]
 
 
 class StateHeader(C.Structure):
@@ -46,8 +47,8 @@ PACKET_DTYPE = np.dtype([('idx', '<u8'), ('bit_off', '<u8'), ('n_bits', '<u4'), 
 # every symbol include/nfc_amd.h declares
 SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', 'nfc_last_error', 'nfc_push',
            'nfc_push_device', 'nfc_sync', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_symbols', 'nfc_read_packets',
-           'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_get_stats',
-           'nfc_host_decode_lut']
+           'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_get_stats',
+           'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_host_decode_lut']
 
 _lib = None
 
@@ -80,9 +81,14 @@ def load():
     L.nfc_read_packets.argtypes = [vp, C.c_int, vp, sz, psz]
     L.nfc_read_packet_bits.argtypes = [vp, C.c_int, sz, vp, sz, psz]
     L.nfc_read_val.argtypes = [vp, sz, vp, sz, psz]
-    L.nfc_get_state.argtypes = [vp, C.POINTER(StateHeader), vp, sz]
-    L.nfc_set_state.argtypes = [vp, C.POINTER(StateHeader), vp, sz]
+    L.nfc_get_state.argtypes = [vp, C.POINTER(StateHeader), vp, sz, vp, sz]
+    L.nfc_set_state.argtypes = [vp, C.POINTER(StateHeader), vp, sz, vp, sz]
+    L.nfc_reset.argtypes = [vp]
     L.nfc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.nfc_device_alloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
+    L.nfc_device_free.argtypes = [C.c_int, vp]
+    L.nfc_device_upload.argtypes = [C.c_int, vp, vp, sz]
+    L.nfc_device_download.argtypes = [C.c_int, vp, vp, sz]
     L.nfc_host_decode_lut.argtypes = [C.POINTER(Params), C.c_int, vp, vp, sz, vp, sz, psz]
     for name in SYMBOLS:
         getattr(L, name)

@@ -7,7 +7,7 @@ from . import _lib
 from ._lib import (EDGE_DTYPE, NFC_FLAG_FORCE_SEQUENTIAL, NFC_FLAG_NO_EDGES, NFC_IN_ENV_F32, NFC_IN_I16_SQ,
                    NFC_IN_IQ_F32, NFC_IN_REAL_F32_SQ, PACKET_DTYPE)
 
-__all__ = ['NfcContext', 'NfcError', 'host_decode_lut', 'NFC_IN_IQ_F32', 'NFC_IN_ENV_F32', 'NFC_IN_REAL_F32_SQ',
+__all__ = ['NfcContext', 'NfcError', 'DeviceBuffer', 'host_decode_lut', 'NFC_IN_IQ_F32', 'NFC_IN_ENV_F32', 'NFC_IN_REAL_F32_SQ',
            'NFC_IN_I16_SQ', 'NFC_FLAG_FORCE_SEQUENTIAL', 'NFC_FLAG_NO_EDGES']
 
 _KIND_DTYPE = {NFC_IN_IQ_F32: (np.float32, 2), NFC_IN_ENV_F32: (np.float32, 1),
@@ -34,6 +34,7 @@ class NfcContext(object):
         self.h = C.c_void_p()
         self.input_kind = input_kind
         self.factor = 1e6 / samp_rate
+        self.av_window = int(av_window)
         p = _params(samp_rate, lo_val, hi_val, av_window, max_len, reader, tag, input_kind, device, i16_scale, flags,
                     chunk_samples)
         rc = self.L.nfc_create(C.byref(p), C.byref(self.h))
@@ -71,7 +72,8 @@ class NfcContext(object):
 
     def push_device(self, dev_ptr, n):
         """Device pointer (int), n samples, 16-byte aligned."""
-        self._chk(self.L.nfc_push_device(self.h, C.c_void_p(int(dev_ptr)), n), 'nfc_push_device')
+        ptr = dev_ptr.ptr if isinstance(dev_ptr, DeviceBuffer) else C.c_void_p(int(dev_ptr))
+        self._chk(self.L.nfc_push_device(self.h, ptr, n), 'nfc_push_device')
         return n
 
     # -- outputs of the last push -----------------------------------------------
@@ -136,16 +138,80 @@ class NfcContext(object):
     def val(self):
         return self._read(self.L.nfc_read_val, self.counts().n_samples, np.int8, 0)
 
-    def get_state(self):
-        h = _lib.StateHeader()
-        self._chk(self.L.nfc_get_state(self.h, C.byref(h), None, 0), 'nfc_get_state')
-        ring = np.zeros(h.av_window, np.float32)
-        self._chk(self.L.nfc_get_state(self.h, C.byref(h), ring.ctypes.data, ring.size), 'nfc_get_state')
-        return h, ring
+    def reset(self):
+        """Start a new stream (state of a fresh context), keeping the device buffers."""
+        self._chk(self.L.nfc_reset(self.h), 'nfc_reset')
 
-    def set_state(self, header, ring):
+    def get_state(self):
+        """(header, ring float32[av_window], [pending bits type 0, pending bits type 1])."""
+        h = _lib.StateHeader()
+        self._chk(self.L.nfc_get_state(self.h, C.byref(h), None, 0, None, 0), 'nfc_get_state')
+        ring = np.zeros(h.av_window, np.float32)
+        p0, p1 = int(h.n_pending_bits[0]), int(h.n_pending_bits[1])
+        pend = np.zeros(p0 + p1, np.uint8)
+        self._chk(self.L.nfc_get_state(self.h, C.byref(h), ring.ctypes.data, ring.size, pend.ctypes.data, pend.size),
+                  'nfc_get_state')
+        return h, ring, [pend[:p0].copy(), pend[p0:].copy()]
+
+    def set_state(self, header, ring, pending=None):
         ring = np.ascontiguousarray(ring, np.float32)
-        self._chk(self.L.nfc_set_state(self.h, C.byref(header), ring.ctypes.data, ring.size), 'nfc_set_state')
+        pend = np.zeros(0, np.uint8) if pending is None else np.ascontiguousarray(np.concatenate(pending), np.uint8)
+        self._chk(self.L.nfc_set_state(self.h, C.byref(header), ring.ctypes.data, ring.size, pend.ctypes.data, pend.size),
+                  'nfc_set_state')
+
+    def state_blob(self):
+        """Boundary state as one uint8 vector: header | ring | pending bits (for RCCL exchange)."""
+        h, ring, pend = self.get_state()
+        return np.concatenate([np.frombuffer(bytes(h), np.uint8), ring.view(np.uint8), pend[0], pend[1]])
+
+    def set_state_blob(self, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        hs = C.sizeof(_lib.StateHeader)
+        h = _lib.StateHeader.from_buffer_copy(blob[:hs].tobytes())
+        rb = 4 * h.av_window
+        ring = blob[hs:hs + rb].view(np.float32)
+        p0, p1 = int(h.n_pending_bits[0]), int(h.n_pending_bits[1])
+        pend = blob[hs + rb:hs + rb + p0 + p1]
+        self.set_state(h, ring, [pend[:p0], pend[p0:]])
+
+    def prime(self, start_index, level):
+        """Speculative start for a time chunk that does not begin the stream: every ring slot at the
+        estimated carrier level, idle state machine, decoders reset.  Pushing an overlap region that ends
+        where the chunk starts then converges to the true boundary state (multi-GPU)."""
+        h = _lib.StateHeader()
+        L = self.av_window
+        ring = np.full(L, np.float32(level), np.float32)
+        h.n_seen = int(start_index)
+        h.ss = float(np.sum(ring.astype(np.float64)))
+        h.last_low = -1
+        h.filled = L
+        h.stable = 1
+        h.cur_state, h.last_bit, h.dur = 0, 0, 1
+        h.miller_state = 0
+        h.manch_state = 2
+        h.av_window = L
+        self.set_state(h, ring)
+
+class DeviceBuffer(object):
+    """Input kept resident in HBM (nfc_device_alloc / nfc_device_upload) for NfcContext.push_device."""
+
+    def __init__(self, host_array, device=0):
+        self.L = _lib.load()
+        self.device = device
+        a = np.ascontiguousarray(host_array)
+        self.nbytes = a.nbytes
+        self.ptr = C.c_void_p()
+        if self.L.nfc_device_alloc(device, a.nbytes, C.byref(self.ptr)) != 0:
+            raise NfcError('nfc_device_alloc: %s' % self.L.nfc_last_error(None).decode())
+        if a.nbytes and self.L.nfc_device_upload(device, self.ptr, a.ctypes.data, a.nbytes) != 0:
+            raise NfcError('nfc_device_upload failed')
+
+    def free(self):
+        if getattr(self, 'ptr', None):
+            self.L.nfc_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    __del__ = free
 
 
 def host_decode_lut(ptype, cur, d, samp_rate=2e6, max_len=50):

@@ -73,6 +73,8 @@ struct nfc_ctx {
     size_t in_bytes_per_sample;
     hipStream_t st = nullptr;
     hipEvent_t ev[8] = {};
+    hipEvent_t kev[2 * 6] = {};  // start/stop pairs around the first k_threshold launches of a batch
+    int n_kev = 0;
     std::string err;
 
     // tables
@@ -148,6 +150,18 @@ void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
     hipLaunchKernelGGL((k_threshold<KIND>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
 }
 void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
+    const bool timed = c->n_kev < 6;
+    if (timed) (void)hipEventRecord(c->kev[2 * c->n_kev], c->st);
+    struct Stop {
+        nfc_ctx *c;
+        bool timed;
+        ~Stop() {
+            if (timed) {
+                (void)hipEventRecord(c->kev[2 * c->n_kev + 1], c->st);
+                c->n_kev++;
+            }
+        }
+    } stop{c, timed};
     switch (c->P.input_kind) {
     case NFC_IN_IQ_F32: launch_threshold<IN_IQ_F32>(c, A, nwork); break;
     case NFC_IN_ENV_F32: launch_threshold<IN_ENV_F32>(c, A, nwork); break;
@@ -228,7 +242,8 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
 
     hipLaunchKernelGGL(k_prepare, dim3(1), dim3(64), 0, c->st, c->d_ring[c->ring_cur].as<float>(), L, c->d_carry.as<Carry>());
 
-    const bool force_seq = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0;
+    // a 256-sample step must not wrap the ring onto itself: short windows take the sequential kernel
+    const bool force_seq = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0 || L < STEP;
     bool need_seq = force_seq;
     c->stats.threshold_passes = 0;
     c->stats.chunks_rerun = 0;
@@ -492,6 +507,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     c->n_runs = c->n_edges = 0;
     for (int t = 0; t < 2; t++) c->n_sym[t] = c->n_close[t] = c->n_bits[t] = 0;
     memset(&c->stats, 0, sizeof c->stats);
+    c->n_kev = 0;
     if (n64 > (1ull << 30)) return fail(c, NFC_ERR_ARG, "batch of %zu samples exceeds 2^30; push it in pieces", n64);
     const uint32_t n = (uint32_t)n64;
     c->last_n = n;
@@ -521,6 +537,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     c->last_skip = skip;
     if (!c->h_carry.stable || skip == n) {
         // the whole batch went into the averaging window: no callback content (transition_sink.py:109-125)
+        HIPCHK(c, hipMemcpyAsync(&c->h_carry, c->d_carry.p, sizeof(Carry), hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
         c->nseen += n;
         c->have_outputs = true;
@@ -548,6 +565,8 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     c->stats.ms_threshold = elapsed_ms(c->ev[1], c->ev[2]);
     c->stats.ms_edges = elapsed_ms(c->ev[2], c->ev[3]);
     c->stats.ms_decode = elapsed_ms(c->ev[3], c->ev[4]);
+    for (int i = 0; i < c->n_kev; i++) c->stats.ms_threshold_kernel[i] = elapsed_ms(c->kev[2 * i], c->kev[2 * i + 1]);
+    c->stats.n_threshold_timed = (uint32_t)c->n_kev;
     c->nseen += n;
     c->last_in = d_in;
     c->have_outputs = true;
@@ -655,6 +674,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     } while (0)
     CRT(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
     for (auto &e : c->ev) CRT(hipEventCreate(&e));
+    for (auto &e : c->kev) CRT(hipEventCreate(&e));
     const size_t lds = (size_t)c->wpb * c->Lpad * 5;
     if (lds > 160 * 1024) {
         nfc_destroy(c);
@@ -715,6 +735,8 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_partials, &c->d_totals};
     for (DevBuf *b : all) b->release();
     for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->kev)
         if (e) (void)hipEventDestroy(e);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
@@ -820,7 +842,34 @@ int nfc_read_val(nfc_ctx *c, size_t first, int8_t *out, size_t cap, size_t *n_ou
     return NFC_OK;
 }
 
-int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap) {
+static void init_carried(nfc_ctx *c) {
+    memset(&c->h_carry, 0, sizeof c->h_carry);
+    c->h_carry.ss_emin = 255;
+    c->h_ecarry = EdgeCarry{0, 0, 1, 0};  // transition_sink.py:22-23,30
+    memset(&c->h_dcarry, 0, sizeof c->h_dcarry);
+    c->h_dcarry.mil_state = 0;             // stage BEGINNING, not started, prev 0 (miller.py:22,29)
+    c->h_dcarry.man_state = (0 + 1) << 1;  // prev_set False, prev 0 (manchester.py:22-25)
+    c->nseen = 0;
+}
+
+static int upload_carried(nfc_ctx *c) {
+    HIPCHK(c, hipMemcpyAsync(c->d_carry.p, &c->h_carry, sizeof(Carry), hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->d_ecarry.p, &c->h_ecarry, sizeof(EdgeCarry), hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->d_dcarry.p, &c->h_dcarry, sizeof(DecCarry), hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));  // the sources are host members that the next call may rewrite
+    return NFC_OK;
+}
+
+int nfc_reset(nfc_ctx *c) {
+    if (!c) return NFC_ERR_ARG;
+    if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
+    init_carried(c);
+    c->have_outputs = false;
+    HIPCHK(c, hipMemsetAsync(c->d_ring[c->ring_cur].p, 0, (size_t)c->Lpad * 4, c->st));
+    return upload_carried(c);
+}
+
+int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap, uint8_t *pending, size_t pending_cap) {
     if (!c || !h) return NFC_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->st));
     memset(h, 0, sizeof *h);
@@ -843,18 +892,26 @@ int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap)
         if (ring_cap < (size_t)c->L) return fail(c, NFC_ERR_ARG, "ring buffer too small");
         HIPCHK(c, hipMemcpy(ring, c->d_ring[c->ring_cur].p, (size_t)c->L * 4, hipMemcpyDeviceToHost));
     }
+    if (pending) {
+        const size_t p0 = c->h_dcarry.pending[0], p1 = c->h_dcarry.pending[1];
+        if (pending_cap < p0 + p1) return fail(c, NFC_ERR_ARG, "pending-bit buffer too small");
+        if (p0) HIPCHK(c, hipMemcpy(pending, c->d_pending[0].p, p0, hipMemcpyDeviceToHost));
+        if (p1) HIPCHK(c, hipMemcpy(pending + p0, c->d_pending[1].p, p1, hipMemcpyDeviceToHost));
+    }
     return NFC_OK;
 }
 
-int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size_t ring_len) {
+int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size_t ring_len, const uint8_t *pending,
+                  size_t pending_len) {
     if (!c || !h || !ring) return NFC_ERR_ARG;
     if (h->av_window != c->L || ring_len != (size_t)c->L) return fail(c, NFC_ERR_ARG, "state was taken with another av_window");
-    if (h->n_pending_bits[0] || h->n_pending_bits[1])
-        return fail(c, NFC_ERR_ARG, "a state with an open packet cannot be transplanted (its bits live on the source device)");
+    const size_t p0 = h->n_pending_bits[0], p1 = h->n_pending_bits[1];
+    if (p0 + p1 != pending_len || ((p0 + p1) && !pending)) return fail(c, NFC_ERR_ARG, "pending bits do not match the header");
+    if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
     HIPCHK(c, hipStreamSynchronize(c->st));
+    init_carried(c);
     c->nseen = h->n_seen;
     c->h_carry.ss = h->ss;
-    c->h_carry.delta = 0;
     c->h_carry.filled = h->filled;
     c->h_carry.stable = h->stable;
     c->h_ecarry.state = h->cur_state;
@@ -864,20 +921,44 @@ int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size
     c->h_dcarry.man_state = h->manch_state;
     for (int t = 0; t < 2; t++) {
         c->h_dcarry.pkt_started[t] = h->pkt_started[t];
-        c->h_dcarry.pending[t] = 0;
+        c->h_dcarry.pending[t] = h->n_pending_bits[t];
+        HIPCHK(c, c->d_pending[t].ensure((size_t)h->n_pending_bits[t] + 16));
     }
+    if (p0) HIPCHK(c, hipMemcpy(c->d_pending[0].p, pending, p0, hipMemcpyHostToDevice));
+    if (p1) HIPCHK(c, hipMemcpy(c->d_pending[1].p, pending + p0, p1, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_ring[c->ring_cur].p, ring, (size_t)c->L * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_carry.p, &c->h_carry, sizeof(Carry), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_ecarry.p, &c->h_ecarry, sizeof(EdgeCarry), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_dcarry.p, &c->h_dcarry, sizeof(DecCarry), hipMemcpyHostToDevice));
     c->have_outputs = false;
-    return NFC_OK;
+    return upload_carried(c);
 }
 
 int nfc_get_stats(nfc_ctx *c, nfc_stats *out) {
     if (!c || !out) return NFC_ERR_ARG;
     *out = c->stats;
     return NFC_OK;
+}
+
+int nfc_device_alloc(int device, size_t bytes, void **out) {
+    if (!out) return NFC_ERR_ARG;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, NFC_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(nullptr, NFC_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return NFC_OK;
+}
+
+int nfc_device_free(int device, void *p) {
+    if (hipSetDevice(device) != hipSuccess) return NFC_ERR_DEVICE;
+    return hipFree(p) == hipSuccess ? NFC_OK : NFC_ERR_DEVICE;
+}
+
+int nfc_device_upload(int device, void *dst, const void *src, size_t bytes) {
+    if (hipSetDevice(device) != hipSuccess) return NFC_ERR_DEVICE;
+    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? NFC_OK : NFC_ERR_DEVICE;
+}
+
+int nfc_device_download(int device, void *dst, const void *src, size_t bytes) {
+    if (hipSetDevice(device) != hipSuccess) return NFC_ERR_DEVICE;
+    return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? NFC_OK : NFC_ERR_DEVICE;
 }
 
 int nfc_host_decode_lut(const nfc_params *p, int type, const int8_t *cur, const int32_t *d, size_t n, uint8_t *sym_out,
