@@ -146,5 +146,9 @@ def test_synthetic_workloads_2M(name, kw):
     r = check_vs_oracle(iq, dict(hi_val=1.1, **kw), kind=api.NFC_IN_IQ_F32)
     st = r['stats']
     assert st.used_sequential == 0
-    assert st.threshold_passes == 2, 'speculation missed: %d passes, %d chunks rerun' % (st.threshold_passes, st.chunks_rerun)
+    # the speculative pass must be certified for (nearly) every time chunk: a full second pass means
+    # the speculation or the margins are broken, even though the result would still be exact
+    assert st.chunks_rerun <= st.n_chunks // 4, 'speculation not certified: %d passes, %d of %d chunks rerun' % (
+        st.threshold_passes, st.chunks_rerun, st.n_chunks)
+    print('%s: %d passes, %d/%d chunks rerun' % (name, st.threshold_passes, st.chunks_rerun, st.n_chunks))
     assert len(r['packets']) > 100

@@ -28,7 +28,7 @@ __host__ __device__ __forceinline__ uint32_t val_to_code(int v) { return v == 1 
 
 struct RunView {
     const uint32_t *starts;  // starts[k-1] = first sample of real run k (k >= 1)
-    const uint8_t *val;      // 2-bit codes
+    const uint64_t *neg, *pos;  // classification bit planes (LOW / HIGH), 64 samples per word
     uint32_t nruns;          // real runs
     uint32_t n;              // samples in the batch
     int32_t skip;            // first stable sample
@@ -42,7 +42,8 @@ struct RunView {
     __device__ __forceinline__ int value(uint32_t k) const {
         if (k == 0) return last_bit_in;
         const uint32_t s = starts[k - 1];
-        return code_to_val((val[s >> 2] >> (2 * (s & 3))) & 3u);
+        if ((neg[s >> 6] >> (s & 63)) & 1ull) return -1;
+        return (int)((pos[s >> 6] >> (s & 63)) & 1ull);
     }
     __device__ __forceinline__ bool virt_empty() const { return nruns >= 1 && (int32_t)starts[0] == skip; }
     // state after the first sample of run k
@@ -110,38 +111,43 @@ struct RunView {
 };
 
 // ---- run starts -------------------------------------------------------------
-// 16 samples per u32 word; a field differs from its predecessor -> run start.
+// 64 samples per word in two bit planes; a sample whose (neg, pos) differs from its predecessor's starts a run.
 struct ChangeMask {
-    const uint32_t *val32;
+    const uint64_t *neg, *pos;
     uint32_t n, skip;
-    uint32_t prev_code;  // code of the carried _last_bit
-    __device__ __forceinline__ uint32_t mask(size_t w) const {
-        const uint32_t c = val32[w];
-        const uint32_t pc = (w == 0) ? prev_code : (val32[w - 1] >> 30);
-        const uint32_t sh = (c << 2) | pc;
-        const uint32_t df = c ^ sh;
-        uint32_t m = (df | (df >> 1)) & 0x55555555u;
-        // keep fields whose sample index is in [skip, n)
-        const long long first = (long long)w * 16;
+    int32_t last_bit_in;  // carried _last_bit
+    __device__ __forceinline__ uint64_t mask(size_t w) const {
+        const uint64_t ng = neg[w], ps = pos[w];
+        uint64_t pn, pp;
+        if (w == 0) {
+            pn = last_bit_in == -1 ? 1ull : 0ull;
+            pp = last_bit_in == 1 ? 1ull : 0ull;
+        } else {
+            pn = neg[w - 1] >> 63;
+            pp = pos[w - 1] >> 63;
+        }
+        uint64_t m = (ng ^ ((ng << 1) | pn)) | (ps ^ ((ps << 1) | pp));
+        // keep samples whose index is in [skip, n)
+        const long long first = (long long)w * 64;
         const long long lo = (long long)skip - first, hi = (long long)n - first;
-        if (lo > 0) m &= (lo >= 16) ? 0u : (0xFFFFFFFFu << (2 * lo));
-        if (hi < 16) m &= (hi <= 0) ? 0u : (0xFFFFFFFFu >> (32 - 2 * hi));
+        if (lo > 0) m &= (lo >= 64) ? 0ull : (~0ull << lo);
+        if (hi < 64) m &= (hi <= 0) ? 0ull : (~0ull >> (64 - hi));
         return m;
     }
 };
 struct LoadChangeCount {
     ChangeMask cm;
-    __device__ __forceinline__ uint32_t operator()(size_t w) const { return (uint32_t)__popc(cm.mask(w)); }
+    __device__ __forceinline__ uint32_t operator()(size_t w) const { return (uint32_t)__popcll(cm.mask(w)); }
 };
 struct StoreRunStarts {
     ChangeMask cm;
     uint32_t *starts;
     __device__ __forceinline__ void operator()(size_t w, uint32_t excl, uint32_t /*cnt*/) const {
-        uint32_t m = cm.mask(w);
+        uint64_t m = cm.mask(w);
         uint32_t k = excl;
         while (m) {
-            const int b = __ffs((int)m) - 1;
-            starts[k++] = (uint32_t)(w * 16 + (b >> 1));
+            const int b = __ffsll((long long)m) - 1;
+            starts[k++] = (uint32_t)(w * 64 + b);
             m &= m - 1;
         }
     }

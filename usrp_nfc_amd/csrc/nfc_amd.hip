@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -68,7 +69,9 @@ struct nfc_ctx {
     int L, mx, C, Lpad, wpb, twords;
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
-    int bands_ok;
+    int bands_ok, fast_ok, nfold;
+    uint64_t selmask;
+    float eps;
     float i16_scale;
     size_t in_bytes_per_sample;
     hipStream_t st = nullptr;
@@ -90,11 +93,13 @@ struct nfc_ctx {
     uint64_t nseen = 0;
 
     // batch buffers
-    DevBuf d_in, d_val, d_ringout[2], d_touched[2], d_info[2], d_ver, d_changed, d_gmin, d_gmax, d_gflags, d_list;
+    DevBuf d_certinfo;
+    DevBuf d_in, d_neg, d_pos, d_ringout[2], d_touched[2], d_info[2], d_ringin, d_meta, d_ver, d_cert, d_gmin, d_gmax,
+        d_gflags, d_list;
     DevBuf d_starts, d_offs, d_edges, d_states, d_sym[2], d_src[2], d_started, d_bits[2], d_pending[2], d_close_end[2],
         d_close_idx[2];
     DevBuf d_partials, d_totals;  // scan scratch; totals: small device scalars
-    std::vector<uint8_t> h_ver, h_changed, h_gmin, h_gmax, h_gflags;
+    std::vector<uint8_t> h_ver, h_cert, h_gmin, h_gmax, h_gflags;
     std::vector<uint32_t> h_list;
 
     // last batch
@@ -173,10 +178,10 @@ void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n) {
     float *ring = c->d_ring[c->ring_cur].as<float>();
     Carry *cr = c->d_carry.as<Carry>();
     switch (c->P.input_kind) {
-    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(64), 0, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
-    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(64), 0, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
-    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(64), 0, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
-    default: hipLaunchKernelGGL((k_fill<IN_I16_SQ>), dim3(1), dim3(64), 0, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
+    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
+    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
+    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
+    default: hipLaunchKernelGGL((k_fill<IN_I16_SQ>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
     }
 }
 void launch_seq_kind(nfc_ctx *c, const SeqArgs &A) {
@@ -207,20 +212,24 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     const int L = c->L;
     const uint32_t nch = (n + c->C - 1) / c->C;
     c->stats.n_chunks = nch;
-    HIPCHK(c, c->d_val.ensure(((size_t)n / 16 + 2) * 4 + 64));
+    const size_t nwords = ((size_t)n + 63) / 64 + 8;
+    HIPCHK(c, c->d_neg.ensure(nwords * 8));
+    HIPCHK(c, c->d_pos.ensure(nwords * 8));
     for (int b = 0; b < 2; b++) {
         HIPCHK(c, c->d_ringout[b].ensure((size_t)nch * L * sizeof(float)));
         HIPCHK(c, c->d_touched[b].ensure((size_t)nch * c->twords * sizeof(uint32_t)));
         HIPCHK(c, c->d_info[b].ensure((size_t)nch * sizeof(ChunkInfo)));
     }
+    HIPCHK(c, c->d_ringin.ensure((size_t)nch * L * sizeof(float)));
+    HIPCHK(c, c->d_meta.ensure((size_t)nch * sizeof(RunMeta)));
     HIPCHK(c, c->d_ver.ensure(nch));
-    HIPCHK(c, c->d_changed.ensure(nch));
+    HIPCHK(c, c->d_cert.ensure(nch));
     HIPCHK(c, c->d_gmin.ensure(nch));
     HIPCHK(c, c->d_gmax.ensure(nch));
     HIPCHK(c, c->d_gflags.ensure(nch));
     HIPCHK(c, c->d_list.ensure((size_t)nch * 4));
     c->h_ver.assign(nch, 0);
-    c->h_changed.assign(nch, 0);
+    c->h_cert.assign(nch, 0);
     c->h_gmin.assign(nch, 255);
     c->h_gmax.assign(nch, 0);
     c->h_gflags.assign(nch, 0);
@@ -249,82 +258,117 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     c->stats.chunks_rerun = 0;
     c->stats.used_sequential = 0;
 
-    if (!force_seq) {
-        ThrArgs A;
-        memset(&A, 0, sizeof A);
-        A.in = d_in;
-        A.n = n;
-        A.skip = skip;
-        A.g0modL = (uint32_t)(c->nseen % (uint64_t)L);
-        A.L = L;
-        A.Lpad = c->Lpad;
-        A.mx = c->mx;
-        A.C = c->C;
-        A.nchunks = (int)nch;
-        A.lo = c->P.lo_val;
-        A.hi = c->P.hi_val;
-        A.hi_plus = c->hi_plus;
-        A.lo_a = c->lo_a;
-        A.lo_b = c->lo_b;
-        A.hi_a = c->hi_a;
-        A.hi_b = c->hi_b;
-        A.bands_ok = c->bands_ok;
-        A.i16_scale = c->i16_scale;
-        A.ring_carry = c->d_ring[c->ring_cur].as<float>();
-        A.carry = c->d_carry.as<Carry>();
-        A.nl0 = nl0;
-        A.kl0 = kl0;
-        for (int b = 0; b < 2; b++) {
-            A.ring_out[b] = c->d_ringout[b].as<float>();
-            A.touched[b] = c->d_touched[b].as<uint32_t>();
-            A.info[b] = c->d_info[b].as<ChunkInfo>();
-        }
-        A.ver = c->d_ver.as<uint8_t>();
-        A.changed = c->d_changed.as<uint8_t>();
-        A.gmin = c->d_gmin.as<uint8_t>();
-        A.gmax = c->d_gmax.as<uint8_t>();
-        A.gflags = c->d_gflags.as<uint8_t>();
-        A.val = c->d_val.as<uint8_t>();
-        A.twords = c->twords;
+    ThrArgs A;
+    memset(&A, 0, sizeof A);
+    A.in = d_in;
+    A.n = n;
+    A.skip = skip;
+    A.g0modL = (uint32_t)(c->nseen % (uint64_t)L);
+    A.L = L;
+    A.Lpad = c->Lpad;
+    A.mx = c->mx;
+    A.C = c->C;
+    A.nchunks = (int)nch;
+    A.lo = c->P.lo_val;
+    A.hi = c->P.hi_val;
+    A.hi_plus = c->hi_plus;
+    A.lo_a = c->lo_a;
+    A.lo_b = c->lo_b;
+    A.hi_a = c->hi_a;
+    A.hi_b = c->hi_b;
+    A.bands_ok = c->bands_ok;
+    A.fast_ok = c->fast_ok;
+    A.i16_scale = c->i16_scale;
+    A.eps = c->eps;
+    A.ring_carry = c->d_ring[c->ring_cur].as<float>();
+    A.carry = c->d_carry.as<Carry>();
+    A.nl0 = nl0;
+    A.kl0 = kl0;
+    A.lo_L = c->P.lo_val / (double)L;
+    A.hi_L = c->P.hi_val / (double)L;
+    for (int f = 0; f < 6; f++) A.fold_sh[f] = (f < c->nfold) ? (1 << f) : 0;
+    A.selmask = c->selmask;
+    for (int b = 0; b < 2; b++) {
+        A.ring_out[b] = c->d_ringout[b].as<float>();
+        A.touched[b] = c->d_touched[b].as<uint32_t>();
+        A.info[b] = c->d_info[b].as<ChunkInfo>();
+    }
+    A.ver = c->d_ver.as<uint8_t>();
+    A.ring_in = c->d_ringin.as<float>();
+    A.meta = c->d_meta.as<RunMeta>();
+    A.gmin = c->d_gmin.as<uint8_t>();
+    A.gmax = c->d_gmax.as<uint8_t>();
+    A.gflags = c->d_gflags.as<uint8_t>();
+    A.neg = c->d_neg.as<uint64_t>();
+    A.pos = c->d_pos.as<uint64_t>();
+    A.twords = c->twords;
 
-        // pass 0: every chunk, speculative incoming state (chunk 0: the carried, exact one)
+    if (!force_seq) {
+        // pass 0: every chunk from a speculated incoming state (chunk 0: the carried, exact one)
         A.list = nullptr;
         A.nlist = 0;
         A.mode = 0;
         launch_threshold_kind(c, A, nch);
         c->stats.threshold_passes++;
 
-        // pass 1..: exact incoming state by look-back; repeat for chunks that can see a changed summary
+        // certify; re-run what cannot be proven from the exact (look-back) state; certify again what can
+        // see a re-run chunk.  Every round makes at least the first pending chunk final.
         c->h_list.clear();
         for (uint32_t k = 1; k < nch; k++) c->h_list.push_back(k);
-        int guard_iter = 0;
+        int rounds = 0;
         while (!c->h_list.empty()) {
-            const uint32_t nl = (uint32_t)c->h_list.size();
-            HIPCHK(c, hipMemcpyAsync(c->d_list.p, c->h_list.data(), (size_t)nl * 4, hipMemcpyHostToDevice, c->st));
+            const uint32_t np = (uint32_t)c->h_list.size();
+            HIPCHK(c, hipMemcpyAsync(c->d_list.p, c->h_list.data(), (size_t)np * 4, hipMemcpyHostToDevice, c->st));
             A.list = c->d_list.as<uint32_t>();
-            A.nlist = nl;
+            A.nlist = np;
+            const bool dbg = getenv("NFC_DEBUG") != nullptr;
+            if (dbg) HIPCHK(c, c->d_certinfo.ensure((size_t)nch * sizeof(CertInfo)));
+            hipLaunchKernelGGL(k_certify, dim3((np + 3) / 4), dim3(256), 0, c->st, A, c->d_cert.as<uint8_t>(),
+                               dbg ? c->d_certinfo.as<CertInfo>() : nullptr);
+            HIPCHK(c, hipMemcpyAsync(c->h_cert.data(), c->d_cert.p, nch, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipMemcpyAsync(c->h_gflags.data(), c->d_gflags.p, nch, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            std::vector<uint32_t> failing;
+            for (uint32_t k : c->h_list)
+                if (!c->h_cert[k]) failing.push_back(k);
+            if (dbg) {
+                std::vector<CertInfo> ci(nch);
+                HIPCHK(c, hipMemcpy(ci.data(), c->d_certinfo.p, (size_t)nch * sizeof(CertInfo), hipMemcpyDeviceToHost));
+                double worst = 0;
+                for (uint32_t k : c->h_list) worst = std::max(worst, (double)ci[k].d / std::max(1e-30f, ci[k].allowed));
+                fprintf(stderr, "[nfc] certify round %d: %u pending, %zu failing, worst d/allowed %.3f\n", rounds, np,
+                        failing.size(), worst);
+                for (size_t i = 0; i < failing.size() && i < 8; i++) {
+                    const CertInfo &x = ci[failing[i]];
+                    fprintf(stderr, "[nfc]   chunk %u: d %.6g allowed %.6g all_robust %u low_ok %u\n", failing[i], x.d,
+                            x.allowed, x.all_robust, x.low_ok);
+                }
+            }
+            if (failing.empty()) break;
+            HIPCHK(c, hipMemcpyAsync(c->d_list.p, failing.data(), failing.size() * 4, hipMemcpyHostToDevice, c->st));
+            A.nlist = (uint32_t)failing.size();
             A.mode = 1;
-            launch_threshold_kind(c, A, nl);
+            launch_threshold_kind(c, A, A.nlist);
             c->stats.threshold_passes++;
-            if (c->stats.threshold_passes > 2) c->stats.chunks_rerun += nl;
-            HIPCHK(c, hipMemcpyAsync(c->h_changed.data(), c->d_changed.p, nch, hipMemcpyDeviceToHost, c->st));
+            c->stats.chunks_rerun += A.nlist;
             HIPCHK(c, hipMemcpyAsync(c->h_gflags.data(), c->d_gflags.p, nch, hipMemcpyDeviceToHost, c->st));
             HIPCHK(c, hipStreamSynchronize(c->st));
             std::vector<uint8_t> ran(nch, 0);
-            for (uint32_t k : c->h_list) {
+            for (uint32_t k : failing) {
                 ran[k] = 1;
                 c->h_ver[k] ^= 1;
             }
             HIPCHK(c, hipMemcpyAsync(c->d_ver.p, c->h_ver.data(), nch, hipMemcpyHostToDevice, c->st));
+            // pending: the re-run chunks (a predecessor may have been re-run beside them) and every
+            // chunk that can see one of them through predecessors that left ring slots untouched
             c->h_list.clear();
             bool vis = false;
             for (uint32_t k = 0; k < nch; k++) {
-                if (vis) c->h_list.push_back(k);
-                const bool ch = ran[k] && c->h_changed[k];
+                if (vis || ran[k]) c->h_list.push_back(k);
                 const bool full = !(c->h_gflags[k] & 2);
-                vis = ch || (vis && !full);
+                vis = ran[k] || (vis && !full);
             }
-            if (++guard_iter > (int)nch + 2) return fail(c, NFC_ERR_INTERNAL, "threshold passes did not converge");
+            if (++rounds > (int)nch + 2) return fail(c, NFC_ERR_INTERNAL, "threshold passes did not converge");
         }
 
         // can every fp64 sum of this batch be proven exact?  (otherwise the summation order matters)
@@ -365,24 +409,13 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
         S.state = c->h_ecarry.state;
         S.last_bit = c->h_ecarry.last_bit;
         S.dur = c->h_ecarry.dur;
-        S.val = c->d_val.as<uint8_t>();
+        S.neg = c->d_neg.as<uint64_t>();
+        S.pos = c->d_pos.as<uint64_t>();
         launch_seq_kind(c, S);
         c->stats.used_sequential = 1;
     } else {
-        FinArgs F;
-        memset(&F, 0, sizeof F);
-        F.L = L;
-        F.nchunks = (int)nch;
-        F.twords = c->twords;
-        F.ring_carry = c->d_ring[c->ring_cur].as<float>();
-        F.ring_next = c->d_ring[1 - c->ring_cur].as<float>();
-        for (int b = 0; b < 2; b++) {
-            F.ring_out[b] = c->d_ringout[b].as<float>();
-            F.touched[b] = c->d_touched[b].as<uint32_t>();
-        }
-        F.ver = c->d_ver.as<uint8_t>();
-        F.carry = c->d_carry.as<Carry>();
-        hipLaunchKernelGGL(k_finalize_state, dim3(1), dim3(64), 0, c->st, F);
+        hipLaunchKernelGGL(k_finalize_state, dim3(1), dim3(64), 0, c->st, A, c->d_ring[1 - c->ring_cur].as<float>(),
+                           c->d_carry.as<Carry>());
         c->ring_cur = 1 - c->ring_cur;
     }
     return NFC_OK;
@@ -393,8 +426,8 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
 // ---------------------------------------------------------------------------
 int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     uint8_t *tot = c->d_totals.as<uint8_t>();
-    const size_t nwords = ((size_t)n + 15) / 16;
-    ChangeMask cm{c->d_val.as<uint32_t>(), n, skip, val_to_code(c->h_ecarry.last_bit)};
+    const size_t nwords = ((size_t)n + 63) / 64;
+    ChangeMask cm{c->d_neg.as<uint64_t>(), c->d_pos.as<uint64_t>(), n, skip, c->h_ecarry.last_bit};
     HIPCHK(c, c->d_partials.ensure((scan_num_tiles<8>(nwords) + 1) * sizeof(uint32_t)));
     scan_phase1<AddU32, 8>(c->st, nwords, LoadChangeCount{cm}, 0u, c->d_partials.as<uint32_t>(), (uint32_t *)(tot + TOT_RUNS));
     uint32_t nruns = 0;
@@ -407,7 +440,8 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
 
     RunView rv;
     rv.starts = c->d_starts.as<uint32_t>();
-    rv.val = c->d_val.as<uint8_t>();
+    rv.neg = c->d_neg.as<uint64_t>();
+    rv.pos = c->d_pos.as<uint64_t>();
     rv.nruns = nruns;
     rv.n = n;
     rv.skip = (int32_t)skip;
@@ -652,6 +686,17 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     band(p->hi_val, c->hi_a, c->hi_b);
     auto sane = [](double v) { return v == 0 || (std::fabs(v) > 1e-100 && std::fabs(v) < 1e100); };
     c->bands_ok = sane(p->lo_val) && sane(p->hi_val) && std::isfinite(p->lo_val) && std::isfinite(p->hi_val);
+    c->fast_ok = c->bands_ok && p->lo_val > 0 && p->hi_val > p->lo_val;
+    {   // a LOW run longer than max_len covers an aligned block of b samples, b the largest power of two
+        // with 2b - 1 <= max_len + 1: the fast path detects those runs by folding the LOW mask
+        int b = 1;
+        while (2 * (2 * b) - 1 <= c->mx + 1 && 2 * b <= 64) b *= 2;
+        c->nfold = 0;
+        while ((1 << c->nfold) < b) c->nfold++;
+        c->selmask = 0;
+        for (int k = 0; k < 64; k += b) c->selmask |= 1ull << k;
+    }
+    c->eps = 0.01f;  // certification margin of the speculative pass, relative to the window sum
     c->i16_scale = p->i16_scale != 0.f ? p->i16_scale : 1.0f / 32768.0f;
     static const size_t bps[4] = {8, 4, 4, 2};
     c->in_bytes_per_sample = bps[p->input_kind];
@@ -727,8 +772,8 @@ void nfc_destroy(nfc_ctx *c) {
     (void)hipSetDevice(c->P.device);
     if (c->st) (void)hipStreamSynchronize(c->st);
     DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_carry, &c->d_ecarry, &c->d_dcarry,
-                     &c->d_ring[0], &c->d_ring[1], &c->d_in, &c->d_val, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
-                     &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_changed, &c->d_gmin, &c->d_gmax,
+                     &c->d_ring[0], &c->d_ring[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
+                     &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cert, &c->d_gmin, &c->d_gmax,
                      &c->d_gflags, &c->d_list, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0],
                      &c->d_pending[1], &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
@@ -831,13 +876,14 @@ int nfc_read_val(nfc_ctx *c, size_t first, int8_t *out, size_t cap, size_t *n_ou
         memset(out, 0, n);
         return NFC_OK;
     }
-    const size_t b0 = first / 4, b1 = (first + n + 3) / 4;
-    std::vector<uint8_t> tmp(b1 - b0);
-    HIPCHK(c, hipMemcpy(tmp.data(), c->d_val.as<uint8_t>() + b0, b1 - b0, hipMemcpyDeviceToHost));
+    const size_t w0 = first / 64, w1 = (first + n + 63) / 64;
+    std::vector<uint64_t> ng(w1 - w0), ps(w1 - w0);
+    HIPCHK(c, hipMemcpy(ng.data(), c->d_neg.as<uint64_t>() + w0, (w1 - w0) * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ps.data(), c->d_pos.as<uint64_t>() + w0, (w1 - w0) * 8, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; i++) {
         const size_t m = first + i;
-        const uint32_t code = (tmp[m / 4 - b0] >> (2 * (m & 3))) & 3u;
-        out[i] = (int8_t)(code == 1 ? 1 : (code == 2 ? -1 : 0));
+        const int lo = (int)((ng[m / 64 - w0] >> (m & 63)) & 1), hi = (int)((ps[m / 64 - w0] >> (m & 63)) & 1);
+        out[i] = (int8_t)(lo ? -1 : (hi ? 1 : 0));
     }
     return NFC_OK;
 }

@@ -1,26 +1,32 @@
 // threshold.hip.h -- envelope + gated running-mean threshold (transition_sink.py:37-82)
 // as time-chunked CDNA4 kernels.
 //
-// The reference classifies sample n from ratio = x[n]*L/ss[n], where ss is the sum
-// of a ring of the last L *accepted* samples; rejected samples leave their ring
-// slot untouched, so ss[n] depends on every earlier classification.  Here the
-// stream is cut into time chunks of C samples, one wavefront per chunk:
+// The reference classifies sample n from ratio = x[n]*L/ss[n], where ss is the sum of a
+// ring of the last L *accepted* samples; rejected samples leave their ring slot untouched,
+// so ss[n] depends on every earlier classification.  Here the stream is cut into time
+// chunks of C samples, one wavefront per chunk, walking 256 samples per step (lane l holds
+// samples l, 64+l, 128+l, 192+l of the step, so a __ballot is 64 consecutive samples):
 //
-//   * inside a chunk the wave walks 256 samples per step (4 contiguous samples
-//     per lane, 16-byte coalesced loads).  It guesses the accept mask from the
-//     step's starting sum, gets every sample's exact sum with a wave prefix
-//     scan of the accepted (x - prev) deltas, reclassifies, and repeats until the
-//     mask is a fixed point -- which is unique and equals the sequential result;
-//   * across chunks the incoming ring is first speculated (pass 0: the last L
-//     raw samples with rejected-looking ones replaced by a level estimate), then
-//     resolved exactly from the predecessors' published (touched, value)
-//     summaries by look-back (pass 1: verify).  A chunk whose summary changed
-//     triggers re-evaluation of the chunks that can see it; when nothing changes
-//     the result is the reference's, by induction from chunk 0.
+//   * fast path of a step: the drift of ss inside the step is bounded by B = sum |x - prev|
+//     over the samples that can be accepted; a sample whose x lies outside the lo/hi bands
+//     widened by B (and by the certification margin, below) has the same classification for
+//     every possible ss, so no per-sample sum is needed -- two wave reductions and a few
+//     ballots per 256 samples;
+//   * exact path (any sample inside a band, long LOW runs, odd parameters): per 64-sample
+//     row, the accept mask is iterated to its unique fixed point with a wave prefix scan of
+//     the accepted (x - prev) deltas -- this equals the sequential result;
+//   * across chunks the incoming ring is first speculated (pass 0: the previous L samples
+//     with rejected-looking ones replaced by a level estimate, classification margins
+//     widened by eps*ss).  k_certify then resolves every chunk's true incoming ring from the
+//     predecessors' (touched, value) summaries by look-back and proves the speculation
+//     harmless when the L1 distance between the two rings is below the margin; the few
+//     chunks that cannot be proven are re-run from the exact state, and chunks that can see
+//     a re-run chunk are certified again.  When nothing is left the result is the
+//     reference's, by induction from chunk 0.
 //
-// All sums are fp64 and exact while the window's exponent spread fits 53 bits
-// (tracked per chunk); otherwise the host runs k_threshold_seq, a one-lane
-// restatement of the loop, so results stay bit-identical in every case.
+// All sums are fp64 and exact while the window's exponent spread fits 53 bits (tracked per
+// chunk); otherwise the host runs k_threshold_seq, a one-lane literal restatement of the
+// loop, so results stay bit-identical in every case.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,8 +34,8 @@
 namespace nfc {
 
 constexpr int STEP = 256;            // samples per wave step
-constexpr int LL_NONE = -(1 << 30);  // "no LOW sample seen" (batch-local index)
-constexpr int MAX_FIX_ITERS = 300;
+constexpr int LL_NONE = -(1 << 30);  // "no such sample" (batch-local index)
+constexpr int MAX_FIX_ITERS = 80;
 
 enum : int { IN_IQ_F32 = 0, IN_ENV_F32 = 1, IN_REAL_F32_SQ = 2, IN_I16_SQ = 3 };
 
@@ -63,6 +69,15 @@ struct ChunkInfo {
     uint32_t n_untouched;
 };
 
+// What a chunk's latest evaluation assumed, for k_certify.
+struct RunMeta {
+    float min_ss;        // smallest step-start sum seen (rounded down)
+    float eps;           // relative margin every fast-path step carried (0: evaluated from the exact state)
+    int32_t nl_in, kl_in;
+    uint32_t all_robust; // every step took the fast path (or eps == 0)
+    uint32_t pad;
+};
+
 struct ThrArgs {
     const void *in;
     uint32_t n;       // samples in the batch
@@ -71,38 +86,66 @@ struct ThrArgs {
     int32_t L, Lpad, mx, C, nchunks;
     double lo, hi, hi_plus, lo_a, lo_b, hi_a, hi_b;
     int32_t bands_ok;
+    int32_t fast_ok;       // lo, hi > 0 and sane: the banded fast path is usable
     float i16_scale;
+    float eps;             // certification margin of pass 0
     const float *ring_carry;
     const Carry *carry;
     int32_t nl0, kl0;      // carried last-non-LOW index and LOW key at the batch start (batch-local, <= -1)
+    double lo_L, hi_L;     // lo / L, hi / L (the fast path's thresholds carry 2^-20 of slack)
+    int32_t fold_sh[6];    // long-LOW-run detector: shifts of the six folds (0 = fold disabled) ...
+    uint64_t selmask;      // ... and the bit that survives the folds in every aligned block
     float *ring_out[2];
     uint32_t *touched[2];  // [nchunks][twords]
     ChunkInfo *info[2];
     const uint8_t *ver;    // which buffer holds chunk c's current summary
-    uint8_t *changed;      // out: summary differs from the current one
+    float *ring_in;        // [nchunks][L] the ring each chunk's latest evaluation started from
+    RunMeta *meta;
     uint8_t *gmin, *gmax, *gflags;  // out: guard exponents / flags of the chunk's latest evaluation
-    uint8_t *val;          // 2-bit codes, 4 samples per byte: 0 accepted, 1 HIGH, 2 LOW
+    uint64_t *neg, *pos;   // classification bit planes, 64 samples per word: LOW / HIGH
     const uint32_t *list;  // chunks to run (nullptr: all)
     uint32_t nlist;
     int32_t mode;          // 0 speculate, 1 resolve exactly
     int32_t twords;        // u32 words per touched bitmap
 };
 
+// ---------------------------------------------------------------------------
+// cross-lane helpers
+// ---------------------------------------------------------------------------
 __device__ __forceinline__ double shfl_up_f64(double v, int d) {
     int lo = __shfl_up(__double2loint(v), d, 64), hi = __shfl_up(__double2hiint(v), d, 64);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double shfl_f64(double v, int l) {
-    int lo = __shfl(__double2loint(v), l, 64), hi = __shfl(__double2hiint(v), l, 64);
+// DPP row_shr / row_bcast reductions (gfx9 family): result valid in lane 63, broadcast by readlane.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i32(int ident, int v) {
+    return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROWMASK, 0xF, false);
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += __int_as_float(dpp_i32<0x111, 0xF>(0, __float_as_int(v)));
+    v += __int_as_float(dpp_i32<0x112, 0xF>(0, __float_as_int(v)));
+    v += __int_as_float(dpp_i32<0x114, 0xF>(0, __float_as_int(v)));
+    v += __int_as_float(dpp_i32<0x118, 0xF>(0, __float_as_int(v)));
+    v += __int_as_float(dpp_i32<0x142, 0xA>(0, __float_as_int(v)));
+    v += __int_as_float(dpp_i32<0x143, 0xC>(0, __float_as_int(v)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp_i32<CTRL, ROWMASK>(0, __double2loint(v));
+    const int hi = dpp_i32<CTRL, ROWMASK>(0, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        int lo = __shfl_xor(__double2loint(v), d, 64), hi = __shfl_xor(__double2hiint(v), d, 64);
-        v += __hiloint2double(hi, lo);
-    }
-    return v;
+    v += dpp_f64<0x111, 0xF>(v);
+    v += dpp_f64<0x112, 0xF>(v);
+    v += dpp_f64<0x114, 0xF>(v);
+    v += dpp_f64<0x118, 0xF>(v);
+    v += dpp_f64<0x142, 0xA>(v);
+    v += dpp_f64<0x143, 0xC>(v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
@@ -124,6 +167,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
     return v;
 }
+__device__ __forceinline__ int last_set(unsigned long long m) { return 63 - __clzll((long long)m); }  // m != 0
 
 // Envelope of one sample (gnuradio complex_to_mag_squared; compiled with
 // -ffp-contract=off so the products and the sum round separately).
@@ -141,32 +185,6 @@ __device__ __forceinline__ float envelope_at(const void *in, size_t m, float i16
     } else {
         const float s = (float)((const int16_t *)in)[m] * i16_scale;
         return s * s;
-    }
-}
-
-// Four consecutive samples starting at m (m % 4 == 0, fully inside the buffer).
-template <int KIND>
-__device__ __forceinline__ void load4(const void *in, size_t m, float i16_scale, float x[4]) {
-    if (KIND == IN_IQ_F32) {
-        const float4 *p = (const float4 *)in + (m >> 1);
-        const float4 a = p[0], b = p[1];
-        const float a0 = a.x * a.x, a1 = a.y * a.y, a2 = a.z * a.z, a3 = a.w * a.w;
-        const float b0 = b.x * b.x, b1 = b.y * b.y, b2 = b.z * b.z, b3 = b.w * b.w;
-        x[0] = a0 + a1;
-        x[1] = a2 + a3;
-        x[2] = b0 + b1;
-        x[3] = b2 + b3;
-    } else if (KIND == IN_ENV_F32) {
-        const float4 a = ((const float4 *)in)[m >> 2];
-        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
-    } else if (KIND == IN_REAL_F32_SQ) {
-        const float4 a = ((const float4 *)in)[m >> 2];
-        x[0] = a.x * a.x; x[1] = a.y * a.y; x[2] = a.z * a.z; x[3] = a.w * a.w;
-    } else {
-        const short4 a = ((const short4 *)in)[m >> 2];
-        const float s0 = (float)a.x * i16_scale, s1 = (float)a.y * i16_scale;
-        const float s2 = (float)a.z * i16_scale, s3 = (float)a.w * i16_scale;
-        x[0] = s0 * s0; x[1] = s1 * s1; x[2] = s2 * s2; x[3] = s3 * s3;
     }
 }
 
@@ -194,18 +212,110 @@ __device__ __forceinline__ void classify_one(const ThrArgs &A, double x64, doubl
     }
 }
 
-// Where a chunk's look-back ends: newest predecessor that saw a non-LOW sample / a LOW sample.
+// LOW bookkeeping at a chunk start.  A LOW key only matters within max_len + 1 samples and a chunk is longer
+// than that, so only the predecessor's key can be live; the last non-LOW index needs a deeper look only when
+// whole chunks were LOW.
 __device__ __forceinline__ void resolve_low_state(const ThrArgs &A, int c, int &nl, int &kl) {
-    nl = LL_NONE;
-    kl = KEY_NONE;
-    bool have_nl = false, have_kl = false;
-    for (int cc = c - 1; cc >= 0 && !(have_nl && have_kl); cc--) {
-        const ChunkInfo ci = A.info[A.ver[cc]][cc];
-        if (!have_nl && ci.last_nonlow != LL_NONE) { nl = ci.last_nonlow; have_nl = true; }
-        if (!have_kl && ci.low_key != KEY_NONE) { kl = ci.low_key; have_kl = true; }
+    const ChunkInfo p = A.info[A.ver[c - 1]][c - 1];
+    kl = p.low_key;
+    nl = p.last_nonlow;
+    for (int cc = c - 2; cc >= 0 && nl == LL_NONE; cc--) nl = A.info[A.ver[cc]][cc].last_nonlow;
+    if (nl == LL_NONE) nl = A.nl0;
+    if (c == 1 && kl == KEY_NONE) kl = A.kl0;
+}
+
+// exact incoming ring value of slot s for chunk c: latest predecessor that accepted a sample into it
+__device__ __forceinline__ float resolve_slot(const ThrArgs &A, int c, int s) {
+    if (c >= 1) {   // common case: the predecessor accepted a sample into the slot; both loads issue at once
+        const int vb = A.ver[c - 1];
+        const uint32_t w = A.touched[vb][(size_t)(c - 1) * A.twords + (s >> 5)];
+        const float v = A.ring_out[vb][(size_t)(c - 1) * A.L + s];
+        if ((w >> (s & 31)) & 1u) return v;
     }
-    if (!have_nl) nl = A.nl0;
-    if (!have_kl) kl = A.kl0;
+    for (int cc = c - 2; cc >= 0; cc--) {
+        const int vb = A.ver[cc];
+        const uint32_t w = A.touched[vb][(size_t)cc * A.twords + (s >> 5)];
+        if ((w >> (s & 31)) & 1u) return A.ring_out[vb][(size_t)cc * A.L + s];
+    }
+    return A.ring_carry[s];
+}
+
+// One 64-sample row (lane l = sample m), exact: iterate the accept mask to its fixed point.
+// Updates ss0, w_nl, w_kl; returns the classification through low/pos ballots.
+__device__ __forceinline__ void row_exact(const ThrArgs &A, int lane, int m, bool act, float x, float prev, float *ring,
+                                          unsigned char *tch, uint32_t slot, double &ss0, int &w_nl, int &w_kl,
+                                          uint32_t &emin, uint32_t &emax, uint32_t &flags, unsigned long long &lowm,
+                                          unsigned long long &posm) {
+    const int mx = A.mx;
+    const double x64 = (double)x;
+    double ss = ss0;
+    bool low = false, acc = false;
+    int val = 0, key = KEY_NONE;
+    for (int iter = 0;; iter++) {
+        bool lw = false, hg = false;
+        if (act) classify_one(A, x64, ss, lw, hg);
+        low = lw;
+        // last non-LOW index before this lane
+        int inc = (act && !lw) ? m : LL_NONE;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc = max(inc, up);
+        }
+        int nl = __shfl_up(inc, 1, 64);
+        if (lane == 0) nl = LL_NONE;
+        nl = max(nl, w_nl);
+        key = KEY_NONE;
+        if (lw) {
+            const int p = m - nl;  // 1-based position in the LOW run
+            const bool bad = (p > mx) && ((p - 1) % mx == 0);
+            key = 2 * m + (bad ? 0 : 1);
+        }
+        int kinc = key;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(kinc, d, 64);
+            if (lane >= d) kinc = max(kinc, up);
+        }
+        int kl = __shfl_up(kinc, 1, 64);
+        if (lane == 0) kl = KEY_NONE;
+        kl = max(kl, w_kl);
+        const bool st2 = (kl & 1) && (m - (kl >> 1)) <= mx + 1;
+        int v = 0;
+        if (lw) v = -1;
+        else if (hg && !st2) v = 1;
+        const bool a = act && (v == 0);
+        const bool same = (iter > 0) && (a == acc);
+        acc = a;
+        val = v;
+        if (iter > 0 && __all(same)) break;
+        if (iter >= MAX_FIX_ITERS) { flags |= 1u; break; }
+        double incs = acc ? (x64 - (double)prev) : 0.0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double up = shfl_up_f64(incs, d);
+            if (lane >= d) incs += up;
+        }
+        double ex = shfl_up_f64(incs, 1);
+        if (lane == 0) ex = 0;
+        ss = ss0 + ex;
+    }
+    double dl = 0;
+    if (acc) {
+        dl = x64 - (double)prev;
+        ring[slot] = x;
+        tch[slot] = 1;
+        if (x != 0.f) {
+            const uint32_t e = max(f32_expfield(x), 1u);
+            emin = min(emin, e);
+            emax = max(emax, e);
+        }
+    }
+    ss0 += wave_sum_f64(dl);
+    w_nl = max(w_nl, wave_max_i32((act && !low) ? m : LL_NONE));
+    w_kl = max(w_kl, wave_max_i32(key));
+    lowm = __ballot(low);
+    posm = __ballot(val == 1);
 }
 
 template <int KIND>
@@ -225,14 +335,17 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     float *ring = (float *)(smem + (size_t)wave * ((size_t)A.Lpad * 5));
     unsigned char *tch = (unsigned char *)(ring + A.Lpad);
     const int L = A.L;
+    const int mx = A.mx;
     const uint32_t m_chunk = c * (uint32_t)A.C;
     const uint32_t n1 = min(A.n, m_chunk + (uint32_t)A.C);
     const uint32_t m_start = max(m_chunk, A.skip);
     const Carry cr = *A.carry;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
 
     uint32_t emin = 255u, emax = 0u;
-    int w_nl, w_kl;  // last non-LOW index / key of the last LOW sample, before the current step
+    int w_nl, w_kl;  // last non-LOW index / key of the last LOW sample, before the current row
     double ss0;
+    float eps = 0.f;  // margin of this evaluation
 
     // ---------------- incoming state ----------------
     if (c == 0) {
@@ -241,25 +354,14 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         w_nl = A.nl0;
         w_kl = A.kl0;
     } else if (A.mode == 1) {
-        // exact: latest predecessor that accepted a sample into the slot, else the carried ring
-        for (int s = lane; s < L; s += 64) {
-            int cc = (int)c - 1;
-            float v;
-            for (;;) {
-                if (cc < 0) { v = A.ring_carry[s]; break; }
-                const int vb = A.ver[cc];
-                const uint32_t w = A.touched[vb][(size_t)cc * A.twords + (s >> 5)];
-                if ((w >> (s & 31)) & 1u) { v = A.ring_out[vb][(size_t)cc * L + s]; break; }
-                cc--;
-            }
-            ring[s] = v;
-        }
+        for (int s = lane; s < L; s += 64) ring[s] = resolve_slot(A, (int)c, s);
         double part = 0;
         for (int s = lane; s < L; s += 64) part += (double)ring[s];
         ss0 = wave_sum_f64(part) + cr.delta;
         resolve_low_state(A, (int)c, w_nl, w_kl);
     } else {
         // speculate: the L samples before the chunk, rejected-looking ones replaced by a level estimate
+        eps = A.eps;
         const uint32_t w0 = m_chunk - (uint32_t)L;
         float mxv = 0.f;
         for (int i = lane; i < L; i += 64) {
@@ -304,9 +406,12 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         for (int s = lane; s < L; s += 64) part += (double)ring[s];
         ss0 = wave_sum_f64(part) + cr.delta;
     }
+    const int nl_in = w_nl, kl_in = w_kl;
+    float *rin = A.ring_in + (size_t)c * L;
     for (int s = lane; s < A.Lpad; s += 64) tch[s] = 0;
     for (int s = lane; s < L; s += 64) {
         const float v = ring[s];
+        rin[s] = v;
         if (v != 0.f) {
             const uint32_t e = max(f32_expfield(v), 1u);
             emin = min(emin, e);
@@ -316,161 +421,196 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
 
     // ---------------- the chunk, 256 samples per step ----------------
     uint32_t flags = 0;
+    uint32_t all_robust = 1;
+    float min_ss = 3.0e38f;
     int chunk_nl = LL_NONE, chunk_kl = KEY_NONE;
+    uint32_t vmin = 0xFFFFFFFFu, vmax = 0u;   // accepted values as raw bits (positive floats order like uints)
     uint32_t slot_step = (A.g0modL + m_chunk) % (uint32_t)L;
-    const int mx = A.mx;
-    for (uint32_t base = m_chunk; base < n1; base += STEP) {
-        const uint32_t m0 = base + 4u * lane;
-        float x[4];
-        if (base + STEP <= A.n) {
-            load4<KIND>(A.in, m0, A.i16_scale, x);
-        } else {
+    const float etaD = 1.0f - 9.5367431640625e-07f, etaU = 1.0f + 9.5367431640625e-07f;  // 1 -+ 2^-20
+    float xn[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) x[j] = (m0 + j < A.n) ? envelope_at<KIND>(A.in, m0 + j, A.i16_scale) : 0.f;
-        }
+    for (int j = 0; j < 4; j++) {
+        const uint32_t m = m_chunk + 64u * j + lane;
+        xn[j] = (m < A.n) ? envelope_at<KIND>(A.in, m, A.i16_scale) : 0.f;
+    }
+    for (uint32_t base = m_chunk; base < n1; base += STEP) {
+        float x[4], prev[4];
         bool act[4];
         uint32_t slot[4];
-        float prev[4];
-        double x64[4];
-        uint32_t s0 = slot_step + 4u * lane;
-        s0 = (s0 >= (uint32_t)L) ? s0 % (uint32_t)L : s0;
+        const bool full = (base >= m_start) && (base + STEP <= n1);   // wave-uniform: every sample of the step is live
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = xn[j];
+        if (base + 2 * STEP <= A.n) {  // prefetch the next step (whole step inside the buffer)
+#pragma unroll
+            for (int j = 0; j < 4; j++) xn[j] = envelope_at<KIND>(A.in, base + STEP + 64u * j + lane, A.i16_scale);
+        } else if (base + STEP < n1) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t m = base + STEP + 64u * j + lane;
+                xn[j] = (m < A.n) ? envelope_at<KIND>(A.in, m, A.i16_scale) : 0.f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t m = m0 + j;
-            act[j] = (m >= m_start) && (m < n1);
-            uint32_t s = s0 + j;
+            const uint32_t m = base + 64u * j + lane;
+            act[j] = full || ((m >= m_start) && (m < n1));
+            uint32_t s = slot_step + 64u * j + lane;
             s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
             slot[j] = s;
             prev[j] = ring[s];
-            x64[j] = (double)x[j];
         }
-        bool low[4], high[4], acc[4];
-        int val[4], key[4];
-        double ssj[4] = {ss0, ss0, ss0, ss0};
-        int lane_nl = LL_NONE, lane_kl = KEY_NONE;
-        int iter = 0;
-        for (;;) {
-            // ratio classification with the current per-sample sums (transition_sink.py:59-71)
-            lane_nl = LL_NONE;
-            bool anyl = false;
+        min_ss = fminf(min_ss, (float)ss0 * etaD);
+
+        // ---- fast path: classification that holds for every sum the step can see ----
+        bool fast = A.fast_ok && ss0 > 1e-30 && ss0 < 1e30;
+        unsigned long long lowm[4], posm[4];
+        if (fast) {
+            // Samples that are LOW for any sum within 30 % of ss0 never enter the ring; the others bound the
+            // drift of the sum inside the step: B = sum |x - prev|.  (By induction over the samples: while the
+            // drift so far is below 25 % no surely-LOW sample is accepted, so the drift stays below B.)
+            const float t_sure = (float)(A.lo_L * 0.70 * ss0) * etaD;
+            const float t_maylow = (float)(A.lo_L * 1.30 * ss0) * etaU;
+            float b = 0.f;
+            bool maylow = false;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                bool lw = false, hg = false;
-                if (act[j]) classify_one(A, x64[j], ssj[j], lw, hg);
-                low[j] = lw;
-                high[j] = hg;
-                anyl |= lw;
-                if (act[j] && !lw) lane_nl = (int)(m0 + j);
+                b += (act[j] && !(x[j] < t_sure)) ? fabsf(x[j] - prev[j]) : 0.f;
+                maylow |= act[j] && (x[j] < t_maylow);
             }
-            const bool step_low = __any(anyl);
+            b = wave_sum_f32(b) * 1.001f;
+            double bt = (double)b + (double)eps * ss0;
+            fast = bt < 0.25 * ss0;
+            double s_dn = ss0 - bt, s_up = ss0 + bt;
+            float thi_up = (float)(A.hi_L * s_up) * etaU;
+            // Second look: a sample that is HIGH for every sum within that bound is rejected unless a LOW sample
+            // put the state machine into state 2 -- impossible while no sample of the step can be LOW and the
+            // carried LOW sample is out of reach.  Leaving those samples out tightens the bound.
             const bool key_live = (w_kl & 1) && ((int)base - (w_kl >> 1)) <= mx + 1;
-            bool st2[4] = {false, false, false, false};
-            lane_kl = KEY_NONE;
-            if (step_low || key_live) {
-                // (1) last non-LOW index before this lane
-                int inc = lane_nl;
+            if (fast && !key_live && !__any(maylow)) {
+                bool h1 = false;
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int up = __shfl_up(inc, d, 64);
-                    if (lane >= d) inc = max(inc, up);
+                for (int j = 0; j < 4; j++) h1 |= act[j] && (x[j] > thi_up);
+                if (__any(h1)) {
+                    float b2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) b2 += (act[j] && !(x[j] > thi_up)) ? fabsf(x[j] - prev[j]) : 0.f;
+                    b2 = wave_sum_f32(b2) * 1.001f;
+                    bt = (double)b2 + (double)eps * ss0;
+                    s_dn = ss0 - bt;
+                    s_up = ss0 + bt;
+                    thi_up = (float)(A.hi_L * s_up) * etaU;
                 }
-                int nl = __shfl_up(inc, 1, 64);
-                if (lane == 0) nl = LL_NONE;
-                nl = max(nl, w_nl);
-                // keys of this lane's LOW samples: position in their LOW run decides "ended on a timeout"
+            }
+            const float tlo_dn = (float)(A.lo_L * s_dn) * etaD, tlo_up = (float)(A.lo_L * s_up) * etaU;
+            const float thi_dn = (float)(A.hi_L * s_dn) * etaD;
+            fast = fast && (tlo_dn > 1e-30f) && (thi_up < 1e30f);
+            bool lw[4], hg[4], amb = false, anyhg = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                lw[j] = act[j] && (x[j] < tlo_dn);
+                hg[j] = act[j] && (x[j] > thi_up);
+                const bool inband = !((x[j] < tlo_dn) || (x[j] > tlo_up)) || !((x[j] < thi_dn) || (x[j] > thi_up));
+                amb |= act[j] && inband;
+                anyhg |= hg[j];
+                lowm[j] = __ballot(lw[j]);
+            }
+            if (__any(amb)) fast = false;
+            if (fast) {
+                // every LOW sample must sit at run position <= max_len (then none ends on a time-out):
+                // a longer run covers an aligned block of LOW samples, or continues the carried run
+                const int lead = (lowm[0] == ~0ull) ? 64 : (__ffsll((long long)~lowm[0]) - 1);
+                const int carry_run = (int)base - 1 - w_nl;
+                unsigned long long hit = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int m = (int)(m0 + j);
-                    key[j] = KEY_NONE;
-                    if (low[j]) {
-                        const int p = m - nl;   // 1-based position in the LOW run
-                        const bool bad = (p > mx) && ((p - 1) % mx == 0);
-                        key[j] = 2 * m + (bad ? 0 : 1);
-                        lane_kl = key[j];
-                    } else if (act[j]) {
-                        nl = m;
+                    unsigned long long t = lowm[j];
+#pragma unroll
+                    for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
+                    hit |= t & A.selmask;
+                }
+                if (hit || ((carry_run > 0) && (carry_run + lead > mx))) fast = false;
+            }
+            if (fast) {
+                double dl = 0;
+                const bool need_st2 = __any(anyhg);
+                int before = (w_kl & 1) ? (w_kl >> 1) : LL_NONE;  // last LOW before the row (every key here is good)
+                int step_nl = LL_NONE, step_ll = LL_NONE;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    bool ps = false;
+                    if (need_st2) {
+                        // HIGH is ignored within max_len + 1 samples after a LOW sample
+                        const int m = (int)(base + 64u * j) + lane;
+                        const unsigned long long below = lowm[j] & lane_lt;
+                        const int lastlow = below ? (int)(base + 64u * j) + last_set(below) : before;
+                        ps = hg[j] && ((m - lastlow) > mx + 1);
                     }
+                    const bool a = act[j] && !lw[j] && !ps;
+                    dl += a ? ((double)x[j] - (double)prev[j]) : 0.0;
+                    if (a) {
+                        ring[slot[j]] = x[j];
+                        tch[slot[j]] = 1;
+                    }
+                    const uint32_t xb = __float_as_uint(x[j]);
+                    vmin = min(vmin, (a && xb != 0u) ? xb : 0xFFFFFFFFu);
+                    vmax = max(vmax, a ? xb : 0u);
+                    posm[j] = need_st2 ? __ballot(ps) : 0ull;
+                    const unsigned long long actm = full ? ~0ull : __ballot(act[j]);
+                    const unsigned long long nonlow = actm & ~lowm[j];
+                    if (lowm[j]) {
+                        before = (int)(base + 64u * j) + last_set(lowm[j]);
+                        step_ll = before;
+                    }
+                    if (nonlow) step_nl = (int)(base + 64u * j) + last_set(nonlow);
                 }
-                // (2) key of the last LOW sample before this lane
-                int kinc = lane_kl;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int up = __shfl_up(kinc, d, 64);
-                    if (lane >= d) kinc = max(kinc, up);
+                ss0 += wave_sum_f64(dl);
+                if (step_ll != LL_NONE) {
+                    w_kl = 2 * step_ll + 1;
+                    chunk_kl = w_kl;
                 }
-                int kl = __shfl_up(kinc, 1, 64);
-                if (lane == 0) kl = KEY_NONE;
-                kl = max(kl, w_kl);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int m = (int)(m0 + j);
-                    st2[j] = (kl & 1) && (m - (kl >> 1)) <= mx + 1;
-                    if (low[j]) kl = key[j];
+                if (step_nl != LL_NONE) {
+                    w_nl = step_nl;
+                    chunk_nl = step_nl;
                 }
             }
-            bool same = true;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int v = 0;
-                if (low[j]) v = -1;
-                else if (high[j] && !st2[j]) v = 1;
-                const bool a = act[j] && (v == 0);
-                if (iter > 0 && a != acc[j]) same = false;
-                acc[j] = a;
-                val[j] = v;
-            }
-            if (iter > 0 && __all(same)) break;
-            if (iter >= MAX_FIX_ITERS) { flags |= 1u; break; }
-            // exact running sums under this accept mask (transition_sink.py:80-82)
-            double l[4];
-            double run = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (acc[j]) run += (x64[j] - (double)prev[j]);
-                l[j] = run;
-            }
-            double incs = run;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const double up = shfl_up_f64(incs, d);
-                if (lane >= d) incs += up;
-            }
-            double ex = shfl_up_f64(incs, 1);
-            if (lane == 0) ex = 0;
-            const double b = ss0 + ex;
-            ssj[0] = b;
-            ssj[1] = b + l[0];
-            ssj[2] = b + l[1];
-            ssj[3] = b + l[2];
-            iter++;
         }
-        // commit the step
-        double run = 0;
-        uint32_t code = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (acc[j]) {
-                run += (x64[j] - (double)prev[j]);
-                ring[slot[j]] = x[j];
-                tch[slot[j]] = 1;
-                if (x[j] != 0.f) {
-                    const uint32_t e = max(f32_expfield(x[j]), 1u);
-                    emin = min(emin, e);
-                    emax = max(emax, e);
-                }
+        if (!fast) {
+            // ---- exact path, one 64-sample row at a time ----
+            if (eps > 0.f) all_robust = 0;
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                const int m = (int)(base + 64u * j) + lane;
+                const int nl_b = w_nl, kl_b = w_kl;
+                unsigned long long lm, pm;
+                const float xj = j == 0 ? x[0] : j == 1 ? x[1] : j == 2 ? x[2] : x[3];
+                const float pj = j == 0 ? prev[0] : j == 1 ? prev[1] : j == 2 ? prev[2] : prev[3];
+                const bool aj = j == 0 ? act[0] : j == 1 ? act[1] : j == 2 ? act[2] : act[3];
+                const uint32_t sj = j == 0 ? slot[0] : j == 1 ? slot[1] : j == 2 ? slot[2] : slot[3];
+                row_exact(A, lane, m, aj, xj, pj, ring, tch, sj, ss0, w_nl, w_kl, emin, emax, flags, lm, pm);
+                if (j == 0) { lowm[0] = lm; posm[0] = pm; }
+                else if (j == 1) { lowm[1] = lm; posm[1] = pm; }
+                else if (j == 2) { lowm[2] = lm; posm[2] = pm; }
+                else { lowm[3] = lm; posm[3] = pm; }
+                if (w_nl != nl_b) chunk_nl = w_nl;
+                if (w_kl != kl_b) chunk_kl = w_kl;
             }
-            code |= (uint32_t)(val[j] == 1 ? 1u : (val[j] == -1 ? 2u : 0u)) << (2 * j);
         }
-        ss0 += wave_sum_f64(run);
-        const int step_nl = wave_max_i32(lane_nl);
-        const int step_kl = wave_max_i32(lane_kl);
-        w_nl = max(w_nl, step_nl);
-        w_kl = max(w_kl, step_kl);
-        chunk_nl = max(chunk_nl, step_nl);
-        chunk_kl = max(chunk_kl, step_kl);
-        if (m0 < A.n) A.val[m0 >> 2] = (unsigned char)code;
+        if (lane < 4) {
+            const uint32_t w = (base >> 6) + lane;
+            if ((size_t)w * 64 < A.n) {
+                const unsigned long long lo4 = lane == 0 ? lowm[0] : lane == 1 ? lowm[1] : lane == 2 ? lowm[2] : lowm[3];
+                const unsigned long long po4 = lane == 0 ? posm[0] : lane == 1 ? posm[1] : lane == 2 ? posm[2] : posm[3];
+                A.neg[w] = lo4;
+                A.pos[w] = po4;
+            }
+        }
         slot_step += STEP;
-        slot_step = (slot_step >= (uint32_t)L) ? slot_step % (uint32_t)L : slot_step;
+        slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
+    }
+    // fold the raw-bit extremes of the fast path into the exponent guard
+    if (vmax != 0u) {
+        emax = max(emax, (vmax >> 31) ? 255u : max((vmax >> 23) & 0xFFu, 1u));
+        if (vmin != 0xFFFFFFFFu) emin = min(emin, max((vmin >> 23) & 0xFFu, 1u));
     }
 
     // ---------------- publish the summary ----------------
@@ -478,27 +618,16 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     const int vb_new = (A.mode == 1) ? (1 - vb_old) : vb_old;  // pass 0 fills buffer ver[c] directly
     float *ro = A.ring_out[vb_new] + (size_t)c * L;
     uint32_t *to = A.touched[vb_new] + (size_t)c * A.twords;
-    bool diff = false;
     uint32_t untouched = 0;
-    const float *ro_old = A.ring_out[vb_old] + (size_t)c * L;
-    const uint32_t *to_old = A.touched[vb_old] + (size_t)c * A.twords;
     for (int sbase = 0; sbase < A.twords * 32; sbase += 64) {
         const int s = sbase + lane;
         const bool t = (s < L) && tch[s];
-        const float v = (s < L) ? ring[s] : 0.f;
         const unsigned long long bal = __ballot(t);
         if (s < L) {
-            ro[s] = v;
+            ro[s] = ring[s];
             if (!t) untouched++;
         }
         const int w = sbase >> 5;
-        if (A.mode == 1) {
-            if (s < L && t && __float_as_uint(ro_old[s]) != __float_as_uint(v)) diff = true;
-            if (lane == 0) {
-                if (to_old[w] != (uint32_t)bal) diff = true;
-                if (w + 1 < A.twords && to_old[w + 1] != (uint32_t)(bal >> 32)) diff = true;
-            }
-        }
         if (lane == 0) {
             to[w] = (uint32_t)bal;
             if (w + 1 < A.twords) to[w + 1] = (uint32_t)(bal >> 32);
@@ -506,16 +635,8 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     }
     emin = wave_min_u32(emin);
     emax = wave_max_u32(emax);
-    untouched = (uint32_t)wave_sum_f64((double)untouched);
+    untouched = (uint32_t)wave_sum_f32((float)untouched);
     flags = wave_max_u32(flags);
-    if (A.mode == 1) {
-        const ChunkInfo old = A.info[vb_old][c];
-        if (old.low_key != chunk_kl || old.last_nonlow != chunk_nl) diff = true;
-        const bool any = __any(diff);
-        if (lane == 0) A.changed[c] = any ? 1 : 0;
-    } else if (lane == 0) {
-        A.changed[c] = 1;
-    }
     if (lane == 0) {
         ChunkInfo ci;
         ci.ss_out = ss0;
@@ -529,35 +650,111 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         A.gmin[c] = (uint8_t)emin;
         A.gmax[c] = (uint8_t)emax;
         A.gflags[c] = (uint8_t)(flags | (untouched ? 2u : 0u));
+        RunMeta mt;
+        mt.min_ss = min_ss;
+        mt.eps = eps;
+        mt.nl_in = nl_in;
+        mt.kl_in = kl_in;
+        mt.all_robust = all_robust;
+        mt.pad = 0;
+        A.meta[c] = mt;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Certification: is what a chunk's latest evaluation assumed about its incoming state
+// close enough to the truth (as resolved from the current summaries) that its result stands?
+//   evaluated from a speculated state (eps > 0): every step was on the fast path and
+//       sum |true ring - assumed ring| <= eps * (smallest step-start sum)
+//   evaluated from a resolved state (eps == 0): the resolved state is still bitwise the same
+// plus equivalent LOW bookkeeping at the chunk start.
+// ---------------------------------------------------------------------------
+struct CertInfo {
+    float d, allowed;
+    uint32_t all_robust, low_ok;
+};
+__global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertInfo *dbg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t slotid = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (slotid >= A.nlist) return;
+    const uint32_t c = A.list[slotid];
+    const int L = A.L;
+    const float *rin = A.ring_in + (size_t)c * L;
+    const RunMeta mt = A.meta[c];
+    const int vb = A.ver[c - 1];
+    const uint32_t *tw = A.touched[vb] + (size_t)(c - 1) * A.twords;
+    const float *ro = A.ring_out[vb] + (size_t)(c - 1) * L;
+    float d = 0.f;
+    bool differ = false;
+    for (int s0 = 0; s0 < L; s0 += 256) {
+        float t[4], u[4];
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int s = s0 + 64 * k + lane;
+            const bool in = s < L;
+            t[k] = in ? ro[s] : 0.f;
+            u[k] = in ? rin[s] : 0.f;
+            w[k] = in ? tw[s >> 5] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int s = s0 + 64 * k + lane;
+            if (s < L) {
+                if (!((w[k] >> (s & 31)) & 1u)) t[k] = resolve_slot(A, (int)c, s);   // rare: look further back
+                d += fabsf(t[k] - u[k]);
+                if (__float_as_uint(t[k]) != __float_as_uint(u[k])) differ = true;
+            }
+        }
+    }
+    d = wave_sum_f32(d) * 1.001f;
+    int nl, kl;
+    resolve_low_state(A, (int)c, nl, kl);
+    const int m0 = (int)(c * (uint32_t)A.C);
+    const int mx = A.mx;
+    auto live = [&](int k) { return (k & 1) && (m0 - (k >> 1)) <= mx + 1; };
+    const bool low_ok = (nl == mt.nl_in) && ((kl == mt.kl_in) || (!live(kl) && !live(mt.kl_in)));
+    bool ok;
+    if (mt.eps > 0.f) ok = mt.all_robust && (d <= mt.eps * mt.min_ss * 0.999f) && low_ok;
+    else ok = !__any(differ) && (nl == mt.nl_in) && (kl == mt.kl_in);
+    if (lane == 0) {
+        cert[c] = ok ? 1 : 0;
+        if (dbg) dbg[c] = CertInfo{d, mt.eps * mt.min_ss, mt.all_robust, (uint32_t)low_ok};
     }
 }
 
 // ---------------------------------------------------------------------------
 // Fill phase (transition_sink.py:109-125): copy the first L samples into the ring,
-// then sum them in the reference's order.  One wave; the sum is one lane.
+// then sum them in the reference's order.  One wave; the sum is one lane reading LDS.
 // ---------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(64) void k_fill(const void *in, uint32_t n, float i16_scale, int L, float *ring, Carry *carry) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lr = (float *)smem;
     const int lane = threadIdx.x;
     const int filled = carry->filled;
     const int can = min((int)n, L - filled);
     for (int i = lane; i < can; i += 64) ring[filled + i] = envelope_at<KIND>(in, (size_t)i, i16_scale);
     __syncthreads();
+    if (filled + can != L) {
+        if (lane == 0) carry->filled = filled + can;
+        return;
+    }
+    for (int i = lane; i < L; i += 64) lr[i] = ring[i];
+    __syncthreads();
     if (lane == 0) {
-        carry->filled = filled + can;
-        if (filled + can == L) {
-            double s = 0, err = 0;
-            for (int i = 0; i < L; i++) {
-                const double v = (double)ring[i];
-                const double t = s + v;            // transition_sink.py:122, sequential
-                const double bv = t - s;           // TwoSum residue: was the addition exact?
-                err += fabs((s - (t - bv)) + (v - bv));
-                s = t;
-            }
-            carry->ss = s;
-            carry->stable = 1;
-            if (err != 0.0) carry->inexact = 1;
+        double s = 0, err = 0;
+        for (int i = 0; i < L; i++) {
+            const double v = (double)lr[i];
+            const double t = s + v;            // transition_sink.py:122, sequential
+            const double bv = t - s;           // TwoSum residue: was the addition exact?
+            err += fabs((s - (t - bv)) + (v - bv));
+            s = t;
         }
+        carry->filled = L;
+        carry->ss = s;
+        carry->stable = 1;
+        if (err != 0.0) carry->inexact = 1;
     }
 }
 
@@ -608,40 +805,24 @@ __global__ __launch_bounds__(64) void k_prepare(const float *ring, int L, Carry 
 
 // After the passes converged: the ring at the end of the batch (look-back over all
 // chunks) and its sum become the carried state.
-struct FinArgs {
-    int32_t L, nchunks, twords;
-    const float *ring_carry;
-    float *ring_next;
-    float *ring_out[2];
-    uint32_t *touched[2];
-    const uint8_t *ver;
-    Carry *carry;
-};
-__global__ __launch_bounds__(64) void k_finalize_state(FinArgs A) {
+__global__ __launch_bounds__(64) void k_finalize_state(ThrArgs A, float *ring_next, Carry *carry) {
     const int lane = threadIdx.x;
     double part = 0;
     for (int s = lane; s < A.L; s += 64) {
-        int cc = A.nchunks - 1;
-        float v;
-        for (;;) {
-            if (cc < 0) { v = A.ring_carry[s]; break; }
-            const int vb = A.ver[cc];
-            const uint32_t w = A.touched[vb][(size_t)cc * A.twords + (s >> 5)];
-            if ((w >> (s & 31)) & 1u) { v = A.ring_out[vb][(size_t)cc * A.L + s]; break; }
-            cc--;
-        }
-        A.ring_next[s] = v;
+        const float v = resolve_slot(A, A.nchunks, s);
+        ring_next[s] = v;
         part += (double)v;
     }
     const double S = wave_sum_f64(part);
-    if (lane == 0) A.carry->ss = S + A.carry->delta;
+    if (lane == 0) carry->ss = S + carry->delta;
 }
 
 // ---------------------------------------------------------------------------
 // Literal sequential restatement of transition_sink.py:55-99 (classification part)
 // on ONE lane.  Used when the fp64 window sums cannot be proven exact (so the
-// summation order matters) and under NFC_FLAG_FORCE_SEQUENTIAL.  Slow by
-// construction; it carries the reference's own state variables.
+// summation order matters), for windows shorter than one step, and under
+// NFC_FLAG_FORCE_SEQUENTIAL.  Slow by construction; it carries the reference's own
+// state variables.
 // ---------------------------------------------------------------------------
 struct SeqArgs {
     const void *in;
@@ -652,7 +833,7 @@ struct SeqArgs {
     float *ring;   // carried ring, updated in place
     Carry *carry;
     int32_t state, last_bit, dur;   // transition_sink._current_state/_last_bit/_dur at the batch start
-    uint8_t *val;
+    uint64_t *neg, *pos;
 };
 template <int KIND>
 __global__ __launch_bounds__(64) void k_threshold_seq(SeqArgs A) {
@@ -661,7 +842,7 @@ __global__ __launch_bounds__(64) void k_threshold_seq(SeqArgs A) {
     double err = 0;
     int state = A.state, last_bit = A.last_bit, dur = A.dur;
     uint32_t slot = (A.g0modL + A.skip) % (uint32_t)A.L;
-    uint32_t code = 0;
+    unsigned long long wn = 0, wp = 0;
     const double Ld = (double)A.L;
     for (uint32_t m = 0; m < A.n; m++) {
         int v = 0;
@@ -687,10 +868,12 @@ __global__ __launch_bounds__(64) void k_threshold_seq(SeqArgs A) {
             else { dur = 1; last_bit = v; }
             if (dur > A.mx) { dur = 1; state = 0; }
         }
-        code |= (uint32_t)(v == 1 ? 1u : (v == -1 ? 2u : 0u)) << (2 * (m & 3));
-        if ((m & 3) == 3 || m + 1 == A.n) {
-            A.val[m >> 2] = (unsigned char)code;
-            code = 0;
+        if (v == -1) wn |= 1ull << (m & 63);
+        if (v == 1) wp |= 1ull << (m & 63);
+        if ((m & 63) == 63 || m + 1 == A.n) {
+            A.neg[m >> 6] = wn;
+            A.pos[m >> 6] = wp;
+            wn = wp = 0;
         }
     }
     A.carry->ss = ss;
