@@ -18,8 +18,8 @@
 namespace nfc {
 
 struct DecTables {
-    const uint64_t *mil_map;  // [(cur+1) * nd + d]
-    const uint32_t *man_map;
+    const uint4 *mil_map;     // [(cur+1) * nd + d]  16 states, one byte each
+    const uint2 *man_map;     //                      8 states, one byte each
     const uint8_t *mil_out;   // [((cur+1) * nd + d) * 16 + state]
     const uint8_t *man_out;   // [((cur+1) * nd + d) * 8 + state]
     int32_t nd;               // max_len + 1
@@ -32,69 +32,66 @@ struct DecCarry {
     uint32_t pending[2];  // bits of the open packet kept from earlier batches, per type
 };
 
-__device__ __forceinline__ int edge_lut_index(const nfc_edge &e, int nd) {
-    const int d = e.d < nd ? e.d : nd - 1;
-    return (e.v + 1) * nd + d;
-}
-
-// ---- pass 1: incoming decoder state of every edge ----------------------------
+// ---- pass 1: every edge as a pair of state maps; pass 2 visits it with its incoming states ----
+// Edges arrive as 16-bit codes (edges.hip.h: edge_code): LUT row | route << 14.
 struct LoadEdgeMaps {
-    const nfc_edge *edges;
+    const uint16_t *ecode;
     DecTables T;
     __device__ __forceinline__ DecMaps operator()(size_t i) const {
-        const nfc_edge e = edges[i];
-        DecMaps m{identity_map(16), (uint32_t)identity_map(8)};
-        const int li = edge_lut_index(e, T.nd);
-        if (e.t == 1 && T.reader) m.mil = T.mil_map[li];
-        else if (e.t == 0 && T.tag) m.man = T.man_map[li];
+        const uint32_t c = ecode[i];
+        const uint32_t li = c & 0x3FFFu, route = c >> 14;
+        DecMaps m = ComposeDec::identity();
+        if (route == 2u && T.reader) {
+            const uint4 v = T.mil_map[li];
+            m.mil[0] = v.x; m.mil[1] = v.y; m.mil[2] = v.z; m.mil[3] = v.w;
+        } else if (route == 1u && T.tag) {
+            const uint2 v = T.man_map[li];
+            m.man[0] = v.x; m.man[1] = v.y;
+        }
         return m;
     }
 };
-struct StoreEdgeStates {
-    uint8_t *states;  // mil | man << 4
-    int32_t mil0, man0;
-    __device__ __forceinline__ void operator()(size_t i, DecMaps excl, DecMaps) const {
-        const uint32_t ms = (uint32_t)(excl.mil >> (4 * mil0)) & 15u;
-        const uint32_t ts = (excl.man >> (4 * man0)) & 15u;
-        states[i] = (uint8_t)(ms | (ts << 4));
+// What an edge emits, one byte: bits 0-1 = 0 nothing, 1 / 2 Miller symbols, 3 one Manchester symbol;
+// bits 2-4 first symbol, bits 5-7 second symbol.
+struct VisitEdgeOut {
+    const uint16_t *ecode;
+    DecTables T;
+    uint8_t *outw;
+    __device__ __forceinline__ void operator()(size_t i, uint32_t st, const DecMaps &) const {
+        const uint32_t c = ecode[i];
+        const uint32_t li = c & 0x3FFFu, route = c >> 14;
+        uint8_t w = 0;
+        if (route == 2u && T.reader) w = T.mil_out[(size_t)li * 16 + (st & 15u)];
+        else if (route == 1u && T.tag) {
+            const uint8_t m = T.man_out[(size_t)li * 8 + ((st >> 4) & 7u)];
+            w = (m & 3u) ? (uint8_t)((m & 0xFCu) | 3u) : (uint8_t)0;
+        }
+        outw[i] = w;
     }
 };
 
-// ---- pass 2: symbols ------------------------------------------------------------
+// ---- symbols ---------------------------------------------------------------------
 // count word: Miller symbols in the low half, Manchester in the high half
-__device__ __forceinline__ uint8_t edge_out_word(const nfc_edge &e, uint8_t st, const DecTables &T, int &type) {
-    const int li = edge_lut_index(e, T.nd);
-    if (e.t == 1 && T.reader) { type = 1; return T.mil_out[(size_t)li * 16 + (st & 15)]; }
-    if (e.t == 0 && T.tag) { type = 0; return T.man_out[(size_t)li * 8 + ((st >> 4) & 7)]; }
-    type = -1;
-    return 0;
-}
 struct LoadSymCounts {
-    const nfc_edge *edges;
-    const uint8_t *states;
-    DecTables T;
+    const uint8_t *outw;
     __device__ __forceinline__ uint64_t operator()(size_t i) const {
-        int type;
-        const uint8_t w = edge_out_word(edges[i], states[i], T, type);
-        const uint64_t n = w & 3u;
-        return type == 1 ? n : (type == 0 ? (n << 32) : 0ull);
+        const uint32_t k = outw[i] & 3u;
+        return k == 3u ? (1ull << 32) : (uint64_t)k;
     }
 };
 struct StoreSymbols {
-    const nfc_edge *edges;
-    const uint8_t *states;
-    DecTables T;
+    const uint8_t *outw;
     uint8_t *sym[2];   // [0] Manchester / tag, [1] Miller / reader
     uint32_t *src[2];  // index of the producing edge
     __device__ __forceinline__ void operator()(size_t i, uint64_t excl, uint64_t) const {
-        int type;
-        const uint8_t w = edge_out_word(edges[i], states[i], T, type);
-        const int n = w & 3;
-        if (type < 0 || n == 0) return;
+        const uint8_t w = outw[i];
+        const uint32_t k = w & 3u;
+        if (k == 0) return;
+        const int type = (k == 3u) ? 0 : 1;
         const uint32_t off = type == 1 ? (uint32_t)excl : (uint32_t)(excl >> 32);
         sym[type][off] = (w >> 2) & 7u;
         src[type][off] = (uint32_t)i;
-        if (n > 1) {
+        if (k == 2u) {
             sym[type][off + 1] = (w >> 5) & 7u;
             src[type][off + 1] = (uint32_t)i;
         }
@@ -102,7 +99,7 @@ struct StoreSymbols {
 };
 
 // ---- framing: PacketProcessor.append_bit (packets.py:67-79) ---------------------
-// state 0 = not started, 1 = started
+// state 0 = not started, 1 = started; nibble map
 __device__ __forceinline__ uint32_t pkt_map(uint8_t s, int start_bit) {
     if (s > 1) return 0x00u;                       // error symbol: started -> not started, not started stays
     if ((int)s == start_bit) return 0x11u;         // start bit: not started -> started (dropped); started stays
@@ -113,45 +110,43 @@ struct LoadPktMaps {
     int start_bit;
     __device__ __forceinline__ uint32_t operator()(size_t i) const { return pkt_map(sym[i], start_bit); }
 };
-struct StorePktStarted {
-    uint8_t *started;
-    int32_t started0;
-    __device__ __forceinline__ void operator()(size_t i, uint32_t excl, uint32_t) const {
-        started[i] = (uint8_t)((excl >> (4 * started0)) & 1u);
+// per symbol: bit 0 = appended to the packet, bit 1 = closes a started packet
+struct VisitPktFlags {
+    const uint8_t *sym;
+    int start_bit;
+    uint8_t *pflags;
+    __device__ __forceinline__ void operator()(size_t i, uint32_t started, uint32_t) const {
+        const uint8_t s = sym[i];
+        uint8_t f;
+        if (s > 1) f = started ? 2 : 0;
+        else f = (!started && (int)s == start_bit) ? 0 : 1;
+        pflags[i] = f;
     }
 };
 // count word: appended bits in the low half, closes in the high half
 struct LoadPktCounts {
-    const uint8_t *sym;
-    const uint8_t *started;
-    int start_bit;
+    const uint8_t *pflags;
     __device__ __forceinline__ uint64_t operator()(size_t i) const {
-        const uint8_t s = sym[i];
-        const bool st = started[i];
-        if (s > 1) return st ? (1ull << 32) : 0ull;
-        return (!st && (int)s == start_bit) ? 0ull : 1ull;
+        const uint32_t f = pflags[i];
+        return (uint64_t)(f & 1u) | ((uint64_t)(f >> 1) << 32);
     }
 };
 struct StorePkt {
     const uint8_t *sym;
-    const uint8_t *started;
+    const uint8_t *pflags;
     const uint32_t *src;
     const nfc_edge *edges;
-    int start_bit;
     uint8_t *bits;       // appended bits, starting with the pending ones of earlier batches
     uint32_t *close_end; // per close: number of bits appended before it (= end offset of the packet)
     uint64_t *close_idx; // per close: sample index of the closing edge
     __device__ __forceinline__ void operator()(size_t i, uint64_t excl, uint64_t) const {
-        const uint8_t s = sym[i];
-        const bool st = started[i];
-        if (s > 1) {
-            if (st) {
-                const uint32_t k = (uint32_t)(excl >> 32);
-                close_end[k] = (uint32_t)excl;
-                close_idx[k] = edges[src[i]].idx;
-            }
-        } else if (st || (int)s != start_bit) {
-            bits[(uint32_t)excl] = s;
+        const uint32_t f = pflags[i];
+        if (f & 2u) {
+            const uint32_t k = (uint32_t)(excl >> 32);
+            close_end[k] = (uint32_t)excl;
+            close_idx[k] = edges[src[i]].idx;
+        } else if (f & 1u) {
+            bits[(uint32_t)excl] = sym[i];
         }
     }
 };
@@ -182,8 +177,9 @@ __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
 // Decoder states after the batch, from the total of the map scan.
 __global__ void k_dec_carry(const DecMaps *total, DecCarry *carry) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    carry->mil_state = (int32_t)((total->mil >> (4 * carry->mil_state)) & 15u);
-    carry->man_state = (int32_t)((total->man >> (4 * carry->man_state)) & 15u);
+    const uint32_t st = ComposeDec::step(*total, (uint32_t)carry->mil_state | ((uint32_t)carry->man_state << 4));
+    carry->mil_state = (int32_t)(st & 15u);
+    carry->man_state = (int32_t)(st >> 4);
 }
 
 }  // namespace nfc

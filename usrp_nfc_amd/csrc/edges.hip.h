@@ -1,14 +1,17 @@
-// edges.hip.h -- run-length / edge timing (transition_sink.py:84-99) from the
-// per-sample classification codes, as a run-level data-parallel computation.
+// edges.hip.h -- run-length / edge timing (transition_sink.py:84-99) from the classification
+// bit planes, one thread per 64-sample word.
 //
-// The reference walks samples keeping (_last_bit, _dur, _current_state).  Grouping
-// samples into maximal runs of equal val makes every emission a closed form of at
-// most the two previous runs (see DESIGN.md "edge stage"):
-//   * a run start emits ((v, d*factor), t) with d = max_len if the state after the
-//     previous run is 0 else the previous run's length folded by the time-outs;
-//   * inside a run of length l, time-outs fire at positions j*max_len + 1.
-// Run 0 is virtual: it continues the previous batch (start = first stable sample -
-// carried _dur, value = carried _last_bit, state = carried _current_state).
+// The reference walks samples keeping (_last_bit, _dur, _current_state).  Those three values at any
+// sample are a closed form of the last two positions where val changed (and of the carried values
+// when fewer than two changes precede it):
+//   _last_bit        = val at the last change
+//   _dur             = ((samples since that change - 1) mod max_len) + 1     (time-outs restart it)
+//   _current_state   = 2 / 1 inside a LOW / HIGH run unless its latest sample fired a time-out;
+//                      inside a val-0 run: 0 once the run is longer than max_len, else whatever
+//                      the previous run left (which, being a LOW/HIGH run, depends on its length only)
+// So an ordered scan hands every word the last two change positions before it; the word's thread then
+// replays the reference loop over its 64 samples, jumping from event to event (val change or
+// time-out), first to count its entries, then -- after a prefix sum -- to write them.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,101 +26,41 @@ struct EdgeCarry {
     int32_t pad;
 };
 
-__host__ __device__ __forceinline__ int code_to_val(uint32_t c) { return c == 1u ? 1 : (c == 2u ? -1 : 0); }
-__host__ __device__ __forceinline__ uint32_t val_to_code(int v) { return v == 1 ? 1u : (v == -1 ? 2u : 0u); }
+constexpr int32_t POS_NONE = INT32_MIN;
 
-struct RunView {
-    const uint32_t *starts;  // starts[k-1] = first sample of real run k (k >= 1)
-    const uint64_t *neg, *pos;  // classification bit planes (LOW / HIGH), 64 samples per word
-    uint32_t nruns;          // real runs
-    uint32_t n;              // samples in the batch
-    int32_t skip;            // first stable sample
-    int32_t mx;
-    int32_t dur_in, last_bit_in, state_in;
-
-    __device__ __forceinline__ long long start(uint32_t k) const {
-        return k == 0 ? (long long)skip - dur_in : (long long)starts[k - 1];
+struct Last2 {   // the two most recent positions (batch-local sample indices) where val changed
+    int32_t s1, s2;
+};
+struct Last2Op {
+    using T = Last2;
+    static __host__ __device__ __forceinline__ T identity() { return T{POS_NONE, POS_NONE}; }
+    static T identity_host() { return identity(); }
+    static __device__ __forceinline__ T op(T a, T b) {
+        if (b.s1 == POS_NONE) return a;
+        if (b.s2 == POS_NONE) return T{b.s1, a.s1};
+        return b;
     }
-    __device__ __forceinline__ long long end(uint32_t k) const { return k < nruns ? (long long)starts[k] : (long long)n; }
-    __device__ __forceinline__ int value(uint32_t k) const {
-        if (k == 0) return last_bit_in;
-        const uint32_t s = starts[k - 1];
-        if ((neg[s >> 6] >> (s & 63)) & 1ull) return -1;
-        return (int)((pos[s >> 6] >> (s & 63)) & 1ull);
-    }
-    __device__ __forceinline__ bool virt_empty() const { return nruns >= 1 && (int32_t)starts[0] == skip; }
-    // state after the first sample of run k
-    __device__ __forceinline__ int state_in_run(uint32_t k) const {
-        const int v = value(k);
-        if (v == -1) return 2;
-        if (v == 1) return 1;
-        if (k == 0) return state_in;
-        return state_after(k - 1);
-    }
-    // state after the last sample of run k (transition_sink.py:95-99 resets it on a time-out)
-    __device__ int state_after(uint32_t k) const {
-        if (k == 0 && virt_empty()) return state_in;
-        const long long l = end(k) - start(k);
-        const int v = value(k);
-        if (v == 0) {
-            if (l >= (long long)mx + 1) return 0;
-            if (k == 0) return state_in;
-            // a zero run follows a non-zero run (or the virtual run), whose state needs no further look-back
-            return state_after_nonzero(k - 1);
-        }
-        return (l > 1 && (l - 1) % mx == 0) ? 0 : (v == -1 ? 2 : 1);
-    }
-    __device__ __forceinline__ int state_after_nonzero(uint32_t k) const {
-        if (k == 0 && virt_empty()) return state_in;
-        const long long l = end(k) - start(k);
-        const int v = value(k);
-        if (v == 0) {  // only the virtual run can be a zero run here
-            return (l >= (long long)mx + 1) ? 0 : state_in;
-        }
-        return (l > 1 && (l - 1) % mx == 0) ? 0 : (v == -1 ? 2 : 1);
-    }
-    __device__ __forceinline__ uint32_t emissions(uint32_t k) const {
-        const long long l = end(k) - start(k);
-        const uint32_t nt = l > 0 ? (uint32_t)((l - 1) / mx) : 0u;
-        return (k >= 1 ? 1u : 0u) + nt;
-    }
-    // e-th emission of run k (0-based; for k >= 1 emission 0 is the run start)
-    __device__ void emission(uint32_t k, uint32_t e, uint64_t g0, nfc_edge &out) const {
-        const int v = value(k);
-        if (k >= 1 && e == 0) {
-            const int lb = value(k - 1);
-            const int ps = state_after(k - 1);
-            const int cs = (v == -1) ? 2 : (v == 1 ? 1 : ps);
-            const long long lp = end(k - 1) - start(k - 1);
-            const int durp = lp <= 0 ? 0 : (int)((lp - 1) % mx) + 1;
-            out.idx = g0 + (uint64_t)start(k);
-            out.d = (ps == 0) ? mx : durp;                   // transition_sink.py:87
-            out.v = (int8_t)(cs == 2 ? lb + 1 : lb);        // transition_sink.py:88
-            out.t = (int8_t)(cs - 1);
-            out.pad = 0;
-            return;
-        }
-        const uint32_t j = (k >= 1) ? e : e + 1;  // time-out number, 1-based
-        int cs;
-        if (v == -1) cs = 2;
-        else if (v == 1) cs = 1;
-        else cs = (j == 1) ? state_in_run(k) : 0;
-        out.idx = g0 + (uint64_t)(start(k) + (long long)j * mx);
-        out.d = mx;                                          // transition_sink.py:97
-        out.v = (int8_t)(cs == 2 ? v + 1 : v);
-        out.t = (int8_t)(cs - 1);
-        out.pad = 0;
+    static __device__ __forceinline__ T shfl_up(T v, int d) {
+        return T{__shfl_up(v.s1, d, 64), __shfl_up(v.s2, d, 64)};
     }
 };
 
-// ---- run starts -------------------------------------------------------------
-// 64 samples per word in two bit planes; a sample whose (neg, pos) differs from its predecessor's starts a run.
-struct ChangeMask {
-    const uint64_t *neg, *pos;
-    uint32_t n, skip;
-    int32_t last_bit_in;  // carried _last_bit
-    __device__ __forceinline__ uint64_t mask(size_t w) const {
-        const uint64_t ng = neg[w], ps = pos[w];
+struct EdgeArgs {
+    const uint64_t *neg, *pos;  // classification bit planes (LOW / HIGH), 64 samples per word
+    uint32_t n, skip;           // samples in the batch; samples before skip belong to the fill phase
+    int32_t mx;
+    int32_t dur_in, last_bit_in, state_in;   // carried _dur / _last_bit / _current_state
+    int32_t nd;                 // max_len + 1 (decoder LUT row length)
+    uint64_t g0;                // global index of batch sample 0
+
+    __device__ __forceinline__ int val_at(int32_t p) const {
+        if ((neg[p >> 6] >> (p & 63)) & 1ull) return -1;
+        return (int)((pos[p >> 6] >> (p & 63)) & 1ull);
+    }
+    // samples of word w whose val differs from the previous sample's (run starts), within [skip, n)
+    __device__ __forceinline__ uint64_t change_mask(size_t w, uint64_t &ng, uint64_t &ps) const {
+        ng = neg[w];
+        ps = pos[w];
         uint64_t pn, pp;
         if (w == 0) {
             pn = last_bit_in == -1 ? 1ull : 0ull;
@@ -127,79 +70,163 @@ struct ChangeMask {
             pp = pos[w - 1] >> 63;
         }
         uint64_t m = (ng ^ ((ng << 1) | pn)) | (ps ^ ((ps << 1) | pp));
-        // keep samples whose index is in [skip, n)
         const long long first = (long long)w * 64;
         const long long lo = (long long)skip - first, hi = (long long)n - first;
         if (lo > 0) m &= (lo >= 64) ? 0ull : (~0ull << lo);
         if (hi < 64) m &= (hi <= 0) ? 0ull : (~0ull >> (64 - hi));
         return m;
     }
+    __device__ __forceinline__ int run_state(int v, int len) const {   // after `len` samples of a LOW / HIGH run
+        return (len > 1 && (len - 1) % mx == 0) ? 0 : (v == -1 ? 2 : 1);
+    }
+    // (_last_bit, _dur, _current_state) after sample p - 1, given the last two change positions before p
+    __device__ __forceinline__ void state_before(int32_t p, Last2 c, int &lb, int &dur, int &st) const {
+        if (c.s1 == POS_NONE) {                       // still in the run carried into the batch
+            lb = last_bit_in;
+            if (p <= (int32_t)skip) { dur = dur_in; st = state_in; return; }
+            const int len = p - ((int32_t)skip - dur_in);
+            dur = ((len - 1) % mx) + 1;
+            if (lb == 0) st = (len >= mx + 1) ? 0 : state_in;
+            else st = run_state(lb, len);
+            return;
+        }
+        lb = val_at(c.s1);
+        const int len = p - c.s1;
+        dur = ((len - 1) % mx) + 1;
+        if (lb != 0) { st = run_state(lb, len); return; }
+        if (len >= mx + 1) { st = 0; return; }
+        // a short val-0 run keeps what the previous (LOW / HIGH, possibly carried) run left
+        if (c.s2 != POS_NONE) { st = run_state(val_at(c.s2), c.s1 - c.s2); return; }
+        if (c.s1 == (int32_t)skip) { st = state_in; return; }      // the carried run had no sample in this batch
+        const int len0 = c.s1 - ((int32_t)skip - dur_in);
+        if (last_bit_in == 0) st = (len0 >= mx + 1) ? 0 : state_in;
+        else st = run_state(last_bit_in, len0);
+    }
 };
-struct LoadChangeCount {
-    ChangeMask cm;
-    __device__ __forceinline__ uint32_t operator()(size_t w) const { return (uint32_t)__popcll(cm.mask(w)); }
-};
-struct StoreRunStarts {
-    ChangeMask cm;
-    uint32_t *starts;
-    __device__ __forceinline__ void operator()(size_t w, uint32_t excl, uint32_t /*cnt*/) const {
-        uint64_t m = cm.mask(w);
-        uint32_t k = excl;
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            starts[k++] = (uint32_t)(w * 64 + b);
+
+// Replay transition_sink.py:84-99 over word w from event to event.  emit(sample, v, d, t) per entry.
+template <class Emit>
+__device__ __forceinline__ uint32_t replay_word(const EdgeArgs &A, size_t w, Last2 ctx, Emit emit) {
+    const int32_t w0 = (int32_t)(w * 64);
+    const int32_t lo = max(w0, (int32_t)A.skip), hi = min(w0 + 64, (int32_t)A.n);
+    if (lo >= hi) return 0;
+    uint64_t ng, ps;
+    uint64_t m = A.change_mask(w, ng, ps);
+    int lb, dur, st;
+    A.state_before(lo, ctx, lb, dur, st);
+    const int mx = A.mx;
+    uint32_t cnt = 0;
+    int32_t p = lo;
+    while (p < hi) {
+        const int32_t nc = m ? w0 + (__ffsll((long long)m) - 1) : hi;
+        if (nc == p) {   // val changes at p (transition_sink.py:86-92)
+            const int b = p - w0;
+            const int v = ((ng >> b) & 1ull) ? -1 : (int)((ps >> b) & 1ull);
+            const int prev_st = st;
+            if (v == -1) st = 2;
+            else if (v == 1) st = 1;
+            emit(p, (st == 2) ? lb + 1 : lb, (prev_st == 0) ? mx : dur, st - 1);
+            cnt++;
+            dur = 1;
+            lb = v;
             m &= m - 1;
+            p++;
+            continue;
+        }
+        int nrem = nc - p;   // samples that continue the run
+        while (nrem > 0) {
+            const int t = mx + 1 - dur;   // samples until _dur exceeds max_len (transition_sink.py:95-99)
+            if (t <= nrem) {
+                const int cs = (lb == -1) ? 2 : ((lb == 1) ? 1 : st);
+                emit(p + t - 1, (cs == 2) ? lb + 1 : lb, mx, cs - 1);
+                cnt++;
+                dur = 1;
+                st = 0;
+                p += t;
+                nrem -= t;
+            } else {
+                dur += nrem;
+                if (lb == -1) st = 2;
+                else if (lb == 1) st = 1;
+                p += nrem;
+                nrem = 0;
+            }
         }
     }
-};
-
-// ---- emission counts per run, then one thread per edge ---------------------------
-struct LoadEmissionCount {
-    RunView rv;
-    __device__ __forceinline__ uint32_t operator()(size_t k) const { return rv.emissions((uint32_t)k); }
-};
-struct StoreEmissionOffset {
-    uint32_t *offs;
-    __device__ __forceinline__ void operator()(size_t k, uint32_t excl, uint32_t) const { offs[k] = excl; }
-};
-
-constexpr int EDGE_ITEMS = 4;
-__global__ __launch_bounds__(256) void k_write_edges(RunView rv, const uint32_t *offs, uint32_t nedges, uint64_t g0,
-                                                      nfc_edge *edges) {
-    const uint32_t e0 = (blockIdx.x * 256u + threadIdx.x) * EDGE_ITEMS;
-    if (e0 >= nedges) return;
-    // last run whose offset <= e0  (offs has nruns+1 entries, ascending; empty runs share an offset)
-    uint32_t lo = 0, hi = rv.nruns + 1;  // search in [lo, hi)
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (offs[mid] <= e0) lo = mid; else hi = mid;
-    }
-    uint32_t k = lo;
-    uint32_t cnt = rv.emissions(k);
-    uint32_t base = offs[k];
-    for (int i = 0; i < EDGE_ITEMS; i++) {
-        const uint32_t e = e0 + i;
-        if (e >= nedges) break;
-        while (e - base >= cnt) {  // advance to the run that owns edge e
-            k++;
-            base = offs[k];
-            cnt = rv.emissions(k);
-        }
-        nfc_edge out;
-        rv.emission(k, e - base, g0, out);
-        edges[e] = out;
-    }
+    return cnt;
 }
 
-// carried (_last_bit, _dur, _current_state) after the batch
-__global__ void k_edge_carry(RunView rv, EdgeCarry *carry) {
+// ---- scan 1: last two change positions before every word; its apply also counts the word's entries ----
+struct LoadLast2 {
+    EdgeArgs A;
+    __device__ __forceinline__ Last2 operator()(size_t w) const {
+        uint64_t ng, ps;
+        const uint64_t m = A.change_mask(w, ng, ps);
+        if (!m) return Last2{POS_NONE, POS_NONE};
+        const int b1 = 63 - __clzll((long long)m);
+        const uint64_t m2 = m & ~(1ull << b1);
+        return Last2{(int32_t)(w * 64) + b1, m2 ? (int32_t)(w * 64) + (63 - __clzll((long long)m2)) : POS_NONE};
+    }
+};
+struct StoreCtxAndCount {
+    EdgeArgs A;
+    Last2 *ctx;
+    uint32_t *cnt;
+    __device__ __forceinline__ void operator()(size_t w, Last2 excl, Last2) const {
+        ctx[w] = excl;
+        cnt[w] = replay_word(A, w, excl, [](int32_t, int, int, int) {});
+    }
+};
+
+// ---- scan 2: where each word's entries go; its apply writes them -------------------------
+struct LoadWordCount {
+    const uint32_t *cnt;
+    __device__ __forceinline__ uint32_t operator()(size_t w) const { return cnt[w]; }
+};
+// per edge, for the decoders: LUT row (v + 1) * nd + d in the low 14 bits, route in the top two
+// (0 dropped, 1 Manchester / tag->reader, 2 Miller / reader->tag; background.py:30-35)
+__device__ __forceinline__ uint16_t edge_code(int v, int d, int t, int nd) {
+    const int dd = d < nd ? d : nd - 1;
+    return (uint16_t)(((v + 1) * nd + dd) | ((t + 1) << 14));
+}
+struct StoreWordEdges {
+    EdgeArgs A;
+    const Last2 *ctx;
+    nfc_edge *edges;
+    uint16_t *ecode;
+    uint32_t cap;
+    __device__ __forceinline__ void operator()(size_t w, uint32_t excl, uint32_t count) const {
+        if (!count) return;
+        uint32_t k = excl;
+        const EdgeArgs &a = A;
+        nfc_edge *e = edges;
+        uint16_t *ec = ecode;
+        const uint32_t cp = cap;
+        replay_word(A, w, ctx[w], [&](int32_t p, int v, int d, int t) {
+            if (k < cp) {
+                nfc_edge o;
+                o.idx = a.g0 + (uint64_t)p;
+                o.d = d;
+                o.v = (int8_t)v;
+                o.t = (int8_t)t;
+                o.pad = 0;
+                e[k] = o;
+                ec[k] = edge_code(v, d, t, a.nd);
+            }
+            k++;
+        });
+    }
+};
+
+// carried (_last_bit, _dur, _current_state) after the batch, from the scan-1 total
+__global__ void k_edge_carry(EdgeArgs A, const Last2 *total, EdgeCarry *carry) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if ((uint32_t)rv.skip >= rv.n) return;  // nothing but fill samples: unchanged
-    const uint32_t k = rv.nruns;
-    const long long l = rv.end(k) - rv.start(k);
-    carry->last_bit = rv.value(k);
-    carry->dur = l <= 0 ? 0 : (int)((l - 1) % rv.mx) + 1;
-    carry->state = rv.state_after(k);
+    if (A.skip >= A.n) return;  // nothing but fill samples: unchanged
+    int lb, dur, st;
+    A.state_before((int32_t)A.n, *total, lb, dur, st);
+    carry->last_bit = lb;
+    carry->dur = dur;
+    carry->state = st;
 }
 
 }  // namespace nfc

@@ -96,9 +96,10 @@ struct nfc_ctx {
     DevBuf d_certinfo;
     DevBuf d_in, d_neg, d_pos, d_ringout[2], d_touched[2], d_info[2], d_ringin, d_meta, d_ver, d_cert, d_gmin, d_gmax,
         d_gflags, d_list;
+    DevBuf d_ctx, d_wcnt, d_ecode;
     DevBuf d_starts, d_offs, d_edges, d_states, d_sym[2], d_src[2], d_started, d_bits[2], d_pending[2], d_close_end[2],
         d_close_idx[2];
-    DevBuf d_partials, d_totals;  // scan scratch; totals: small device scalars
+    DevBuf d_partials, d_aggs, d_totals;  // scan scratch; totals: small device scalars
     std::vector<uint8_t> h_ver, h_cert, h_gmin, h_gmax, h_gflags;
     std::vector<uint32_t> h_list;
 
@@ -139,12 +140,13 @@ int fail(nfc_ctx *c, int code, const char *fmt, ...) {
 enum : int {
     TOT_RUNS = 0,       // u32
     TOT_EDGES = 8,      // u32
-    TOT_DECMAP = 16,    // DecMaps (16 bytes)
-    TOT_SYMS = 32,      // u64: miller | manchester << 32
-    TOT_PKTMAP0 = 40,   // u32
-    TOT_PKTMAP1 = 48,   // u32
-    TOT_PKT0 = 56,      // u64: bits | closes << 32
-    TOT_PKT1 = 64,
+    TOT_DECMAP = 16,    // DecMaps (24 bytes)
+    TOT_SYMS = 48,      // u64: miller | manchester << 32
+    TOT_PKTMAP0 = 56,   // u32
+    TOT_PKTMAP1 = 64,   // u32
+    TOT_PKT0 = 72,      // u64: bits | closes << 32
+    TOT_PKT1 = 80,
+    TOT_LAST2 = 88,     // Last2 (8 bytes)
     TOT_BYTES = 128
 };
 
@@ -427,45 +429,37 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
 int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     uint8_t *tot = c->d_totals.as<uint8_t>();
     const size_t nwords = ((size_t)n + 63) / 64;
-    ChangeMask cm{c->d_neg.as<uint64_t>(), c->d_pos.as<uint64_t>(), n, skip, c->h_ecarry.last_bit};
-    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<8>(nwords) + 1) * sizeof(uint32_t)));
-    scan_phase1<AddU32, 8>(c->st, nwords, LoadChangeCount{cm}, 0u, c->d_partials.as<uint32_t>(), (uint32_t *)(tot + TOT_RUNS));
-    uint32_t nruns = 0;
-    HIPCHK(c, hipMemcpyAsync(&nruns, tot + TOT_RUNS, 4, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    c->n_runs = nruns;
-    HIPCHK(c, c->d_starts.ensure(((size_t)nruns + 1) * 4));
-    scan_phase2<AddU32, 8>(c->st, nwords, LoadChangeCount{cm}, StoreRunStarts{cm, c->d_starts.as<uint32_t>()},
-                           c->d_partials.as<uint32_t>());
-
-    RunView rv;
-    rv.starts = c->d_starts.as<uint32_t>();
-    rv.neg = c->d_neg.as<uint64_t>();
-    rv.pos = c->d_pos.as<uint64_t>();
-    rv.nruns = nruns;
-    rv.n = n;
-    rv.skip = (int32_t)skip;
-    rv.mx = c->mx;
-    rv.dur_in = c->h_ecarry.dur;
-    rv.last_bit_in = c->h_ecarry.last_bit;
-    rv.state_in = c->h_ecarry.state;
-
-    const size_t nitems = (size_t)nruns + 1;  // virtual run + real runs
-    HIPCHK(c, c->d_offs.ensure((nitems + 1) * 4));
-    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<4>(nitems) + 1) * sizeof(uint32_t)));
-    device_scan<AddU32, 4>(c->st, nitems, LoadEmissionCount{rv}, StoreEmissionOffset{c->d_offs.as<uint32_t>()}, 0u,
-                           c->d_partials.as<uint32_t>(), (uint32_t *)(tot + TOT_EDGES));
+    EdgeArgs E;
+    E.neg = c->d_neg.as<uint64_t>();
+    E.pos = c->d_pos.as<uint64_t>();
+    E.n = n;
+    E.skip = skip;
+    E.mx = c->mx;
+    E.dur_in = c->h_ecarry.dur;
+    E.last_bit_in = c->h_ecarry.last_bit;
+    E.state_in = c->h_ecarry.state;
+    E.nd = c->mx + 1;
+    E.g0 = g0;
+    HIPCHK(c, c->d_ctx.ensure((nwords + 1) * sizeof(Last2)));
+    HIPCHK(c, c->d_wcnt.ensure((nwords + 1) * 4));
+    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<4>(nwords) + 1) * sizeof(Last2)));
+    Last2 *ctx = c->d_ctx.as<Last2>();
+    uint32_t *wcnt = c->d_wcnt.as<uint32_t>();
+    // scan 1: the two latest val changes before every 64-sample word; each word then counts its entries
+    device_scan<Last2Op, 4>(c->st, nwords, LoadLast2{E}, StoreCtxAndCount{E, ctx, wcnt}, Last2Op::identity(),
+                            c->d_partials.as<Last2>(), (Last2 *)(tot + TOT_LAST2));
+    // scan 2: entry offsets; then every word writes its entries
+    scan_phase1<AddU32, 8>(c->st, nwords, LoadWordCount{wcnt}, 0u, c->d_partials.as<uint32_t>(), (uint32_t *)(tot + TOT_EDGES));
     uint32_t nedges = 0;
     HIPCHK(c, hipMemcpyAsync(&nedges, tot + TOT_EDGES, 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     c->n_edges = nedges;
     HIPCHK(c, c->d_edges.ensure(((size_t)nedges + 1) * sizeof(nfc_edge)));
-    if (nedges) {
-        const uint32_t per = 256 * EDGE_ITEMS;
-        hipLaunchKernelGGL(k_write_edges, dim3((nedges + per - 1) / per), dim3(256), 0, c->st, rv, c->d_offs.as<uint32_t>(), nedges,
-                           g0, c->d_edges.as<nfc_edge>());
-    }
-    hipLaunchKernelGGL(k_edge_carry, dim3(1), dim3(64), 0, c->st, rv, c->d_ecarry.as<EdgeCarry>());
+    HIPCHK(c, c->d_ecode.ensure(((size_t)nedges + 8) * 2));
+    scan_phase2<AddU32, 8>(c->st, nwords, LoadWordCount{wcnt},
+                           StoreWordEdges{E, ctx, c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), nedges},
+                           c->d_partials.as<uint32_t>());
+    hipLaunchKernelGGL(k_edge_carry, dim3(1), dim3(64), 0, c->st, E, (const Last2 *)(tot + TOT_LAST2), c->d_ecarry.as<EdgeCarry>());
     return NFC_OK;
 }
 
@@ -476,21 +470,22 @@ int run_decode(nfc_ctx *c) {
     uint8_t *tot = c->d_totals.as<uint8_t>();
     const uint32_t ne = c->n_edges;
     const nfc_edge *edges = c->d_edges.as<nfc_edge>();
-    HIPCHK(c, c->d_states.ensure((size_t)ne + 16));
+    constexpr int DI = 16;  // edges per thread in the decoder-state scan
+    HIPCHK(c, c->d_states.ensure((size_t)ne + 16));   // one out-word per edge
     HIPCHK(c, c->d_sym[1].ensure((size_t)2 * ne + 16));
     HIPCHK(c, c->d_src[1].ensure(((size_t)2 * ne + 16) * 4));
     HIPCHK(c, c->d_sym[0].ensure((size_t)ne + 16));
     HIPCHK(c, c->d_src[0].ensure(((size_t)ne + 16) * 4));
     HIPCHK(c, c->d_partials.ensure((scan_num_tiles<4>(ne) + 1) * sizeof(DecMaps)));
+    HIPCHK(c, c->d_aggs.ensure((fsm_num_threads<DI>(ne) + 1) * sizeof(DecMaps)));
 
-    DecMaps idm{identity_map(16), (uint32_t)identity_map(8)};
-    device_scan<ComposeDec, 4>(c->st, ne, LoadEdgeMaps{edges, c->T},
-                               StoreEdgeStates{c->d_states.as<uint8_t>(), c->h_dcarry.mil_state, c->h_dcarry.man_state}, idm,
-                               c->d_partials.as<DecMaps>(), (DecMaps *)(tot + TOT_DECMAP));
-    StoreSymbols ss{edges, c->d_states.as<uint8_t>(), c->T, {c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()},
+    uint8_t *outw = c->d_states.as<uint8_t>();
+    device_fsm_scan<ComposeDec, DI>(c->st, ne, LoadEdgeMaps{c->d_ecode.as<uint16_t>(), c->T}, VisitEdgeOut{c->d_ecode.as<uint16_t>(), c->T, outw},
+                                    (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4),
+                                    c->d_partials.as<DecMaps>(), c->d_aggs.as<DecMaps>(), (DecMaps *)(tot + TOT_DECMAP));
+    StoreSymbols ss{outw, {c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()},
                     {c->d_src[0].as<uint32_t>(), c->d_src[1].as<uint32_t>()}};
-    device_scan<AddU64, 4>(c->st, ne, LoadSymCounts{edges, c->d_states.as<uint8_t>(), c->T}, ss, 0ull,
-                           c->d_partials.as<uint64_t>(), (uint64_t *)(tot + TOT_SYMS));
+    device_scan<AddU64, 8>(c->st, ne, LoadSymCounts{outw}, ss, 0ull, c->d_partials.as<uint64_t>(), (uint64_t *)(tot + TOT_SYMS));
     hipLaunchKernelGGL(k_dec_carry, dim3(1), dim3(64), 0, c->st, (const DecMaps *)(tot + TOT_DECMAP), c->d_dcarry.as<DecCarry>());
     uint64_t nsyms = 0;
     HIPCHK(c, hipMemcpyAsync(&nsyms, tot + TOT_SYMS, 8, hipMemcpyDeviceToHost, c->st));
@@ -498,6 +493,7 @@ int run_decode(nfc_ctx *c) {
     c->n_sym[1] = (uint32_t)nsyms;
     c->n_sym[0] = (uint32_t)(nsyms >> 32);
 
+    constexpr int PI = 16;
     for (int t = 0; t < 2; t++) {
         const uint32_t ns = c->n_sym[t];
         const uint32_t pend = c->h_dcarry.pending[t];
@@ -508,17 +504,18 @@ int run_decode(nfc_ctx *c) {
         HIPCHK(c, c->d_close_end[t].ensure(((size_t)ns + 4) * 4));
         HIPCHK(c, c->d_close_idx[t].ensure(((size_t)ns + 4) * 8));
         HIPCHK(c, c->d_partials.ensure((scan_num_tiles<8>(ns) + 1) * sizeof(uint64_t)));
+        HIPCHK(c, c->d_aggs.ensure((fsm_num_threads<PI>(ns) + 1) * sizeof(uint32_t)));
         if (pend) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t].p, pend, hipMemcpyDeviceToDevice, c->st));
         const uint8_t *sym = c->d_sym[t].as<uint8_t>();
+        uint8_t *pflags = c->d_started.as<uint8_t>();
         uint32_t *maptot = (uint32_t *)(tot + (t ? TOT_PKTMAP1 : TOT_PKTMAP0));
         uint64_t *pktot = (uint64_t *)(tot + (t ? TOT_PKT1 : TOT_PKT0));
-        device_scan<ComposePkt, 8>(c->st, ns, LoadPktMaps{sym, start_bit},
-                                   StorePktStarted{c->d_started.as<uint8_t>(), c->h_dcarry.pkt_started[t]},
-                                   (uint32_t)identity_map(2), c->d_partials.as<uint32_t>(), maptot);
-        StorePkt sp{sym, c->d_started.as<uint8_t>(), c->d_src[t].as<uint32_t>(), edges, start_bit, c->d_bits[t].as<uint8_t>(),
+        device_fsm_scan<ComposePkt, PI>(c->st, ns, LoadPktMaps{sym, start_bit}, VisitPktFlags{sym, start_bit, pflags},
+                                        (uint32_t)c->h_dcarry.pkt_started[t], c->d_partials.as<uint32_t>(),
+                                        c->d_aggs.as<uint32_t>(), maptot);
+        StorePkt sp{sym, pflags, c->d_src[t].as<uint32_t>(), edges, c->d_bits[t].as<uint8_t>(),
                     c->d_close_end[t].as<uint32_t>(), c->d_close_idx[t].as<uint64_t>()};
-        device_scan<AddU64, 8>(c->st, ns, LoadPktCounts{sym, c->d_started.as<uint8_t>(), start_bit}, sp, (uint64_t)pend,
-                               c->d_partials.as<uint64_t>(), pktot);
+        device_scan<AddU64, 8>(c->st, ns, LoadPktCounts{pflags}, sp, (uint64_t)pend, c->d_partials.as<uint64_t>(), pktot);
         PktFinish F{c->d_bits[t].as<uint8_t>(), c->d_pending[t].as<uint8_t>(), c->d_close_end[t].as<uint32_t>(), pktot, maptot,
                     c->d_dcarry.as<DecCarry>(), t, (uint32_t)std::min<size_t>(c->d_pending[t].cap, 0xFFFFFFFFu)};
         hipLaunchKernelGGL(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
@@ -733,16 +730,21 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     }
     // decoder LUTs
     DecoderTables t = build_tables(p->samp_rate, c->mx);
-    CRT(c->d_mil_map.ensure(t.miller_map.size() * 8));
-    CRT(c->d_man_map.ensure(t.manch_map.size() * 4));
+    std::vector<uint8_t> milb(t.miller_map.size() * 16), manb(t.manch_map.size() * 8);
+    for (size_t i = 0; i < t.miller_map.size(); i++)
+        for (int s = 0; s < 16; s++) milb[i * 16 + s] = (uint8_t)((t.miller_map[i] >> (4 * s)) & 15u);
+    for (size_t i = 0; i < t.manch_map.size(); i++)
+        for (int s = 0; s < 8; s++) manb[i * 8 + s] = (uint8_t)((t.manch_map[i] >> (4 * s)) & 15u);
+    CRT(c->d_mil_map.ensure(milb.size()));
+    CRT(c->d_man_map.ensure(manb.size()));
     CRT(c->d_mil_out.ensure(t.miller_out.size()));
     CRT(c->d_man_out.ensure(t.manch_out.size()));
-    CRT(hipMemcpy(c->d_mil_map.p, t.miller_map.data(), t.miller_map.size() * 8, hipMemcpyHostToDevice));
-    CRT(hipMemcpy(c->d_man_map.p, t.manch_map.data(), t.manch_map.size() * 4, hipMemcpyHostToDevice));
+    CRT(hipMemcpy(c->d_mil_map.p, milb.data(), milb.size(), hipMemcpyHostToDevice));
+    CRT(hipMemcpy(c->d_man_map.p, manb.data(), manb.size(), hipMemcpyHostToDevice));
     CRT(hipMemcpy(c->d_mil_out.p, t.miller_out.data(), t.miller_out.size(), hipMemcpyHostToDevice));
     CRT(hipMemcpy(c->d_man_out.p, t.manch_out.data(), t.manch_out.size(), hipMemcpyHostToDevice));
-    c->T.mil_map = c->d_mil_map.as<uint64_t>();
-    c->T.man_map = c->d_man_map.as<uint32_t>();
+    c->T.mil_map = c->d_mil_map.as<uint4>();
+    c->T.man_map = c->d_man_map.as<uint2>();
     c->T.mil_out = c->d_mil_out.as<uint8_t>();
     c->T.man_out = c->d_man_out.as<uint8_t>();
     c->T.nd = c->mx + 1;
@@ -774,10 +776,10 @@ void nfc_destroy(nfc_ctx *c) {
     DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_carry, &c->d_ecarry, &c->d_dcarry,
                      &c->d_ring[0], &c->d_ring[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cert, &c->d_gmin, &c->d_gmax,
-                     &c->d_gflags, &c->d_list, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
+                     &c->d_gflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0],
                      &c->d_pending[1], &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_totals};
+                     &c->d_partials, &c->d_aggs, &c->d_totals};
     for (DevBuf *b : all) b->release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);

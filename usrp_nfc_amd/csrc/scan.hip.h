@@ -39,7 +39,14 @@ struct AddU64 {  // also used as two packed u32 counters (no carry between halve
     }
 };
 
-// State maps packed 4 bits per state: h = "f then g", h[s] = g[f[s]].
+// ---- finite-state maps ---------------------------------------------------------
+// A map sends every state to its successor; "f then g" is h[s] = g[f[s]].
+// Decoder maps are stored one byte per state so that v_perm_b32 does four look-ups at once.
+__host__ __device__ constexpr uint64_t identity_map(int nstates) {   // nibble form (framing machine, host tables)
+    uint64_t m = 0;
+    for (int s = 0; s < nstates; s++) m |= (uint64_t)s << (4 * s);
+    return m;
+}
 template <int NSTATES>
 __device__ __forceinline__ uint64_t compose_map(uint64_t f, uint64_t g) {
     uint64_t h = 0;
@@ -50,44 +57,58 @@ __device__ __forceinline__ uint64_t compose_map(uint64_t f, uint64_t g) {
     }
     return h;
 }
-__host__ __device__ constexpr uint64_t identity_map(int nstates) {
-    uint64_t m = 0;
-    for (int s = 0; s < nstates; s++) m |= (uint64_t)s << (4 * s);
-    return m;
+// four look-ups into a 16-byte table g0..g3; sel holds four indices 0..15
+__device__ __forceinline__ uint32_t lookup16x4(uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3, uint32_t sel) {
+    const uint32_t s7 = sel & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(g1, g0, s7);
+    const uint32_t hi = __builtin_amdgcn_perm(g3, g2, s7);
+    const uint32_t m = ((sel >> 3) & 0x01010101u) * 0xFFu;
+    return (hi & m) | (lo & ~m);
 }
 
-// Both decoders at once: Miller map (16 states, 64 bits) + Manchester map (8 states, 32 bits).
+// Both decoders at once: Miller map (16 states, 16 bytes) + Manchester map (8 states, 8 bytes).
 struct DecMaps {
-    uint64_t mil;
-    uint32_t man;
+    uint32_t mil[4];
+    uint32_t man[2];
 };
 struct ComposeDec {
     using T = DecMaps;
-    static __device__ __forceinline__ T identity() { return T{identity_map(16), (uint32_t)identity_map(8)}; }
-    static __device__ __forceinline__ T op(T a, T b) {
-        return T{compose_map<16>(a.mil, b.mil), (uint32_t)compose_map<8>(a.man, b.man)};
+    static __host__ __device__ __forceinline__ T identity() {
+        return T{{0x03020100u, 0x07060504u, 0x0B0A0908u, 0x0F0E0D0Cu}, {0x03020100u, 0x07060504u}};
     }
-    static __device__ __forceinline__ T shfl_up(T v, int d) {
+    static T identity_host() { return identity(); }
+    static __device__ __forceinline__ T op(const T &a, const T &b) {
         T r;
-        r.mil = AddU64::shfl_up(v.mil, d);
-        r.man = (uint32_t)__shfl_up((int)v.man, d, 64);
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.mil[k] = lookup16x4(b.mil[0], b.mil[1], b.mil[2], b.mil[3], a.mil[k]);
+        r.man[0] = __builtin_amdgcn_perm(b.man[1], b.man[0], a.man[0]);
+        r.man[1] = __builtin_amdgcn_perm(b.man[1], b.man[0], a.man[1]);
         return r;
     }
-    static __device__ __forceinline__ T shfl(T v, int l) {
+    static __device__ __forceinline__ T shfl_up(const T &v, int d) {
         T r;
-        r.mil = AddU64::shfl(v.mil, l);
-        r.man = (uint32_t)__shfl((int)v.man, l, 64);
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.mil[k] = (uint32_t)__shfl_up((int)v.mil[k], d, 64);
+        r.man[0] = (uint32_t)__shfl_up((int)v.man[0], d, 64);
+        r.man[1] = (uint32_t)__shfl_up((int)v.man[1], d, 64);
         return r;
+    }
+    // states packed as miller | manchester << 4
+    static __device__ __forceinline__ uint32_t step(const T &m, uint32_t st) {
+        const uint32_t a = lookup16x4(m.mil[0], m.mil[1], m.mil[2], m.mil[3], st & 15u) & 15u;
+        const uint32_t b = __builtin_amdgcn_perm(m.man[1], m.man[0], (st >> 4) & 7u) & 15u;
+        return a | (b << 4);
     }
 };
 
-// Packet framing: 2 states (started or not) -> 8-bit map, kept in a u32.
+// Packet framing: 2 states (started or not) -> 8-bit nibble map, kept in a u32.
 struct ComposePkt {
     using T = uint32_t;
-    static __device__ __forceinline__ T identity() { return (uint32_t)identity_map(2); }
+    static __host__ __device__ __forceinline__ T identity() { return (uint32_t)identity_map(2); }
+    static T identity_host() { return identity(); }
     static __device__ __forceinline__ T op(T a, T b) { return (uint32_t)compose_map<2>(a, b); }
     static __device__ __forceinline__ T shfl_up(T v, int d) { return (T)__shfl_up((int)v, d, 64); }
-    static __device__ __forceinline__ T shfl(T v, int l) { return (T)__shfl((int)v, l, 64); }
+    static __device__ __forceinline__ uint32_t step(T m, uint32_t st) { return (m >> (4 * st)) & 1u; }
 };
 
 // ---- block-level helpers ----------------------------------------------------
@@ -181,12 +202,71 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(size_t n, Load load, 
     }
 }
 
-// Host-side driver.  `partials` must hold scan_num_tiles(n, ITEMS) entries.
+// tiles of BLOCK*ITEMS items
 template <int ITEMS>
 inline size_t scan_num_tiles(size_t n) {
     const size_t tile = (size_t)SCAN_BLOCK * ITEMS;
     return (n + tile - 1) / tile;
 }
+
+// ---- state-tracking variant for finite-state maps ---------------------------------
+// Pass 1 also keeps every thread's aggregate, so that pass 2 needs one block scan per thread and then
+// walks its items applying each map to a STATE (one look-up) instead of composing maps.
+template <class Tr, int ITEMS, class Load>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_fsm_reduce(size_t n, Load load, typename Tr::T *partials,
+                                                          typename Tr::T *aggs) {
+    using T = typename Tr::T;
+    __shared__ T lds[SCAN_WAVES];
+    const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const size_t base = tid * ITEMS;
+    T agg = Tr::identity();
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const size_t idx = base + i;
+        if (idx < n) agg = Tr::op(agg, load(idx));
+    }
+    aggs[tid] = agg;
+    T total;
+    (void)block_exclusive<Tr>(agg, lds, total);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+template <class Tr, int ITEMS, class Load, class Visit>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_fsm_apply(size_t n, Load load, Visit visit, const typename Tr::T *partials,
+                                                         const typename Tr::T *aggs, uint32_t state0) {
+    using T = typename Tr::T;
+    __shared__ T lds[SCAN_WAVES];
+    const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const size_t base = tid * ITEMS;
+    T total;
+    const T excl = block_exclusive<Tr>(aggs[tid], lds, total);
+    uint32_t st = Tr::step(Tr::op(partials[blockIdx.x], excl), state0);
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const size_t idx = base + i;
+        if (idx < n) {
+            const T item = load(idx);
+            visit(idx, st, item);
+            st = Tr::step(item, st);
+        }
+    }
+}
+template <int ITEMS>
+inline size_t fsm_num_threads(size_t n) { return scan_num_tiles<ITEMS>(n) * SCAN_BLOCK; }
+
+// visit(i, state before item i, item map); *total_out = composition of all maps
+template <class Tr, int ITEMS, class Load, class Visit>
+inline void device_fsm_scan(hipStream_t st, size_t n, Load load, Visit visit, uint32_t state0, typename Tr::T *partials,
+                            typename Tr::T *aggs, typename Tr::T *total_out) {
+    const size_t tiles = scan_num_tiles<ITEMS>(n);
+    if (tiles)
+        hipLaunchKernelGGL((k_fsm_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, load, partials, aggs);
+    hipLaunchKernelGGL((k_scan_partials<Tr>), dim3(1), dim3(SCAN_BLOCK), 0, st, tiles, partials, Tr::identity_host(), total_out);
+    if (tiles)
+        hipLaunchKernelGGL((k_fsm_apply<Tr, ITEMS, Load, Visit>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, load, visit,
+                           partials, aggs, state0);
+}
+
+// Host-side driver.  `partials` must hold scan_num_tiles(n, ITEMS) entries.
 
 // Phase 1: tile aggregates -> exclusive tile prefixes (seeded) and the grand total in *total_out.
 template <class Tr, int ITEMS, class Load>

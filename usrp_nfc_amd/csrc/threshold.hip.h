@@ -740,16 +740,39 @@ __global__ __launch_bounds__(64) void k_fill(const void *in, uint32_t n, float i
         if (lane == 0) carry->filled = filled + can;
         return;
     }
-    for (int i = lane; i < L; i += 64) lr[i] = ring[i];
+    // If the exponent spread of the window proves every partial sum exact, any order gives the reference's
+    // sum; otherwise add in the reference's order on one lane and note whether a rounding happened.
+    double part = 0;
+    uint32_t emin = 255u, emax = 0u;
+    for (int i = lane; i < L; i += 64) {
+        const float v = ring[i];
+        lr[i] = v;
+        part += (double)v;
+        if (v != 0.f) {
+            const uint32_t e = max(f32_expfield(v), 1u);
+            emin = min(emin, e);
+            emax = max(emax, e);
+        }
+    }
+    emin = wave_min_u32(emin);
+    emax = wave_max_u32(emax);
+    const double S = wave_sum_f64(part);
+    int lg = 0;
+    while ((1 << lg) < L) lg++;
+    const bool exact = (emax < 255u) && ((int)emax + 2 + lg - ((int)emin - 23) <= 52);
     __syncthreads();
     if (lane == 0) {
-        double s = 0, err = 0;
-        for (int i = 0; i < L; i++) {
-            const double v = (double)lr[i];
-            const double t = s + v;            // transition_sink.py:122, sequential
-            const double bv = t - s;           // TwoSum residue: was the addition exact?
-            err += fabs((s - (t - bv)) + (v - bv));
-            s = t;
+        double s = S;
+        double err = 0;
+        if (!exact) {
+            s = 0;
+            for (int i = 0; i < L; i++) {
+                const double v = (double)lr[i];
+                const double t = s + v;            // transition_sink.py:122, sequential
+                const double bv = t - s;           // TwoSum residue: was the addition exact?
+                err += fabs((s - (t - bv)) + (v - bv));
+                s = t;
+            }
         }
         carry->filled = L;
         carry->ss = s;
