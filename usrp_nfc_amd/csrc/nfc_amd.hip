@@ -64,6 +64,28 @@ struct DevBuf {
 
 }  // namespace
 
+// totals layout (device scalars inside DevState)
+enum : int {
+    TOT_RUNS = 0,       // u32
+    TOT_EDGES = 8,      // u32
+    TOT_DECMAP = 16,    // DecMaps (24 bytes)
+    TOT_SYMS = 48,      // u64: miller | manchester << 32
+    TOT_PKTMAP0 = 56,   // u32
+    TOT_PKTMAP1 = 64,   // u32
+    TOT_PKT0 = 72,      // u64: bits | closes << 32
+    TOT_PKT1 = 80,
+    TOT_LAST2 = 88,     // Last2 (8 bytes)
+    TOT_BYTES = 128
+};
+
+// Everything the host mirrors after a batch, in one block so that one copy fetches it.
+struct DevState {
+    Carry carry;
+    EdgeCarry ecarry;
+    DecCarry dcarry;
+    uint8_t totals[TOT_BYTES];
+};
+
 struct nfc_ctx {
     nfc_params P;
     int L, mx, C, Lpad, wpb, twords;
@@ -85,7 +107,10 @@ struct nfc_ctx {
     DecTables T;
 
     // carried state
-    DevBuf d_carry, d_ecarry, d_dcarry, d_ring[2];
+    DevBuf d_state, d_ring[2];
+    DevState *hs = nullptr;        // pinned host mirror of d_state
+    uint8_t *h_cflags = nullptr;   // pinned mirror of the per-chunk flag sections
+    size_t h_cflags_cap = 0;
     int ring_cur = 0;
     Carry h_carry;
     EdgeCarry h_ecarry;
@@ -94,13 +119,12 @@ struct nfc_ctx {
 
     // batch buffers
     DevBuf d_certinfo;
-    DevBuf d_in, d_neg, d_pos, d_ringout[2], d_touched[2], d_info[2], d_ringin, d_meta, d_ver, d_cert, d_gmin, d_gmax,
-        d_gflags, d_list;
+    DevBuf d_in, d_neg, d_pos, d_ringout[2], d_touched[2], d_info[2], d_ringin, d_meta, d_ver, d_cflags, d_list;
     DevBuf d_ctx, d_wcnt, d_ecode;
     DevBuf d_starts, d_offs, d_edges, d_states, d_sym[2], d_src[2], d_started, d_bits[2], d_pending[2], d_close_end[2],
         d_close_idx[2];
-    DevBuf d_partials, d_aggs, d_totals;  // scan scratch; totals: small device scalars
-    std::vector<uint8_t> h_ver, h_cert, h_gmin, h_gmax, h_gflags;
+    DevBuf d_partials, d_aggs;  // scan scratch
+    std::vector<uint8_t> h_ver;
     std::vector<uint32_t> h_list;
 
     // last batch
@@ -129,26 +153,43 @@ int fail(nfc_ctx *c, int code, const char *fmt, ...) {
     return code;
 }
 
+inline Carry *dC(nfc_ctx *c) { return &((DevState *)c->d_state.p)->carry; }
+inline EdgeCarry *dE(nfc_ctx *c) { return &((DevState *)c->d_state.p)->ecarry; }
+inline DecCarry *dD(nfc_ctx *c) { return &((DevState *)c->d_state.p)->dcarry; }
+inline uint8_t *dT(nfc_ctx *c) { return ((DevState *)c->d_state.p)->totals; }
+
+// one copy brings the whole mirrored block to pinned host memory
+inline hipError_t mirror_async(nfc_ctx *c) {
+    return hipMemcpyAsync(c->hs, c->d_state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->st);
+}
+inline void adopt_mirror(nfc_ctx *c) {
+    c->h_carry = c->hs->carry;
+    c->h_ecarry = c->hs->ecarry;
+    c->h_dcarry = c->hs->dcarry;
+}
+// carried state set from the host without a copy engine round trip: the values travel as kernel arguments
+__global__ void k_set_state(DevState *d, Carry a, EdgeCarry b, DecCarry e, int zero_totals) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    d->carry = a;
+    d->ecarry = b;
+    d->dcarry = e;
+    if (zero_totals)
+        for (int i = 0; i < TOT_BYTES; i++) d->totals[i] = 0;
+}
+inline void push_state(nfc_ctx *c, int zero_totals = 0) {
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(64), 0, c->st, (DevState *)c->d_state.p, c->h_carry, c->h_ecarry, c->h_dcarry,
+                       zero_totals);
+}
+__global__ void k_set_ecarry(DevState *d, EdgeCarry b) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) d->ecarry = b;
+}
+
 #define HIPCHK(c, call)                                                                              \
     do {                                                                                             \
         hipError_t e__ = (call);                                                                     \
         if (e__ != hipSuccess)                                                                       \
             return fail((c), NFC_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
     } while (0)
-
-// totals layout (device scalars in d_totals)
-enum : int {
-    TOT_RUNS = 0,       // u32
-    TOT_EDGES = 8,      // u32
-    TOT_DECMAP = 16,    // DecMaps (24 bytes)
-    TOT_SYMS = 48,      // u64: miller | manchester << 32
-    TOT_PKTMAP0 = 56,   // u32
-    TOT_PKTMAP1 = 64,   // u32
-    TOT_PKT0 = 72,      // u64: bits | closes << 32
-    TOT_PKT1 = 80,
-    TOT_LAST2 = 88,     // Last2 (8 bytes)
-    TOT_BYTES = 128
-};
 
 template <int KIND>
 void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
@@ -178,7 +219,7 @@ void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
 }
 void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n) {
     float *ring = c->d_ring[c->ring_cur].as<float>();
-    Carry *cr = c->d_carry.as<Carry>();
+    Carry *cr = dC(c);
     switch (c->P.input_kind) {
     case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
     case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
@@ -225,16 +266,18 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     HIPCHK(c, c->d_ringin.ensure((size_t)nch * L * sizeof(float)));
     HIPCHK(c, c->d_meta.ensure((size_t)nch * sizeof(RunMeta)));
     HIPCHK(c, c->d_ver.ensure(nch));
-    HIPCHK(c, c->d_cert.ensure(nch));
-    HIPCHK(c, c->d_gmin.ensure(nch));
-    HIPCHK(c, c->d_gmax.ensure(nch));
-    HIPCHK(c, c->d_gflags.ensure(nch));
+    HIPCHK(c, c->d_cflags.ensure((size_t)4 * nch));   // sections: cert | gflags | gmin | gmax
+    if (c->h_cflags_cap < (size_t)4 * nch) {
+        if (c->h_cflags) (void)hipHostFree(c->h_cflags);
+        c->h_cflags_cap = (size_t)4 * nch + 4096;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_cflags, c->h_cflags_cap, hipHostMallocDefault));
+    }
+    uint8_t *d_cert = c->d_cflags.as<uint8_t>(), *d_gflags = d_cert + nch, *d_gmin = d_cert + 2 * (size_t)nch,
+            *d_gmax = d_cert + 3 * (size_t)nch;
+    const uint8_t *h_cert = c->h_cflags, *h_gflags = c->h_cflags + nch, *h_gmin = c->h_cflags + 2 * (size_t)nch,
+                  *h_gmax = c->h_cflags + 3 * (size_t)nch;
     HIPCHK(c, c->d_list.ensure((size_t)nch * 4));
     c->h_ver.assign(nch, 0);
-    c->h_cert.assign(nch, 0);
-    c->h_gmin.assign(nch, 255);
-    c->h_gmax.assign(nch, 0);
-    c->h_gflags.assign(nch, 0);
     HIPCHK(c, hipMemsetAsync(c->d_ver.p, 0, nch, c->st));
 
     // carried "HIGH ignored" bookkeeping from (_current_state, _last_bit, _dur) at the first stable sample
@@ -251,7 +294,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
         kl0 = KEY_NONE;
     }
 
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(64), 0, c->st, c->d_ring[c->ring_cur].as<float>(), L, c->d_carry.as<Carry>());
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(64), 0, c->st, c->d_ring[c->ring_cur].as<float>(), L, dC(c));
 
     // a 256-sample step must not wrap the ring onto itself: short windows take the sequential kernel
     const bool force_seq = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0 || L < STEP;
@@ -283,7 +326,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     A.i16_scale = c->i16_scale;
     A.eps = c->eps;
     A.ring_carry = c->d_ring[c->ring_cur].as<float>();
-    A.carry = c->d_carry.as<Carry>();
+    A.carry = dC(c);
     A.nl0 = nl0;
     A.kl0 = kl0;
     A.lo_L = c->P.lo_val / (double)L;
@@ -298,9 +341,9 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     A.ver = c->d_ver.as<uint8_t>();
     A.ring_in = c->d_ringin.as<float>();
     A.meta = c->d_meta.as<RunMeta>();
-    A.gmin = c->d_gmin.as<uint8_t>();
-    A.gmax = c->d_gmax.as<uint8_t>();
-    A.gflags = c->d_gflags.as<uint8_t>();
+    A.gmin = d_gmin;
+    A.gmax = d_gmax;
+    A.gflags = d_gflags;
     A.neg = c->d_neg.as<uint64_t>();
     A.pos = c->d_pos.as<uint64_t>();
     A.twords = c->twords;
@@ -315,24 +358,31 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
 
         // certify; re-run what cannot be proven from the exact (look-back) state; certify again what can
         // see a re-run chunk.  Every round makes at least the first pending chunk final.
+        const bool dbg = getenv("NFC_DEBUG") != nullptr;
+        bool first_round = true;
         c->h_list.clear();
         for (uint32_t k = 1; k < nch; k++) c->h_list.push_back(k);
         int rounds = 0;
+        bool mirrored = false;
         while (!c->h_list.empty()) {
             const uint32_t np = (uint32_t)c->h_list.size();
-            HIPCHK(c, hipMemcpyAsync(c->d_list.p, c->h_list.data(), (size_t)np * 4, hipMemcpyHostToDevice, c->st));
-            A.list = c->d_list.as<uint32_t>();
+            if (first_round) {
+                A.list = nullptr;   // k_certify: chunks 1 .. nch-1
+            } else {
+                HIPCHK(c, hipMemcpyAsync(c->d_list.p, c->h_list.data(), (size_t)np * 4, hipMemcpyHostToDevice, c->st));
+                A.list = c->d_list.as<uint32_t>();
+            }
             A.nlist = np;
-            const bool dbg = getenv("NFC_DEBUG") != nullptr;
             if (dbg) HIPCHK(c, c->d_certinfo.ensure((size_t)nch * sizeof(CertInfo)));
-            hipLaunchKernelGGL(k_certify, dim3((np + 3) / 4), dim3(256), 0, c->st, A, c->d_cert.as<uint8_t>(),
+            hipLaunchKernelGGL(k_certify, dim3((np + 3) / 4), dim3(256), 0, c->st, A, d_cert,
                                dbg ? c->d_certinfo.as<CertInfo>() : nullptr);
-            HIPCHK(c, hipMemcpyAsync(c->h_cert.data(), c->d_cert.p, nch, hipMemcpyDeviceToHost, c->st));
-            HIPCHK(c, hipMemcpyAsync(c->h_gflags.data(), c->d_gflags.p, nch, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, mirror_async(c));
             HIPCHK(c, hipStreamSynchronize(c->st));
+            mirrored = true;
             std::vector<uint32_t> failing;
             for (uint32_t k : c->h_list)
-                if (!c->h_cert[k]) failing.push_back(k);
+                if (!h_cert[k]) failing.push_back(k);
             if (dbg) {
                 std::vector<CertInfo> ci(nch);
                 HIPCHK(c, hipMemcpy(ci.data(), c->d_certinfo.p, (size_t)nch * sizeof(CertInfo), hipMemcpyDeviceToHost));
@@ -347,14 +397,17 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
                 }
             }
             if (failing.empty()) break;
+            first_round = false;
             HIPCHK(c, hipMemcpyAsync(c->d_list.p, failing.data(), failing.size() * 4, hipMemcpyHostToDevice, c->st));
+            A.list = c->d_list.as<uint32_t>();
             A.nlist = (uint32_t)failing.size();
             A.mode = 1;
             launch_threshold_kind(c, A, A.nlist);
             c->stats.threshold_passes++;
             c->stats.chunks_rerun += A.nlist;
-            HIPCHK(c, hipMemcpyAsync(c->h_gflags.data(), c->d_gflags.p, nch, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
             HIPCHK(c, hipStreamSynchronize(c->st));
+            mirrored = false;
             std::vector<uint8_t> ran(nch, 0);
             for (uint32_t k : failing) {
                 ran[k] = 1;
@@ -367,24 +420,25 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
             bool vis = false;
             for (uint32_t k = 0; k < nch; k++) {
                 if (vis || ran[k]) c->h_list.push_back(k);
-                const bool full = !(c->h_gflags[k] & 2);
+                const bool full = !(h_gflags[k] & 2);
                 vis = ran[k] || (vis && !full);
             }
             if (++rounds > (int)nch + 2) return fail(c, NFC_ERR_INTERNAL, "threshold passes did not converge");
         }
 
         // can every fp64 sum of this batch be proven exact?  (otherwise the summation order matters)
-        HIPCHK(c, hipMemcpyAsync(c->h_gmin.data(), c->d_gmin.p, nch, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipMemcpyAsync(c->h_gmax.data(), c->d_gmax.p, nch, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipMemcpyAsync(c->h_gflags.data(), c->d_gflags.p, nch, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipMemcpyAsync(&c->h_carry, c->d_carry.p, sizeof(Carry), hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipStreamSynchronize(c->st));
+        if (!mirrored) {
+            HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, mirror_async(c));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+        }
+        c->h_carry = c->hs->carry;
         int emin = 255, emax = 0;
         bool flagged = false;
         for (uint32_t k = 0; k < nch; k++) {
-            emin = std::min(emin, (int)c->h_gmin[k]);
-            emax = std::max(emax, (int)c->h_gmax[k]);
-            if (c->h_gflags[k] & 1) flagged = true;
+            emin = std::min(emin, (int)h_gmin[k]);
+            emax = std::max(emax, (int)h_gmax[k]);
+            if (h_gflags[k] & 1) flagged = true;
         }
         int low = emin - 23, high = emax + 2 + ceil_log2(L);
         if (c->h_carry.ss_emin != 255) low = std::min(low, c->h_carry.ss_emin);
@@ -407,7 +461,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
         S.hi_plus = c->hi_plus;
         S.i16_scale = c->i16_scale;
         S.ring = c->d_ring[c->ring_cur].as<float>();
-        S.carry = c->d_carry.as<Carry>();
+        S.carry = dC(c);
         S.state = c->h_ecarry.state;
         S.last_bit = c->h_ecarry.last_bit;
         S.dur = c->h_ecarry.dur;
@@ -417,7 +471,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
         c->stats.used_sequential = 1;
     } else {
         hipLaunchKernelGGL(k_finalize_state, dim3(1), dim3(64), 0, c->st, A, c->d_ring[1 - c->ring_cur].as<float>(),
-                           c->d_carry.as<Carry>());
+                           dC(c));
         c->ring_cur = 1 - c->ring_cur;
     }
     return NFC_OK;
@@ -427,7 +481,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
 // edge stage
 // ---------------------------------------------------------------------------
 int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
-    uint8_t *tot = c->d_totals.as<uint8_t>();
+    uint8_t *tot = dT(c);
     const size_t nwords = ((size_t)n + 63) / 64;
     EdgeArgs E;
     E.neg = c->d_neg.as<uint64_t>();
@@ -450,16 +504,17 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
                             c->d_partials.as<Last2>(), (Last2 *)(tot + TOT_LAST2));
     // scan 2: entry offsets; then every word writes its entries
     scan_phase1<AddU32, 8>(c->st, nwords, LoadWordCount{wcnt}, 0u, c->d_partials.as<uint32_t>(), (uint32_t *)(tot + TOT_EDGES));
-    uint32_t nedges = 0;
-    HIPCHK(c, hipMemcpyAsync(&nedges, tot + TOT_EDGES, 4, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, mirror_async(c));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    uint32_t nedges;
+    memcpy(&nedges, c->hs->totals + TOT_EDGES, 4);
     c->n_edges = nedges;
     HIPCHK(c, c->d_edges.ensure(((size_t)nedges + 1) * sizeof(nfc_edge)));
     HIPCHK(c, c->d_ecode.ensure(((size_t)nedges + 8) * 2));
     scan_phase2<AddU32, 8>(c->st, nwords, LoadWordCount{wcnt},
                            StoreWordEdges{E, ctx, c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), nedges},
                            c->d_partials.as<uint32_t>());
-    hipLaunchKernelGGL(k_edge_carry, dim3(1), dim3(64), 0, c->st, E, (const Last2 *)(tot + TOT_LAST2), c->d_ecarry.as<EdgeCarry>());
+    hipLaunchKernelGGL(k_edge_carry, dim3(1), dim3(64), 0, c->st, E, (const Last2 *)(tot + TOT_LAST2), dE(c));
     return NFC_OK;
 }
 
@@ -467,7 +522,7 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
 // decode + framing
 // ---------------------------------------------------------------------------
 int run_decode(nfc_ctx *c) {
-    uint8_t *tot = c->d_totals.as<uint8_t>();
+    uint8_t *tot = dT(c);
     const uint32_t ne = c->n_edges;
     const nfc_edge *edges = c->d_edges.as<nfc_edge>();
     constexpr int DI = 16;  // edges per thread in the decoder-state scan
@@ -486,10 +541,11 @@ int run_decode(nfc_ctx *c) {
     StoreSymbols ss{outw, {c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()},
                     {c->d_src[0].as<uint32_t>(), c->d_src[1].as<uint32_t>()}};
     device_scan<AddU64, 8>(c->st, ne, LoadSymCounts{outw}, ss, 0ull, c->d_partials.as<uint64_t>(), (uint64_t *)(tot + TOT_SYMS));
-    hipLaunchKernelGGL(k_dec_carry, dim3(1), dim3(64), 0, c->st, (const DecMaps *)(tot + TOT_DECMAP), c->d_dcarry.as<DecCarry>());
-    uint64_t nsyms = 0;
-    HIPCHK(c, hipMemcpyAsync(&nsyms, tot + TOT_SYMS, 8, hipMemcpyDeviceToHost, c->st));
+    hipLaunchKernelGGL(k_dec_carry, dim3(1), dim3(64), 0, c->st, (const DecMaps *)(tot + TOT_DECMAP), dD(c));
+    HIPCHK(c, mirror_async(c));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    uint64_t nsyms;
+    memcpy(&nsyms, c->hs->totals + TOT_SYMS, 8);
     c->n_sym[1] = (uint32_t)nsyms;
     c->n_sym[0] = (uint32_t)(nsyms >> 32);
 
@@ -517,19 +573,10 @@ int run_decode(nfc_ctx *c) {
                     c->d_close_end[t].as<uint32_t>(), c->d_close_idx[t].as<uint64_t>()};
         device_scan<AddU64, 8>(c->st, ns, LoadPktCounts{pflags}, sp, (uint64_t)pend, c->d_partials.as<uint64_t>(), pktot);
         PktFinish F{c->d_bits[t].as<uint8_t>(), c->d_pending[t].as<uint8_t>(), c->d_close_end[t].as<uint32_t>(), pktot, maptot,
-                    c->d_dcarry.as<DecCarry>(), t, (uint32_t)std::min<size_t>(c->d_pending[t].cap, 0xFFFFFFFFu)};
+                    dD(c), t, (uint32_t)std::min<size_t>(c->d_pending[t].cap, 0xFFFFFFFFu)};
         hipLaunchKernelGGL(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
     }
-    uint64_t pk[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(&pk[0], tot + TOT_PKT0, 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(&pk[1], tot + TOT_PKT1, 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(&c->h_dcarry, c->d_dcarry.p, sizeof(DecCarry), hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    for (int t = 0; t < 2; t++) {
-        c->n_bits[t] = (uint32_t)pk[t];
-        c->n_close[t] = (uint32_t)(pk[t] >> 32);
-    }
-    return NFC_OK;
+    return NFC_OK;   // totals and carries are mirrored by the caller's final copy
 }
 
 int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
@@ -562,14 +609,15 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
             c->h_ecarry.state = 0;
             c->h_ecarry.last_bit = 0;
             c->h_ecarry.dur = c->L % c->mx;  // transition_sink.py:123
-            HIPCHK(c, hipMemcpyAsync(c->d_ecarry.p, &c->h_ecarry, sizeof(EdgeCarry), hipMemcpyHostToDevice, c->st));
+            hipLaunchKernelGGL(k_set_ecarry, dim3(1), dim3(64), 0, c->st, (DevState *)c->d_state.p, c->h_ecarry);
         }
     }
     c->last_skip = skip;
     if (!c->h_carry.stable || skip == n) {
         // the whole batch went into the averaging window: no callback content (transition_sink.py:109-125)
-        HIPCHK(c, hipMemcpyAsync(&c->h_carry, c->d_carry.p, sizeof(Carry), hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, mirror_async(c));
         HIPCHK(c, hipStreamSynchronize(c->st));
+        c->h_carry = c->hs->carry;
         c->nseen += n;
         c->have_outputs = true;
         return NFC_OK;
@@ -585,13 +633,26 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         HIPCHK(c, hipEventRecord(c->ev[3], c->st));
         rc = run_decode(c);
         if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(&c->h_ecarry, c->d_ecarry.p, sizeof(EdgeCarry), hipMemcpyDeviceToHost, c->st));
     } else {
         HIPCHK(c, hipEventRecord(c->ev[3], c->st));
     }
     HIPCHK(c, hipEventRecord(c->ev[4], c->st));
-    HIPCHK(c, hipMemcpyAsync(&c->h_carry, c->d_carry.p, sizeof(Carry), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, mirror_async(c));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    {
+        const EdgeCarry keep = c->h_ecarry;
+        adopt_mirror(c);
+        if (c->P.flags & NFC_FLAG_NO_EDGES) c->h_ecarry = keep;
+        else {
+            uint64_t pk[2];
+            memcpy(&pk[0], c->hs->totals + TOT_PKT0, 8);
+            memcpy(&pk[1], c->hs->totals + TOT_PKT1, 8);
+            for (int t = 0; t < 2; t++) {
+                c->n_bits[t] = (uint32_t)pk[t];
+                c->n_close[t] = (uint32_t)(pk[t] >> 32);
+            }
+        }
+    }
     c->stats.ms_total = elapsed_ms(c->ev[0], c->ev[4]);
     c->stats.ms_threshold = elapsed_ms(c->ev[1], c->ev[2]);
     c->stats.ms_edges = elapsed_ms(c->ev[2], c->ev[3]);
@@ -751,19 +812,16 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     c->T.reader = p->enable_reader ? 1 : 0;
     c->T.tag = p->enable_tag ? 1 : 0;
     // carried state
-    CRT(c->d_carry.ensure(sizeof(Carry)));
-    CRT(c->d_ecarry.ensure(sizeof(EdgeCarry)));
-    CRT(c->d_dcarry.ensure(sizeof(DecCarry)));
-    CRT(c->d_totals.ensure(TOT_BYTES));
+    CRT(c->d_state.ensure(sizeof(DevState)));
+    CRT(hipHostMalloc((void **)&c->hs, sizeof(DevState), hipHostMallocDefault));
+    memset(c->hs, 0, sizeof(DevState));
     for (int b = 0; b < 2; b++) {
         CRT(c->d_ring[b].ensure((size_t)c->Lpad * 4));
         CRT(hipMemset(c->d_ring[b].p, 0, (size_t)c->Lpad * 4));
         CRT(c->d_pending[b].ensure(1024));
     }
-    CRT(hipMemcpy(c->d_carry.p, &c->h_carry, sizeof(Carry), hipMemcpyHostToDevice));
-    CRT(hipMemcpy(c->d_ecarry.p, &c->h_ecarry, sizeof(EdgeCarry), hipMemcpyHostToDevice));
-    CRT(hipMemcpy(c->d_dcarry.p, &c->h_dcarry, sizeof(DecCarry), hipMemcpyHostToDevice));
-    CRT(hipMemset(c->d_totals.p, 0, TOT_BYTES));
+    push_state(c, 1);
+    CRT(hipStreamSynchronize(c->st));
 #undef CRT
     *out = c;
     return NFC_OK;
@@ -773,14 +831,15 @@ void nfc_destroy(nfc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->P.device);
     if (c->st) (void)hipStreamSynchronize(c->st);
-    DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_carry, &c->d_ecarry, &c->d_dcarry,
+    DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_state,
                      &c->d_ring[0], &c->d_ring[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
-                     &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cert, &c->d_gmin, &c->d_gmax,
-                     &c->d_gflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
+                     &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0],
                      &c->d_pending[1], &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs, &c->d_totals};
+                     &c->d_partials, &c->d_aggs};
     for (DevBuf *b : all) b->release();
+    if (c->hs) (void)hipHostFree(c->hs);
+    if (c->h_cflags) (void)hipHostFree(c->h_cflags);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->kev)
@@ -901,10 +960,7 @@ static void init_carried(nfc_ctx *c) {
 }
 
 static int upload_carried(nfc_ctx *c) {
-    HIPCHK(c, hipMemcpyAsync(c->d_carry.p, &c->h_carry, sizeof(Carry), hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(c->d_ecarry.p, &c->h_ecarry, sizeof(EdgeCarry), hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(c->d_dcarry.p, &c->h_dcarry, sizeof(DecCarry), hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));  // the sources are host members that the next call may rewrite
+    push_state(c);
     return NFC_OK;
 }
 

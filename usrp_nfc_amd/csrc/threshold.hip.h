@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertI
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t slotid = blockIdx.x * (blockDim.x >> 6) + wave;
     if (slotid >= A.nlist) return;
-    const uint32_t c = A.list[slotid];
+    const uint32_t c = A.list ? A.list[slotid] : slotid + 1;
     const int L = A.L;
     const float *rin = A.ring_in + (size_t)c * L;
     const RunMeta mt = A.meta[c];
