@@ -26,6 +26,7 @@
 #include "edges.hip.h"
 #include "scan.hip.h"
 #include "threshold.hip.h"
+#include "threshold_rr.hip.h"
 
 using namespace nfc;
 
@@ -91,7 +92,7 @@ struct nfc_ctx {
     int L, mx, C, Lpad, wpb, twords;
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
-    int bands_ok, fast_ok, nfold;
+    int bands_ok, fast_ok, nfold, use_rr;
     uint64_t selmask;
     float eps;
     float i16_scale;
@@ -193,6 +194,10 @@ __global__ void k_set_ecarry(DevState *d, EdgeCarry b) {
 
 template <int KIND>
 void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
+    if (c->use_rr) {   // ring in registers: no LDS, four waves (chunks) per workgroup
+        hipLaunchKernelGGL((k_threshold_rr<KIND>), dim3((nwork + 3) / 4), dim3(256), 0, c->st, A);
+        return;
+    }
     const uint32_t blocks = (nwork + c->wpb - 1) / c->wpb;
     const size_t lds = (size_t)c->wpb * c->Lpad * 5;
     hipLaunchKernelGGL((k_threshold<KIND>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
@@ -253,7 +258,9 @@ double elapsed_ms(hipEvent_t a, hipEvent_t b) {
 // ---------------------------------------------------------------------------
 int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     const int L = c->L;
-    const uint32_t nch = (n + c->C - 1) / c->C;
+    // register-ring kernel: chunks are aligned to the ring (chunk c starts at sample c*C - off, slot 0)
+    const uint32_t off = c->use_rr ? (uint32_t)(c->nseen % (uint64_t)L) : 0u;
+    const uint32_t nch = (uint32_t)(((uint64_t)n + off + c->C - 1) / c->C);
     c->stats.n_chunks = nch;
     const size_t nwords = ((size_t)n + 63) / 64 + 8;
     HIPCHK(c, c->d_neg.ensure(nwords * 8));
@@ -347,6 +354,8 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     A.neg = c->d_neg.as<uint64_t>();
     A.pos = c->d_pos.as<uint64_t>();
     A.twords = c->twords;
+    A.off = (int32_t)off;
+    A.nrows = (L + 63) / 64;
 
     if (!force_seq) {
         // pass 0: every chunk from a speculated incoming state (chunk 0: the carried, exact one)
@@ -731,7 +740,13 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     int C = p->chunk_samples > 0 ? p->chunk_samples : 16384;
     C = std::max(C, 2 * c->L);
     C = std::max(C, c->mx + 2);
-    C = (C + STEP - 1) / STEP * STEP;
+    c->use_rr = (c->L >= STEP && c->L <= 64 * RR_ROWS && getenv("NFC_RR")) ? 1 : 0;   // experimental: ring in registers
+    if (c->use_rr) {
+        C = std::max(2, (C + c->L / 2) / c->L) * c->L;   // whole ring periods
+        while (C < c->mx + 2) C += c->L;
+    } else {
+        C = (C + STEP - 1) / STEP * STEP;
+    }
     c->C = C;
     c->wpb = std::max(1, std::min(4, (int)(65536 / ((size_t)c->Lpad * 5))));
     c->hi_plus = p->hi_val + 0.1;  // transition_sink.py:63
@@ -746,9 +761,9 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     c->bands_ok = sane(p->lo_val) && sane(p->hi_val) && std::isfinite(p->lo_val) && std::isfinite(p->hi_val);
     c->fast_ok = c->bands_ok && p->lo_val > 0 && p->hi_val > p->lo_val;
     {   // a LOW run longer than max_len covers an aligned block of b samples, b the largest power of two
-        // with 2b - 1 <= max_len + 1: the fast path detects those runs by folding the LOW mask
+        // with 3b - 2 <= max_len + 1: the fast path detects those runs by folding the LOW mask
         int b = 1;
-        while (2 * (2 * b) - 1 <= c->mx + 1 && 2 * b <= 64) b *= 2;
+        while (3 * (2 * b) - 2 <= c->mx + 1 && 2 * b <= 64) b *= 2;   // (3b - 2: rows of the register ring may be short)
         c->nfold = 0;
         while ((1 << c->nfold) < b) c->nfold++;
         c->selmask = 0;

@@ -107,6 +107,8 @@ struct ThrArgs {
     uint32_t nlist;
     int32_t mode;          // 0 speculate, 1 resolve exactly
     int32_t twords;        // u32 words per touched bitmap
+    int32_t off;           // chunk c covers samples [c*C - off, (c+1)*C - off)  (register-ring kernel: ring-aligned)
+    int32_t nrows;         // ceil(L / 64)
 };
 
 // ---------------------------------------------------------------------------
@@ -242,10 +244,9 @@ __device__ __forceinline__ float resolve_slot(const ThrArgs &A, int c, int s) {
 
 // One 64-sample row (lane l = sample m), exact: iterate the accept mask to its fixed point.
 // Updates ss0, w_nl, w_kl; returns the classification through low/pos ballots.
-__device__ __forceinline__ void row_exact(const ThrArgs &A, int lane, int m, bool act, float x, float prev, float *ring,
-                                          unsigned char *tch, uint32_t slot, double &ss0, int &w_nl, int &w_kl,
-                                          uint32_t &emin, uint32_t &emax, uint32_t &flags, unsigned long long &lowm,
-                                          unsigned long long &posm) {
+__device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, bool act, float x, float prev, double &ss0,
+                                          int &w_nl, int &w_kl, uint32_t &emin, uint32_t &emax, uint32_t &flags,
+                                          unsigned long long &lowm, unsigned long long &posm) {
     const int mx = A.mx;
     const double x64 = (double)x;
     double ss = ss0;
@@ -303,8 +304,6 @@ __device__ __forceinline__ void row_exact(const ThrArgs &A, int lane, int m, boo
     double dl = 0;
     if (acc) {
         dl = x64 - (double)prev;
-        ring[slot] = x;
-        tch[slot] = 1;
         if (x != 0.f) {
             const uint32_t e = max(f32_expfield(x), 1u);
             emin = min(emin, e);
@@ -316,6 +315,7 @@ __device__ __forceinline__ void row_exact(const ThrArgs &A, int lane, int m, boo
     w_kl = max(w_kl, wave_max_i32(key));
     lowm = __ballot(low);
     posm = __ballot(val == 1);
+    return acc;   // the caller stores x into the ring slot
 }
 
 template <int KIND>
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     unsigned char *tch = (unsigned char *)(ring + A.Lpad);
     const int L = A.L;
     const int mx = A.mx;
-    const uint32_t m_chunk = c * (uint32_t)A.C;
+    const uint32_t m_chunk = c * (uint32_t)A.C;   // this kernel runs with A.off == 0
     const uint32_t n1 = min(A.n, m_chunk + (uint32_t)A.C);
     const uint32_t m_start = max(m_chunk, A.skip);
     const Carry cr = *A.carry;
@@ -586,7 +586,10 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 const float pj = j == 0 ? prev[0] : j == 1 ? prev[1] : j == 2 ? prev[2] : prev[3];
                 const bool aj = j == 0 ? act[0] : j == 1 ? act[1] : j == 2 ? act[2] : act[3];
                 const uint32_t sj = j == 0 ? slot[0] : j == 1 ? slot[1] : j == 2 ? slot[2] : slot[3];
-                row_exact(A, lane, m, aj, xj, pj, ring, tch, sj, ss0, w_nl, w_kl, emin, emax, flags, lm, pm);
+                if (row_exact(A, lane, m, aj, xj, pj, ss0, w_nl, w_kl, emin, emax, flags, lm, pm)) {
+                    ring[sj] = xj;
+                    tch[sj] = 1;
+                }
                 if (j == 0) { lowm[0] = lm; posm[0] = pm; }
                 else if (j == 1) { lowm[1] = lm; posm[1] = pm; }
                 else if (j == 2) { lowm[2] = lm; posm[2] = pm; }
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertI
     d = wave_sum_f32(d) * 1.001f;
     int nl, kl;
     resolve_low_state(A, (int)c, nl, kl);
-    const int m0 = (int)(c * (uint32_t)A.C);
+    const int m0 = (int)(c * (uint32_t)A.C) - A.off;
     const int mx = A.mx;
     auto live = [&](int k) { return (k & 1) && (m0 - (k >> 1)) <= mx + 1; };
     const bool low_ok = (nl == mt.nl_in) && ((kl == mt.kl_in) || (!live(kl) && !live(mt.kl_in)));
