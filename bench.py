@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--samples', type=float, default=1e8, help='samples per GPU')
     ap.add_argument('--workload', default='miller', choices=['miller', 'manchester', 'all'])
+    ap.add_argument('--chunk', type=int, default=0, help='time-chunk samples of the threshold kernel (0: library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     return ap.parse_args()
@@ -108,7 +109,7 @@ def main():
     flags = decoder_flags(a.workload)
     d_own = api.DeviceBuffer(own, dev)
     d_ov = api.DeviceBuffer(ov, dev) if len(ov) else None
-    ctx = api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32, device=dev, **flags)
+    ctx = api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32, device=dev, chunk_samples=a.chunk, **flags)
 
     def barrier():
         if dist is not None:

@@ -92,7 +92,7 @@ struct nfc_ctx {
     int L, mx, C, Lpad, wpb, twords;
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
-    int bands_ok, fast_ok, nfold, use_rr;
+    int bands_ok, fast_ok, nfold, use_rr, rows_per_step, C_min, wave_slots;
     uint64_t selmask;
     float eps;
     float i16_scale;
@@ -200,7 +200,8 @@ void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
     }
     const uint32_t blocks = (nwork + c->wpb - 1) / c->wpb;
     const size_t lds = (size_t)c->wpb * c->Lpad * 5;
-    hipLaunchKernelGGL((k_threshold<KIND>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
+    if (c->rows_per_step == 8) hipLaunchKernelGGL((k_threshold<KIND, 8>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
+    else hipLaunchKernelGGL((k_threshold<KIND, 4>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
 }
 void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
     const bool timed = c->n_kev < 6;
@@ -258,6 +259,15 @@ double elapsed_ms(hipEvent_t a, hipEvent_t b) {
 // ---------------------------------------------------------------------------
 int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     const int L = c->L;
+    // Chunk length for this batch: one wave per chunk, and a chunk's latency is what the launch takes, so
+    // aim at one full round of resident waves (no second, half-empty round), never below the configured size.
+    if (!c->P.chunk_samples && !c->use_rr) {
+        const uint64_t slots = (uint64_t)c->wave_slots;
+        const int stp = 64 * c->rows_per_step;
+        uint64_t want = ((uint64_t)n + slots - 1) / slots;
+        want = (want + stp - 1) / stp * stp;
+        c->C = (int)std::max<uint64_t>(want, (uint64_t)c->C_min);
+    }
     // register-ring kernel: chunks are aligned to the ring (chunk c starts at sample c*C - off, slot 0)
     const uint32_t off = c->use_rr ? (uint32_t)(c->nseen % (uint64_t)L) : 0u;
     const uint32_t nch = (uint32_t)(((uint64_t)n + off + c->C - 1) / c->C);
@@ -740,14 +750,18 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     int C = p->chunk_samples > 0 ? p->chunk_samples : 16384;
     C = std::max(C, 2 * c->L);
     C = std::max(C, c->mx + 2);
+    c->rows_per_step = 4;
     c->use_rr = (c->L >= STEP && c->L <= 64 * RR_ROWS && getenv("NFC_RR")) ? 1 : 0;   // experimental: ring in registers
     if (c->use_rr) {
         C = std::max(2, (C + c->L / 2) / c->L) * c->L;   // whole ring periods
         while (C < c->mx + 2) C += c->L;
     } else {
-        C = (C + STEP - 1) / STEP * STEP;
+        c->rows_per_step = (c->L >= 512 && getenv("NFC_ROWS8")) ? 8 : 4;   // 8-row steps: measured no faster (register pressure)
+        const int stp = 64 * c->rows_per_step;
+        C = (C + stp - 1) / stp * stp;
     }
     c->C = C;
+    c->C_min = C;
     c->wpb = std::max(1, std::min(4, (int)(65536 / ((size_t)c->Lpad * 5))));
     c->hi_plus = p->hi_val + 0.1;  // transition_sink.py:63
     const double eps = std::ldexp(1.0, -48);
@@ -790,6 +804,13 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             return rc__;                                                                               \
         }                                                                                              \
     } while (0)
+    {
+        hipDeviceProp_t prop;
+        CRT(hipGetDeviceProperties(&prop, p->device));
+        const size_t lds_wave = (size_t)c->Lpad * 5;
+        int per_cu = (int)std::min<size_t>(16, (size_t)(160 * 1024) / (lds_wave * c->wpb) * c->wpb);   // LDS- and VGPR-bound
+        c->wave_slots = std::max(1, prop.multiProcessorCount * std::max(1, per_cu));
+    }
     CRT(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
     for (auto &e : c->ev) CRT(hipEventCreate(&e));
     for (auto &e : c->kev) CRT(hipEventCreate(&e));
@@ -799,10 +820,14 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         return fail(nullptr, NFC_ERR_ARG, "av_window too large for one wave's LDS ring");
     }
     if (lds > 64 * 1024) {
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_IQ_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_IQ_F32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_IQ_F32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // decoder LUTs
     DecoderTables t = build_tables(p->samp_rate, c->mx);

@@ -31,9 +31,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace nfc {
 
-constexpr int STEP = 256;            // samples per wave step
+constexpr int STEP = 256;            // smallest step (4 rows of 64 samples); the wide variant walks 512
 constexpr int LL_NONE = -(1 << 30);  // "no such sample" (batch-local index)
 constexpr int MAX_FIX_ITERS = 80;
 
@@ -114,6 +116,16 @@ struct ThrArgs {
 // ---------------------------------------------------------------------------
 // cross-lane helpers
 // ---------------------------------------------------------------------------
+// Wave-uniform values the compiler cannot prove uniform (wave index, chunk id, running sum, ...) are
+// moved to scalar registers explicitly: branches on them become scalar branches and the wave masks
+// (__ballot results) stay in SGPRs instead of being rebuilt lane by lane.
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double rfl(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 __device__ __forceinline__ double shfl_up_f64(double v, int d) {
     int lo = __shfl_up(__double2loint(v), d, 64), hi = __shfl_up(__double2hiint(v), d, 64);
     return __hiloint2double(hi, lo);
@@ -152,22 +164,22 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-    return v;
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
+    return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    return v;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    return v;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 __device__ __forceinline__ int last_set(unsigned long long m) { return 63 - __clzll((long long)m); }  // m != 0
 
@@ -188,6 +200,36 @@ __device__ __forceinline__ float envelope_at(const void *in, size_t m, float i16
         const float s = (float)((const int16_t *)in)[m] * i16_scale;
         return s * s;
     }
+}
+
+// The same in two halves, so that a load can stay in flight across loop iterations: the raw sample
+// is fetched steps ahead and only turned into the envelope when its step begins.
+template <int KIND> struct RawOf { using T = float; };
+template <> struct RawOf<IN_IQ_F32> { using T = float2; };
+template <> struct RawOf<IN_I16_SQ> { using T = int16_t; };
+template <int KIND>
+__device__ __forceinline__ typename RawOf<KIND>::T load_raw(const void *in, size_t m) {
+    return ((const typename RawOf<KIND>::T *)in)[m];
+}
+template <int KIND>
+__device__ __forceinline__ float env_of(typename RawOf<KIND>::T v, float i16_scale) {
+    if constexpr (KIND == IN_IQ_F32) {
+        const float a = v.x * v.x, b = v.y * v.y;
+        return a + b;
+    } else if constexpr (KIND == IN_ENV_F32) {
+        return v;
+    } else if constexpr (KIND == IN_REAL_F32_SQ) {
+        return v * v;
+    } else {
+        const float s = (float)v * i16_scale;
+        return s * s;
+    }
+}
+template <int KIND>
+__device__ __forceinline__ typename RawOf<KIND>::T raw_zero() {
+    if constexpr (KIND == IN_IQ_F32) return make_float2(0.f, 0.f);
+    else if constexpr (KIND == IN_I16_SQ) return (int16_t)0;
+    else return 0.f;
 }
 
 __device__ __forceinline__ uint32_t f32_expfield(float v) { return (__float_as_uint(v) >> 23) & 0xFFu; }
@@ -290,7 +332,7 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
         acc = a;
         val = v;
         if (iter > 0 && __all(same)) break;
-        if (iter >= MAX_FIX_ITERS) { flags |= 1u; break; }
+        if (iter >= MAX_FIX_ITERS) { flags |= 1u; break; }   // (iter is uniform: a scalar branch)
         double incs = acc ? (x64 - (double)prev) : 0.0;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -310,7 +352,7 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
             emax = max(emax, e);
         }
     }
-    ss0 += wave_sum_f64(dl);
+    ss0 = rfl(ss0 + wave_sum_f64(dl));
     w_nl = max(w_nl, wave_max_i32((act && !low) ? m : LL_NONE));
     w_kl = max(w_kl, wave_max_i32(key));
     lowm = __ballot(low);
@@ -318,16 +360,17 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
     return acc;   // the caller stores x into the ring slot
 }
 
-template <int KIND>
+template <int KIND, int NR>
 __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
+    constexpr uint32_t STEPN = 64u * NR;   // samples per step: NR rows of 64
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
     const uint32_t slotid = blockIdx.x * wpb + wave;
     uint32_t c;
     if (A.list) {
         if (slotid >= A.nlist) return;
-        c = A.list[slotid];
+        c = rfl(A.list[slotid]);
     } else {
         if (slotid >= (uint32_t)A.nchunks) return;
         c = slotid;
@@ -406,6 +449,9 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         for (int s = lane; s < L; s += 64) part += (double)ring[s];
         ss0 = wave_sum_f64(part) + cr.delta;
     }
+    ss0 = rfl(ss0);
+    w_nl = rfl(w_nl);
+    w_kl = rfl(w_kl);
     const int nl_in = w_nl, kl_in = w_kl;
     float *rin = A.ring_in + (size_t)c * L;
     for (int s = lane; s < A.Lpad; s += 64) tch[s] = 0;
@@ -419,7 +465,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         }
     }
 
-    // ---------------- the chunk, 256 samples per step ----------------
+    // ---------------- the chunk, NR rows of 64 samples per step ----------------
     uint32_t flags = 0;
     uint32_t all_robust = 1;
     float min_ss = 3.0e38f;
@@ -427,33 +473,40 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     uint32_t vmin = 0xFFFFFFFFu, vmax = 0u;   // accepted values as raw bits (positive floats order like uints)
     uint32_t slot_step = (A.g0modL + m_chunk) % (uint32_t)L;
     const float etaD = 1.0f - 9.5367431640625e-07f, etaU = 1.0f + 9.5367431640625e-07f;  // 1 -+ 2^-20
-    float xn[4];
+    // raw samples of the next two steps stay in flight while the current step is classified
+    using Raw = typename RawOf<KIND>::T;
+    Raw r1[NR], r2[NR];
+    auto fetch = [&](uint32_t b, Raw (&r)[NR]) {
+        if (b + STEPN <= A.n) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t m = m_chunk + 64u * j + lane;
-        xn[j] = (m < A.n) ? envelope_at<KIND>(A.in, m, A.i16_scale) : 0.f;
-    }
-    for (uint32_t base = m_chunk; base < n1; base += STEP) {
-        float x[4], prev[4];
-        bool act[4];
-        uint32_t slot[4];
-        const bool full = (base >= m_start) && (base + STEP <= n1);   // wave-uniform: every sample of the step is live
+            for (int j = 0; j < NR; j++) r[j] = load_raw<KIND>(A.in, (size_t)b + 64u * j + lane);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = xn[j];
-        if (base + 2 * STEP <= A.n) {  // prefetch the next step (whole step inside the buffer)
-#pragma unroll
-            for (int j = 0; j < 4; j++) xn[j] = envelope_at<KIND>(A.in, base + STEP + 64u * j + lane, A.i16_scale);
-        } else if (base + STEP < n1) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t m = base + STEP + 64u * j + lane;
-                xn[j] = (m < A.n) ? envelope_at<KIND>(A.in, m, A.i16_scale) : 0.f;
+            for (int j = 0; j < NR; j++) {
+                const uint32_t m = b + 64u * j + lane;
+                r[j] = (m < A.n) ? load_raw<KIND>(A.in, m) : raw_zero<KIND>();
             }
         }
+    };
+    fetch(m_chunk, r1);
+    fetch(m_chunk + STEPN, r2);
+    // One step.  FULL = every sample of the step is live (all but the first / last step of a chunk): the
+    // activity masks fold away at compile time.
+    auto do_step = [&](uint32_t base, auto fullc) {
+        constexpr bool full = decltype(fullc)::value;
+        float x[NR], prev[NR];
+        bool act[NR];
+        uint32_t slot[NR];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NR; j++) {
+            x[j] = env_of<KIND>(r1[j], A.i16_scale);
+            r1[j] = r2[j];
+        }
+        if (base + 2 * STEPN < n1) fetch(base + 2 * STEPN, r2);
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
             const uint32_t m = base + 64u * j + lane;
-            act[j] = full || ((m >= m_start) && (m < n1));
+            act[j] = full ? true : ((m >= m_start) && (m < n1));
             uint32_t s = slot_step + 64u * j + lane;
             s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
             slot[j] = s;
@@ -462,108 +515,127 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         min_ss = fminf(min_ss, (float)ss0 * etaD);
 
         // ---- fast path: classification that holds for every sum the step can see ----
-        bool fast = A.fast_ok && ss0 > 1e-30 && ss0 < 1e30;
-        unsigned long long lowm[4], posm[4];
-        if (fast) {
+        // Written as straight-line code on wave masks (a v_cmp IS the ballot); whether the step may
+        // commit is decided once, at the end.
+        unsigned long long lowm[NR], posm[NR];
+        bool fast = false;
+        if (uni(A.fast_ok && ss0 > 1e-30 && ss0 < 1e30)) {
             // Samples that are LOW for any sum within 30 % of ss0 never enter the ring; the others bound the
             // drift of the sum inside the step: B = sum |x - prev|.  (By induction over the samples: while the
             // drift so far is below 25 % no surely-LOW sample is accepted, so the drift stays below B.)
             const float t_sure = (float)(A.lo_L * 0.70 * ss0) * etaD;
             const float t_maylow = (float)(A.lo_L * 1.30 * ss0) * etaU;
+            unsigned long long actm[NR];
             float b = 0.f;
-            bool maylow = false;
+            unsigned long long maylow = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                b += (act[j] && !(x[j] < t_sure)) ? fabsf(x[j] - prev[j]) : 0.f;
-                maylow |= act[j] && (x[j] < t_maylow);
+            for (int j = 0; j < NR; j++) {
+                actm[j] = full ? ~0ull : __ballot(act[j]);
+                const float ad = fabsf(x[j] - prev[j]);
+                b += (act[j] && !(x[j] < t_sure)) ? ad : 0.f;
+                maylow |= __ballot(x[j] < t_maylow) & actm[j];
             }
             b = wave_sum_f32(b) * 1.001f;
             double bt = (double)b + (double)eps * ss0;
-            fast = bt < 0.25 * ss0;
-            double s_dn = ss0 - bt, s_up = ss0 + bt;
-            float thi_up = (float)(A.hi_L * s_up) * etaU;
+            bool ok = uni(bt < 0.25 * ss0);
+            float thi_up = (float)(A.hi_L * (ss0 + bt)) * etaU;
             // Second look: a sample that is HIGH for every sum within that bound is rejected unless a LOW sample
             // put the state machine into state 2 -- impossible while no sample of the step can be LOW and the
             // carried LOW sample is out of reach.  Leaving those samples out tightens the bound.
             const bool key_live = (w_kl & 1) && ((int)base - (w_kl >> 1)) <= mx + 1;
-            if (fast && !key_live && !__any(maylow)) {
-                bool h1 = false;
+            if (ok && !key_live && maylow == 0) {
+                unsigned long long h1 = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) h1 |= act[j] && (x[j] > thi_up);
-                if (__any(h1)) {
+                for (int j = 0; j < NR; j++) h1 |= __ballot(x[j] > thi_up) & actm[j];
+                if (h1) {
                     float b2 = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) b2 += (act[j] && !(x[j] > thi_up)) ? fabsf(x[j] - prev[j]) : 0.f;
+                    for (int j = 0; j < NR; j++) b2 += (act[j] && !(x[j] > thi_up)) ? fabsf(x[j] - prev[j]) : 0.f;
                     b2 = wave_sum_f32(b2) * 1.001f;
                     bt = (double)b2 + (double)eps * ss0;
-                    s_dn = ss0 - bt;
-                    s_up = ss0 + bt;
-                    thi_up = (float)(A.hi_L * s_up) * etaU;
+                    thi_up = (float)(A.hi_L * (ss0 + bt)) * etaU;
                 }
             }
+            const double s_dn = ss0 - bt, s_up = ss0 + bt;
             const float tlo_dn = (float)(A.lo_L * s_dn) * etaD, tlo_up = (float)(A.lo_L * s_up) * etaU;
             const float thi_dn = (float)(A.hi_L * s_dn) * etaD;
-            fast = fast && (tlo_dn > 1e-30f) && (thi_up < 1e30f);
-            bool lw[4], hg[4], amb = false, anyhg = false;
+            ok = ok && uni((tlo_dn > 1e-30f) && (thi_up < 1e30f));
+            unsigned long long him[NR], amb = 0, anyhi = 0, anylow = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                lw[j] = act[j] && (x[j] < tlo_dn);
-                hg[j] = act[j] && (x[j] > thi_up);
-                const bool inband = !((x[j] < tlo_dn) || (x[j] > tlo_up)) || !((x[j] < thi_dn) || (x[j] > thi_up));
-                amb |= act[j] && inband;
-                anyhg |= hg[j];
-                lowm[j] = __ballot(lw[j]);
+            for (int j = 0; j < NR; j++) {
+                const unsigned long long lo1 = __ballot(x[j] < tlo_dn), lo0 = __ballot(x[j] > tlo_up);
+                const unsigned long long hi1 = __ballot(x[j] > thi_up), hi0 = __ballot(x[j] < thi_dn);
+                amb |= ~((lo1 | lo0) & (hi1 | hi0)) & actm[j];
+                lowm[j] = lo1 & actm[j];
+                him[j] = hi1 & actm[j];
+                anylow |= lowm[j];
+                anyhi |= him[j];
             }
-            if (__any(amb)) fast = false;
-            if (fast) {
+            ok = ok && (amb == 0);
+            if (ok && anylow) {
                 // every LOW sample must sit at run position <= max_len (then none ends on a time-out):
                 // a longer run covers an aligned block of LOW samples, or continues the carried run
                 const int lead = (lowm[0] == ~0ull) ? 64 : (__ffsll((long long)~lowm[0]) - 1);
                 const int carry_run = (int)base - 1 - w_nl;
                 unsigned long long hit = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < NR; j++) {
                     unsigned long long t = lowm[j];
 #pragma unroll
                     for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
                     hit |= t & A.selmask;
                 }
-                if (hit || ((carry_run > 0) && (carry_run + lead > mx))) fast = false;
+                if (hit || ((carry_run > 0) && (carry_run + lead > mx))) ok = false;
             }
-            if (fast) {
-                double dl = 0;
-                const bool need_st2 = __any(anyhg);
+            if (ok) {
+                fast = true;
                 int before = (w_kl & 1) ? (w_kl >> 1) : LL_NONE;  // last LOW before the row (every key here is good)
                 int step_nl = LL_NONE, step_ll = LL_NONE;
+                double dl = 0;
+                if (anyhi == 0) {
+                    // nothing HIGH: a sample is accepted unless it is LOW; accepted values lie inside the bands,
+                    // so their exponent range comes from the thresholds
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    bool ps = false;
-                    if (need_st2) {
+                    for (int j = 0; j < NR; j++) {
+                        const bool a = act[j] && !(x[j] < tlo_dn);
+                        dl += a ? ((double)x[j] - (double)prev[j]) : 0.0;
+                        if (a) {
+                            ring[slot[j]] = x[j];
+                            tch[slot[j]] = 1;
+                        }
+                        posm[j] = 0ull;
+                    }
+                    vmin = min(vmin, __float_as_uint(tlo_dn));
+                    vmax = max(vmax, __float_as_uint(thi_up));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
                         // HIGH is ignored within max_len + 1 samples after a LOW sample
-                        const int m = (int)(base + 64u * j) + lane;
+                        const int rb = (int)(base + 64u * j);
                         const unsigned long long below = lowm[j] & lane_lt;
-                        const int lastlow = below ? (int)(base + 64u * j) + last_set(below) : before;
-                        ps = hg[j] && ((m - lastlow) > mx + 1);
+                        const int lastlow = below ? rb + last_set(below) : before;
+                        const bool ps = (x[j] > thi_up) && act[j] && ((rb + lane - lastlow) > mx + 1);
+                        const bool a = act[j] && !(x[j] < tlo_dn) && !ps;
+                        dl += a ? ((double)x[j] - (double)prev[j]) : 0.0;
+                        if (a) {
+                            ring[slot[j]] = x[j];
+                            tch[slot[j]] = 1;
+                        }
+                        const uint32_t xb = __float_as_uint(x[j]);
+                        vmin = min(vmin, (a && xb != 0u) ? xb : 0xFFFFFFFFu);
+                        vmax = max(vmax, a ? xb : 0u);
+                        posm[j] = __ballot(ps);
+                        before = lowm[j] ? rb + last_set(lowm[j]) : before;
                     }
-                    const bool a = act[j] && !lw[j] && !ps;
-                    dl += a ? ((double)x[j] - (double)prev[j]) : 0.0;
-                    if (a) {
-                        ring[slot[j]] = x[j];
-                        tch[slot[j]] = 1;
-                    }
-                    const uint32_t xb = __float_as_uint(x[j]);
-                    vmin = min(vmin, (a && xb != 0u) ? xb : 0xFFFFFFFFu);
-                    vmax = max(vmax, a ? xb : 0u);
-                    posm[j] = need_st2 ? __ballot(ps) : 0ull;
-                    const unsigned long long actm = full ? ~0ull : __ballot(act[j]);
-                    const unsigned long long nonlow = actm & ~lowm[j];
-                    if (lowm[j]) {
-                        before = (int)(base + 64u * j) + last_set(lowm[j]);
-                        step_ll = before;
-                    }
-                    if (nonlow) step_nl = (int)(base + 64u * j) + last_set(nonlow);
                 }
-                ss0 += wave_sum_f64(dl);
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const int rb = (int)(base + 64u * j);
+                    const unsigned long long nonlow = actm[j] & ~lowm[j];
+                    step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
+                    step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
+                }
+                ss0 = rfl(ss0 + wave_sum_f64(dl));
                 if (step_ll != LL_NONE) {
                     w_kl = 2 * step_ll + 1;
                     chunk_kl = w_kl;
@@ -577,38 +649,59 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         if (!fast) {
             // ---- exact path, one 64-sample row at a time ----
             if (eps > 0.f) all_robust = 0;
+            float xs[NR], pv[NR];
+            uint32_t am = 0;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                xs[j] = x[j];
+                pv[j] = prev[j];
+                am |= act[j] ? (1u << j) : 0u;
+            }
 #pragma unroll 1
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < NR; j++) {
                 const int m = (int)(base + 64u * j) + lane;
                 const int nl_b = w_nl, kl_b = w_kl;
                 unsigned long long lm, pm;
-                const float xj = j == 0 ? x[0] : j == 1 ? x[1] : j == 2 ? x[2] : x[3];
-                const float pj = j == 0 ? prev[0] : j == 1 ? prev[1] : j == 2 ? prev[2] : prev[3];
-                const bool aj = j == 0 ? act[0] : j == 1 ? act[1] : j == 2 ? act[2] : act[3];
-                const uint32_t sj = j == 0 ? slot[0] : j == 1 ? slot[1] : j == 2 ? slot[2] : slot[3];
-                if (row_exact(A, lane, m, aj, xj, pj, ss0, w_nl, w_kl, emin, emax, flags, lm, pm)) {
+                float xj = xs[0], pj = pv[0];
+                uint32_t sj = slot[0];
+#pragma unroll
+                for (int k = 1; k < NR; k++) {
+                    xj = (j == k) ? xs[k] : xj;
+                    pj = (j == k) ? pv[k] : pj;
+                    sj = (j == k) ? slot[k] : sj;
+                }
+                if (row_exact(A, lane, m, (am >> j) & 1u, xj, pj, ss0, w_nl, w_kl, emin, emax, flags, lm, pm)) {
                     ring[sj] = xj;
                     tch[sj] = 1;
                 }
-                if (j == 0) { lowm[0] = lm; posm[0] = pm; }
-                else if (j == 1) { lowm[1] = lm; posm[1] = pm; }
-                else if (j == 2) { lowm[2] = lm; posm[2] = pm; }
-                else { lowm[3] = lm; posm[3] = pm; }
+#pragma unroll
+                for (int k = 0; k < NR; k++) {
+                    lowm[k] = (j == k) ? lm : lowm[k];
+                    posm[k] = (j == k) ? pm : posm[k];
+                }
                 if (w_nl != nl_b) chunk_nl = w_nl;
                 if (w_kl != kl_b) chunk_kl = w_kl;
             }
         }
-        if (lane < 4) {
+        {   // one coalesced store of the step's NR words per plane
+            unsigned long long lo4 = lowm[0], po4 = posm[0];
+#pragma unroll
+            for (int k = 1; k < NR; k++) {
+                lo4 = (lane == k) ? lowm[k] : lo4;
+                po4 = (lane == k) ? posm[k] : po4;
+            }
             const uint32_t w = (base >> 6) + lane;
-            if ((size_t)w * 64 < A.n) {
-                const unsigned long long lo4 = lane == 0 ? lowm[0] : lane == 1 ? lowm[1] : lane == 2 ? lowm[2] : lowm[3];
-                const unsigned long long po4 = lane == 0 ? posm[0] : lane == 1 ? posm[1] : lane == 2 ? posm[2] : posm[3];
+            if (lane < NR && (size_t)w * 64 < A.n) {
                 A.neg[w] = lo4;
                 A.pos[w] = po4;
             }
         }
-        slot_step += STEP;
+        slot_step += STEPN;
         slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
+    };
+    for (uint32_t base = m_chunk; base < n1; base += STEPN) {
+        if ((base >= m_start) && (base + STEPN <= n1)) do_step(base, std::true_type{});
+        else do_step(base, std::false_type{});
     }
     // fold the raw-bit extremes of the fast path into the exponent guard
     if (vmax != 0u) {
