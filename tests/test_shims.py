@@ -1,0 +1,91 @@
+"""The reference-named Python modules (decoder / transition_sink / background): call surface on
+CPU, behaviour on the GPU against the golden vectors and the oracle."""
+import inspect
+
+import numpy as np
+import pytest
+
+from tests.golden_util import Case
+
+
+def test_reference_call_surface():
+    from usrp_nfc_amd import background, decoder, packets, transition_sink, utilities
+    # decoder.py:16
+    p = inspect.signature(decoder.decoder.__init__).parameters
+    assert list(p)[:8] == ['self', 'src', 'dst', 'repeat', 'reader', 'tag', 'samp_rate', 'emulator']
+    assert (p['src'].default, p['dst'].default, p['repeat'].default, p['reader'].default, p['tag'].default,
+            p['samp_rate'].default, p['emulator'].default) == ("uhd", None, False, True, True, 2e6, None)
+    # transition_sink.py:12
+    p = inspect.signature(transition_sink.transition_sink.__init__).parameters
+    assert list(p)[:7] == ['self', 'samp_rate', 'callback', 'lo_val', 'hi_val', 'av_window', 'max_len']
+    assert (p['lo_val'].default, p['hi_val'].default, p['av_window'].default, p['max_len'].default) == (0.1, 1.1, 2000, 50)
+    assert hasattr(transition_sink.transition_sink, 'work')
+    # background.py:17,27
+    p = inspect.signature(background.background.__init__).parameters
+    assert list(p)[:4] == ['self', 'reader', 'tag', 'emulator']
+    assert hasattr(background.background, 'append')
+    # constants (utilities.py:7-23, packets.py:19-28)
+    assert utilities.PulseLength.HALF == 4.72 and utilities.ErrorCode.WRONG_DUR == 6
+    assert packets.PacketType.start_bit(0) == 1 and packets.PacketType.start_bit(1) == 0
+
+
+class _Fsm(object):
+    def __init__(self):
+        self.got = []
+
+    def process_bits(self, bits, packet_type):
+        self.got.append((packet_type, list(bits)))
+
+
+@pytest.mark.gpu
+def test_transition_sink_work_contract_and_chunk_invariance():
+    from usrp_nfc_amd.transition_sink import transition_sink
+    c = Case('fx_ultralight_txn')
+    for call_len, batch in ((8192, 1 << 22), (1000, 5000), (4097, 4097)):
+        out = []
+        ts = transition_sink(c.params['samp_rate'], out.extend, hi_val=c.params['hi_val'], batch=batch)
+        i = 0
+        while i < len(c.x):
+            i += ts.work([c.x[i:i + call_len]], None)
+        ts.stop()
+        assert out == c.transitions
+        ts.close()
+
+
+@pytest.mark.gpu
+def test_decoder_background_deliver_packets_to_fsm():
+    from usrp_nfc_amd.decoder import decoder
+    c = Case('fx_ultralight_txn')
+    s = np.sqrt(c.x.astype(np.float64)).astype(np.float32)   # a "recording": the path squares it (decoder.py:26-27)
+    f = _Fsm()
+    d = decoder(src=s, reader=True, tag=True, samp_rate=2e6, fsm=f, batch=10000)
+    back = d.run()
+    from oracle import c_oracle as co
+    o = co.COracle(**c.params)
+    o.push_real_sq(s)
+    assert f.got == o.packets() == back.packets
+    assert len(f.got) == 19
+    assert back.symbols[0] == o.symbols(0).tolist() and back.symbols[1] == o.symbols(1).tolist()
+
+
+@pytest.mark.gpu
+def test_decoder_reads_16bit_wav(tmp_path):
+    import wave
+    from usrp_nfc_amd import synth
+    from usrp_nfc_amd.decoder import decoder
+    frames = synth.txn_frames()
+    m = synth.modulation_profile(frames, gap_us=90.0, depth=0.12)
+    env = synth.envelope_f32(synth.iq_from_profile(m, seed=5))          # what usrp_src records (|IQ|^2)
+    pcm = np.clip(np.round(env / env.max() * 30000), -32768, 32767).astype('<i2')
+    path = str(tmp_path / 'ultralight_synth.wav')
+    w = wave.open(path, 'wb')
+    w.setnchannels(1); w.setsampwidth(2); w.setframerate(2000000)
+    w.writeframes(pcm.tobytes()); w.close()
+    f = _Fsm()
+    decoder(src=path, reader=True, tag=True, samp_rate=2e6, fsm=f).run()
+    from oracle import c_oracle as co
+    o = co.COracle(samp_rate=2e6, hi_val=1.09)
+    sc = np.float32(1.0 / 32768.0)
+    o.push_real_sq((pcm.astype(np.float32) * sc).astype(np.float32))
+    assert f.got == o.packets()
+    assert len(f.got) >= 17

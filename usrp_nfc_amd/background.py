@@ -1,0 +1,56 @@
+"""Drop-in for the reference's background module (background.py:17-52).
+
+The reference's ``background`` owns the Miller / Manchester decoders and the
+CombinedPacketProcessor and is fed lists of transitions through ``append``.  Here
+those three stages run on the GPU inside the same context as the threshold stage,
+so ``background`` is the host-side sink of their results: every closed packet is
+handed, in stream order, to ``fsm.process_bits(bits, packet_type)`` exactly as
+packets.py:96-98 does.  There is no busy-spinning thread; delivery is synchronous
+with ``transition_sink.work`` / ``flush``.
+
+``background(reader, tag, emulator)`` keeps the reference signature.  ``fsm`` may
+be passed explicitly (any object with ``process_bits``); by default the reference's
+own ``fsm`` module is used when it is importable (it is Python 2), else packets are
+only recorded in ``self.packets``.
+"""
+from .packets import PacketType
+
+
+class _Recorder(object):
+    def process_bits(self, bits, packet_type):
+        pass
+
+
+class background(object):
+    def __init__(self, reader=False, tag=False, emulator=None, fsm=None):
+        self.reader = bool(reader)   # Modified-Miller decoder present (background.py:20)
+        self.tag = bool(tag)         # Manchester decoder present      (background.py:21)
+        self.packets = []            # (packet_type, [bits]) in stream order
+        self.symbols = {PacketType.TAG_TO_READER: [], PacketType.READER_TO_TAG: []}
+        self.transitions = None      # set to a list to also keep the raw transitions
+        if fsm is None:
+            try:                      # packets.py:88-92
+                import fsm as _ref_fsm
+                if emulator:
+                    fsm = _ref_fsm.fsm(emulator.process_packet)
+                    emulator.set_encoder(fsm.process_outgoing)
+                else:
+                    fsm = _ref_fsm.fsm()
+            except Exception:
+                fsm = _Recorder()
+        self._fsm = fsm
+
+    # -- reference surface ---------------------------------------------------------
+    def append(self, transitions):
+        """background.py:27-28.  With the GPU path the decoders have already consumed these
+        transitions on the device; the list is kept only when ``self.transitions`` is a list."""
+        if self.transitions is not None:
+            self.transitions.extend(transitions)
+
+    # -- GPU delivery (called by transition_sink after each batch) ---------------------
+    def _deliver(self, ctx):
+        for t in (PacketType.TAG_TO_READER, PacketType.READER_TO_TAG):
+            self.symbols[t].extend(ctx.symbols(t).tolist())
+        for ptype, bits in ctx.packets():
+            self.packets.append((ptype, bits))
+            self._fsm.process_bits(bits, ptype)
