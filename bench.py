@@ -82,15 +82,6 @@ def make_capture_slice(workload, n_per_rank, rank, world):
     return ov, own
 
 
-def carrier_level(iq_head):
-    """Robust unloaded-carrier level of an IQ excerpt (same estimate the threshold kernel speculates with)."""
-    x = synth.envelope_f32(iq_head)
-    half = 0.5 * x.max()
-    ca = x[x >= half].mean()
-    sel = x[(x >= half) & (x <= ca)]
-    return float(sel.mean() if len(sel) else ca)
-
-
 def main():
     a = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -98,12 +89,17 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     n = int(a.samples)
     dist = None
+    backend = os.environ.get('NFC_BENCH_BACKEND', 'nccl')   # 'gloo': plumbing test of the N>1 path on one GPU
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    dev = local if world > 1 else 0
+        ndev = max(1, torch.cuda.device_count())
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
+    dev = (local % ndev) if world > 1 else 0
 
     ov, own = make_capture_slice(a.workload, n, rank, world)
     flags = decoder_flags(a.workload)
@@ -115,42 +111,23 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == 'nccl':
+                torch.cuda.synchronize()
 
-    redo_count = 0
-
-    level = carrier_level(ov[:2 * 4096]) if len(ov) else 0.0
+    from usrp_nfc_amd import sharding
+    if dist is not None:
+        import torch
+        comm = sharding.TorchDistComm(dist, torch.device('cuda', local) if backend == 'nccl' else torch.device('cpu'))   # nccl == RCCL over xGMI
+    else:
+        comm = sharding.LocalComm()
+    level = sharding.carrier_level(synth.envelope_f32(ov[:2 * 4096])) if len(ov) else 0.0
     g_lo = rank * n
+    redo_count = 0
 
     def one_step():
         nonlocal redo_count
-        if d_ov is None:
-            ctx.reset()
-        else:
-            # speculate the boundary state: start OVERLAP samples early from a primed (level-estimate) state
-            ctx.prime(g_lo - len(ov) // 2, level)
-            ctx.push_device(d_ov, len(ov) // 2)
-        spec_in = ctx.state_blob() if world > 1 else None
-        ctx.push_device(d_own, n)
-        if world > 1:
-            import torch
-            # boundary exchange: every rank's end state over RCCL; a rank whose speculated start state
-            # differs from its predecessor's true end state re-decodes its chunk from the true state
-            mine = ctx.state_blob()
-            ln = torch.tensor([len(mine)], device='cuda', dtype=torch.int64)
-            lens = [torch.zeros_like(ln) for _ in range(world)]
-            dist.all_gather(lens, ln)
-            cap = int(max(int(x) for x in lens))
-            buf = torch.zeros(cap, dtype=torch.uint8, device='cuda')
-            buf[:len(mine)] = torch.from_numpy(mine).cuda()
-            allb = [torch.zeros_like(buf) for _ in range(world)]
-            dist.all_gather(allb, buf)
-            if rank > 0:
-                prev = allb[rank - 1][:int(lens[rank - 1])].cpu().numpy()
-                if len(prev) != len(spec_in) or not np.array_equal(prev, spec_in):
-                    redo_count += 1
-                    ctx.set_state_blob(prev)
-                    ctx.push_device(d_own, n)
+        redo_count += sharding.decode_shard(ctx, comm, lambda: ctx.push_device(d_ov, len(ov) // 2),
+                                            lambda: ctx.push_device(d_own, n), g_lo - len(ov) // 2, level)
         return ctx.stats()
 
     for _ in range(a.warmup):
@@ -167,7 +144,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        tmax = torch.tensor([dt], device='cuda' if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

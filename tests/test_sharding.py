@@ -1,0 +1,177 @@
+"""Time sharding across ranks (usrp_nfc_amd/sharding.py): world_size-2 gloo run on CPU with an
+oracle-backed engine (the protocol is host logic), and the same boundary hand-off on one GPU."""
+import os
+import pickle
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import py_oracle as po
+from usrp_nfc_amd import sharding, synth
+
+N_PER = 36000
+OVERLAP = 24000
+
+
+def capture(world):
+    m = synth.tiled_profile(synth.modulation_profile(synth.txn_frames(), lead_in=0, tail=0), world * N_PER)
+    iq = synth.iq_from_profile(m, seed=77)
+    return synth.envelope_f32(iq), iq
+
+
+class OracleEngine(object):
+    """The CPU restatement behind the engine interface decode_shard expects (test stand-in for NfcContext)."""
+
+    def __init__(self, hi_val=1.1):
+        self.hi = hi_val
+        self.reset()
+
+    def reset(self):
+        self.sink = po.BitSink()
+        self.router = po.Router(po.MillerDecoder(self.sink), po.ManchesterDecoder(self.sink))
+        self.out = []
+        self.ts = po.TransitionSink(2e6, self._cb, hi_val=self.hi)
+
+    def _cb(self, lst):
+        self.out.extend(lst)
+        self.router.append(lst)
+
+    def prime(self, start_index, level):
+        self.reset()
+        ts = self.ts
+        L = ts.length
+        ts.ring = [float(np.float32(level))] * L
+        ts.total = float(np.sum(np.full(L, np.float32(level), np.float32).astype(np.float64)))
+        ts.filled, ts.stable = L, True
+        ts.index = start_index % L
+        ts.dur, ts.last_bit, ts.state = 1, 0, 0
+
+    def push(self, x):
+        self.out = []
+        self.sink.packets = []
+        self.sink.symbols = [[], []]
+        po.drive_sink(self.ts, x, 8192)
+
+    def _state(self):
+        ts, md, mn = self.ts, self.router.reader_dec, self.router.tag_dec
+        L = ts.length
+        ring = [ts.ring[(ts.index + i) % L] for i in range(L)]   # oldest first: independent of the rotation
+        return (ring, ts.total, ts.dur, ts.last_bit, ts.state,
+                (md.prev if md.started else 0, md.started, md.stage()), (mn.prev_set, mn.prev),
+                [(p.started, list(p.cur)) for p in self.sink.procs])
+
+    def state_blob(self):
+        return np.frombuffer(pickle.dumps(self._state(), protocol=4), np.uint8)
+
+    def set_state_blob(self, blob):
+        ring, total, dur, lb, st, mil, man, procs = pickle.loads(bytes(blob))
+        ts = self.ts
+        L = ts.length
+        for i in range(L):
+            ts.ring[(ts.index + i) % L] = ring[i]
+        ts.total, ts.dur, ts.last_bit, ts.state = total, dur, lb, st
+        md, mn = self.router.reader_dec, self.router.tag_dec
+        md.prev, md.started = mil[0], mil[1]
+        md.set_stage(mil[2])
+        mn.prev_set, mn.prev = man
+        for p, (s, c) in zip(self.sink.procs, procs):
+            p.started, p.cur = s, list(c)
+
+
+def _worker(rank, world, port, wrong_level, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import torch
+        x, _ = capture(world)
+        lo = rank * N_PER
+        own = x[lo:lo + N_PER]
+        nov = 64 if wrong_level else OVERLAP          # sabotage: an overlap far too short to converge
+        ov = x[lo - nov:lo] if rank else x[:0]
+        eng = OracleEngine()
+        comm = sharding.TorchDistComm(dist, torch.device('cpu'))
+        level = sharding.carrier_level(ov[:4096]) if rank else 0.0
+        redos = sharding.decode_shard(eng, comm, lambda: eng.push(ov), lambda: eng.push(own), lo - len(ov), level)
+        res = [None] * world
+        dist.all_gather_object(res, (redos, eng.out, eng.sink.packets))
+        if rank == 0:
+            q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('wrong_level', [False, True])
+def test_two_ranks_gloo(wrong_level):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, wrong_level, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, _ = capture(world)
+    ref = po.run_path(x, hi_val=1.1)
+    got_tr = [t for _, tr, _ in res for t in tr]
+    got_pk = [p for _, _, pk in res for p in pk]
+    assert got_tr == ref['transitions']
+    assert got_pk == ref['packets']
+    if wrong_level:
+        assert res[1][0] == 1      # the speculation was sabotaged: exactly one re-decode, result still exact
+    else:
+        assert res[1][0] == 0      # the overlap speculation hit the true boundary state
+
+
+@pytest.mark.gpu
+def test_boundary_handoff_on_gpu():
+    from oracle import c_oracle as co
+    from usrp_nfc_amd import api
+    world = 3
+    _, iq = capture(world)
+    o = co.COracle(hi_val=1.1)
+    o.push_iq(iq)
+    edges, packets = [], []
+    prev_end = None
+    for r in range(world):
+        lo = r * N_PER
+        own = iq[2 * lo:2 * (lo + N_PER)]
+        ctx = api.NfcContext(hi_val=1.1)
+        if r == 0:
+            ctx.reset()
+        else:
+            ov = iq[2 * (lo - OVERLAP):2 * lo]
+            ctx.prime(lo - OVERLAP, sharding.carrier_level(synth.envelope_f32(ov[:8192])))
+            ctx.push(ov)
+            spec = ctx.state_blob()
+            assert np.array_equal(spec, prev_end), 'speculated boundary state differs from the true one'
+            # and the explicit hand-off gives the same decode
+            ctx2 = api.NfcContext(hi_val=1.1)
+            ctx2.set_state_blob(prev_end)
+            ctx2.push(own)
+            alt = (ctx2.transitions(), ctx2.packets())
+            ctx2.close()
+        ctx.push(own)
+        tr, pk = ctx.transitions(), ctx.packets()
+        if r:
+            assert alt == (tr, pk)
+        edges += tr
+        packets += pk
+        prev_end = ctx.state_blob()
+        ctx.close()
+    assert edges == o.transitions()
+    assert packets == o.packets()
