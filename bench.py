@@ -166,13 +166,13 @@ def main():
             'dtype': 'f32 envelope / f64 window sums / u8 symbols', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: Miller-only decode, synthetic IQ @2 Msps' if a.workload == 'miller'
                        else 'workload=%s' % a.workload,
-                       'samples_per_gpu': n, 'time_chunk_samples': 16384, 'parallelism': 'time-chunk x%d' % world,
+                       'samples_per_gpu': n, 'time_chunk_samples': int(st.chunk_samples), 'time_chunks': int(st.n_chunks), 'parallelism': 'time-chunk x%d' % world,
                        'edges_per_gpu': n_edges, 'symbols_reader': int(cnt.n_symbols[1]),
                        'symbols_tag': int(cnt.n_symbols[0]), 'packets': int(cnt.n_packets[0] + cnt.n_packets[1]),
                        'boundary_redos': redo_count},
             'roofline': {'bound': 'hbm', 'kernel': 'k_threshold (fused envelope + gated-mean threshold)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'avg_launch_ms': k_avg,
+                         'traffic': hbm_traffic(a, n), 'avg_launch_ms': k_avg,
                          'launches_per_step': float(np.mean(n_pass)) if n_pass else None,
                          'algorithmic_bytes_per_launch': alg_bytes},
             'stage_ms_last_step': {'total_device': st.ms_total, 'threshold': st.ms_threshold, 'edges': st.ms_edges,
@@ -187,6 +187,19 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def hbm_traffic(a, n):
+    """HBM bytes per k_threshold launch from the rocprofv3 PMC passes recorded under profiles/ (separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md).  None unless the recorded run matches this workload."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
+        if rec.get('workload') == a.workload and int(rec.get('samples', 0)) == n:
+            return rec['bytes_per_launch']
+    except Exception:
+        pass
+    return None
 
 
 def parity_check(a, own, flags, n):

@@ -108,7 +108,7 @@ typedef struct {
     uint64_t bytes_in;        /* input bytes of the last batch */
     double ms_threshold_kernel[6]; /* hipEvent duration of each k_threshold launch of the last batch (first 6) */
     uint32_t n_threshold_timed;
-    uint32_t reserved;
+    uint32_t chunk_samples;   /* time-chunk length the threshold kernel used for the last batch */
 } nfc_stats;
 
 /* Everything a successor time chunk needs from its predecessor:

@@ -31,7 +31,7 @@ class Stats(C.Structure):
     _fields_ = [('ms_total', C.c_double), ('ms_threshold', C.c_double), ('ms_edges', C.c_double),
                 ('ms_decode', C.c_double), ('threshold_passes', C.c_uint32), ('chunks_rerun', C.c_uint32),
                 ('used_sequential', C.c_uint32), ('n_chunks', C.c_uint32), ('bytes_in', C.c_uint64),
-                ('ms_threshold_kernel', C.c_double * 6), ('n_threshold_timed', C.c_uint32), ('reserved', C.c_uint32)]
+                ('ms_threshold_kernel', C.c_double * 6), ('n_threshold_timed', C.c_uint32), ('chunk_samples', C.c_uint32)]
 
 
 class StateHeader(C.Structure):

@@ -272,6 +272,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     const uint32_t off = c->use_rr ? (uint32_t)(c->nseen % (uint64_t)L) : 0u;
     const uint32_t nch = (uint32_t)(((uint64_t)n + off + c->C - 1) / c->C);
     c->stats.n_chunks = nch;
+    c->stats.chunk_samples = (uint32_t)c->C;
     const size_t nwords = ((size_t)n + 63) / 64 + 8;
     HIPCHK(c, c->d_neg.ensure(nwords * 8));
     HIPCHK(c, c->d_pos.ensure(nwords * 8));
