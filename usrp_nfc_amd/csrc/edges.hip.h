@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/nfc_amd.h"
+#include "scan.hip.h"
 
 namespace nfc {
 
@@ -217,6 +218,77 @@ struct StoreWordEdges {
         });
     }
 };
+
+// The writer proper: a workgroup owns 512 consecutive words (two per thread).  It places its entries with a
+// block scan, replays its words into LDS, and copies the staged entries out with full-width coalesced
+// stores (a thread's own entries are only ~4 x 16 B apart from its neighbour's -- written directly they
+// touch a cache line per lane).  Tiles with more entries than fit the stage write directly.
+constexpr int EW_ITEMS = 2;
+constexpr int EW_CAP = 3072;   // staged entries per workgroup: 48 KB of nfc_edge + 6 KB of codes
+__global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const Last2 *ctx, const uint32_t *wcnt,
+                                                           const uint32_t *tile_base, nfc_edge *edges, uint16_t *ecode,
+                                                           uint32_t cap) {
+    __shared__ __attribute__((aligned(16))) nfc_edge s_edge[EW_CAP];
+    __shared__ uint16_t s_code[EW_CAP];
+    __shared__ uint32_t s_scan[SCAN_WAVES];
+    const size_t w0 = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * EW_ITEMS;
+    uint32_t c[EW_ITEMS], mine = 0;
+#pragma unroll
+    for (int i = 0; i < EW_ITEMS; i++) {
+        c[i] = (w0 + i < nwords) ? wcnt[w0 + i] : 0u;
+        mine += c[i];
+    }
+    uint32_t total;
+    uint32_t off = block_exclusive<AddU32>(mine, s_scan, total);
+    const uint32_t gbase = tile_base[blockIdx.x];
+    const bool staged = total <= (uint32_t)EW_CAP;
+#pragma unroll
+    for (int i = 0; i < EW_ITEMS; i++) {
+        if (!c[i]) continue;
+        uint32_t k = off;
+        const int nd = A.nd;
+        const uint64_t g0 = A.g0;
+        if (staged) {
+            replay_word(A, w0 + i, ctx[w0 + i], [&](int32_t p, int v, int d, int t) {
+                nfc_edge o;
+                o.idx = g0 + (uint64_t)p;
+                o.d = d;
+                o.v = (int8_t)v;
+                o.t = (int8_t)t;
+                o.pad = 0;
+                s_edge[k] = o;
+                s_code[k] = edge_code(v, d, t, nd);
+                k++;
+            });
+        } else {
+            replay_word(A, w0 + i, ctx[w0 + i], [&](int32_t p, int v, int d, int t) {
+                const uint32_t g = gbase + k;
+                if (g < cap) {
+                    nfc_edge o;
+                    o.idx = g0 + (uint64_t)p;
+                    o.d = d;
+                    o.v = (int8_t)v;
+                    o.t = (int8_t)t;
+                    o.pad = 0;
+                    edges[g] = o;
+                    ecode[g] = edge_code(v, d, t, nd);
+                }
+                k++;
+            });
+        }
+        off += c[i];
+    }
+    if (staged) {
+        __syncthreads();
+        const uint4 *src = (const uint4 *)s_edge;
+        uint4 *dst = (uint4 *)(edges + gbase);
+        for (uint32_t i = threadIdx.x; i < total; i += SCAN_BLOCK)
+            if (gbase + i < cap) {
+                dst[i] = src[i];
+                ecode[gbase + i] = s_code[i];
+            }
+    }
+}
 
 // carried (_last_bit, _dur, _current_state) after the batch, from the scan-1 total
 __global__ void k_edge_carry(EdgeArgs A, const Last2 *total, EdgeCarry *carry) {

@@ -522,8 +522,10 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     // scan 1: the two latest val changes before every 64-sample word; each word then counts its entries
     device_scan<Last2Op, 4>(c->st, nwords, LoadLast2{E}, StoreCtxAndCount{E, ctx, wcnt}, Last2Op::identity(),
                             c->d_partials.as<Last2>(), (Last2 *)(tot + TOT_LAST2));
-    // scan 2: entry offsets; then every word writes its entries
-    scan_phase1<AddU32, 8>(c->st, nwords, LoadWordCount{wcnt}, 0u, c->d_partials.as<uint32_t>(), (uint32_t *)(tot + TOT_EDGES));
+    // scan 2: entry offsets per 512-word tile; then every tile stages and writes its entries
+    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<EW_ITEMS>(nwords) + 1) * sizeof(uint32_t)));
+    scan_phase1<AddU32, EW_ITEMS>(c->st, nwords, LoadWordCount{wcnt}, 0u, c->d_partials.as<uint32_t>(),
+                                  (uint32_t *)(tot + TOT_EDGES));
     HIPCHK(c, mirror_async(c));
     HIPCHK(c, hipStreamSynchronize(c->st));
     uint32_t nedges;
@@ -531,9 +533,9 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     c->n_edges = nedges;
     HIPCHK(c, c->d_edges.ensure(((size_t)nedges + 1) * sizeof(nfc_edge)));
     HIPCHK(c, c->d_ecode.ensure(((size_t)nedges + 8) * 2));
-    scan_phase2<AddU32, 8>(c->st, nwords, LoadWordCount{wcnt},
-                           StoreWordEdges{E, ctx, c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), nedges},
-                           c->d_partials.as<uint32_t>());
+    if (nwords)
+        hipLaunchKernelGGL(k_write_edges, dim3((unsigned)scan_num_tiles<EW_ITEMS>(nwords)), dim3(SCAN_BLOCK), 0, c->st, E, nwords,
+                           ctx, wcnt, c->d_partials.as<uint32_t>(), c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), nedges);
     hipLaunchKernelGGL(k_edge_carry, dim3(1), dim3(64), 0, c->st, E, (const Last2 *)(tot + TOT_LAST2), dE(c));
     return NFC_OK;
 }

@@ -406,47 +406,64 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         // speculate: the L samples before the chunk, rejected-looking ones replaced by a level estimate
         eps = A.eps;
         const uint32_t w0 = m_chunk - (uint32_t)L;
+        const uint32_t slot0 = (A.g0modL + w0) % (uint32_t)L;   // ring slot of sample w0 (uniform)
         float mxv = 0.f;
-        for (int i = lane; i < L; i += 64) {
-            const uint32_t m = w0 + i;
-            const float x = envelope_at<KIND>(A.in, m, A.i16_scale);
-            const uint32_t slot = (A.g0modL + m) % (uint32_t)L;
-            ring[slot] = x;
-            mxv = fmaxf(mxv, x);
+        for (int i0 = 0; i0 < L; i0 += 512) {   // eight independent loads in flight per lane
+            typename RawOf<KIND>::T rw[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + 64 * k + lane;
+                rw[k] = (i < L) ? load_raw<KIND>(A.in, (size_t)w0 + i) : raw_zero<KIND>();
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + 64 * k + lane;
+                if (i < L) {
+                    const float x = env_of<KIND>(rw[k], A.i16_scale);
+                    uint32_t slot = slot0 + (uint32_t)i;
+                    slot = (slot >= (uint32_t)L) ? slot - (uint32_t)L : slot;
+                    ring[slot] = x;
+                    mxv = fmaxf(mxv, x);
+                }
+            }
         }
         mxv = wave_max_f32(mxv);
         const float half = 0.5f * mxv;
-        double sa = 0, na = 0;
+        float sa = 0.f, na = 0.f;
         for (int s = lane; s < L; s += 64) {
             const float x = ring[s];
-            if (x >= half) { sa += (double)x; na += 1.0; }
+            if (x >= half) { sa += x; na += 1.f; }
         }
-        sa = wave_sum_f64(sa);
-        na = wave_sum_f64(na);
-        const float ca = (na > 0) ? (float)(sa / na) : mxv;
-        double sb = 0, nb = 0;
+        sa = wave_sum_f32(sa);
+        na = wave_sum_f32(na);
+        const float ca = (na > 0.f) ? sa / na : mxv;
+        float sb = 0.f, nb = 0.f;
         for (int s = lane; s < L; s += 64) {
             const float x = ring[s];
-            if (x >= half && x <= ca) { sb += (double)x; nb += 1.0; }
+            if (x >= half && x <= ca) { sb += x; nb += 1.f; }
         }
-        sb = wave_sum_f64(sb);
-        nb = wave_sum_f64(nb);
-        const float c0 = (nb > 0) ? (float)(sb / nb) : ca;
+        sb = wave_sum_f32(sb);
+        nb = wave_sum_f32(nb);
+        const float c0 = (nb > 0.f) ? sb / nb : ca;
         const float tlo = (float)A.lo * c0, thi = (float)A.hi * c0;
+        // ring slot s last saw sample m = w0 + ((s - slot0) mod L)
         int ll = LL_NONE, nl = LL_NONE;
-        for (int i = lane; i < L; i += 64) {
-            const uint32_t m = w0 + i;
-            const uint32_t slot = (A.g0modL + m) % (uint32_t)L;
-            const float x = ring[slot];
-            if (x < tlo) ll = max(ll, (int)m);
-            else nl = max(nl, (int)m);
-            if (!(x >= tlo && x <= thi)) ring[slot] = c0;
+        double part = 0;
+        for (int s = lane; s < L; s += 64) {
+            const int rel = (s >= (int)slot0) ? s - (int)slot0 : s - (int)slot0 + L;
+            const int m = (int)w0 + rel;
+            float x = ring[s];
+            if (x < tlo) ll = max(ll, m);
+            else nl = max(nl, m);
+            if (!(x >= tlo && x <= thi)) {
+                x = c0;
+                ring[s] = c0;
+            }
+            part += (double)x;
         }
         ll = wave_max_i32(ll);
         w_nl = wave_max_i32(nl);
         w_kl = (ll == LL_NONE) ? KEY_NONE : 2 * ll + 1;
-        double part = 0;
-        for (int s = lane; s < L; s += 64) part += (double)ring[s];
         ss0 = wave_sum_f64(part) + cr.delta;
     }
     ss0 = rfl(ss0);
@@ -490,88 +507,90 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     };
     fetch(m_chunk, r1);
     fetch(m_chunk + STEPN, r2);
-    // One step.  FULL = every sample of the step is live (all but the first / last step of a chunk): the
-    // activity masks fold away at compile time.
-    auto do_step = [&](uint32_t base, auto fullc) {
-        constexpr bool full = decltype(fullc)::value;
+    // Every step of a chunk is whole except the batch's last one and the stretch before the first stable
+    // sample (chunk lengths are multiples of the step): those rare partial steps take the exact row path.
+    const float loLf = (float)A.lo_L, hiLf = (float)A.hi_L;   // thresholds in f32 carry 2^-18 of slack (>> 4 roundings)
+    const float slD = 1.0f - 3.814697265625e-06f, slU = 1.0f + 3.814697265625e-06f;
+    for (uint32_t base = m_chunk; base < n1; base += STEPN) {
         float x[NR], prev[NR];
-        bool act[NR];
         uint32_t slot[NR];
+        const bool full = (base >= m_start) && (base + STEPN <= n1);   // uniform
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             x[j] = env_of<KIND>(r1[j], A.i16_scale);
             r1[j] = r2[j];
         }
         if (base + 2 * STEPN < n1) fetch(base + 2 * STEPN, r2);
+        if (slot_step + STEPN <= (uint32_t)L) {   // the step does not wrap the ring: immediate offsets
+            const float *rp = ring + slot_step + lane;
 #pragma unroll
-        for (int j = 0; j < NR; j++) {
-            const uint32_t m = base + 64u * j + lane;
-            act[j] = full ? true : ((m >= m_start) && (m < n1));
-            uint32_t s = slot_step + 64u * j + lane;
-            s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
-            slot[j] = s;
-            prev[j] = ring[s];
+            for (int j = 0; j < NR; j++) {
+                slot[j] = slot_step + 64u * j + lane;
+                prev[j] = rp[64 * j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                uint32_t s = slot_step + 64u * j + lane;
+                s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
+                slot[j] = s;
+                prev[j] = ring[s];
+            }
         }
-        min_ss = fminf(min_ss, (float)ss0 * etaD);
+        const float ssf = (float)ss0;
+        min_ss = fminf(min_ss, ssf * etaD);
 
         // ---- fast path: classification that holds for every sum the step can see ----
-        // Written as straight-line code on wave masks (a v_cmp IS the ballot); whether the step may
-        // commit is decided once, at the end.
+        // Straight-line code on wave masks (a v_cmp IS the ballot); whether the step may commit is decided once.
         unsigned long long lowm[NR], posm[NR];
         bool fast = false;
-        if (uni(A.fast_ok && ss0 > 1e-30 && ss0 < 1e30)) {
+        if (full && A.fast_ok && ssf > 1e-30f && ssf < 1e30f) {
             // Samples that are LOW for any sum within 30 % of ss0 never enter the ring; the others bound the
             // drift of the sum inside the step: B = sum |x - prev|.  (By induction over the samples: while the
             // drift so far is below 25 % no surely-LOW sample is accepted, so the drift stays below B.)
-            const float t_sure = (float)(A.lo_L * 0.70 * ss0) * etaD;
-            const float t_maylow = (float)(A.lo_L * 1.30 * ss0) * etaU;
-            unsigned long long actm[NR];
+            const float t_sure = ssf * loLf * 0.70f, t_maylow = ssf * loLf * 1.30f;
             float b = 0.f;
             unsigned long long maylow = 0;
 #pragma unroll
             for (int j = 0; j < NR; j++) {
-                actm[j] = full ? ~0ull : __ballot(act[j]);
-                const float ad = fabsf(x[j] - prev[j]);
-                b += (act[j] && !(x[j] < t_sure)) ? ad : 0.f;
-                maylow |= __ballot(x[j] < t_maylow) & actm[j];
+                b += (x[j] < t_sure) ? 0.f : fabsf(x[j] - prev[j]);
+                maylow |= __ballot(x[j] < t_maylow);
             }
             b = wave_sum_f32(b) * 1.001f;
-            double bt = (double)b + (double)eps * ss0;
-            bool ok = uni(bt < 0.25 * ss0);
-            float thi_up = (float)(A.hi_L * (ss0 + bt)) * etaU;
+            float bt = b + eps * ssf;
+            bool ok = bt < 0.25f * ssf;
+            float thi_up = (ssf + bt) * slU * hiLf;
             // Second look: a sample that is HIGH for every sum within that bound is rejected unless a LOW sample
             // put the state machine into state 2 -- impossible while no sample of the step can be LOW and the
             // carried LOW sample is out of reach.  Leaving those samples out tightens the bound.
             const bool key_live = (w_kl & 1) && ((int)base - (w_kl >> 1)) <= mx + 1;
-            if (ok && !key_live && maylow == 0) {
+            if (!key_live && maylow == 0) {
                 unsigned long long h1 = 0;
 #pragma unroll
-                for (int j = 0; j < NR; j++) h1 |= __ballot(x[j] > thi_up) & actm[j];
+                for (int j = 0; j < NR; j++) h1 |= __ballot(x[j] > thi_up);
                 if (h1) {
                     float b2 = 0.f;
 #pragma unroll
-                    for (int j = 0; j < NR; j++) b2 += (act[j] && !(x[j] > thi_up)) ? fabsf(x[j] - prev[j]) : 0.f;
+                    for (int j = 0; j < NR; j++) b2 += (x[j] > thi_up) ? 0.f : fabsf(x[j] - prev[j]);
                     b2 = wave_sum_f32(b2) * 1.001f;
-                    bt = (double)b2 + (double)eps * ss0;
-                    thi_up = (float)(A.hi_L * (ss0 + bt)) * etaU;
+                    bt = fminf(bt, b2 + eps * ssf);
+                    thi_up = (ssf + bt) * slU * hiLf;
                 }
             }
-            const double s_dn = ss0 - bt, s_up = ss0 + bt;
-            const float tlo_dn = (float)(A.lo_L * s_dn) * etaD, tlo_up = (float)(A.lo_L * s_up) * etaU;
-            const float thi_dn = (float)(A.hi_L * s_dn) * etaD;
-            ok = ok && uni((tlo_dn > 1e-30f) && (thi_up < 1e30f));
+            const float dn = (ssf - bt) * slD, up = (ssf + bt) * slU;
+            const float tlo_dn = dn * loLf, tlo_up = up * loLf, thi_dn = dn * hiLf;
             unsigned long long him[NR], amb = 0, anyhi = 0, anylow = 0;
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 const unsigned long long lo1 = __ballot(x[j] < tlo_dn), lo0 = __ballot(x[j] > tlo_up);
                 const unsigned long long hi1 = __ballot(x[j] > thi_up), hi0 = __ballot(x[j] < thi_dn);
-                amb |= ~((lo1 | lo0) & (hi1 | hi0)) & actm[j];
-                lowm[j] = lo1 & actm[j];
-                him[j] = hi1 & actm[j];
-                anylow |= lowm[j];
-                anyhi |= him[j];
+                amb |= ~((lo1 | lo0) & (hi1 | hi0));
+                lowm[j] = lo1;
+                him[j] = hi1;
+                anylow |= lo1;
+                anyhi |= hi1;
             }
-            ok = ok && (amb == 0);
+            ok = __all(ok && (tlo_dn > 1e-30f) && (thi_up < 1e30f)) && (amb == 0);
             if (ok && anylow) {
                 // every LOW sample must sit at run position <= max_len (then none ends on a time-out):
                 // a longer run covers an aligned block of LOW samples, or continues the carried run
@@ -589,15 +608,13 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
             }
             if (ok) {
                 fast = true;
-                int before = (w_kl & 1) ? (w_kl >> 1) : LL_NONE;  // last LOW before the row (every key here is good)
-                int step_nl = LL_NONE, step_ll = LL_NONE;
                 double dl = 0;
                 if (anyhi == 0) {
                     // nothing HIGH: a sample is accepted unless it is LOW; accepted values lie inside the bands,
                     // so their exponent range comes from the thresholds
 #pragma unroll
                     for (int j = 0; j < NR; j++) {
-                        const bool a = act[j] && !(x[j] < tlo_dn);
+                        const bool a = !(x[j] < tlo_dn);
                         dl += a ? ((double)x[j] - (double)prev[j]) : 0.0;
                         if (a) {
                             ring[slot[j]] = x[j];
@@ -608,14 +625,15 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                     vmin = min(vmin, __float_as_uint(tlo_dn));
                     vmax = max(vmax, __float_as_uint(thi_up));
                 } else {
+                    int before = (w_kl & 1) ? (w_kl >> 1) : LL_NONE;  // last LOW before the row (every key here is good)
 #pragma unroll
                     for (int j = 0; j < NR; j++) {
                         // HIGH is ignored within max_len + 1 samples after a LOW sample
                         const int rb = (int)(base + 64u * j);
                         const unsigned long long below = lowm[j] & lane_lt;
                         const int lastlow = below ? rb + last_set(below) : before;
-                        const bool ps = (x[j] > thi_up) && act[j] && ((rb + lane - lastlow) > mx + 1);
-                        const bool a = act[j] && !(x[j] < tlo_dn) && !ps;
+                        const bool ps = (x[j] > thi_up) && ((rb + lane - lastlow) > mx + 1);
+                        const bool a = !(x[j] < tlo_dn) && !ps;
                         dl += a ? ((double)x[j] - (double)prev[j]) : 0.0;
                         if (a) {
                             ring[slot[j]] = x[j];
@@ -628,10 +646,11 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                         before = lowm[j] ? rb + last_set(lowm[j]) : before;
                     }
                 }
+                int step_nl = LL_NONE, step_ll = LL_NONE;
 #pragma unroll
                 for (int j = 0; j < NR; j++) {
                     const int rb = (int)(base + 64u * j);
-                    const unsigned long long nonlow = actm[j] & ~lowm[j];
+                    const unsigned long long nonlow = ~lowm[j];
                     step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
                     step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
                 }
@@ -650,16 +669,15 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
             // ---- exact path, one 64-sample row at a time ----
             if (eps > 0.f) all_robust = 0;
             float xs[NR], pv[NR];
-            uint32_t am = 0;
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 xs[j] = x[j];
                 pv[j] = prev[j];
-                am |= act[j] ? (1u << j) : 0u;
             }
 #pragma unroll 1
             for (int j = 0; j < NR; j++) {
                 const int m = (int)(base + 64u * j) + lane;
+                const bool aj = ((uint32_t)m >= m_start) && ((uint32_t)m < n1);
                 const int nl_b = w_nl, kl_b = w_kl;
                 unsigned long long lm, pm;
                 float xj = xs[0], pj = pv[0];
@@ -670,7 +688,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                     pj = (j == k) ? pv[k] : pj;
                     sj = (j == k) ? slot[k] : sj;
                 }
-                if (row_exact(A, lane, m, (am >> j) & 1u, xj, pj, ss0, w_nl, w_kl, emin, emax, flags, lm, pm)) {
+                if (row_exact(A, lane, m, aj, xj, pj, ss0, w_nl, w_kl, emin, emax, flags, lm, pm)) {
                     ring[sj] = xj;
                     tch[sj] = 1;
                 }
@@ -698,10 +716,6 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         }
         slot_step += STEPN;
         slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
-    };
-    for (uint32_t base = m_chunk; base < n1; base += STEPN) {
-        if ((base >= m_start) && (base + STEPN <= n1)) do_step(base, std::true_type{});
-        else do_step(base, std::false_type{});
     }
     // fold the raw-bit extremes of the fast path into the exponent guard
     if (vmax != 0u) {
