@@ -92,7 +92,7 @@ struct nfc_ctx {
     int L, mx, C, Lpad, wpb, twords;
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
-    int bands_ok, fast_ok, nfold, use_rr, rows_per_step, C_min, wave_slots;
+    int bands_ok, fast_ok, nfold, use_rr, rows_per_step, C_min, wave_slots, lds_per_slot;
     uint64_t selmask;
     float eps;
     float i16_scale;
@@ -199,7 +199,7 @@ void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
         return;
     }
     const uint32_t blocks = (nwork + c->wpb - 1) / c->wpb;
-    const size_t lds = (size_t)c->wpb * c->Lpad * 5;
+    const size_t lds = (size_t)c->wpb * c->Lpad * c->lds_per_slot;
     if (c->rows_per_step == 8) hipLaunchKernelGGL((k_threshold<KIND, 8>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
     else hipLaunchKernelGGL((k_threshold<KIND, 4>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
 }
@@ -350,6 +350,8 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     A.lo_L = c->P.lo_val / (double)L;
     A.hi_L = c->P.hi_val / (double)L;
     for (int f = 0; f < 6; f++) A.fold_sh[f] = (f < c->nfold) ? (1 << f) : 0;
+    A.probe_mid = (1 << c->nfold) / 2;
+    A.probe_end = (1 << c->nfold) - 1;
     A.selmask = c->selmask;
     for (int b = 0; b < 2; b++) {
         A.ring_out[b] = c->d_ringout[b].as<float>();
@@ -765,7 +767,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     }
     c->C = C;
     c->C_min = C;
-    c->wpb = std::max(1, std::min(4, (int)(65536 / ((size_t)c->Lpad * 5))));
+    c->lds_per_slot = (p->input_kind == NFC_IN_ENV_F32) ? 5 : 4;   // ring (+ touched byte map for raw envelopes)
+    c->wpb = std::max(1, std::min(4, (int)(65536 / ((size_t)c->Lpad * c->lds_per_slot))));
     c->hi_plus = p->hi_val + 0.1;  // transition_sink.py:63
     const double eps = std::ldexp(1.0, -48);
     auto band = [&](double v, double &a, double &b) {
@@ -810,14 +813,14 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     {
         hipDeviceProp_t prop;
         CRT(hipGetDeviceProperties(&prop, p->device));
-        const size_t lds_wave = (size_t)c->Lpad * 5;
-        int per_cu = (int)std::min<size_t>(16, (size_t)(160 * 1024) / (lds_wave * c->wpb) * c->wpb);   // LDS- and VGPR-bound
+        const size_t lds_wave = (size_t)c->Lpad * c->lds_per_slot;
+        int per_cu = (int)std::min<size_t>(20, (size_t)(160 * 1024) / (lds_wave * c->wpb) * c->wpb);   // LDS- and VGPR-bound
         c->wave_slots = std::max(1, prop.multiProcessorCount * std::max(1, per_cu));
     }
     CRT(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
     for (auto &e : c->ev) CRT(hipEventCreate(&e));
     for (auto &e : c->kev) CRT(hipEventCreate(&e));
-    const size_t lds = (size_t)c->wpb * c->Lpad * 5;
+    const size_t lds = (size_t)c->wpb * c->Lpad * c->lds_per_slot;
     if (lds > 160 * 1024) {
         nfc_destroy(c);
         return fail(nullptr, NFC_ERR_ARG, "av_window too large for one wave's LDS ring");

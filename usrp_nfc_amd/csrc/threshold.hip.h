@@ -96,6 +96,7 @@ struct ThrArgs {
     int32_t nl0, kl0;      // carried last-non-LOW index and LOW key at the batch start (batch-local, <= -1)
     double lo_L, hi_L;     // lo / L, hi / L (the fast path's thresholds carry 2^-20 of slack)
     int32_t fold_sh[6];    // long-LOW-run detector: shifts of the six folds (0 = fold disabled) ...
+    int32_t probe_mid, probe_end;   // ... pre-filter probes: b/2 and b-1 for aligned blocks of b samples
     uint64_t selmask;      // ... and the bit that survives the folds in every aligned block
     float *ring_out[2];
     uint32_t *touched[2];  // [nchunks][twords]
@@ -375,8 +376,14 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         if (slotid >= (uint32_t)A.nchunks) return;
         c = slotid;
     }
-    float *ring = (float *)(smem + (size_t)wave * ((size_t)A.Lpad * 5));
+    // Envelopes are >= 0, so the ring keeps "not yet accepted into during this chunk" in the SIGN bit of a slot
+    // (-|v|: untouched); the first accepted sample stores +x.  (A raw-envelope input may be negative: that
+    // kind keeps a byte map after the ring.)
+    constexpr bool SIGN_T = (KIND != IN_ENV_F32);
+    const size_t lds_wave = SIGN_T ? (size_t)A.Lpad * 4 : (size_t)A.Lpad * 5;
+    float *ring = (float *)(smem + (size_t)wave * lds_wave);
     unsigned char *tch = (unsigned char *)(ring + A.Lpad);
+    auto mark = [&](uint32_t sl) { if constexpr (!SIGN_T) tch[sl] = 1; };
     const int L = A.L;
     const int mx = A.mx;
     const uint32_t m_chunk = c * (uint32_t)A.C;   // this kernel runs with A.off == 0
@@ -471,10 +478,12 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     w_kl = rfl(w_kl);
     const int nl_in = w_nl, kl_in = w_kl;
     float *rin = A.ring_in + (size_t)c * L;
-    for (int s = lane; s < A.Lpad; s += 64) tch[s] = 0;
+    if constexpr (!SIGN_T)
+        for (int s = lane; s < A.Lpad; s += 64) tch[s] = 0;
     for (int s = lane; s < L; s += 64) {
         const float v = ring[s];
         rin[s] = v;
+        if constexpr (SIGN_T) ring[s] = __uint_as_float(__float_as_uint(v) | 0x80000000u);
         if (v != 0.f) {
             const uint32_t e = max(f32_expfield(v), 1u);
             emin = min(emin, e);
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 slot[j] = slot_step + 64u * j + lane;
-                prev[j] = rp[64 * j];
+                prev[j] = SIGN_T ? fabsf(rp[64 * j]) : rp[64 * j];
             }
         } else {
 #pragma unroll
@@ -534,7 +543,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 uint32_t s = slot_step + 64u * j + lane;
                 s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
                 slot[j] = s;
-                prev[j] = ring[s];
+                prev[j] = SIGN_T ? fabsf(ring[s]) : ring[s];
             }
         }
         const float ssf = (float)ss0;
@@ -596,13 +605,19 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 // a longer run covers an aligned block of LOW samples, or continues the carried run
                 const int lead = (lowm[0] == ~0ull) ? 64 : (__ffsll((long long)~lowm[0]) - 1);
                 const int carry_run = (int)base - 1 - w_nl;
+                // an all-LOW aligned block has its first, middle and last sample LOW: three probes filter first
+                unsigned long long pre = 0;
+#pragma unroll
+                for (int j = 0; j < NR; j++) pre |= lowm[j] & (lowm[j] >> A.probe_mid) & (lowm[j] >> A.probe_end);
                 unsigned long long hit = 0;
+                if (pre & A.selmask) {
 #pragma unroll
-                for (int j = 0; j < NR; j++) {
-                    unsigned long long t = lowm[j];
+                    for (int j = 0; j < NR; j++) {
+                        unsigned long long t = lowm[j];
 #pragma unroll
-                    for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
-                    hit |= t & A.selmask;
+                        for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
+                        hit |= t & A.selmask;
+                    }
                 }
                 if (hit || ((carry_run > 0) && (carry_run + lead > mx))) ok = false;
             }
@@ -618,7 +633,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                         dl += a ? ((double)x[j] - (double)prev[j]) : 0.0;
                         if (a) {
                             ring[slot[j]] = x[j];
-                            tch[slot[j]] = 1;
+                            mark(slot[j]);
                         }
                         posm[j] = 0ull;
                     }
@@ -637,7 +652,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                         dl += a ? ((double)x[j] - (double)prev[j]) : 0.0;
                         if (a) {
                             ring[slot[j]] = x[j];
-                            tch[slot[j]] = 1;
+                            mark(slot[j]);
                         }
                         const uint32_t xb = __float_as_uint(x[j]);
                         vmin = min(vmin, (a && xb != 0u) ? xb : 0xFFFFFFFFu);
@@ -646,13 +661,16 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                         before = lowm[j] ? rb + last_set(lowm[j]) : before;
                     }
                 }
-                int step_nl = LL_NONE, step_ll = LL_NONE;
+                int step_nl = (int)(base + STEPN) - 1, step_ll = LL_NONE;   // nothing LOW: the last sample is the last non-LOW
+                if (anylow) {
+                    step_nl = LL_NONE;
 #pragma unroll
-                for (int j = 0; j < NR; j++) {
-                    const int rb = (int)(base + 64u * j);
-                    const unsigned long long nonlow = ~lowm[j];
-                    step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
-                    step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
+                    for (int j = 0; j < NR; j++) {
+                        const int rb = (int)(base + 64u * j);
+                        const unsigned long long nonlow = ~lowm[j];
+                        step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
+                        step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
+                    }
                 }
                 ss0 = rfl(ss0 + wave_sum_f64(dl));
                 if (step_ll != LL_NONE) {
@@ -690,7 +708,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 }
                 if (row_exact(A, lane, m, aj, xj, pj, ss0, w_nl, w_kl, emin, emax, flags, lm, pm)) {
                     ring[sj] = xj;
-                    tch[sj] = 1;
+                    mark(sj);
                 }
 #pragma unroll
                 for (int k = 0; k < NR; k++) {
@@ -731,10 +749,11 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     uint32_t untouched = 0;
     for (int sbase = 0; sbase < A.twords * 32; sbase += 64) {
         const int s = sbase + lane;
-        const bool t = (s < L) && tch[s];
+        const float rv = (s < L) ? ring[s] : 0.f;
+        const bool t = (s < L) && (SIGN_T ? !(__float_as_uint(rv) >> 31) : (tch[s] != 0));
         const unsigned long long bal = __ballot(t);
         if (s < L) {
-            ro[s] = ring[s];
+            ro[s] = SIGN_T ? fabsf(rv) : rv;
             if (!t) untouched++;
         }
         const int w = sbase >> 5;
