@@ -83,12 +83,14 @@ struct StoreSymbols {
     const uint8_t *outw;
     uint8_t *sym[2];   // [0] Manchester / tag, [1] Miller / reader
     uint32_t *src[2];  // index of the producing edge
+    uint32_t cap[2];   // buffer capacities (an overflow is detected by the host from the totals)
     __device__ __forceinline__ void operator()(size_t i, uint64_t excl, uint64_t) const {
         const uint8_t w = outw[i];
         const uint32_t k = w & 3u;
         if (k == 0) return;
         const int type = (k == 3u) ? 0 : 1;
         const uint32_t off = type == 1 ? (uint32_t)excl : (uint32_t)(excl >> 32);
+        if (off + 1 >= cap[type]) return;
         sym[type][off] = (w >> 2) & 7u;
         src[type][off] = (uint32_t)i;
         if (k == 2u) {
@@ -151,15 +153,17 @@ struct StorePkt {
     }
 };
 
-// After framing: keep the open packet's bits for the next batch and update the carry.
+// After framing: keep the open packet's bits for the next batch and publish the carry.  Reads nothing that it
+// (or a sibling carry kernel) writes, so the edge / decode stages of a batch can be repeated as a whole.
 struct PktFinish {
-    uint8_t *bits;
-    uint8_t *pending;        // [cap]
+    const uint8_t *bits;
+    uint8_t *pending_next;   // [cap]  (the other half of the double buffer)
     const uint32_t *close_end;
     const uint64_t *totals;  // (appended incl. pending) | closes << 32
     const uint32_t *map_total;
     DecCarry *carry;
     int type;
+    int32_t started_in;
     uint32_t pending_cap;
 };
 __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
@@ -167,19 +171,24 @@ __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
     const uint32_t nbits = (uint32_t)tot, ncl = (uint32_t)(tot >> 32);
     const uint32_t from = ncl ? F.close_end[ncl - 1] : 0u;
     const uint32_t keep = nbits - from;
-    for (uint32_t i = threadIdx.x; i < keep && i < F.pending_cap; i += blockDim.x) F.pending[i] = F.bits[from + i];
+    for (uint32_t i = threadIdx.x; i < keep && i < F.pending_cap; i += blockDim.x) F.pending_next[i] = F.bits[from + i];
     if (threadIdx.x == 0) {
         F.carry->pending[F.type] = keep;
-        F.carry->pkt_started[F.type] = (int32_t)((*F.map_total >> (4 * F.carry->pkt_started[F.type])) & 1u);
+        F.carry->pkt_started[F.type] = (int32_t)((*F.map_total >> (4 * F.started_in)) & 1u);
     }
 }
 
 // Decoder states after the batch, from the total of the map scan.
-__global__ void k_dec_carry(const DecMaps *total, DecCarry *carry) {
+// Also splits the packed symbol totals into the two per-type counts the framing scans read from the device.
+__global__ void k_dec_carry(const DecMaps *total, uint32_t state_in, DecCarry *carry, const uint64_t *sym_total,
+                            uint32_t *nsym) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t st = ComposeDec::step(*total, (uint32_t)carry->mil_state | ((uint32_t)carry->man_state << 4));
+    const uint32_t st = ComposeDec::step(*total, state_in);
     carry->mil_state = (int32_t)(st & 15u);
     carry->man_state = (int32_t)(st >> 4);
+    const uint64_t t = *sym_total;
+    nsym[1] = (uint32_t)t;           // Miller / reader
+    nsym[0] = (uint32_t)(t >> 32);   // Manchester / tag
 }
 
 }  // namespace nfc

@@ -2,9 +2,8 @@
 // MI355X-native ISO-14443A IQ -> bit path.  gfx950 only; no CPU fallback.
 //
 // One nfc_push = one batch:
-//   k_fill (first av_window samples only) -> k_prepare
-//   -> k_threshold pass 0 (speculate) -> pass 1 (verify) [-> re-evaluations | k_threshold_seq]
-//   -> k_finalize_state
+//   k_fill (first av_window samples, then the per-batch preparation)
+//   -> k_threshold pass 0 (speculate) -> k_certify (+ end-of-batch ring) [-> re-runs from the exact state | k_threshold_seq]
 //   -> run starts (scan) -> emission counts (scan) -> k_write_edges -> k_edge_carry
 //   -> decoder state maps (scan) -> symbols (scan) -> k_dec_carry
 //   -> per type: framing maps (scan) -> packet bits / closes (scan) -> k_pkt_finish
@@ -76,6 +75,7 @@ enum : int {
     TOT_PKT0 = 72,      // u64: bits | closes << 32
     TOT_PKT1 = 80,
     TOT_LAST2 = 88,     // Last2 (8 bytes)
+    TOT_NSYM = 96,      // u32[2]: symbols per packet type
     TOT_BYTES = 128
 };
 
@@ -122,9 +122,11 @@ struct nfc_ctx {
     DevBuf d_certinfo;
     DevBuf d_in, d_neg, d_pos, d_ringout[2], d_touched[2], d_info[2], d_ringin, d_meta, d_ver, d_cflags, d_list;
     DevBuf d_ctx, d_wcnt, d_ecode;
-    DevBuf d_starts, d_offs, d_edges, d_states, d_sym[2], d_src[2], d_started, d_bits[2], d_pending[2], d_close_end[2],
+    DevBuf d_starts, d_offs, d_edges, d_states, d_sym[2], d_src[2], d_started, d_bits[2], d_pending[2][2], d_close_end[2],
         d_close_idx[2];
-    DevBuf d_partials, d_aggs;  // scan scratch
+    DevBuf d_partials, d_partials2, d_aggs;  // scan scratch
+    uint32_t cap_edges = 0, cap_sym[2] = {0, 0};   // capacity estimates of the edge / symbol buffers
+    int pend_cur = 0;                               // which half of d_pending holds the open packets' bits
     std::vector<uint8_t> h_ver;
     std::vector<uint32_t> h_list;
 
@@ -223,14 +225,16 @@ void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
     default: launch_threshold<IN_I16_SQ>(c, A, nwork); break;
     }
 }
-void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n) {
+void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n, int nchunks) {
     float *ring = c->d_ring[c->ring_cur].as<float>();
     Carry *cr = dC(c);
+    EdgeCarryInit eci{(int32_t *)dE(c), c->L % c->mx};
+    uint8_t *ver = c->d_ver.as<uint8_t>();
     switch (c->P.input_kind) {
-    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
-    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
-    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
-    default: hipLaunchKernelGGL((k_fill<IN_I16_SQ>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr); break;
+    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks); break;
+    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks); break;
+    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks); break;
+    default: hipLaunchKernelGGL((k_fill<IN_I16_SQ>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks); break;
     }
 }
 void launch_seq_kind(nfc_ctx *c, const SeqArgs &A) {
@@ -296,7 +300,6 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
                   *h_gmax = c->h_cflags + 3 * (size_t)nch;
     HIPCHK(c, c->d_list.ensure((size_t)nch * 4));
     c->h_ver.assign(nch, 0);
-    HIPCHK(c, hipMemsetAsync(c->d_ver.p, 0, nch, c->st));
 
     // carried "HIGH ignored" bookkeeping from (_current_state, _last_bit, _dur) at the first stable sample
     const int s0 = (int)skip;
@@ -312,7 +315,8 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
         kl0 = KEY_NONE;
     }
 
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(64), 0, c->st, c->d_ring[c->ring_cur].as<float>(), L, dC(c));
+    // fill (if the window is not full yet) + per-batch preparation (delta, guard span, version bytes): one launch
+    launch_fill_kind(c, d_in, n, (int)nch);
 
     // a 256-sample step must not wrap the ring onto itself: short windows take the sequential kernel
     const bool force_seq = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0 || L < STEP;
@@ -396,8 +400,8 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
             }
             A.nlist = np;
             if (dbg) HIPCHK(c, c->d_certinfo.ensure((size_t)nch * sizeof(CertInfo)));
-            hipLaunchKernelGGL(k_certify, dim3((np + 3) / 4), dim3(256), 0, c->st, A, d_cert,
-                               dbg ? c->d_certinfo.as<CertInfo>() : nullptr);
+            hipLaunchKernelGGL(k_certify, dim3((np + 1 + 3) / 4), dim3(256), 0, c->st, A, d_cert,
+                               dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[1 - c->ring_cur].as<float>(), dC(c));
             HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
             HIPCHK(c, mirror_async(c));
             HIPCHK(c, hipStreamSynchronize(c->st));
@@ -492,8 +496,9 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
         launch_seq_kind(c, S);
         c->stats.used_sequential = 1;
     } else {
-        hipLaunchKernelGGL(k_finalize_state, dim3(1), dim3(64), 0, c->st, A, c->d_ring[1 - c->ring_cur].as<float>(),
-                           dC(c));
+        // the end-of-batch ring was resolved beside the last certification unless chunks were re-run after it
+        if (c->stats.threshold_passes > 1 || nch == 1)
+            hipLaunchKernelGGL(k_finalize_state, dim3(1), dim3(64), 0, c->st, A, c->d_ring[1 - c->ring_cur].as<float>(), dC(c));
         c->ring_cur = 1 - c->ring_cur;
     }
     return NFC_OK;
@@ -502,6 +507,10 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
 // ---------------------------------------------------------------------------
 // edge stage
 // ---------------------------------------------------------------------------
+// Both stages run without a host round trip: buffers and grids are sized from capacity estimates (last batch's
+// counts with head-room), the true counts stay on the device, and the caller checks them after the batch's
+// final sync -- on overflow the two stages are simply repeated with larger estimates (they are idempotent:
+// carried values come in by value and go out to write-only slots).
 int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     uint8_t *tot = dT(c);
     const size_t nwords = ((size_t)n + 63) / 64;
@@ -522,22 +531,18 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     Last2 *ctx = c->d_ctx.as<Last2>();
     uint32_t *wcnt = c->d_wcnt.as<uint32_t>();
     // scan 1: the two latest val changes before every 64-sample word; each word then counts its entries
-    device_scan<Last2Op, 4>(c->st, nwords, LoadLast2{E}, StoreCtxAndCount{E, ctx, wcnt}, Last2Op::identity(),
+    device_scan<Last2Op, 4>(c->st, nwords, nullptr, LoadLast2{E}, StoreCtxAndCount{E, ctx, wcnt}, Last2Op::identity(),
                             c->d_partials.as<Last2>(), (Last2 *)(tot + TOT_LAST2));
     // scan 2: entry offsets per 512-word tile; then every tile stages and writes its entries
-    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<EW_ITEMS>(nwords) + 1) * sizeof(uint32_t)));
-    scan_phase1<AddU32, EW_ITEMS>(c->st, nwords, LoadWordCount{wcnt}, 0u, c->d_partials.as<uint32_t>(),
+    HIPCHK(c, c->d_partials2.ensure((scan_num_tiles<EW_ITEMS>(nwords) + 1) * sizeof(uint32_t)));
+    scan_phase1<AddU32, EW_ITEMS>(c->st, nwords, nullptr, LoadWordCount{wcnt}, 0u, c->d_partials2.as<uint32_t>(),
                                   (uint32_t *)(tot + TOT_EDGES));
-    HIPCHK(c, mirror_async(c));
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    uint32_t nedges;
-    memcpy(&nedges, c->hs->totals + TOT_EDGES, 4);
-    c->n_edges = nedges;
-    HIPCHK(c, c->d_edges.ensure(((size_t)nedges + 1) * sizeof(nfc_edge)));
-    HIPCHK(c, c->d_ecode.ensure(((size_t)nedges + 8) * 2));
+    const uint32_t cap = c->cap_edges;
+    HIPCHK(c, c->d_edges.ensure(((size_t)cap + 1) * sizeof(nfc_edge)));
+    HIPCHK(c, c->d_ecode.ensure(((size_t)cap + 8) * 2));
     if (nwords)
         hipLaunchKernelGGL(k_write_edges, dim3((unsigned)scan_num_tiles<EW_ITEMS>(nwords)), dim3(SCAN_BLOCK), 0, c->st, E, nwords,
-                           ctx, wcnt, c->d_partials.as<uint32_t>(), c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), nedges);
+                           ctx, wcnt, c->d_partials2.as<uint32_t>(), c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), cap);
     hipLaunchKernelGGL(k_edge_carry, dim3(1), dim3(64), 0, c->st, E, (const Last2 *)(tot + TOT_LAST2), dE(c));
     return NFC_OK;
 }
@@ -547,57 +552,58 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
 // ---------------------------------------------------------------------------
 int run_decode(nfc_ctx *c) {
     uint8_t *tot = dT(c);
-    const uint32_t ne = c->n_edges;
+    const uint32_t ce = c->cap_edges;                      // capacity; the count is on the device
+    const uint32_t *ne_dev = (const uint32_t *)(tot + TOT_EDGES);
     const nfc_edge *edges = c->d_edges.as<nfc_edge>();
     constexpr int DI = 16;  // edges per thread in the decoder-state scan
-    HIPCHK(c, c->d_states.ensure((size_t)ne + 16));   // one out-word per edge
-    HIPCHK(c, c->d_sym[1].ensure((size_t)2 * ne + 16));
-    HIPCHK(c, c->d_src[1].ensure(((size_t)2 * ne + 16) * 4));
-    HIPCHK(c, c->d_sym[0].ensure((size_t)ne + 16));
-    HIPCHK(c, c->d_src[0].ensure(((size_t)ne + 16) * 4));
-    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<4>(ne) + 1) * sizeof(DecMaps)));
-    HIPCHK(c, c->d_aggs.ensure((fsm_num_threads<DI>(ne) + 1) * sizeof(DecMaps)));
+    const uint32_t cs[2] = {c->cap_sym[0], c->cap_sym[1]};
+    HIPCHK(c, c->d_states.ensure((size_t)ce + 16));   // one out-word per edge
+    for (int t = 0; t < 2; t++) {
+        HIPCHK(c, c->d_sym[t].ensure((size_t)cs[t] + 16));
+        HIPCHK(c, c->d_src[t].ensure(((size_t)cs[t] + 16) * 4));
+    }
+    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<4>(ce) + 1) * sizeof(DecMaps)));
+    HIPCHK(c, c->d_aggs.ensure((fsm_num_threads<DI>(ce) + 1) * sizeof(DecMaps)));
 
     uint8_t *outw = c->d_states.as<uint8_t>();
-    device_fsm_scan<ComposeDec, DI>(c->st, ne, LoadEdgeMaps{c->d_ecode.as<uint16_t>(), c->T}, VisitEdgeOut{c->d_ecode.as<uint16_t>(), c->T, outw},
-                                    (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4),
+    const uint32_t dec_state_in = (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4);
+    device_fsm_scan<ComposeDec, DI>(c->st, ce, ne_dev, LoadEdgeMaps{c->d_ecode.as<uint16_t>(), c->T},
+                                    VisitEdgeOut{c->d_ecode.as<uint16_t>(), c->T, outw}, dec_state_in,
                                     c->d_partials.as<DecMaps>(), c->d_aggs.as<DecMaps>(), (DecMaps *)(tot + TOT_DECMAP));
     StoreSymbols ss{outw, {c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()},
-                    {c->d_src[0].as<uint32_t>(), c->d_src[1].as<uint32_t>()}};
-    device_scan<AddU64, 8>(c->st, ne, LoadSymCounts{outw}, ss, 0ull, c->d_partials.as<uint64_t>(), (uint64_t *)(tot + TOT_SYMS));
-    hipLaunchKernelGGL(k_dec_carry, dim3(1), dim3(64), 0, c->st, (const DecMaps *)(tot + TOT_DECMAP), dD(c));
-    HIPCHK(c, mirror_async(c));
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    uint64_t nsyms;
-    memcpy(&nsyms, c->hs->totals + TOT_SYMS, 8);
-    c->n_sym[1] = (uint32_t)nsyms;
-    c->n_sym[0] = (uint32_t)(nsyms >> 32);
+                    {c->d_src[0].as<uint32_t>(), c->d_src[1].as<uint32_t>()}, {cs[0], cs[1]}};
+    device_scan<AddU64, 8>(c->st, ce, ne_dev, LoadSymCounts{outw}, ss, 0ull, c->d_partials.as<uint64_t>(),
+                           (uint64_t *)(tot + TOT_SYMS));
+    hipLaunchKernelGGL(k_dec_carry, dim3(1), dim3(64), 0, c->st, (const DecMaps *)(tot + TOT_DECMAP), dec_state_in, dD(c),
+                       (const uint64_t *)(tot + TOT_SYMS), (uint32_t *)(tot + TOT_NSYM));
 
     constexpr int PI = 16;
+    const int pn = 1 - c->pend_cur;   // the open packets' bits go to the other half of the double buffer
     for (int t = 0; t < 2; t++) {
-        const uint32_t ns = c->n_sym[t];
+        const uint32_t ns = cs[t];   // capacity
+        const uint32_t *ns_dev = (const uint32_t *)(tot + TOT_NSYM) + t;
         const uint32_t pend = c->h_dcarry.pending[t];
         const int start_bit = (t == 0) ? 1 : 0;  // packets.py:24-28
         HIPCHK(c, c->d_started.ensure((size_t)ns + 16));
         HIPCHK(c, c->d_bits[t].ensure((size_t)pend + ns + 16));
-        HIPCHK(c, c->d_pending[t].ensure((size_t)pend + ns + 16, true, c->st));
+        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend + ns + 16));
         HIPCHK(c, c->d_close_end[t].ensure(((size_t)ns + 4) * 4));
         HIPCHK(c, c->d_close_idx[t].ensure(((size_t)ns + 4) * 8));
         HIPCHK(c, c->d_partials.ensure((scan_num_tiles<8>(ns) + 1) * sizeof(uint64_t)));
         HIPCHK(c, c->d_aggs.ensure((fsm_num_threads<PI>(ns) + 1) * sizeof(uint32_t)));
-        if (pend) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t].p, pend, hipMemcpyDeviceToDevice, c->st));
+        if (pend) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t][c->pend_cur].p, pend, hipMemcpyDeviceToDevice, c->st));
         const uint8_t *sym = c->d_sym[t].as<uint8_t>();
         uint8_t *pflags = c->d_started.as<uint8_t>();
         uint32_t *maptot = (uint32_t *)(tot + (t ? TOT_PKTMAP1 : TOT_PKTMAP0));
         uint64_t *pktot = (uint64_t *)(tot + (t ? TOT_PKT1 : TOT_PKT0));
-        device_fsm_scan<ComposePkt, PI>(c->st, ns, LoadPktMaps{sym, start_bit}, VisitPktFlags{sym, start_bit, pflags},
+        device_fsm_scan<ComposePkt, PI>(c->st, ns, ns_dev, LoadPktMaps{sym, start_bit}, VisitPktFlags{sym, start_bit, pflags},
                                         (uint32_t)c->h_dcarry.pkt_started[t], c->d_partials.as<uint32_t>(),
                                         c->d_aggs.as<uint32_t>(), maptot);
         StorePkt sp{sym, pflags, c->d_src[t].as<uint32_t>(), edges, c->d_bits[t].as<uint8_t>(),
                     c->d_close_end[t].as<uint32_t>(), c->d_close_idx[t].as<uint64_t>()};
-        device_scan<AddU64, 8>(c->st, ns, LoadPktCounts{pflags}, sp, (uint64_t)pend, c->d_partials.as<uint64_t>(), pktot);
-        PktFinish F{c->d_bits[t].as<uint8_t>(), c->d_pending[t].as<uint8_t>(), c->d_close_end[t].as<uint32_t>(), pktot, maptot,
-                    dD(c), t, (uint32_t)std::min<size_t>(c->d_pending[t].cap, 0xFFFFFFFFu)};
+        device_scan<AddU64, 8>(c->st, ns, ns_dev, LoadPktCounts{pflags}, sp, (uint64_t)pend, c->d_partials.as<uint64_t>(), pktot);
+        PktFinish F{c->d_bits[t].as<uint8_t>(), c->d_pending[t][pn].as<uint8_t>(), c->d_close_end[t].as<uint32_t>(), pktot, maptot,
+                    dD(c), t, c->h_dcarry.pkt_started[t], (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu)};
         hipLaunchKernelGGL(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
     }
     return NFC_OK;   // totals and carries are mirrored by the caller's final copy
@@ -624,21 +630,25 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     HIPCHK(c, hipEventRecord(c->ev[0], c->st));
 
     uint32_t skip = 0;
+    bool fills = false;
     if (!c->h_carry.stable) {
+        fills = true;
         skip = (uint32_t)std::min<uint64_t>(n, (uint64_t)(c->L - c->h_carry.filled));
-        launch_fill_kind(c, d_in, n);
         c->h_carry.filled += (int)skip;
         if (c->h_carry.filled == c->L) {
             c->h_carry.stable = 1;
             c->h_ecarry.state = 0;
             c->h_ecarry.last_bit = 0;
-            c->h_ecarry.dur = c->L % c->mx;  // transition_sink.py:123
-            hipLaunchKernelGGL(k_set_ecarry, dim3(1), dim3(64), 0, c->st, (DevState *)c->d_state.p, c->h_ecarry);
+            c->h_ecarry.dur = c->L % c->mx;  // transition_sink.py:123 (k_fill sets the device copy)
         }
     }
     c->last_skip = skip;
     if (!c->h_carry.stable || skip == n) {
         // the whole batch went into the averaging window: no callback content (transition_sink.py:109-125)
+        if (fills) {
+            HIPCHK(c, c->d_ver.ensure(16));
+            launch_fill_kind(c, d_in, n, 0);
+        }
         HIPCHK(c, mirror_async(c));
         HIPCHK(c, hipStreamSynchronize(c->st));
         c->h_carry = c->hs->carry;
@@ -651,22 +661,54 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     int rc = run_threshold(c, d_in, n, skip);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev[2], c->st));
+    const EdgeCarry ecarry_in = c->h_ecarry;
     if (!(c->P.flags & NFC_FLAG_NO_EDGES)) {
-        rc = run_edges(c, n, skip, c->nseen);
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->ev[3], c->st));
-        rc = run_decode(c);
-        if (rc) return rc;
+        // capacity estimates: the previous batch's counts with head-room (first batch: a guess)
+        if (!c->cap_edges) c->cap_edges = (uint32_t)std::min<uint64_t>((uint64_t)n / 8 + 65536, 0xFFFFFF00u);
+        for (int attempt = 0;; attempt++) {
+            for (int t = 0; t < 2; t++) {
+                const uint64_t ub = (t == 1 ? 2ull : 1ull) * c->cap_edges + 16;   // <= 2 (Miller) / 1 (Manchester) symbols per edge
+                if (!c->cap_sym[t] || c->cap_sym[t] > ub) c->cap_sym[t] = (uint32_t)std::min<uint64_t>(ub, 0xFFFFFF00u);
+            }
+            rc = run_edges(c, n, skip, c->nseen);
+            if (rc) return rc;
+            if (attempt == 0) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+            rc = run_decode(c);
+            if (rc) return rc;
+            HIPCHK(c, mirror_async(c));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            uint32_t ne, ns[2];
+            memcpy(&ne, c->hs->totals + TOT_EDGES, 4);
+            memcpy(ns, c->hs->totals + TOT_NSYM, 8);
+            const bool fit = ne <= c->cap_edges && ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1];
+            if (fit) {
+                c->n_edges = ne;
+                c->n_sym[0] = ns[0];
+                c->n_sym[1] = ns[1];
+                break;
+            }
+            // a buffer was too small: the stages read carried values by value and wrote only write-only slots, so
+            // they can simply run again with room for what was counted
+            if (attempt >= 3) return fail(c, NFC_ERR_INTERNAL, "edge / symbol capacity did not settle");
+            c->cap_edges = (uint32_t)std::min<uint64_t>((uint64_t)std::max(ne, c->cap_edges) * 5 / 4 + 65536, 0xFFFFFF00u);
+            c->cap_sym[0] = (uint32_t)std::min<uint64_t>((uint64_t)ns[0] * 5 / 4 + 65536, 0xFFFFFF00u);
+            c->cap_sym[1] = (uint32_t)std::min<uint64_t>((uint64_t)ns[1] * 5 / 4 + 65536, 0xFFFFFF00u);
+        }
+        // next batch's estimates
+        c->cap_edges = (uint32_t)std::min<uint64_t>((uint64_t)c->n_edges * 5 / 4 + 65536, 0xFFFFFF00u);
+        c->cap_sym[0] = (uint32_t)std::min<uint64_t>((uint64_t)c->n_sym[0] * 5 / 4 + 65536, 0xFFFFFF00u);
+        c->cap_sym[1] = (uint32_t)std::min<uint64_t>((uint64_t)c->n_sym[1] * 5 / 4 + 65536, 0xFFFFFF00u);
+        c->pend_cur = 1 - c->pend_cur;
     } else {
         HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+        HIPCHK(c, mirror_async(c));
+        HIPCHK(c, hipStreamSynchronize(c->st));
     }
     HIPCHK(c, hipEventRecord(c->ev[4], c->st));
-    HIPCHK(c, mirror_async(c));
     HIPCHK(c, hipStreamSynchronize(c->st));
     {
-        const EdgeCarry keep = c->h_ecarry;
         adopt_mirror(c);
-        if (c->P.flags & NFC_FLAG_NO_EDGES) c->h_ecarry = keep;
+        if (c->P.flags & NFC_FLAG_NO_EDGES) c->h_ecarry = ecarry_in;
         else {
             uint64_t pk[2];
             memcpy(&pk[0], c->hs->totals + TOT_PKT0, 8);
@@ -864,7 +906,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     for (int b = 0; b < 2; b++) {
         CRT(c->d_ring[b].ensure((size_t)c->Lpad * 4));
         CRT(hipMemset(c->d_ring[b].p, 0, (size_t)c->Lpad * 4));
-        CRT(c->d_pending[b].ensure(1024));
+        CRT(c->d_pending[b][0].ensure(1024));
+        CRT(c->d_pending[b][1].ensure(1024));
     }
     push_state(c, 1);
     CRT(hipStreamSynchronize(c->st));
@@ -880,8 +923,8 @@ void nfc_destroy(nfc_ctx *c) {
     DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_state,
                      &c->d_ring[0], &c->d_ring[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
-                     &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0],
-                     &c->d_pending[1], &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
+                     &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
+                     &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
                      &c->d_partials, &c->d_aggs};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
@@ -1045,8 +1088,8 @@ int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap,
     if (pending) {
         const size_t p0 = c->h_dcarry.pending[0], p1 = c->h_dcarry.pending[1];
         if (pending_cap < p0 + p1) return fail(c, NFC_ERR_ARG, "pending-bit buffer too small");
-        if (p0) HIPCHK(c, hipMemcpy(pending, c->d_pending[0].p, p0, hipMemcpyDeviceToHost));
-        if (p1) HIPCHK(c, hipMemcpy(pending + p0, c->d_pending[1].p, p1, hipMemcpyDeviceToHost));
+        if (p0) HIPCHK(c, hipMemcpy(pending, c->d_pending[0][c->pend_cur].p, p0, hipMemcpyDeviceToHost));
+        if (p1) HIPCHK(c, hipMemcpy(pending + p0, c->d_pending[1][c->pend_cur].p, p1, hipMemcpyDeviceToHost));
     }
     return NFC_OK;
 }
@@ -1072,10 +1115,10 @@ int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size
     for (int t = 0; t < 2; t++) {
         c->h_dcarry.pkt_started[t] = h->pkt_started[t];
         c->h_dcarry.pending[t] = h->n_pending_bits[t];
-        HIPCHK(c, c->d_pending[t].ensure((size_t)h->n_pending_bits[t] + 16));
+        HIPCHK(c, c->d_pending[t][c->pend_cur].ensure((size_t)h->n_pending_bits[t] + 16));
     }
-    if (p0) HIPCHK(c, hipMemcpy(c->d_pending[0].p, pending, p0, hipMemcpyHostToDevice));
-    if (p1) HIPCHK(c, hipMemcpy(c->d_pending[1].p, pending + p0, p1, hipMemcpyHostToDevice));
+    if (p0) HIPCHK(c, hipMemcpy(c->d_pending[0][c->pend_cur].p, pending, p0, hipMemcpyHostToDevice));
+    if (p1) HIPCHK(c, hipMemcpy(c->d_pending[1][c->pend_cur].p, pending + p0, p1, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_ring[c->ring_cur].p, ring, (size_t)c->L * 4, hipMemcpyHostToDevice));
     c->have_outputs = false;
     return upload_carried(c);

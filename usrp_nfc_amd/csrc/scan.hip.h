@@ -144,8 +144,10 @@ __device__ __forceinline__ typename Tr::T block_exclusive(typename Tr::T v, type
 
 // ---- the three kernels --------------------------------------------------------
 template <class Tr, int ITEMS, class Load>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(size_t n, Load load, typename Tr::T *partials) {
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(size_t n, const uint32_t *n_dev, Load load, typename Tr::T *partials) {
     using T = typename Tr::T;
+    if (n_dev) n = min(n, (size_t)*n_dev);   // the item count may live on the device (n is then the capacity)
+    if ((size_t)blockIdx.x * SCAN_BLOCK * ITEMS >= n) return;
     __shared__ T lds[SCAN_WAVES];
     const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * ITEMS;
     T agg = Tr::identity();
@@ -161,9 +163,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(size_t n, Load load,
 
 // partials[i] <- op(seed, exclusive prefix of partials)[i]; total (with the seed) stored to *total_out.
 template <class Tr>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_partials(size_t nparts, typename Tr::T *partials,
-                                                             typename Tr::T seed, typename Tr::T *total_out) {
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_partials(size_t nparts, const uint32_t *n_dev, uint32_t tile,
+                                                             typename Tr::T *partials, typename Tr::T seed,
+                                                             typename Tr::T *total_out) {
     using T = typename Tr::T;
+    if (n_dev) nparts = min(nparts, ((size_t)*n_dev + tile - 1) / tile);
     __shared__ T lds[SCAN_WAVES];
     T carry = seed;
     for (size_t base = 0; base < nparts; base += SCAN_BLOCK) {
@@ -178,9 +182,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_partials(size_t nparts, typ
 }
 
 template <class Tr, int ITEMS, class Load, class Store>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(size_t n, Load load, Store store,
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(size_t n, const uint32_t *n_dev, Load load, Store store,
                                                           const typename Tr::T *partials) {
     using T = typename Tr::T;
+    if (n_dev) n = min(n, (size_t)*n_dev);
+    if ((size_t)blockIdx.x * SCAN_BLOCK * ITEMS >= n) return;
     __shared__ T lds[SCAN_WAVES];
     const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * ITEMS;
     T item[ITEMS];
@@ -213,9 +219,11 @@ inline size_t scan_num_tiles(size_t n) {
 // Pass 1 also keeps every thread's aggregate, so that pass 2 needs one block scan per thread and then
 // walks its items applying each map to a STATE (one look-up) instead of composing maps.
 template <class Tr, int ITEMS, class Load>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_fsm_reduce(size_t n, Load load, typename Tr::T *partials,
+__global__ __launch_bounds__(SCAN_BLOCK) void k_fsm_reduce(size_t n, const uint32_t *n_dev, Load load, typename Tr::T *partials,
                                                           typename Tr::T *aggs) {
     using T = typename Tr::T;
+    if (n_dev) n = min(n, (size_t)*n_dev);
+    if ((size_t)blockIdx.x * SCAN_BLOCK * ITEMS >= n) return;
     __shared__ T lds[SCAN_WAVES];
     const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const size_t base = tid * ITEMS;
@@ -231,9 +239,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_fsm_reduce(size_t n, Load load, 
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 template <class Tr, int ITEMS, class Load, class Visit>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_fsm_apply(size_t n, Load load, Visit visit, const typename Tr::T *partials,
-                                                         const typename Tr::T *aggs, uint32_t state0) {
+__global__ __launch_bounds__(SCAN_BLOCK) void k_fsm_apply(size_t n, const uint32_t *n_dev, Load load, Visit visit,
+                                                         const typename Tr::T *partials, const typename Tr::T *aggs,
+                                                         uint32_t state0) {
     using T = typename Tr::T;
+    if (n_dev) n = min(n, (size_t)*n_dev);
+    if ((size_t)blockIdx.x * SCAN_BLOCK * ITEMS >= n) return;
     __shared__ T lds[SCAN_WAVES];
     const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const size_t base = tid * ITEMS;
@@ -253,43 +264,47 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_fsm_apply(size_t n, Load load, V
 template <int ITEMS>
 inline size_t fsm_num_threads(size_t n) { return scan_num_tiles<ITEMS>(n) * SCAN_BLOCK; }
 
-// visit(i, state before item i, item map); *total_out = composition of all maps
+// visit(i, state before item i, item map); *total_out = composition of all maps.
+// n_dev != nullptr: the true item count is *n_dev on the device and n is only the capacity the grid is sized for.
 template <class Tr, int ITEMS, class Load, class Visit>
-inline void device_fsm_scan(hipStream_t st, size_t n, Load load, Visit visit, uint32_t state0, typename Tr::T *partials,
-                            typename Tr::T *aggs, typename Tr::T *total_out) {
+inline void device_fsm_scan(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Visit visit, uint32_t state0,
+                            typename Tr::T *partials, typename Tr::T *aggs, typename Tr::T *total_out) {
     const size_t tiles = scan_num_tiles<ITEMS>(n);
     if (tiles)
-        hipLaunchKernelGGL((k_fsm_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, load, partials, aggs);
-    hipLaunchKernelGGL((k_scan_partials<Tr>), dim3(1), dim3(SCAN_BLOCK), 0, st, tiles, partials, Tr::identity_host(), total_out);
+        hipLaunchKernelGGL((k_fsm_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load, partials,
+                           aggs);
+    hipLaunchKernelGGL((k_scan_partials<Tr>), dim3(1), dim3(SCAN_BLOCK), 0, st, tiles, n_dev, (uint32_t)(SCAN_BLOCK * ITEMS),
+                       partials, Tr::identity_host(), total_out);
     if (tiles)
-        hipLaunchKernelGGL((k_fsm_apply<Tr, ITEMS, Load, Visit>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, load, visit,
-                           partials, aggs, state0);
+        hipLaunchKernelGGL((k_fsm_apply<Tr, ITEMS, Load, Visit>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load,
+                           visit, partials, aggs, state0);
 }
 
 // Host-side driver.  `partials` must hold scan_num_tiles(n, ITEMS) entries.
 
 // Phase 1: tile aggregates -> exclusive tile prefixes (seeded) and the grand total in *total_out.
 template <class Tr, int ITEMS, class Load>
-inline void scan_phase1(hipStream_t st, size_t n, Load load, typename Tr::T seed, typename Tr::T *partials,
+inline void scan_phase1(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, typename Tr::T seed, typename Tr::T *partials,
                         typename Tr::T *total_out) {
     const size_t tiles = scan_num_tiles<ITEMS>(n);
     if (tiles)
-        hipLaunchKernelGGL((k_scan_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, load, partials);
-    hipLaunchKernelGGL((k_scan_partials<Tr>), dim3(1), dim3(SCAN_BLOCK), 0, st, tiles, partials, seed, total_out);
+        hipLaunchKernelGGL((k_scan_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load, partials);
+    hipLaunchKernelGGL((k_scan_partials<Tr>), dim3(1), dim3(SCAN_BLOCK), 0, st, tiles, n_dev, (uint32_t)(SCAN_BLOCK * ITEMS), partials,
+                       seed, total_out);
 }
 // Phase 2: every item gets its exclusive prefix.
 template <class Tr, int ITEMS, class Load, class Store>
-inline void scan_phase2(hipStream_t st, size_t n, Load load, Store store, const typename Tr::T *partials) {
+inline void scan_phase2(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, const typename Tr::T *partials) {
     const size_t tiles = scan_num_tiles<ITEMS>(n);
     if (tiles)
-        hipLaunchKernelGGL((k_scan_apply<Tr, ITEMS, Load, Store>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, load,
+        hipLaunchKernelGGL((k_scan_apply<Tr, ITEMS, Load, Store>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load,
                            store, partials);
 }
 template <class Tr, int ITEMS, class Load, class Store>
-inline void device_scan(hipStream_t st, size_t n, Load load, Store store, typename Tr::T seed,
+inline void device_scan(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, typename Tr::T seed,
                         typename Tr::T *partials, typename Tr::T *total_out) {
-    scan_phase1<Tr, ITEMS, Load>(st, n, load, seed, partials, total_out);
-    scan_phase2<Tr, ITEMS, Load, Store>(st, n, load, store, partials);
+    scan_phase1<Tr, ITEMS, Load>(st, n, n_dev, load, seed, partials, total_out);
+    scan_phase2<Tr, ITEMS, Load, Store>(st, n, n_dev, load, store, partials);
 }
 
 }  // namespace nfc

@@ -802,9 +802,26 @@ struct CertInfo {
     float d, allowed;
     uint32_t all_robust, low_ok;
 };
-__global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertInfo *dbg) {
+__device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_next, Carry *carry, int lane) {
+    double part = 0;
+    for (int s = lane; s < A.L; s += 64) {
+        const float v = resolve_slot(A, A.nchunks, s);
+        ring_next[s] = v;
+        part += (double)v;
+    }
+    const double S = wave_sum_f64(part);
+    if (lane == 0) carry->ss = S + carry->delta;
+}
+
+// One extra wave (slot == nlist) resolves the end-of-batch ring meanwhile: if every chunk certifies, that is
+// the carried state of the next batch (otherwise k_finalize_state runs again after the re-runs).
+__global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertInfo *dbg, float *ring_next, Carry *carry) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t slotid = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (slotid == A.nlist && ring_next) {
+        finalize_state(A, ring_next, carry, lane);
+        return;
+    }
     if (slotid >= A.nlist) return;
     const uint32_t c = A.list ? A.list[slotid] : slotid + 1;
     const int L = A.L;
@@ -852,15 +869,72 @@ __global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertI
     }
 }
 
+// Lowest / highest set bit of a double on the f32 exponent-field scale (bit value 2^(field-127)).
+__device__ __forceinline__ void f64_bit_span(double v, int &elow, int &ehigh) {
+    if (v == 0) { elow = 255; ehigh = 0; return; }
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int e = (int)((b >> 52) & 0x7FF);
+    unsigned long long m = b & 0xFFFFFFFFFFFFFull;
+    if (e) m |= 1ull << 52;
+    const int tz = __ffsll((long long)m) - 1;
+    const int unb = (e ? e : 1) - 1023;   // exponent of the hidden-bit position
+    elow = unb - 52 + tz + 127;
+    ehigh = unb + 127;
+    if (e == 0x7FF) { elow = -4000; ehigh = 4000; }   // inf/nan: never provably exact
+}
+
+// Per batch: S(ring), delta = ss - S(ring), and the guard span of the carried values; also resets the
+// summary version bytes.  Runs as the tail of k_fill (one launch per batch for both).
+__device__ __forceinline__ void prepare_batch(const float *ring, int L, Carry *carry, uint8_t *ver, int nchunks) {
+    const int lane = threadIdx.x;
+    for (int i = lane; i < nchunks; i += 64) ver[i] = 0;
+    double part = 0;
+    uint32_t emin = 255u, emax = 0u;
+    for (int s = lane; s < L; s += 64) {
+        const float v = ring[s];
+        part += (double)v;
+        if (v != 0.f) {
+            const uint32_t e = max(f32_expfield(v), 1u);
+            emin = min(emin, e);
+            emax = max(emax, e);
+        }
+    }
+    const double S = wave_sum_f64(part);
+    emin = wave_min_u32(emin);
+    emax = wave_max_u32(emax);
+    if (lane == 0) {
+        const double ss = carry->ss;
+        const double delta = ss - S;
+        carry->delta = delta;
+        int el, eh, el2, eh2;
+        f64_bit_span(ss, el, eh);
+        f64_bit_span(delta, el2, eh2);
+        carry->ss_emin = min(el, el2);
+        carry->ss_emax = max(eh, eh2);
+        carry->ring_emin = (int)emin;
+        carry->ring_emax = (int)emax;
+    }
+}
+
+struct EdgeCarryInit {
+    int32_t *dst;   // -> EdgeCarry {state, last_bit, dur}
+    int32_t dur0;   // av_window % max_len
+};
+
 // ---------------------------------------------------------------------------
 // Fill phase (transition_sink.py:109-125): copy the first L samples into the ring,
 // then sum them in the reference's order.  One wave; the sum is one lane reading LDS.
 // ---------------------------------------------------------------------------
 template <int KIND>
-__global__ __launch_bounds__(64) void k_fill(const void *in, uint32_t n, float i16_scale, int L, float *ring, Carry *carry) {
+__global__ __launch_bounds__(64) void k_fill(const void *in, uint32_t n, float i16_scale, int L, float *ring, Carry *carry,
+                                             EdgeCarryInit eci, uint8_t *ver, int nchunks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *lr = (float *)smem;
     const int lane = threadIdx.x;
+    if (carry->stable) {   // nothing to fill: only the per-batch preparation
+        prepare_batch(ring, L, carry, ver, nchunks);
+        return;
+    }
     const int filled = carry->filled;
     const int can = min((int)n, L - filled);
     for (int i = lane; i < can; i += 64) ring[filled + i] = envelope_at<KIND>(in, (size_t)i, i16_scale);
@@ -907,66 +981,20 @@ __global__ __launch_bounds__(64) void k_fill(const void *in, uint32_t n, float i
         carry->ss = s;
         carry->stable = 1;
         if (err != 0.0) carry->inexact = 1;
+        // work has just been rebound to work_stable: _dur = length % max (transition_sink.py:123)
+        eci.dst[0] = 0;
+        eci.dst[1] = 0;
+        eci.dst[2] = eci.dur0;
     }
-}
-
-// Lowest / highest set bit of a double on the f32 exponent-field scale (bit value 2^(field-127)).
-__device__ __forceinline__ void f64_bit_span(double v, int &elow, int &ehigh) {
-    if (v == 0) { elow = 255; ehigh = 0; return; }
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const int e = (int)((b >> 52) & 0x7FF);
-    unsigned long long m = b & 0xFFFFFFFFFFFFFull;
-    if (e) m |= 1ull << 52;
-    const int tz = __ffsll((long long)m) - 1;
-    const int unb = (e ? e : 1) - 1023;   // exponent of the hidden-bit position
-    elow = unb - 52 + tz + 127;
-    ehigh = unb + 127;
-    if (e == 0x7FF) { elow = -4000; ehigh = 4000; }   // inf/nan: never provably exact
-}
-
-// Per batch: S(ring), delta = ss - S(ring), and the guard span of the carried values.
-__global__ __launch_bounds__(64) void k_prepare(const float *ring, int L, Carry *carry) {
-    const int lane = threadIdx.x;
-    double part = 0;
-    uint32_t emin = 255u, emax = 0u;
-    for (int s = lane; s < L; s += 64) {
-        const float v = ring[s];
-        part += (double)v;
-        if (v != 0.f) {
-            const uint32_t e = max(f32_expfield(v), 1u);
-            emin = min(emin, e);
-            emax = max(emax, e);
-        }
-    }
-    const double S = wave_sum_f64(part);
-    emin = wave_min_u32(emin);
-    emax = wave_max_u32(emax);
-    if (lane == 0) {
-        const double ss = carry->ss;
-        const double delta = ss - S;
-        carry->delta = delta;
-        int el, eh, el2, eh2;
-        f64_bit_span(ss, el, eh);
-        f64_bit_span(delta, el2, eh2);
-        carry->ss_emin = min(el, el2);
-        carry->ss_emax = max(eh, eh2);
-        carry->ring_emin = (int)emin;
-        carry->ring_emax = (int)emax;
-    }
+    __syncthreads();
+    __threadfence_block();
+    prepare_batch(ring, L, carry, ver, nchunks);
 }
 
 // After the passes converged: the ring at the end of the batch (look-back over all
 // chunks) and its sum become the carried state.
 __global__ __launch_bounds__(64) void k_finalize_state(ThrArgs A, float *ring_next, Carry *carry) {
-    const int lane = threadIdx.x;
-    double part = 0;
-    for (int s = lane; s < A.L; s += 64) {
-        const float v = resolve_slot(A, A.nchunks, s);
-        ring_next[s] = v;
-        part += (double)v;
-    }
-    const double S = wave_sum_f64(part);
-    if (lane == 0) carry->ss = S + carry->delta;
+    finalize_state(A, ring_next, carry, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
