@@ -519,6 +519,19 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     // Every step of a chunk is whole except the batch's last one and the stretch before the first stable
     // sample (chunk lengths are multiples of the step): those rare partial steps take the exact row path.
     const float loLf = (float)A.lo_L, hiLf = (float)A.hi_L;   // thresholds in f32 carry 2^-18 of slack (>> 4 roundings)
+    // The fast path never needs the exact sum: its classifications hold for every sum within the step's margin,
+    // so it tracks the sum in f32 (ssf) and pays for the accumulated rounding with RND * ss of extra margin
+    // (each step adds < 2^-22 relative; ssf is re-derived from the ring at least every 256 steps).  The exact
+    // fp64 sum is re-derived from the ring -- S(ring) + delta -- whenever the exact path needs it.
+    const float RND = 2.44140625e-04f;   // 2^-12
+    float ssf = (float)ss0;
+    bool ss0_valid = true;
+    int steps_since_sync = 0;
+    auto exact_sum = [&]() {
+        double part = 0;
+        for (int s2 = lane; s2 < L; s2 += 64) part += (double)(SIGN_T ? fabsf(ring[s2]) : ring[s2]);
+        return rfl(wave_sum_f64(part) + cr.delta);
+    };
     const float slD = 1.0f - 3.814697265625e-06f, slU = 1.0f + 3.814697265625e-06f;
     for (uint32_t base = m_chunk; base < n1; base += STEPN) {
         float x[NR], prev[NR];
@@ -546,8 +559,13 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 prev[j] = SIGN_T ? fabsf(ring[s]) : ring[s];
             }
         }
-        const float ssf = (float)ss0;
-        min_ss = fminf(min_ss, ssf * etaD);
+        if (!ss0_valid && steps_since_sync >= 256) {
+            ss0 = exact_sum();
+            ssf = (float)ss0;
+            ss0_valid = true;
+            steps_since_sync = 0;
+        }
+        min_ss = fminf(min_ss, ssf * (etaD - RND));
 
         // ---- fast path: classification that holds for every sum the step can see ----
         // Straight-line code on wave masks (a v_cmp IS the ballot); whether the step may commit is decided once.
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 maylow |= __ballot(x[j] < t_maylow);
             }
             b = wave_sum_f32(b) * 1.001f;
-            float bt = b + eps * ssf;
+            float bt = b + (eps + RND) * ssf;
             bool ok = bt < 0.25f * ssf;
             float thi_up = (ssf + bt) * slU * hiLf;
             // Second look: a sample that is HIGH for every sum within that bound is rejected unless a LOW sample
@@ -582,7 +600,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
 #pragma unroll
                     for (int j = 0; j < NR; j++) b2 += (x[j] > thi_up) ? 0.f : fabsf(x[j] - prev[j]);
                     b2 = wave_sum_f32(b2) * 1.001f;
-                    bt = fminf(bt, b2 + eps * ssf);
+                    bt = fminf(bt, b2 + (eps + RND) * ssf);
                     thi_up = (ssf + bt) * slU * hiLf;
                 }
             }
@@ -623,14 +641,14 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
             }
             if (ok) {
                 fast = true;
-                double dl = 0;
+                float dl = 0.f;
                 if (anyhi == 0) {
                     // nothing HIGH: a sample is accepted unless it is LOW; accepted values lie inside the bands,
                     // so their exponent range comes from the thresholds
 #pragma unroll
                     for (int j = 0; j < NR; j++) {
                         const bool a = !(x[j] < tlo_dn);
-                        dl += a ? ((double)x[j] - (double)prev[j]) : 0.0;
+                        dl += a ? (x[j] - prev[j]) : 0.f;
                         if (a) {
                             ring[slot[j]] = x[j];
                             mark(slot[j]);
@@ -649,7 +667,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                         const int lastlow = below ? rb + last_set(below) : before;
                         const bool ps = (x[j] > thi_up) && ((rb + lane - lastlow) > mx + 1);
                         const bool a = !(x[j] < tlo_dn) && !ps;
-                        dl += a ? ((double)x[j] - (double)prev[j]) : 0.0;
+                        dl += a ? (x[j] - prev[j]) : 0.f;
                         if (a) {
                             ring[slot[j]] = x[j];
                             mark(slot[j]);
@@ -672,7 +690,9 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                         step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
                     }
                 }
-                ss0 = rfl(ss0 + wave_sum_f64(dl));
+                ssf += wave_sum_f32(dl);
+                ss0_valid = false;
+                steps_since_sync++;
                 if (step_ll != LL_NONE) {
                     w_kl = 2 * step_ll + 1;
                     chunk_kl = w_kl;
@@ -686,6 +706,11 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         if (!fast) {
             // ---- exact path, one 64-sample row at a time ----
             if (eps > 0.f) all_robust = 0;
+            if (!ss0_valid) {
+                ss0 = exact_sum();
+                ss0_valid = true;
+                steps_since_sync = 0;
+            }
             float xs[NR], pv[NR];
 #pragma unroll
             for (int j = 0; j < NR; j++) {
@@ -718,6 +743,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 if (w_nl != nl_b) chunk_nl = w_nl;
                 if (w_kl != kl_b) chunk_kl = w_kl;
             }
+            ssf = (float)ss0;
         }
         {   // one coalesced store of the step's NR words per plane
             unsigned long long lo4 = lowm[0], po4 = posm[0];
@@ -768,7 +794,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     flags = wave_max_u32(flags);
     if (lane == 0) {
         ChunkInfo ci;
-        ci.ss_out = ss0;
+        ci.ss_out = ss0_valid ? ss0 : (double)ssf;   // informational
         ci.low_key = chunk_kl;
         ci.last_nonlow = chunk_nl;
         ci.emin = emin;
