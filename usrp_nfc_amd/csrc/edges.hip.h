@@ -9,9 +9,11 @@
 //   _current_state   = 2 / 1 inside a LOW / HIGH run unless its latest sample fired a time-out;
 //                      inside a val-0 run: 0 once the run is longer than max_len, else whatever
 //                      the previous run left (which, being a LOW/HIGH run, depends on its length only)
-// So an ordered scan hands every word the last two change positions before it; the word's thread then
-// replays the reference loop over its 64 samples, jumping from event to event (val change or
-// time-out), first to count its entries, then -- after a prefix sum -- to write them.
+// So an ordered scan hands every word the last two change positions before it.  The word's thread then
+// marks the samples that produce an entry -- val changes, and time-outs every max_len samples after a
+// run's first sample -- in a 64-bit event mask; after a prefix sum over the popcounts one thread per
+// ENTRY rebuilds the three values before its sample from the closed form, takes the reference's step
+// for that one sample (transition_sink.py:84-99) and writes the entry: stores are dense and in order.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -52,7 +54,15 @@ struct EdgeArgs {
     int32_t mx;
     int32_t dur_in, last_bit_in, state_in;   // carried _dur / _last_bit / _current_state
     int32_t nd;                 // max_len + 1 (decoder LUT row length)
+    uint32_t mx_magic;          // floor(2^32 / max_len) (0xFFFFFFFF for max_len 1): modulo without a divide
     uint64_t g0;                // global index of batch sample 0
+    uint64_t per_mask;          // bits 0, max_len, 2 max_len, ... < 64
+
+    __device__ __forceinline__ int mod_mx(int x) const {   // x mod max_len for 0 <= x < 2^31
+        const uint32_t q = __umulhi((uint32_t)x, mx_magic);   // floor(x / mx) or one less
+        const uint32_t r = (uint32_t)x - q * (uint32_t)mx;
+        return (int)(r >= (uint32_t)mx ? r - (uint32_t)mx : r);
+    }
 
     __device__ __forceinline__ int val_at(int32_t p) const {
         if ((neg[p >> 6] >> (p & 63)) & 1ull) return -1;
@@ -78,7 +88,7 @@ struct EdgeArgs {
         return m;
     }
     __device__ __forceinline__ int run_state(int v, int len) const {   // after `len` samples of a LOW / HIGH run
-        return (len > 1 && (len - 1) % mx == 0) ? 0 : (v == -1 ? 2 : 1);
+        return (len > 1 && mod_mx(len - 1) == 0) ? 0 : (v == -1 ? 2 : 1);
     }
     // (_last_bit, _dur, _current_state) after sample p - 1, given the last two change positions before p
     __device__ __forceinline__ void state_before(int32_t p, Last2 c, int &lb, int &dur, int &st) const {
@@ -86,14 +96,14 @@ struct EdgeArgs {
             lb = last_bit_in;
             if (p <= (int32_t)skip) { dur = dur_in; st = state_in; return; }
             const int len = p - ((int32_t)skip - dur_in);
-            dur = ((len - 1) % mx) + 1;
+            dur = mod_mx(len - 1) + 1;
             if (lb == 0) st = (len >= mx + 1) ? 0 : state_in;
             else st = run_state(lb, len);
             return;
         }
         lb = val_at(c.s1);
         const int len = p - c.s1;
-        dur = ((len - 1) % mx) + 1;
+        dur = mod_mx(len - 1) + 1;
         if (lb != 0) { st = run_state(lb, len); return; }
         if (len >= mx + 1) { st = 0; return; }
         // a short val-0 run keeps what the previous (LOW / HIGH, possibly carried) run left
@@ -105,59 +115,63 @@ struct EdgeArgs {
     }
 };
 
-// Replay transition_sink.py:84-99 over word w from event to event.  emit(sample, v, d, t) per entry.
-template <class Emit>
-__device__ __forceinline__ uint32_t replay_word(const EdgeArgs &A, size_t w, Last2 ctx, Emit emit) {
+__device__ __forceinline__ uint64_t low_mask(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }   // bits [0, k)
+
+// Samples of word w that produce an entry: the val changes m, and the time-outs -- sample s + k max_len
+// (k >= 1) of a run whose first sample is s, up to the run's end (transition_sink.py:95-99: _dur is 1 at s
+// and exceeds max_len max_len samples later, where it restarts at 1).
+__device__ __forceinline__ uint64_t event_mask(const EdgeArgs &A, size_t w, Last2 ctx, uint64_t m) {
     const int32_t w0 = (int32_t)(w * 64);
     const int32_t lo = max(w0, (int32_t)A.skip), hi = min(w0 + 64, (int32_t)A.n);
-    if (lo >= hi) return 0;
-    uint64_t ng, ps;
-    uint64_t m = A.change_mask(w, ng, ps);
-    int lb, dur, st;
-    A.state_before(lo, ctx, lb, dur, st);
-    const int mx = A.mx;
-    uint32_t cnt = 0;
-    int32_t p = lo;
-    while (p < hi) {
-        const int32_t nc = m ? w0 + (__ffsll((long long)m) - 1) : hi;
-        if (nc == p) {   // val changes at p (transition_sink.py:86-92)
-            const int b = p - w0;
-            const int v = ((ng >> b) & 1ull) ? -1 : (int)((ps >> b) & 1ull);
-            const int prev_st = st;
-            if (v == -1) st = 2;
-            else if (v == 1) st = 1;
-            emit(p, (st == 2) ? lb + 1 : lb, (prev_st == 0) ? mx : dur, st - 1);
-            cnt++;
-            dur = 1;
-            lb = v;
-            m &= m - 1;
-            p++;
-            continue;
-        }
-        int nrem = nc - p;   // samples that continue the run
-        while (nrem > 0) {
-            const int t = mx + 1 - dur;   // samples until _dur exceeds max_len (transition_sink.py:95-99)
-            if (t <= nrem) {
-                const int cs = (lb == -1) ? 2 : ((lb == 1) ? 1 : st);
-                emit(p + t - 1, (cs == 2) ? lb + 1 : lb, mx, cs - 1);
-                cnt++;
-                dur = 1;
-                st = 0;
-                p += t;
-                nrem -= t;
-            } else {
-                dur += nrem;
-                if (lb == -1) st = 2;
-                else if (lb == 1) st = 1;
-                p += nrem;
-                nrem = 0;
-            }
+    if (lo >= hi) return 0ull;
+    // the run carried into the word started at s (before the batch: where its carried _dur puts it)
+    const int32_t s = (ctx.s1 != POS_NONE) ? ctx.s1 : (int32_t)A.skip - A.dur_in;
+    const int32_t pmin = max(lo, s + 1);
+    const int r = A.mod_mx(pmin - s);
+    const int32_t p0 = r ? pmin + (A.mx - r) : pmin;   // its first time-out at or after lo
+    uint64_t t = 0ull;
+    if (p0 - w0 < 64) t = (A.per_mask << (p0 - w0)) & low_mask(m ? __ffsll((long long)m) - 1 : 64);
+    if (A.mx < 64) {   // runs that start inside the word can time out inside it
+        uint64_t rest = m;
+        while (rest) {
+            const int b = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            t |= (A.per_mask << b) & ~(1ull << b) & low_mask(rest ? __ffsll((long long)rest) - 1 : 64);
         }
     }
-    return cnt;
+    return (m | t) & low_mask(hi - w0);
 }
 
-// ---- scan 1: last two change positions before every word; its apply also counts the word's entries ----
+// The entry of the event at bit b of a word (ng / ps: its planes, m: its changes, ctx: the two changes before it).
+__device__ __forceinline__ void event_entry(const EdgeArgs &A, int32_t w0, int b, uint64_t ng, uint64_t ps, uint64_t m,
+                                            Last2 ctx, int &v, int &d, int &t) {
+    const uint64_t mb = m & low_mask(b);
+    Last2 c = ctx;
+    if (mb) {
+        const int b1 = 63 - __clzll((long long)mb);
+        const uint64_t m2 = mb & ~(1ull << b1);
+        c.s2 = m2 ? w0 + (63 - __clzll((long long)m2)) : ctx.s1;
+        c.s1 = w0 + b1;
+    }
+    int lb, dur, st;
+    A.state_before(w0 + b, c, lb, dur, st);
+    if ((m >> b) & 1ull) {   // val changes here (transition_sink.py:86-92)
+        const int val = ((ng >> b) & 1ull) ? -1 : (int)((ps >> b) & 1ull);
+        const int prev_st = st;
+        if (val == -1) st = 2;
+        else if (val == 1) st = 1;
+        v = (st == 2) ? lb + 1 : lb;
+        d = (prev_st == 0) ? A.mx : dur;
+        t = st - 1;
+    } else {                 // _dur exceeds max_len (transition_sink.py:95-99)
+        const int cs = (lb == -1) ? 2 : ((lb == 1) ? 1 : st);
+        v = (cs == 2) ? lb + 1 : lb;
+        d = A.mx;
+        t = cs - 1;
+    }
+}
+
+// ---- scan 1: last two change positions before every word; its apply also marks the word's events ----
 struct LoadLast2 {
     EdgeArgs A;
     __device__ __forceinline__ Last2 operator()(size_t w) const {
@@ -169,20 +183,22 @@ struct LoadLast2 {
         return Last2{(int32_t)(w * 64) + b1, m2 ? (int32_t)(w * 64) + (63 - __clzll((long long)m2)) : POS_NONE};
     }
 };
-struct StoreCtxAndCount {
+struct StoreCtxAndEvents {
     EdgeArgs A;
     Last2 *ctx;
-    uint32_t *cnt;
+    uint64_t *evm;
     __device__ __forceinline__ void operator()(size_t w, Last2 excl, Last2) const {
+        uint64_t ng, ps;
+        const uint64_t m = A.change_mask(w, ng, ps);
         ctx[w] = excl;
-        cnt[w] = replay_word(A, w, excl, [](int32_t, int, int, int) {});
+        evm[w] = event_mask(A, w, excl, m);
     }
 };
 
-// ---- scan 2: where each word's entries go; its apply writes them -------------------------
+// ---- scan 2: where each word's entries go ------------------------------------------------
 struct LoadWordCount {
-    const uint32_t *cnt;
-    __device__ __forceinline__ uint32_t operator()(size_t w) const { return cnt[w]; }
+    const uint64_t *evm;
+    __device__ __forceinline__ uint32_t operator()(size_t w) const { return (uint32_t)__popcll(evm[w]); }
 };
 // per edge, for the decoders: LUT row (v + 1) * nd + d in the low 14 bits, route in the top two
 // (0 dropped, 1 Manchester / tag->reader, 2 Miller / reader->tag; background.py:30-35)
@@ -190,103 +206,73 @@ __device__ __forceinline__ uint16_t edge_code(int v, int d, int t, int nd) {
     const int dd = d < nd ? d : nd - 1;
     return (uint16_t)(((v + 1) * nd + dd) | ((t + 1) << 14));
 }
-struct StoreWordEdges {
-    EdgeArgs A;
-    const Last2 *ctx;
-    nfc_edge *edges;
-    uint16_t *ecode;
-    uint32_t cap;
-    __device__ __forceinline__ void operator()(size_t w, uint32_t excl, uint32_t count) const {
-        if (!count) return;
-        uint32_t k = excl;
-        const EdgeArgs &a = A;
-        nfc_edge *e = edges;
-        uint16_t *ec = ecode;
-        const uint32_t cp = cap;
-        replay_word(A, w, ctx[w], [&](int32_t p, int v, int d, int t) {
-            if (k < cp) {
-                nfc_edge o;
-                o.idx = a.g0 + (uint64_t)p;
-                o.d = d;
-                o.v = (int8_t)v;
-                o.t = (int8_t)t;
-                o.pad = 0;
-                e[k] = o;
-                ec[k] = edge_code(v, d, t, a.nd);
-            }
-            k++;
-        });
-    }
-};
 
-// The writer proper: a workgroup owns 512 consecutive words (two per thread).  It places its entries with a
-// block scan, replays its words into LDS, and copies the staged entries out with full-width coalesced
-// stores (a thread's own entries are only ~4 x 16 B apart from its neighbour's -- written directly they
-// touch a cache line per lane).  Tiles with more entries than fit the stage write directly.
+// The writer: a workgroup owns 512 consecutive words (two per thread).  It places its entries with a block
+// scan, lists them as (word, bit) in LDS, and then works one thread per entry, so that consecutive lanes
+// store consecutive 16-byte entries.
 constexpr int EW_ITEMS = 2;
-constexpr int EW_CAP = 3072;   // staged entries per workgroup: 48 KB of nfc_edge + 6 KB of codes
-__global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const Last2 *ctx, const uint32_t *wcnt,
+constexpr int EW_WORDS = SCAN_BLOCK * EW_ITEMS;
+constexpr int EW_CAP = 4096;   // entries listed per round (a tile holds 2150 on the bench workloads, 32768 at most)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const Last2 *ctx, const uint64_t *evm,
                                                            const uint32_t *tile_base, nfc_edge *edges, uint16_t *ecode,
                                                            uint32_t cap) {
-    __shared__ __attribute__((aligned(16))) nfc_edge s_edge[EW_CAP];
-    __shared__ uint16_t s_code[EW_CAP];
+    __shared__ uint64_t s_ng[EW_WORDS], s_ps[EW_WORDS], s_m[EW_WORDS];
+    __shared__ Last2 s_ctx[EW_WORDS];
+    __shared__ uint16_t s_ev[EW_CAP];
     __shared__ uint32_t s_scan[SCAN_WAVES];
-    const size_t w0 = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * EW_ITEMS;
-    uint32_t c[EW_ITEMS], mine = 0;
+    const int wl0 = (int)threadIdx.x * EW_ITEMS;
+    const size_t wt = (size_t)blockIdx.x * EW_WORDS;   // first word of the tile
+    uint64_t ev[EW_ITEMS];
+    uint32_t mine = 0;
 #pragma unroll
     for (int i = 0; i < EW_ITEMS; i++) {
-        c[i] = (w0 + i < nwords) ? wcnt[w0 + i] : 0u;
-        mine += c[i];
+        const size_t w = wt + wl0 + i;
+        ev[i] = 0ull;
+        if (w < nwords) {
+            uint64_t ng, ps;
+            s_m[wl0 + i] = A.change_mask(w, ng, ps);
+            s_ng[wl0 + i] = ng;
+            s_ps[wl0 + i] = ps;
+            s_ctx[wl0 + i] = ctx[w];
+            ev[i] = evm[w];
+        }
+        mine += (uint32_t)__popcll(ev[i]);
     }
     uint32_t total;
-    uint32_t off = block_exclusive<AddU32>(mine, s_scan, total);
+    const uint32_t off = block_exclusive<AddU32>(mine, s_scan, total);
     const uint32_t gbase = tile_base[blockIdx.x];
-    const bool staged = total <= (uint32_t)EW_CAP;
+    for (uint32_t rbase = 0; rbase < total; rbase += EW_CAP) {
+        uint32_t k = off - rbase;   // wraps below the round: the unsigned compare drops those
 #pragma unroll
-    for (int i = 0; i < EW_ITEMS; i++) {
-        if (!c[i]) continue;
-        uint32_t k = off;
-        const int nd = A.nd;
-        const uint64_t g0 = A.g0;
-        if (staged) {
-            replay_word(A, w0 + i, ctx[w0 + i], [&](int32_t p, int v, int d, int t) {
+        for (int i = 0; i < EW_ITEMS; i++) {
+            uint64_t e = ev[i];
+            while (e) {
+                if (k < (uint32_t)EW_CAP) s_ev[k] = (uint16_t)(((wl0 + i) << 6) | (__ffsll((long long)e) - 1));
+                e &= e - 1;
+                k++;
+            }
+        }
+        __syncthreads();
+        const uint32_t cnt = min((uint32_t)EW_CAP, total - rbase);
+        for (uint32_t j = threadIdx.x; j < cnt; j += SCAN_BLOCK) {
+            const uint32_t code = s_ev[j];
+            const int wl = (int)(code >> 6), b = (int)(code & 63u);
+            const int32_t w0 = (int32_t)((wt + wl) * 64);
+            int v, d, t;
+            event_entry(A, w0, b, s_ng[wl], s_ps[wl], s_m[wl], s_ctx[wl], v, d, t);
+            const uint32_t g = gbase + rbase + j;
+            if (g < cap) {
                 nfc_edge o;
-                o.idx = g0 + (uint64_t)p;
+                o.idx = A.g0 + (uint64_t)(w0 + b);
                 o.d = d;
                 o.v = (int8_t)v;
                 o.t = (int8_t)t;
                 o.pad = 0;
-                s_edge[k] = o;
-                s_code[k] = edge_code(v, d, t, nd);
-                k++;
-            });
-        } else {
-            replay_word(A, w0 + i, ctx[w0 + i], [&](int32_t p, int v, int d, int t) {
-                const uint32_t g = gbase + k;
-                if (g < cap) {
-                    nfc_edge o;
-                    o.idx = g0 + (uint64_t)p;
-                    o.d = d;
-                    o.v = (int8_t)v;
-                    o.t = (int8_t)t;
-                    o.pad = 0;
-                    edges[g] = o;
-                    ecode[g] = edge_code(v, d, t, nd);
-                }
-                k++;
-            });
-        }
-        off += c[i];
-    }
-    if (staged) {
-        __syncthreads();
-        const uint4 *src = (const uint4 *)s_edge;
-        uint4 *dst = (uint4 *)(edges + gbase);
-        for (uint32_t i = threadIdx.x; i < total; i += SCAN_BLOCK)
-            if (gbase + i < cap) {
-                dst[i] = src[i];
-                ecode[gbase + i] = s_code[i];
+                edges[g] = o;
+                ecode[g] = edge_code(v, d, t, A.nd);
             }
+        }
+        __syncthreads();
     }
 }
 

@@ -525,15 +525,18 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     E.state_in = c->h_ecarry.state;
     E.nd = c->mx + 1;
     E.g0 = g0;
+    E.mx_magic = c->mx > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c->mx) : 0xFFFFFFFFu;
+    E.per_mask = 0;
+    for (int b = 0; b < 64; b += c->mx) E.per_mask |= 1ull << b;
     HIPCHK(c, c->d_ctx.ensure((nwords + 1) * sizeof(Last2)));
-    HIPCHK(c, c->d_wcnt.ensure((nwords + 1) * 4));
+    HIPCHK(c, c->d_wcnt.ensure((nwords + 1) * 8));
     HIPCHK(c, c->d_partials.ensure((scan_num_tiles<4>(nwords) + 1) * sizeof(Last2)));
     Last2 *ctx = c->d_ctx.as<Last2>();
-    uint32_t *wcnt = c->d_wcnt.as<uint32_t>();
-    // scan 1: the two latest val changes before every 64-sample word; each word then counts its entries
-    device_scan<Last2Op, 4>(c->st, nwords, nullptr, LoadLast2{E}, StoreCtxAndCount{E, ctx, wcnt}, Last2Op::identity(),
+    uint64_t *wcnt = c->d_wcnt.as<uint64_t>();   // event masks
+    // scan 1: the two latest val changes before every 64-sample word; each word then marks its entries
+    device_scan<Last2Op, 4>(c->st, nwords, nullptr, LoadLast2{E}, StoreCtxAndEvents{E, ctx, wcnt}, Last2Op::identity(),
                             c->d_partials.as<Last2>(), (Last2 *)(tot + TOT_LAST2));
-    // scan 2: entry offsets per 512-word tile; then every tile stages and writes its entries
+    // scan 2: entry offsets per 512-word tile; then every tile writes its entries, one thread per entry
     HIPCHK(c, c->d_partials2.ensure((scan_num_tiles<EW_ITEMS>(nwords) + 1) * sizeof(uint32_t)));
     scan_phase1<AddU32, EW_ITEMS>(c->st, nwords, nullptr, LoadWordCount{wcnt}, 0u, c->d_partials2.as<uint32_t>(),
                                   (uint32_t *)(tot + TOT_EDGES));

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     int chunk_nl = LL_NONE, chunk_kl = KEY_NONE;
     uint32_t vmin = 0xFFFFFFFFu, vmax = 0u;   // accepted values as raw bits (positive floats order like uints)
     uint32_t slot_step = (A.g0modL + m_chunk) % (uint32_t)L;
-    const float etaD = 1.0f - 9.5367431640625e-07f, etaU = 1.0f + 9.5367431640625e-07f;  // 1 -+ 2^-20
+    const float etaD = 1.0f - 9.5367431640625e-07f;  // 1 - 2^-20
     // raw samples of the next two steps stay in flight while the current step is classified
     using Raw = typename RawOf<KIND>::T;
     Raw r1[NR], r2[NR];
