@@ -171,7 +171,8 @@ __device__ __forceinline__ void event_entry(const EdgeArgs &A, int32_t w0, int b
     }
 }
 
-// ---- scan 1: last two change positions before every word; its apply also marks the word's events ----
+// ---- scan 1: last two change positions before every word; its apply also marks the word's events and
+// sums their counts per tile (the aggregates of scan 2: where each word's entries go) ----
 struct LoadLast2 {
     EdgeArgs A;
     __device__ __forceinline__ Last2 operator()(size_t w) const {
@@ -187,19 +188,16 @@ struct StoreCtxAndEvents {
     EdgeArgs A;
     Last2 *ctx;
     uint64_t *evm;
-    __device__ __forceinline__ void operator()(size_t w, Last2 excl, Last2) const {
+    __device__ __forceinline__ uint32_t operator()(size_t w, Last2 excl, Last2) const {   // returns the word's entry count
         uint64_t ng, ps;
         const uint64_t m = A.change_mask(w, ng, ps);
+        const uint64_t e = event_mask(A, w, excl, m);
         ctx[w] = excl;
-        evm[w] = event_mask(A, w, excl, m);
+        evm[w] = e;
+        return (uint32_t)__popcll(e);
     }
 };
 
-// ---- scan 2: where each word's entries go ------------------------------------------------
-struct LoadWordCount {
-    const uint64_t *evm;
-    __device__ __forceinline__ uint32_t operator()(size_t w) const { return (uint32_t)__popcll(evm[w]); }
-};
 // per edge, for the decoders: LUT row (v + 1) * nd + d in the low 14 bits, route in the top two
 // (0 dropped, 1 Manchester / tag->reader, 2 Miller / reader->tag; background.py:30-35)
 __device__ __forceinline__ uint16_t edge_code(int v, int d, int t, int nd) {
@@ -276,15 +274,20 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
     }
 }
 
-// carried (_last_bit, _dur, _current_state) after the batch, from the scan-1 total
-__global__ void k_edge_carry(EdgeArgs A, const Last2 *total, EdgeCarry *carry) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (A.skip >= A.n) return;  // nothing but fill samples: unchanged
-    int lb, dur, st;
-    A.state_before((int32_t)A.n, *total, lb, dur, st);
-    carry->last_bit = lb;
-    carry->dur = dur;
-    carry->state = st;
-}
+// carried (_last_bit, _dur, _current_state) after the batch, from the scan-1 total; runs as the epilogue of the
+// entry-count scan's partials pass
+struct EdgeCarryEpilogue {
+    EdgeArgs A;
+    const Last2 *total;
+    EdgeCarry *carry;
+    __device__ __forceinline__ void operator()(uint32_t) const {
+        if (A.skip >= A.n) return;  // nothing but fill samples: unchanged
+        int lb, dur, st;
+        A.state_before((int32_t)A.n, *total, lb, dur, st);
+        carry->last_bit = lb;
+        carry->dur = dur;
+        carry->state = st;
+    }
+};
 
 }  // namespace nfc

@@ -530,23 +530,26 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     for (int b = 0; b < 64; b += c->mx) E.per_mask |= 1ull << b;
     HIPCHK(c, c->d_ctx.ensure((nwords + 1) * sizeof(Last2)));
     HIPCHK(c, c->d_wcnt.ensure((nwords + 1) * 8));
-    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<4>(nwords) + 1) * sizeof(Last2)));
+    const size_t tiles = scan_num_tiles<EW_ITEMS>(nwords);   // 512 words per tile in every pass of the stage
+    HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(Last2)));
+    HIPCHK(c, c->d_partials2.ensure((tiles + 1) * sizeof(uint32_t)));
     Last2 *ctx = c->d_ctx.as<Last2>();
-    uint64_t *wcnt = c->d_wcnt.as<uint64_t>();   // event masks
-    // scan 1: the two latest val changes before every 64-sample word; each word then marks its entries
-    device_scan<Last2Op, 4>(c->st, nwords, nullptr, LoadLast2{E}, StoreCtxAndEvents{E, ctx, wcnt}, Last2Op::identity(),
-                            c->d_partials.as<Last2>(), (Last2 *)(tot + TOT_LAST2));
-    // scan 2: entry offsets per 512-word tile; then every tile writes its entries, one thread per entry
-    HIPCHK(c, c->d_partials2.ensure((scan_num_tiles<EW_ITEMS>(nwords) + 1) * sizeof(uint32_t)));
-    scan_phase1<AddU32, EW_ITEMS>(c->st, nwords, nullptr, LoadWordCount{wcnt}, 0u, c->d_partials2.as<uint32_t>(),
-                                  (uint32_t *)(tot + TOT_EDGES));
+    uint64_t *evm = c->d_wcnt.as<uint64_t>();   // event masks
+    // scan 1: the two latest val changes before every 64-sample word; each word then marks its entries, and the
+    // tiles' entry counts are the aggregates of scan 2 (entry offsets per tile)
+    scan_reduce<Last2Op, EW_ITEMS>(c->st, nwords, nullptr, LoadLast2{E}, c->d_partials.as<Last2>());
+    scan_partials<Last2Op>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials.as<Last2>(), Last2Op::identity(),
+                           (Last2 *)(tot + TOT_LAST2));
+    scan_apply_sum<Last2Op, EW_ITEMS, AddU32>(c->st, nwords, nullptr, LoadLast2{E}, StoreCtxAndEvents{E, ctx, evm},
+                                              c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>());
+    scan_partials<AddU32>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials2.as<uint32_t>(), 0u, (uint32_t *)(tot + TOT_EDGES),
+                          EdgeCarryEpilogue{E, (const Last2 *)(tot + TOT_LAST2), dE(c)});
     const uint32_t cap = c->cap_edges;
     HIPCHK(c, c->d_edges.ensure(((size_t)cap + 1) * sizeof(nfc_edge)));
     HIPCHK(c, c->d_ecode.ensure(((size_t)cap + 8) * 2));
     if (nwords)
-        hipLaunchKernelGGL(k_write_edges, dim3((unsigned)scan_num_tiles<EW_ITEMS>(nwords)), dim3(SCAN_BLOCK), 0, c->st, E, nwords,
-                           ctx, wcnt, c->d_partials2.as<uint32_t>(), c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), cap);
-    hipLaunchKernelGGL(k_edge_carry, dim3(1), dim3(64), 0, c->st, E, (const Last2 *)(tot + TOT_LAST2), dE(c));
+        hipLaunchKernelGGL(k_write_edges, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, ctx, evm,
+                           c->d_partials2.as<uint32_t>(), c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), cap);
     return NFC_OK;
 }
 
@@ -558,32 +561,53 @@ int run_decode(nfc_ctx *c) {
     const uint32_t ce = c->cap_edges;                      // capacity; the count is on the device
     const uint32_t *ne_dev = (const uint32_t *)(tot + TOT_EDGES);
     const nfc_edge *edges = c->d_edges.as<nfc_edge>();
-    constexpr int DI = 16;  // edges per thread in the decoder-state scan
     const uint32_t cs[2] = {c->cap_sym[0], c->cap_sym[1]};
+    const size_t tiles = dec_num_tiles(ce);
     HIPCHK(c, c->d_states.ensure((size_t)ce + 16));   // one out-word per edge
     for (int t = 0; t < 2; t++) {
         HIPCHK(c, c->d_sym[t].ensure((size_t)cs[t] + 16));
         HIPCHK(c, c->d_src[t].ensure(((size_t)cs[t] + 16) * 4));
     }
-    HIPCHK(c, c->d_partials.ensure((scan_num_tiles<4>(ce) + 1) * sizeof(DecMaps)));
-    HIPCHK(c, c->d_aggs.ensure((fsm_num_threads<DI>(ce) + 1) * sizeof(DecMaps)));
+    HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(DecMaps)));
+    HIPCHK(c, c->d_partials2.ensure((tiles + 1) * sizeof(uint64_t)));
+    HIPCHK(c, c->d_aggs.ensure((tiles * SCAN_BLOCK + 1) * sizeof(DecMaps)));
 
+    // decoder states: tile maps -> tile prefixes -> every thread walks its edges; the walk's symbol counts per
+    // tile feed the scan that places the symbols
+    const uint16_t *ecode = c->d_ecode.as<uint16_t>();
     uint8_t *outw = c->d_states.as<uint8_t>();
     const uint32_t dec_state_in = (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4);
-    device_fsm_scan<ComposeDec, DI>(c->st, ce, ne_dev, LoadEdgeMaps{c->d_ecode.as<uint16_t>(), c->T},
-                                    VisitEdgeOut{c->d_ecode.as<uint16_t>(), c->T, outw}, dec_state_in,
-                                    c->d_partials.as<DecMaps>(), c->d_aggs.as<DecMaps>(), (DecMaps *)(tot + TOT_DECMAP));
-    StoreSymbols ss{outw, {c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()},
-                    {c->d_src[0].as<uint32_t>(), c->d_src[1].as<uint32_t>()}, {cs[0], cs[1]}};
-    device_scan<AddU64, 8>(c->st, ce, ne_dev, LoadSymCounts{outw}, ss, 0ull, c->d_partials.as<uint64_t>(),
-                           (uint64_t *)(tot + TOT_SYMS));
-    hipLaunchKernelGGL(k_dec_carry, dim3(1), dim3(64), 0, c->st, (const DecMaps *)(tot + TOT_DECMAP), dec_state_in, dD(c),
-                       (const uint64_t *)(tot + TOT_SYMS), (uint32_t *)(tot + TOT_NSYM));
+    const bool lds_tables = 4 * c->T.nd <= DEC_LDS_ROWS;
+    DecMaps *dparts = c->d_partials.as<DecMaps>(), *daggs = c->d_aggs.as<DecMaps>();
+    uint64_t *sums = c->d_partials2.as<uint64_t>();
+    if (tiles) {
+        if (lds_tables)
+            hipLaunchKernelGGL(k_dec_reduce<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
+        else
+            hipLaunchKernelGGL(k_dec_reduce<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
+    }
+    scan_partials<ComposeDec>(c->st, tiles, ne_dev, DEC_TILE, dparts, ComposeDec::identity_host(), (DecMaps *)(tot + TOT_DECMAP));
+    if (tiles) {
+        if (lds_tables)
+            hipLaunchKernelGGL(k_dec_apply<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
+                               dec_state_in, outw, sums);
+        else
+            hipLaunchKernelGGL(k_dec_apply<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
+                               dec_state_in, outw, sums);
+    }
+    scan_partials<AddU64>(c->st, tiles, ne_dev, DEC_TILE, sums, 0ull, (uint64_t *)(tot + TOT_SYMS),
+                          DecCarryEpilogue{(const DecMaps *)(tot + TOT_DECMAP), dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM)});
+    if (tiles) {
+        SymOut so{{c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()}, {c->d_src[0].as<uint32_t>(), c->d_src[1].as<uint32_t>()}, {cs[0], cs[1]}};
+        hipLaunchKernelGGL(k_sym_store, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, sums, so);
+    }
 
-    constexpr int PI = 16;
+    // framing, per decoder that exists (background.py:17-25); the other type has no symbols and keeps its carry
     const int pn = 1 - c->pend_cur;   // the open packets' bits go to the other half of the double buffer
     for (int t = 0; t < 2; t++) {
+        if (!(t == 0 ? c->T.tag : c->T.reader)) continue;
         const uint32_t ns = cs[t];   // capacity
+        const size_t ptiles = dec_num_tiles(ns);
         const uint32_t *ns_dev = (const uint32_t *)(tot + TOT_NSYM) + t;
         const uint32_t pend = c->h_dcarry.pending[t];
         const int start_bit = (t == 0) ? 1 : 0;  // packets.py:24-28
@@ -592,19 +616,28 @@ int run_decode(nfc_ctx *c) {
         HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend + ns + 16));
         HIPCHK(c, c->d_close_end[t].ensure(((size_t)ns + 4) * 4));
         HIPCHK(c, c->d_close_idx[t].ensure(((size_t)ns + 4) * 8));
-        HIPCHK(c, c->d_partials.ensure((scan_num_tiles<8>(ns) + 1) * sizeof(uint64_t)));
-        HIPCHK(c, c->d_aggs.ensure((fsm_num_threads<PI>(ns) + 1) * sizeof(uint32_t)));
+        HIPCHK(c, c->d_partials.ensure((ptiles + 1) * sizeof(uint64_t)));
+        HIPCHK(c, c->d_partials2.ensure((ptiles + 1) * sizeof(uint64_t)));
+        HIPCHK(c, c->d_aggs.ensure((ptiles * SCAN_BLOCK + 1) * sizeof(uint32_t)));
         if (pend) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t][c->pend_cur].p, pend, hipMemcpyDeviceToDevice, c->st));
         const uint8_t *sym = c->d_sym[t].as<uint8_t>();
         uint8_t *pflags = c->d_started.as<uint8_t>();
         uint32_t *maptot = (uint32_t *)(tot + (t ? TOT_PKTMAP1 : TOT_PKTMAP0));
         uint64_t *pktot = (uint64_t *)(tot + (t ? TOT_PKT1 : TOT_PKT0));
-        device_fsm_scan<ComposePkt, PI>(c->st, ns, ns_dev, LoadPktMaps{sym, start_bit}, VisitPktFlags{sym, start_bit, pflags},
-                                        (uint32_t)c->h_dcarry.pkt_started[t], c->d_partials.as<uint32_t>(),
-                                        c->d_aggs.as<uint32_t>(), maptot);
-        StorePkt sp{sym, pflags, c->d_src[t].as<uint32_t>(), edges, c->d_bits[t].as<uint8_t>(),
-                    c->d_close_end[t].as<uint32_t>(), c->d_close_idx[t].as<uint64_t>()};
-        device_scan<AddU64, 8>(c->st, ns, ns_dev, LoadPktCounts{pflags}, sp, (uint64_t)pend, c->d_partials.as<uint64_t>(), pktot);
+        uint32_t *pparts = c->d_partials.as<uint32_t>(), *paggs = c->d_aggs.as<uint32_t>();
+        uint64_t *psums = c->d_partials2.as<uint64_t>();
+        if (ptiles)
+            hipLaunchKernelGGL(k_pkt_reduce, dim3((unsigned)ptiles), dim3(SCAN_BLOCK), 0, c->st, sym, (size_t)ns, ns_dev, start_bit, pparts, paggs);
+        scan_partials<ComposePkt>(c->st, ptiles, ns_dev, DEC_TILE, pparts, ComposePkt::identity_host(), maptot);
+        if (ptiles)
+            hipLaunchKernelGGL(k_pkt_apply, dim3((unsigned)ptiles), dim3(SCAN_BLOCK), 0, c->st, sym, (size_t)ns, ns_dev, start_bit, pparts, paggs,
+                               (uint32_t)c->h_dcarry.pkt_started[t], pflags, psums);
+        scan_partials<AddU64>(c->st, ptiles, ns_dev, DEC_TILE, psums, (uint64_t)pend, pktot);
+        if (ptiles) {
+            PktOut po{c->d_src[t].as<uint32_t>(), edges, c->d_bits[t].as<uint8_t>(), c->d_close_end[t].as<uint32_t>(),
+                      c->d_close_idx[t].as<uint64_t>()};
+            hipLaunchKernelGGL(k_pkt_store, dim3((unsigned)ptiles), dim3(SCAN_BLOCK), 0, c->st, sym, pflags, (size_t)ns, ns_dev, psums, po);
+        }
         PktFinish F{c->d_bits[t].as<uint8_t>(), c->d_pending[t][pn].as<uint8_t>(), c->d_close_end[t].as<uint32_t>(), pktot, maptot,
                     dD(c), t, c->h_dcarry.pkt_started[t], (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu)};
         hipLaunchKernelGGL(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
@@ -887,18 +920,22 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         for (int s = 0; s < 16; s++) milb[i * 16 + s] = (uint8_t)((t.miller_map[i] >> (4 * s)) & 15u);
     for (size_t i = 0; i < t.manch_map.size(); i++)
         for (int s = 0; s < 8; s++) manb[i * 8 + s] = (uint8_t)((t.manch_map[i] >> (4 * s)) & 15u);
+    // walking form: next state | out byte << 8 per (LUT row, state)
+    std::vector<uint16_t> mils(milb.size()), mans(manb.size());
+    for (size_t i = 0; i < milb.size(); i++) mils[i] = (uint16_t)(milb[i] | (t.miller_out[i] << 8));
+    for (size_t i = 0; i < manb.size(); i++) mans[i] = (uint16_t)(manb[i] | (t.manch_out[i] << 8));
     CRT(c->d_mil_map.ensure(milb.size()));
     CRT(c->d_man_map.ensure(manb.size()));
-    CRT(c->d_mil_out.ensure(t.miller_out.size()));
-    CRT(c->d_man_out.ensure(t.manch_out.size()));
+    CRT(c->d_mil_out.ensure(mils.size() * 2));
+    CRT(c->d_man_out.ensure(mans.size() * 2));
     CRT(hipMemcpy(c->d_mil_map.p, milb.data(), milb.size(), hipMemcpyHostToDevice));
     CRT(hipMemcpy(c->d_man_map.p, manb.data(), manb.size(), hipMemcpyHostToDevice));
-    CRT(hipMemcpy(c->d_mil_out.p, t.miller_out.data(), t.miller_out.size(), hipMemcpyHostToDevice));
-    CRT(hipMemcpy(c->d_man_out.p, t.manch_out.data(), t.manch_out.size(), hipMemcpyHostToDevice));
+    CRT(hipMemcpy(c->d_mil_out.p, mils.data(), mils.size() * 2, hipMemcpyHostToDevice));
+    CRT(hipMemcpy(c->d_man_out.p, mans.data(), mans.size() * 2, hipMemcpyHostToDevice));
     c->T.mil_map = c->d_mil_map.as<uint4>();
     c->T.man_map = c->d_man_map.as<uint2>();
-    c->T.mil_out = c->d_mil_out.as<uint8_t>();
-    c->T.man_out = c->d_man_out.as<uint8_t>();
+    c->T.mil_step = c->d_mil_out.as<uint16_t>();
+    c->T.man_step = c->d_man_out.as<uint16_t>();
     c->T.nd = c->mx + 1;
     c->T.reader = p->enable_reader ? 1 : 0;
     c->T.tag = p->enable_tag ? 1 : 0;

@@ -7,6 +7,9 @@
 // fly from whatever it reads) and consumed by a Store functor.  A blocked
 // arrangement (thread t owns ITEMS consecutive items) keeps the order, which the
 // transducer compositions need.
+// Every launch costs a few microseconds whatever it does, so stages chain their scans: an apply pass may
+// return a value per item whose tile sums are the next scan's aggregates (k_scan_apply_sum), and the
+// single-workgroup partials pass takes an epilogue for the one-thread bookkeeping that follows a scan.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,6 +26,7 @@ struct AddU32 {
     static __device__ __forceinline__ T op(T a, T b) { return a + b; }
     static __device__ __forceinline__ T shfl_up(T v, int d) { return (T)__shfl_up((int)v, d, 64); }
     static __device__ __forceinline__ T shfl(T v, int l) { return (T)__shfl((int)v, l, 64); }
+    static __device__ __forceinline__ T shfl_xor(T v, int d) { return (T)__shfl_xor((int)v, d, 64); }
 };
 
 struct AddU64 {  // also used as two packed u32 counters (no carry between halves while each < 2^32)
@@ -35,6 +39,10 @@ struct AddU64 {  // also used as two packed u32 counters (no carry between halve
     }
     static __device__ __forceinline__ T shfl(T v, int l) {
         int lo = __shfl((int)(uint32_t)v, l, 64), hi = __shfl((int)(uint32_t)(v >> 32), l, 64);
+        return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+    }
+    static __device__ __forceinline__ T shfl_xor(T v, int d) {
+        int lo = __shfl_xor((int)(uint32_t)v, d, 64), hi = __shfl_xor((int)(uint32_t)(v >> 32), d, 64);
         return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
     }
 };
@@ -113,8 +121,8 @@ struct ComposePkt {
 
 // ---- block-level helpers ----------------------------------------------------
 // Inclusive scan of one value per thread across the block; returns the exclusive
-// prefix of this thread and the block total.  lds must hold SCAN_WAVES entries.
-template <class Tr>
+// prefix of this thread and the block total.  lds must hold WAVES entries.
+template <class Tr, int WAVES = SCAN_WAVES>
 __device__ __forceinline__ typename Tr::T block_exclusive(typename Tr::T v, typename Tr::T *lds,
                                                           typename Tr::T &block_total) {
     using T = typename Tr::T;
@@ -130,7 +138,7 @@ __device__ __forceinline__ typename Tr::T block_exclusive(typename Tr::T v, type
     T wave_prefix = Tr::identity();
     T total = Tr::identity();
 #pragma unroll
-    for (int w = 0; w < SCAN_WAVES; w++) {
+    for (int w = 0; w < WAVES; w++) {
         T x = lds[w];
         if (w < wave) wave_prefix = Tr::op(wave_prefix, x);
         total = Tr::op(total, x);
@@ -140,6 +148,28 @@ __device__ __forceinline__ typename Tr::T block_exclusive(typename Tr::T v, type
     T excl = Tr::shfl_up(inc, 1);
     if (lane == 0) excl = Tr::identity();
     return Tr::op(wave_prefix, excl);
+}
+// Block total of a commutative sum, valid in every thread.
+template <class Tr, int WAVES = SCAN_WAVES>
+__device__ __forceinline__ typename Tr::T block_sum(typename Tr::T v, typename Tr::T *lds) {
+    using T = typename Tr::T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = Tr::op(v, Tr::shfl_xor(v, d));
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    T total = Tr::identity();
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) total = Tr::op(total, lds[w]);
+    __syncthreads();
+    return total;
+}
+
+// tiles of BLOCK*ITEMS items
+template <int ITEMS>
+inline size_t scan_num_tiles(size_t n) {
+    const size_t tile = (size_t)SCAN_BLOCK * ITEMS;
+    return (n + tile - 1) / tile;
 }
 
 // ---- the three kernels --------------------------------------------------------
@@ -161,24 +191,78 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(size_t n, const uint
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 
-// partials[i] <- op(seed, exclusive prefix of partials)[i]; total (with the seed) stored to *total_out.
-template <class Tr>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_partials(size_t nparts, const uint32_t *n_dev, uint32_t tile,
-                                                             typename Tr::T *partials, typename Tr::T seed,
-                                                             typename Tr::T *total_out) {
+// partials[i] <- op(seed, exclusive prefix of partials)[i]; the total (with the seed) goes to *total_out and
+// to the epilogue, which thread 0 runs once (carried-state bookkeeping that would otherwise be a launch).
+// One workgroup, eight consecutive partials per thread, so that every load of a round is in flight at once;
+// the workgroup is sized for a single round (256 / 512 / 1024 threads cover 2048 / 4096 / 8192 tiles).
+constexpr int PART_ITEMS = 8;
+struct NoEpilogue {
+    template <class T>
+    __device__ __forceinline__ void operator()(const T &) const {}
+};
+template <class Tr, int BLOCK, class Epi>
+__global__ __launch_bounds__(BLOCK) void k_scan_partials(size_t nparts, const uint32_t *n_dev, uint32_t tile,
+                                                        typename Tr::T *partials, typename Tr::T seed,
+                                                        typename Tr::T *total_out, Epi epi) {
     using T = typename Tr::T;
+    constexpr int WAVES = BLOCK / 64;
     if (n_dev) nparts = min(nparts, ((size_t)*n_dev + tile - 1) / tile);
-    __shared__ T lds[SCAN_WAVES];
+    __shared__ T lds[WAVES + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     T carry = seed;
-    for (size_t base = 0; base < nparts; base += SCAN_BLOCK) {
-        const size_t i = base + threadIdx.x;
-        T v = (i < nparts) ? partials[i] : Tr::identity();
-        T total;
-        T excl = block_exclusive<Tr>(v, lds, total);
-        if (i < nparts) partials[i] = Tr::op(carry, excl);
-        carry = Tr::op(carry, total);
+    for (size_t base = 0; base < nparts; base += (size_t)BLOCK * PART_ITEMS) {
+        const size_t i0 = base + (size_t)threadIdx.x * PART_ITEMS;
+        T v[PART_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PART_ITEMS; k++) v[k] = (i0 + k < nparts) ? partials[i0 + k] : Tr::identity();
+        T inc = v[0];
+#pragma unroll
+        for (int k = 1; k < PART_ITEMS; k++) inc = Tr::op(inc, v[k]);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            T up = Tr::shfl_up(inc, d);
+            if (lane >= d) inc = Tr::op(up, inc);
+        }
+        T excl = Tr::shfl_up(inc, 1);
+        if (lane == 0) excl = Tr::identity();
+        if (lane == 63) lds[wave] = inc;
+        __syncthreads();
+        if (wave == 0) {   // scan of the wave totals
+            T x = (lane < WAVES) ? lds[lane] : Tr::identity();
+#pragma unroll
+            for (int d = 1; d < WAVES; d <<= 1) {
+                T up = Tr::shfl_up(x, d);
+                if (lane >= d) x = Tr::op(up, x);
+            }
+            T ex = Tr::shfl_up(x, 1);
+            if (lane == 0) ex = Tr::identity();
+            if (lane < WAVES) lds[lane] = ex;
+            if (lane == WAVES - 1) lds[WAVES] = x;
+        }
+        __syncthreads();
+        T run = Tr::op(carry, Tr::op(lds[wave], excl));
+        carry = Tr::op(carry, lds[WAVES]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PART_ITEMS; k++) {
+            if (i0 + k < nparts) partials[i0 + k] = run;
+            run = Tr::op(run, v[k]);
+        }
     }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
+    if (threadIdx.x == 0) {
+        if (total_out) *total_out = carry;
+        epi(carry);
+    }
+}
+template <class Tr, class Epi = NoEpilogue>
+inline void scan_partials(hipStream_t st, size_t tiles, const uint32_t *n_dev, uint32_t tile, typename Tr::T *partials,
+                          typename Tr::T seed, typename Tr::T *total_out, Epi epi = Epi()) {
+    if (tiles <= 256 * PART_ITEMS)
+        hipLaunchKernelGGL((k_scan_partials<Tr, 256, Epi>), dim3(1), dim3(256), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
+    else if (tiles <= 512 * PART_ITEMS)
+        hipLaunchKernelGGL((k_scan_partials<Tr, 512, Epi>), dim3(1), dim3(512), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
+    else
+        hipLaunchKernelGGL((k_scan_partials<Tr, 1024, Epi>), dim3(1), dim3(1024), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
 }
 
 template <class Tr, int ITEMS, class Load, class Store>
@@ -207,104 +291,62 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(size_t n, const uint3
         run = Tr::op(run, item[i]);
     }
 }
-
-// tiles of BLOCK*ITEMS items
-template <int ITEMS>
-inline size_t scan_num_tiles(size_t n) {
-    const size_t tile = (size_t)SCAN_BLOCK * ITEMS;
-    return (n + tile - 1) / tile;
-}
-
-// ---- state-tracking variant for finite-state maps ---------------------------------
-// Pass 1 also keeps every thread's aggregate, so that pass 2 needs one block scan per thread and then
-// walks its items applying each map to a STATE (one look-up) instead of composing maps.
-template <class Tr, int ITEMS, class Load>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_fsm_reduce(size_t n, const uint32_t *n_dev, Load load, typename Tr::T *partials,
-                                                          typename Tr::T *aggs) {
+// The same, with store() returning a count per item: the tile's sum of them lands in sums[tile] -- the
+// aggregates of the next scan (over the same tiling), which then needs no reduce launch of its own.
+template <class Tr, int ITEMS, class Tr2, class Load, class Store>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply_sum(size_t n, const uint32_t *n_dev, Load load, Store store,
+                                                              const typename Tr::T *partials, typename Tr2::T *sums) {
     using T = typename Tr::T;
+    using T2 = typename Tr2::T;
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * SCAN_BLOCK * ITEMS >= n) return;
     __shared__ T lds[SCAN_WAVES];
-    const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    const size_t base = tid * ITEMS;
+    __shared__ T2 lds2[SCAN_WAVES];
+    const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * ITEMS;
+    T item[ITEMS];
     T agg = Tr::identity();
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const size_t idx = base + i;
-        if (idx < n) agg = Tr::op(agg, load(idx));
+        item[i] = (idx < n) ? load(idx) : Tr::identity();
+        agg = Tr::op(agg, item[i]);
     }
-    aggs[tid] = agg;
     T total;
-    (void)block_exclusive<Tr>(agg, lds, total);
-    if (threadIdx.x == 0) partials[blockIdx.x] = total;
-}
-template <class Tr, int ITEMS, class Load, class Visit>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_fsm_apply(size_t n, const uint32_t *n_dev, Load load, Visit visit,
-                                                         const typename Tr::T *partials, const typename Tr::T *aggs,
-                                                         uint32_t state0) {
-    using T = typename Tr::T;
-    if (n_dev) n = min(n, (size_t)*n_dev);
-    if ((size_t)blockIdx.x * SCAN_BLOCK * ITEMS >= n) return;
-    __shared__ T lds[SCAN_WAVES];
-    const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    const size_t base = tid * ITEMS;
-    T total;
-    const T excl = block_exclusive<Tr>(aggs[tid], lds, total);
-    uint32_t st = Tr::step(Tr::op(partials[blockIdx.x], excl), state0);
+    T excl = block_exclusive<Tr>(agg, lds, total);
+    T run = Tr::op(partials[blockIdx.x], excl);
+    T2 mine = Tr2::identity();
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const size_t idx = base + i;
-        if (idx < n) {
-            const T item = load(idx);
-            visit(idx, st, item);
-            st = Tr::step(item, st);
-        }
+        if (idx < n) mine = Tr2::op(mine, store(idx, run, item[i]));
+        run = Tr::op(run, item[i]);
     }
+    const T2 sum = block_sum<Tr2>(mine, lds2);
+    if (threadIdx.x == 0) sums[blockIdx.x] = sum;
 }
-template <int ITEMS>
-inline size_t fsm_num_threads(size_t n) { return scan_num_tiles<ITEMS>(n) * SCAN_BLOCK; }
 
-// visit(i, state before item i, item map); *total_out = composition of all maps.
+// Host-side drivers.  `partials` must hold scan_num_tiles<ITEMS>(n) entries.
 // n_dev != nullptr: the true item count is *n_dev on the device and n is only the capacity the grid is sized for.
-template <class Tr, int ITEMS, class Load, class Visit>
-inline void device_fsm_scan(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Visit visit, uint32_t state0,
-                            typename Tr::T *partials, typename Tr::T *aggs, typename Tr::T *total_out) {
-    const size_t tiles = scan_num_tiles<ITEMS>(n);
-    if (tiles)
-        hipLaunchKernelGGL((k_fsm_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load, partials,
-                           aggs);
-    hipLaunchKernelGGL((k_scan_partials<Tr>), dim3(1), dim3(SCAN_BLOCK), 0, st, tiles, n_dev, (uint32_t)(SCAN_BLOCK * ITEMS),
-                       partials, Tr::identity_host(), total_out);
-    if (tiles)
-        hipLaunchKernelGGL((k_fsm_apply<Tr, ITEMS, Load, Visit>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load,
-                           visit, partials, aggs, state0);
-}
-
-// Host-side driver.  `partials` must hold scan_num_tiles(n, ITEMS) entries.
-
-// Phase 1: tile aggregates -> exclusive tile prefixes (seeded) and the grand total in *total_out.
 template <class Tr, int ITEMS, class Load>
-inline void scan_phase1(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, typename Tr::T seed, typename Tr::T *partials,
-                        typename Tr::T *total_out) {
+inline void scan_reduce(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, typename Tr::T *partials) {
     const size_t tiles = scan_num_tiles<ITEMS>(n);
     if (tiles)
         hipLaunchKernelGGL((k_scan_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load, partials);
-    hipLaunchKernelGGL((k_scan_partials<Tr>), dim3(1), dim3(SCAN_BLOCK), 0, st, tiles, n_dev, (uint32_t)(SCAN_BLOCK * ITEMS), partials,
-                       seed, total_out);
 }
-// Phase 2: every item gets its exclusive prefix.
 template <class Tr, int ITEMS, class Load, class Store>
-inline void scan_phase2(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, const typename Tr::T *partials) {
+inline void scan_apply(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, const typename Tr::T *partials) {
     const size_t tiles = scan_num_tiles<ITEMS>(n);
     if (tiles)
         hipLaunchKernelGGL((k_scan_apply<Tr, ITEMS, Load, Store>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load,
                            store, partials);
 }
-template <class Tr, int ITEMS, class Load, class Store>
-inline void device_scan(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, typename Tr::T seed,
-                        typename Tr::T *partials, typename Tr::T *total_out) {
-    scan_phase1<Tr, ITEMS, Load>(st, n, n_dev, load, seed, partials, total_out);
-    scan_phase2<Tr, ITEMS, Load, Store>(st, n, n_dev, load, store, partials);
+template <class Tr, int ITEMS, class Tr2, class Load, class Store>
+inline void scan_apply_sum(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, const typename Tr::T *partials,
+                           typename Tr2::T *sums) {
+    const size_t tiles = scan_num_tiles<ITEMS>(n);
+    if (tiles)
+        hipLaunchKernelGGL((k_scan_apply_sum<Tr, ITEMS, Tr2, Load, Store>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev,
+                           load, store, partials, sums);
 }
 
 }  // namespace nfc
