@@ -169,6 +169,10 @@ int nfc_set_state(nfc_ctx *ctx, const nfc_state_header *hdr, const float *ring, 
 int nfc_reset(nfc_ctx *ctx);
 
 int nfc_get_stats(nfc_ctx *ctx, nfc_stats *out);
+/* How much of nfc_stats' timing is collected.  Every HIP event recorded between two kernels costs the stream a
+ * few microseconds, so the default is 0: no events (the ms_* fields stay 0).  1: ms_total and the threshold
+ * kernels' own launch durations (ms_threshold_kernel).  2: also the per-stage split. */
+int nfc_set_timing(nfc_ctx *ctx, int level);
 
 /* Device memory helpers so that a caller without HIP bindings (ctypes) can keep its input
  * resident in HBM and use nfc_push_device. */

@@ -87,6 +87,10 @@ class NfcContext(object):
         self._chk(self.L.nfc_get_stats(self.h, C.byref(s)), 'nfc_get_stats')
         return s
 
+    def set_timing(self, level):
+        """0: no HIP events in the stream (default), 1: batch total + threshold kernel durations, 2: + per-stage split."""
+        self._chk(self.L.nfc_set_timing(self.h, int(level)), 'nfc_set_timing')
+
     def _read(self, fn, total, dtype, *lead):
         out = np.zeros(int(total), dtype)
         got = C.c_size_t(0)

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/nfc_amd.h"
@@ -76,6 +77,7 @@ enum : int {
     TOT_PKT1 = 80,
     TOT_LAST2 = 88,     // Last2 (8 bytes)
     TOT_NSYM = 96,      // u32[2]: symbols per packet type
+    TOT_CERT = 104,     // CertSummary (16 bytes)
     TOT_BYTES = 128
 };
 
@@ -99,6 +101,7 @@ struct nfc_ctx {
     size_t in_bytes_per_sample;
     hipStream_t st = nullptr;
     hipEvent_t ev[8] = {};
+    int timing = 0;   // 0: no events in the stream, 1: batch total + threshold kernels, 2: + stages (nfc_set_timing)
     hipEvent_t kev[2 * 6] = {};  // start/stop pairs around the first k_threshold launches of a batch
     int n_kev = 0;
     std::string err;
@@ -171,7 +174,9 @@ inline void adopt_mirror(nfc_ctx *c) {
     c->h_dcarry = c->hs->dcarry;
 }
 // carried state set from the host without a copy engine round trip: the values travel as kernel arguments
-__global__ void k_set_state(DevState *d, Carry a, EdgeCarry b, DecCarry e, int zero_totals) {
+__global__ void k_set_state(DevState *d, Carry a, EdgeCarry b, DecCarry e, int zero_totals, float *zero_ring, int ring_len) {
+    if (zero_ring)
+        for (int i = threadIdx.x; i < ring_len; i += blockDim.x) zero_ring[i] = 0.f;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     d->carry = a;
     d->ecarry = b;
@@ -179,9 +184,9 @@ __global__ void k_set_state(DevState *d, Carry a, EdgeCarry b, DecCarry e, int z
     if (zero_totals)
         for (int i = 0; i < TOT_BYTES; i++) d->totals[i] = 0;
 }
-inline void push_state(nfc_ctx *c, int zero_totals = 0) {
-    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(64), 0, c->st, (DevState *)c->d_state.p, c->h_carry, c->h_ecarry, c->h_dcarry,
-                       zero_totals);
+inline void push_state(nfc_ctx *c, int zero_totals = 0, bool zero_ring = false) {
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(256), 0, c->st, (DevState *)c->d_state.p, c->h_carry, c->h_ecarry, c->h_dcarry,
+                       zero_totals, zero_ring ? c->d_ring[c->ring_cur].as<float>() : (float *)nullptr, c->Lpad);
 }
 __global__ void k_set_ecarry(DevState *d, EdgeCarry b) {
     if (threadIdx.x == 0 && blockIdx.x == 0) d->ecarry = b;
@@ -206,7 +211,7 @@ void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
     else hipLaunchKernelGGL((k_threshold<KIND, 4>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
 }
 void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
-    const bool timed = c->n_kev < 6;
+    const bool timed = c->timing >= 1 && c->n_kev < 6;
     if (timed) (void)hipEventRecord(c->kev[2 * c->n_kev], c->st);
     struct Stop {
         nfc_ctx *c;
@@ -230,11 +235,12 @@ void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n, int nchunks) {
     Carry *cr = dC(c);
     EdgeCarryInit eci{(int32_t *)dE(c), c->L % c->mx};
     uint8_t *ver = c->d_ver.as<uint8_t>();
+    CertSummary *sum = (CertSummary *)(dT(c) + TOT_CERT);
     switch (c->P.input_kind) {
-    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks); break;
-    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks); break;
-    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks); break;
-    default: hipLaunchKernelGGL((k_fill<IN_I16_SQ>), dim3(1), dim3(64), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks); break;
+    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum); break;
+    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum); break;
+    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum); break;
+    default: hipLaunchKernelGGL((k_fill<IN_I16_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum); break;
     }
 }
 void launch_seq_kind(nfc_ctx *c, const SeqArgs &A) {
@@ -261,7 +267,12 @@ double elapsed_ms(hipEvent_t a, hipEvent_t b) {
 // ---------------------------------------------------------------------------
 // threshold stage
 // ---------------------------------------------------------------------------
-int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
+// `ahead`, when given, enqueues the stages that follow (edges, decode) behind the first certification WITHOUT
+// waiting for its verdict: certification almost always succeeds, so the host round trip that reads the verdict
+// overlaps those stages instead of idling the GPU.  *clean reports that the verdict let that work stand.
+int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const std::function<int()> *ahead, bool *clean) {
+    bool ran_ahead = false;
+    *clean = false;
     const int L = c->L;
     // Chunk length for this batch: one wave per chunk, and a chunk's latency is what the launch takes, so
     // aim at one full round of resident waves (no second, half-empty round), never below the configured size.
@@ -389,7 +400,9 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
         c->h_list.clear();
         for (uint32_t k = 1; k < nch; k++) c->h_list.push_back(k);
         int rounds = 0;
-        bool mirrored = false;
+        bool have_summary = false;
+        CertSummary summary{};
+        uint8_t *tot = dT(c);
         while (!c->h_list.empty()) {
             const uint32_t np = (uint32_t)c->h_list.size();
             if (first_round) {
@@ -400,13 +413,29 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
             }
             A.nlist = np;
             if (dbg) HIPCHK(c, c->d_certinfo.ensure((size_t)nch * sizeof(CertInfo)));
-            hipLaunchKernelGGL(k_certify, dim3((np + 1 + 3) / 4), dim3(256), 0, c->st, A, d_cert,
-                               dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[1 - c->ring_cur].as<float>(), dC(c));
-            HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
+            // the first round also resolves the end-of-batch state (last workgroup) and leaves its verdict as a
+            // summary in the mirrored state block; later rounds (after re-runs) read the per-chunk flags
+            CertSummary *d_sum = (CertSummary *)(tot + TOT_CERT);
+            hipLaunchKernelGGL(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, d_cert,
+                               dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[1 - c->ring_cur].as<float>(), dC(c),
+                               first_round ? d_sum : (CertSummary *)nullptr);
+            if (!first_round) HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
             HIPCHK(c, mirror_async(c));
+            if (first_round && ahead) {
+                const int rc = (*ahead)();
+                if (rc) return rc;
+                ran_ahead = true;
+            }
             HIPCHK(c, hipStreamSynchronize(c->st));
-            mirrored = true;
             std::vector<uint32_t> failing;
+            if (first_round) {
+                memcpy(&summary, c->hs->totals + TOT_CERT, sizeof summary);
+                if (summary.n_fail == 0 && !dbg) {
+                    have_summary = true;
+                    break;
+                }
+                HIPCHK(c, hipMemcpy(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost));
+            }
             for (uint32_t k : c->h_list)
                 if (!h_cert[k]) failing.push_back(k);
             if (dbg) {
@@ -433,7 +462,6 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
             c->stats.chunks_rerun += A.nlist;
             HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
             HIPCHK(c, hipStreamSynchronize(c->st));
-            mirrored = false;
             std::vector<uint8_t> ran(nch, 0);
             for (uint32_t k : failing) {
                 ran[k] = 1;
@@ -453,19 +481,23 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
         }
 
         // can every fp64 sum of this batch be proven exact?  (otherwise the summation order matters)
-        if (!mirrored) {
+        int emin = 255, emax = 0;
+        bool flagged = false;
+        if (have_summary && c->stats.threshold_passes == 1) {
+            emin = (int)summary.emin;
+            emax = (int)summary.emax;
+            flagged = summary.flagged != 0;
+        } else {
             HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
             HIPCHK(c, mirror_async(c));
             HIPCHK(c, hipStreamSynchronize(c->st));
+            for (uint32_t k = 0; k < nch; k++) {
+                emin = std::min(emin, (int)h_gmin[k]);
+                emax = std::max(emax, (int)h_gmax[k]);
+                if (h_gflags[k] & 1) flagged = true;
+            }
         }
         c->h_carry = c->hs->carry;
-        int emin = 255, emax = 0;
-        bool flagged = false;
-        for (uint32_t k = 0; k < nch; k++) {
-            emin = std::min(emin, (int)h_gmin[k]);
-            emax = std::max(emax, (int)h_gmax[k]);
-            if (h_gflags[k] & 1) flagged = true;
-        }
         int low = emin - 23, high = emax + 2 + ceil_log2(L);
         if (c->h_carry.ss_emin != 255) low = std::min(low, c->h_carry.ss_emin);
         high = std::max(high, c->h_carry.ss_emax);
@@ -498,8 +530,9 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip) {
     } else {
         // the end-of-batch ring was resolved beside the last certification unless chunks were re-run after it
         if (c->stats.threshold_passes > 1 || nch == 1)
-            hipLaunchKernelGGL(k_finalize_state, dim3(1), dim3(64), 0, c->st, A, c->d_ring[1 - c->ring_cur].as<float>(), dC(c));
+            hipLaunchKernelGGL(k_finalize_state, dim3(1), dim3(FIN_BLOCK), 0, c->st, A, c->d_ring[1 - c->ring_cur].as<float>(), dC(c));
         c->ring_cur = 1 - c->ring_cur;
+        *clean = ran_ahead && c->stats.threshold_passes == 1;
     }
     return NFC_OK;
 }
@@ -663,7 +696,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         return NFC_OK;
     }
     if (((uintptr_t)d_in & 15u) != 0) return fail(c, NFC_ERR_ARG, "device input must be 16-byte aligned");
-    HIPCHK(c, hipEventRecord(c->ev[0], c->st));
+    if (c->timing >= 1) HIPCHK(c, hipEventRecord(c->ev[0], c->st));
 
     uint32_t skip = 0;
     bool fills = false;
@@ -693,26 +726,42 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         return NFC_OK;
     }
 
-    HIPCHK(c, hipEventRecord(c->ev[1], c->st));
-    int rc = run_threshold(c, d_in, n, skip);
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[2], c->st));
+    if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[1], c->st));
+    const bool want_edges = !(c->P.flags & NFC_FLAG_NO_EDGES);
     const EdgeCarry ecarry_in = c->h_ecarry;
-    if (!(c->P.flags & NFC_FLAG_NO_EDGES)) {
+    const uint64_t g0 = c->nseen;
+    auto size_caps = [&]() {
         // capacity estimates: the previous batch's counts with head-room (first batch: a guess)
         if (!c->cap_edges) c->cap_edges = (uint32_t)std::min<uint64_t>((uint64_t)n / 8 + 65536, 0xFFFFFF00u);
+        for (int t = 0; t < 2; t++) {
+            const uint64_t ub = (t == 1 ? 2ull : 1ull) * c->cap_edges + 16;   // <= 2 (Miller) / 1 (Manchester) symbols per edge
+            if (!c->cap_sym[t] || c->cap_sym[t] > ub) c->cap_sym[t] = (uint32_t)std::min<uint64_t>(ub, 0xFFFFFF00u);
+        }
+    };
+    bool ev3_done = false;
+    auto edges_and_decode = [&]() -> int {
+        size_caps();
+        if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[2], c->st));
+        int r = run_edges(c, n, skip, g0);
+        if (r) return r;
+        if (!ev3_done && c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+        ev3_done = true;
+        r = run_decode(c);
+        if (r) return r;
+        HIPCHK(c, mirror_async(c));
+        return NFC_OK;
+    };
+    const std::function<int()> ahead = edges_and_decode;
+    bool clean = false;
+    int rc = run_threshold(c, d_in, n, skip, want_edges ? &ahead : nullptr, &clean);
+    if (rc) return rc;
+    if (want_edges) {
         for (int attempt = 0;; attempt++) {
-            for (int t = 0; t < 2; t++) {
-                const uint64_t ub = (t == 1 ? 2ull : 1ull) * c->cap_edges + 16;   // <= 2 (Miller) / 1 (Manchester) symbols per edge
-                if (!c->cap_sym[t] || c->cap_sym[t] > ub) c->cap_sym[t] = (uint32_t)std::min<uint64_t>(ub, 0xFFFFFF00u);
+            if (attempt > 0 || !clean) {
+                rc = edges_and_decode();
+                if (rc) return rc;
+                HIPCHK(c, hipStreamSynchronize(c->st));
             }
-            rc = run_edges(c, n, skip, c->nseen);
-            if (rc) return rc;
-            if (attempt == 0) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
-            rc = run_decode(c);
-            if (rc) return rc;
-            HIPCHK(c, mirror_async(c));
-            HIPCHK(c, hipStreamSynchronize(c->st));
             uint32_t ne, ns[2];
             memcpy(&ne, c->hs->totals + TOT_EDGES, 4);
             memcpy(ns, c->hs->totals + TOT_NSYM, 8);
@@ -736,12 +785,17 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         c->cap_sym[1] = (uint32_t)std::min<uint64_t>((uint64_t)c->n_sym[1] * 5 / 4 + 65536, 0xFFFFFF00u);
         c->pend_cur = 1 - c->pend_cur;
     } else {
-        HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+        if (c->timing >= 2) {
+            HIPCHK(c, hipEventRecord(c->ev[2], c->st));
+            HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+        }
         HIPCHK(c, mirror_async(c));
         HIPCHK(c, hipStreamSynchronize(c->st));
     }
-    HIPCHK(c, hipEventRecord(c->ev[4], c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (c->timing >= 1) {
+        HIPCHK(c, hipEventRecord(c->ev[4], c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+    }
     {
         adopt_mirror(c);
         if (c->P.flags & NFC_FLAG_NO_EDGES) c->h_ecarry = ecarry_in;
@@ -755,10 +809,12 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
             }
         }
     }
-    c->stats.ms_total = elapsed_ms(c->ev[0], c->ev[4]);
-    c->stats.ms_threshold = elapsed_ms(c->ev[1], c->ev[2]);
-    c->stats.ms_edges = elapsed_ms(c->ev[2], c->ev[3]);
-    c->stats.ms_decode = elapsed_ms(c->ev[3], c->ev[4]);
+    if (c->timing >= 1) c->stats.ms_total = elapsed_ms(c->ev[0], c->ev[4]);
+    if (c->timing >= 2) {
+        c->stats.ms_threshold = elapsed_ms(c->ev[1], c->ev[2]);
+        c->stats.ms_edges = elapsed_ms(c->ev[2], c->ev[3]);
+        c->stats.ms_decode = elapsed_ms(c->ev[3], c->ev[4]);
+    }
     for (int i = 0; i < c->n_kev; i++) c->stats.ms_threshold_kernel[i] = elapsed_ms(c->kev[2 * i], c->kev[2 * i + 1]);
     c->stats.n_threshold_timed = (uint32_t)c->n_kev;
     c->nseen += n;
@@ -1093,13 +1149,19 @@ static int upload_carried(nfc_ctx *c) {
     return NFC_OK;
 }
 
+int nfc_set_timing(nfc_ctx *c, int level) {
+    if (!c || level < 0 || level > 2) return NFC_ERR_ARG;
+    c->timing = level;
+    return NFC_OK;
+}
+
 int nfc_reset(nfc_ctx *c) {
     if (!c) return NFC_ERR_ARG;
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
     init_carried(c);
     c->have_outputs = false;
-    HIPCHK(c, hipMemsetAsync(c->d_ring[c->ring_cur].p, 0, (size_t)c->Lpad * 4, c->st));
-    return upload_carried(c);
+    push_state(c, 0, true);   // carried values and a zeroed window in one launch
+    return NFC_OK;
 }
 
 int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap, uint8_t *pending, size_t pending_cap) {

@@ -828,26 +828,71 @@ struct CertInfo {
     float d, allowed;
     uint32_t all_robust, low_ok;
 };
-__device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_next, Carry *carry, int lane) {
+// What the host needs to know after the first certification, small enough to travel in the mirrored state block:
+// how many chunks failed, and the batch-wide exponent guard of the fp64 sums.
+struct CertSummary {
+    uint32_t n_fail;            // chunks whose certification failed (atomic; zeroed by k_fill)
+    uint32_t emin, emax;        // exponent fields over every chunk's accepted values
+    uint32_t flagged;           // some chunk met a value it cannot vouch for
+};
+constexpr int FIN_BLOCK = 256;
+// The ring at the end of the batch (look-back over all chunks) and its sum become the carried state; with
+// `sum` the guard summary of the batch is folded too.  One workgroup of FIN_BLOCK threads.
+__device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_next, Carry *carry, CertSummary *sum) {
+    __shared__ double s_part[FIN_BLOCK / 64];
+    __shared__ uint32_t s_mn[FIN_BLOCK / 64], s_mx[FIN_BLOCK / 64], s_fl[FIN_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double part = 0;
-    for (int s = lane; s < A.L; s += 64) {
+    for (int s = tid; s < A.L; s += FIN_BLOCK) {
         const float v = resolve_slot(A, A.nchunks, s);
         ring_next[s] = v;
         part += (double)v;
     }
-    const double S = wave_sum_f64(part);
-    if (lane == 0) carry->ss = S + carry->delta;
+    uint32_t mn = 255u, mx = 0u, fl = 0u;
+    if (sum)
+        for (int k = tid; k < A.nchunks; k += FIN_BLOCK) {
+            mn = min(mn, (uint32_t)A.gmin[k]);
+            mx = max(mx, (uint32_t)A.gmax[k]);
+            fl |= (uint32_t)A.gflags[k] & 1u;
+        }
+    part = wave_sum_f64(part);
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    fl = wave_max_u32(fl);
+    if (lane == 0) {
+        s_part[wave] = part;
+        s_mn[wave] = mn;
+        s_mx[wave] = mx;
+        s_fl[wave] = fl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double S = 0;
+        for (int w = 0; w < FIN_BLOCK / 64; w++) {
+            S += s_part[w];
+            mn = min(mn, s_mn[w]);
+            mx = max(mx, s_mx[w]);
+            fl |= s_fl[w];
+        }
+        carry->ss = S + carry->delta;
+        if (sum) {
+            sum->emin = mn;
+            sum->emax = mx;
+            sum->flagged = fl;
+        }
+    }
 }
 
-// One extra wave (slot == nlist) resolves the end-of-batch ring meanwhile: if every chunk certifies, that is
+// One extra workgroup (the last) resolves the end-of-batch ring meanwhile: if every chunk certifies, that is
 // the carried state of the next batch (otherwise k_finalize_state runs again after the re-runs).
-__global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertInfo *dbg, float *ring_next, Carry *carry) {
+__global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertInfo *dbg, float *ring_next, Carry *carry,
+                                                 CertSummary *sum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t slotid = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (slotid == A.nlist && ring_next) {
-        finalize_state(A, ring_next, carry, lane);
+    if (ring_next && blockIdx.x == gridDim.x - 1) {
+        finalize_state(A, ring_next, carry, sum);
         return;
     }
+    const uint32_t slotid = blockIdx.x * (blockDim.x >> 6) + wave;
     if (slotid >= A.nlist) return;
     const uint32_t c = A.list ? A.list[slotid] : slotid + 1;
     const int L = A.L;
@@ -891,6 +936,7 @@ __global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertI
     else ok = !__any(differ) && (nl == mt.nl_in) && (kl == mt.kl_in);
     if (lane == 0) {
         cert[c] = ok ? 1 : 0;
+        if (!ok && sum) atomicAdd(&sum->n_fail, 1u);
         if (dbg) dbg[c] = CertInfo{d, mt.eps * mt.min_ss, mt.all_robust, (uint32_t)low_ok};
     }
 }
@@ -909,14 +955,41 @@ __device__ __forceinline__ void f64_bit_span(double v, int &elow, int &ehigh) {
     if (e == 0x7FF) { elow = -4000; ehigh = 4000; }   // inf/nan: never provably exact
 }
 
+// Block-wide reductions for the one-workgroup kernels below (FILL_BLOCK threads).
+constexpr int FILL_BLOCK = 512;
+struct FillRed {
+    double part[FILL_BLOCK / 64];
+    uint32_t mn[FILL_BLOCK / 64], mx[FILL_BLOCK / 64];
+};
+__device__ __forceinline__ void fill_reduce(FillRed &r, double &part, uint32_t &emin, uint32_t &emax) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    part = wave_sum_f64(part);
+    emin = wave_min_u32(emin);
+    emax = wave_max_u32(emax);
+    __syncthreads();   // r may still be read from an earlier use
+    if (lane == 0) {
+        r.part[wave] = part;
+        r.mn[wave] = emin;
+        r.mx[wave] = emax;
+    }
+    __syncthreads();
+    part = 0;
+    for (int w = 0; w < FILL_BLOCK / 64; w++) {
+        part += r.part[w];
+        emin = min(emin, r.mn[w]);
+        emax = max(emax, r.mx[w]);
+    }
+}
+
 // Per batch: S(ring), delta = ss - S(ring), and the guard span of the carried values; also resets the
-// summary version bytes.  Runs as the tail of k_fill (one launch per batch for both).
-__device__ __forceinline__ void prepare_batch(const float *ring, int L, Carry *carry, uint8_t *ver, int nchunks) {
-    const int lane = threadIdx.x;
-    for (int i = lane; i < nchunks; i += 64) ver[i] = 0;
+// summary version bytes and the certification summary.  Runs as the tail of k_fill (one launch per batch for both).
+__device__ __forceinline__ void prepare_batch(const float *ring, int L, Carry *carry, uint8_t *ver, int nchunks, CertSummary *sum,
+                                              FillRed &red) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nchunks; i += FILL_BLOCK) ver[i] = 0;
     double part = 0;
     uint32_t emin = 255u, emax = 0u;
-    for (int s = lane; s < L; s += 64) {
+    for (int s = tid; s < L; s += FILL_BLOCK) {
         const float v = ring[s];
         part += (double)v;
         if (v != 0.f) {
@@ -925,10 +998,9 @@ __device__ __forceinline__ void prepare_batch(const float *ring, int L, Carry *c
             emax = max(emax, e);
         }
     }
-    const double S = wave_sum_f64(part);
-    emin = wave_min_u32(emin);
-    emax = wave_max_u32(emax);
-    if (lane == 0) {
+    fill_reduce(red, part, emin, emax);
+    if (tid == 0) {
+        const double S = part;
         const double ss = carry->ss;
         const double delta = ss - S;
         carry->delta = delta;
@@ -939,6 +1011,7 @@ __device__ __forceinline__ void prepare_batch(const float *ring, int L, Carry *c
         carry->ss_emax = max(eh, eh2);
         carry->ring_emin = (int)emin;
         carry->ring_emax = (int)emax;
+        if (sum) *sum = CertSummary{0u, 255u, 0u, 0u};
     }
 }
 
@@ -949,31 +1022,33 @@ struct EdgeCarryInit {
 
 // ---------------------------------------------------------------------------
 // Fill phase (transition_sink.py:109-125): copy the first L samples into the ring,
-// then sum them in the reference's order.  One wave; the sum is one lane reading LDS.
+// then sum them in the reference's order.  One workgroup; the ordered sum, when the
+// exponent spread cannot prove every order equal, is one lane reading LDS.
 // ---------------------------------------------------------------------------
 template <int KIND>
-__global__ __launch_bounds__(64) void k_fill(const void *in, uint32_t n, float i16_scale, int L, float *ring, Carry *carry,
-                                             EdgeCarryInit eci, uint8_t *ver, int nchunks) {
+__global__ __launch_bounds__(FILL_BLOCK) void k_fill(const void *in, uint32_t n, float i16_scale, int L, float *ring, Carry *carry,
+                                                     EdgeCarryInit eci, uint8_t *ver, int nchunks, CertSummary *sum) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ FillRed red;
     float *lr = (float *)smem;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     if (carry->stable) {   // nothing to fill: only the per-batch preparation
-        prepare_batch(ring, L, carry, ver, nchunks);
+        prepare_batch(ring, L, carry, ver, nchunks, sum, red);
         return;
     }
     const int filled = carry->filled;
     const int can = min((int)n, L - filled);
-    for (int i = lane; i < can; i += 64) ring[filled + i] = envelope_at<KIND>(in, (size_t)i, i16_scale);
+    for (int i = tid; i < can; i += FILL_BLOCK) ring[filled + i] = envelope_at<KIND>(in, (size_t)i, i16_scale);
     __syncthreads();
     if (filled + can != L) {
-        if (lane == 0) carry->filled = filled + can;
+        if (tid == 0) carry->filled = filled + can;
         return;
     }
     // If the exponent spread of the window proves every partial sum exact, any order gives the reference's
     // sum; otherwise add in the reference's order on one lane and note whether a rounding happened.
     double part = 0;
     uint32_t emin = 255u, emax = 0u;
-    for (int i = lane; i < L; i += 64) {
+    for (int i = tid; i < L; i += FILL_BLOCK) {
         const float v = ring[i];
         lr[i] = v;
         part += (double)v;
@@ -983,14 +1058,12 @@ __global__ __launch_bounds__(64) void k_fill(const void *in, uint32_t n, float i
             emax = max(emax, e);
         }
     }
-    emin = wave_min_u32(emin);
-    emax = wave_max_u32(emax);
-    const double S = wave_sum_f64(part);
+    fill_reduce(red, part, emin, emax);   // (its barriers also publish lr)
+    const double S = part;
     int lg = 0;
     while ((1 << lg) < L) lg++;
     const bool exact = (emax < 255u) && ((int)emax + 2 + lg - ((int)emin - 23) <= 52);
-    __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         double s = S;
         double err = 0;
         if (!exact) {
@@ -1012,15 +1085,14 @@ __global__ __launch_bounds__(64) void k_fill(const void *in, uint32_t n, float i
         eci.dst[1] = 0;
         eci.dst[2] = eci.dur0;
     }
-    __syncthreads();
-    __threadfence_block();
-    prepare_batch(ring, L, carry, ver, nchunks);
+    __syncthreads();   // thread 0's carry->ss is read by prepare_batch's thread 0 only; the ring by everyone
+    prepare_batch(ring, L, carry, ver, nchunks, sum, red);
 }
 
 // After the passes converged: the ring at the end of the batch (look-back over all
 // chunks) and its sum become the carried state.
-__global__ __launch_bounds__(64) void k_finalize_state(ThrArgs A, float *ring_next, Carry *carry) {
-    finalize_state(A, ring_next, carry, (int)threadIdx.x);
+__global__ __launch_bounds__(FIN_BLOCK) void k_finalize_state(ThrArgs A, float *ring_next, Carry *carry) {
+    finalize_state(A, ring_next, carry, nullptr);
 }
 
 // ---------------------------------------------------------------------------
