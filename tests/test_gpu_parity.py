@@ -152,3 +152,14 @@ def test_synthetic_workloads_2M(name, kw):
         st.threshold_passes, st.chunks_rerun, st.n_chunks)
     print('%s: %d passes, %d/%d chunks rerun' % (name, st.threshold_passes, st.chunks_rerun, st.n_chunks))
     assert len(r['packets']) > 100
+
+
+@pytest.mark.parametrize('n', [2_000_001, 2_000_063, 2_000_064, 2_000_191, 1_999_999])
+def test_ragged_batch_end(n):
+    # a batch that does not end on a 256-sample step: its last step runs with the lanes past the end masked,
+    # on the certified fast path -- no chunk may need a second pass for it
+    iq = synth.workload('all', n)
+    r = check_vs_oracle(iq, dict(hi_val=1.1), kind=api.NFC_IN_IQ_F32)
+    st = r['stats']
+    assert st.used_sequential == 0
+    assert st.chunks_rerun == 0 and st.threshold_passes == 1, (st.threshold_passes, st.chunks_rerun)

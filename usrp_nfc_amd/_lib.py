@@ -62,7 +62,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.build()
+    path = os.environ.get('NFC_AMD_LIB') or _build.build()   # NFC_AMD_LIB: a variant build (kernel experiments)
     L = C.CDLL(path)
     vp, sz, psz = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)
     L.nfc_abi_version.restype = C.c_int

@@ -516,8 +516,8 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     };
     fetch(m_chunk, r1);
     fetch(m_chunk + STEPN, r2);
-    // Every step of a chunk is whole except the batch's last one and the stretch before the first stable
-    // sample (chunk lengths are multiples of the step): those rare partial steps take the exact row path.
+    // Every step of a chunk is whole except the batch's last one (masked, see `tail`) and the stretch before the
+    // first stable sample, which takes the exact row path (chunk lengths are multiples of the step).
     const float loLf = (float)A.lo_L, hiLf = (float)A.hi_L;   // thresholds in f32 carry 2^-18 of slack (>> 4 roundings)
     // The fast path never needs the exact sum: its classifications hold for every sum within the step's margin,
     // so it tracks the sum in f32 (ssf) and pays for the accumulated rounding with RND * ss of extra margin
@@ -536,7 +536,8 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     for (uint32_t base = m_chunk; base < n1; base += STEPN) {
         float x[NR], prev[NR];
         uint32_t slot[NR];
-        const bool full = (base >= m_start) && (base + STEPN <= n1);   // uniform
+        const bool full = (base >= m_start);                // uniform; false only inside the fill stretch of chunk 0
+        const bool tail = (base + STEPN > n1);              // uniform; the batch's last, ragged step
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             x[j] = env_of<KIND>(r1[j], A.i16_scale);
@@ -557,6 +558,21 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
                 slot[j] = s;
                 prev[j] = SIGN_T ? fabsf(ring[s]) : ring[s];
+            }
+        }
+        unsigned long long unt[NR];   // tail only: lanes past the end whose slot had not been touched
+        if (tail) {
+            // Lanes past the batch's end ride along as samples that cannot matter: each repeats the value its slot
+            // holds (no drift; if "accepted" the slot keeps its value), and the touched flag such a store sets
+            // is taken back after the step.
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const bool inact = base + 64u * j + lane >= n1;
+                bool untouched;
+                if constexpr (SIGN_T) untouched = (__float_as_uint(ring[slot[j]]) >> 31) != 0u;
+                else untouched = tch[slot[j]] == 0;
+                unt[j] = __ballot(inact && untouched);
+                if (inact) x[j] = prev[j];
             }
         }
         if (!ss0_valid && steps_since_sync >= 256) {
@@ -688,6 +704,24 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                         const unsigned long long nonlow = ~lowm[j];
                         step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
                         step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
+                    }
+                }
+                if (tail) {   // lanes past the end are not samples
+                    step_nl = LL_NONE;
+                    step_ll = LL_NONE;
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
+                        const int rb = (int)(base + 64u * j);
+                        const unsigned long long am = __ballot(base + 64u * j + lane < n1);
+                        lowm[j] &= am;
+                        posm[j] &= am;
+                        const unsigned long long nonlow = ~lowm[j] & am;
+                        step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
+                        step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
+                        if ((unt[j] >> lane) & 1ull) {
+                            if constexpr (SIGN_T) ring[slot[j]] = __uint_as_float(__float_as_uint(x[j]) | 0x80000000u);
+                            else tch[slot[j]] = 0;
+                        }
                     }
                 }
                 ssf += wave_sum_f32(dl);
