@@ -129,6 +129,9 @@ struct nfc_ctx {
         d_close_idx[2];
     DevBuf d_partials, d_partials2, d_aggs;  // scan scratch
     uint32_t cap_edges = 0, cap_sym[2] = {0, 0};   // capacity estimates of the edge / symbol buffers
+    uint64_t cap_edges_floor = 0, cap_sym_floor[2] = {0, 0};   // raised when an estimate proved too small for this batch
+    double edge_rate = 0.125;                      // entries per sample seen lately (peak-hold with slow decay)
+    double sym_rate[2] = {1.0, 2.0};               // symbols per entry, per type (start at the upper bounds)
     int pend_cur = 0;                               // which half of d_pending holds the open packets' bits
     std::vector<uint8_t> h_ver;
     std::vector<uint32_t> h_list;
@@ -731,11 +734,14 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     const EdgeCarry ecarry_in = c->h_ecarry;
     const uint64_t g0 = c->nseen;
     auto size_caps = [&]() {
-        // capacity estimates: the previous batch's counts with head-room (first batch: a guess)
-        if (!c->cap_edges) c->cap_edges = (uint32_t)std::min<uint64_t>((uint64_t)n / 8 + 65536, 0xFFFFFF00u);
+        // capacity estimates from the densities of the previous batches (batches of very different lengths alternate
+        // when a capture is sharded: a short overlap, then the shard), with head-room
+        const uint64_t ce = (uint64_t)((double)n * c->edge_rate * 1.25) + 65536;
+        c->cap_edges = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ce, c->cap_edges_floor), 0xFFFFFF00u);
         for (int t = 0; t < 2; t++) {
             const uint64_t ub = (t == 1 ? 2ull : 1ull) * c->cap_edges + 16;   // <= 2 (Miller) / 1 (Manchester) symbols per edge
-            if (!c->cap_sym[t] || c->cap_sym[t] > ub) c->cap_sym[t] = (uint32_t)std::min<uint64_t>(ub, 0xFFFFFF00u);
+            const uint64_t cs = (uint64_t)((double)c->cap_edges * c->sym_rate[t] * 1.1) + 65536;
+            c->cap_sym[t] = (uint32_t)std::min<uint64_t>(std::min(ub, std::max<uint64_t>(cs, c->cap_sym_floor[t])), 0xFFFFFF00u);
         }
     };
     bool ev3_done = false;
@@ -775,14 +781,17 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
             // a buffer was too small: the stages read carried values by value and wrote only write-only slots, so
             // they can simply run again with room for what was counted
             if (attempt >= 3) return fail(c, NFC_ERR_INTERNAL, "edge / symbol capacity did not settle");
-            c->cap_edges = (uint32_t)std::min<uint64_t>((uint64_t)std::max(ne, c->cap_edges) * 5 / 4 + 65536, 0xFFFFFF00u);
-            c->cap_sym[0] = (uint32_t)std::min<uint64_t>((uint64_t)ns[0] * 5 / 4 + 65536, 0xFFFFFF00u);
-            c->cap_sym[1] = (uint32_t)std::min<uint64_t>((uint64_t)ns[1] * 5 / 4 + 65536, 0xFFFFFF00u);
+            c->cap_edges_floor = (uint64_t)std::max(ne, c->cap_edges) * 5 / 4 + 65536;
+            c->cap_sym_floor[0] = (uint64_t)ns[0] * 5 / 4 + 65536;
+            c->cap_sym_floor[1] = (uint64_t)ns[1] * 5 / 4 + 65536;
         }
         // next batch's estimates
-        c->cap_edges = (uint32_t)std::min<uint64_t>((uint64_t)c->n_edges * 5 / 4 + 65536, 0xFFFFFF00u);
-        c->cap_sym[0] = (uint32_t)std::min<uint64_t>((uint64_t)c->n_sym[0] * 5 / 4 + 65536, 0xFFFFFF00u);
-        c->cap_sym[1] = (uint32_t)std::min<uint64_t>((uint64_t)c->n_sym[1] * 5 / 4 + 65536, 0xFFFFFF00u);
+        // densities for the next batch's estimates
+        c->cap_edges_floor = 0;
+        c->cap_sym_floor[0] = c->cap_sym_floor[1] = 0;
+        c->edge_rate = std::max({(double)c->n_edges / (double)n, c->edge_rate * 0.9, 1.0 / 64});
+        for (int t = 0; t < 2; t++)
+            if (c->n_edges) c->sym_rate[t] = std::max((double)c->n_sym[t] / (double)c->n_edges, c->sym_rate[t] * 0.9);
         c->pend_cur = 1 - c->pend_cur;
     } else {
         if (c->timing >= 2) {
