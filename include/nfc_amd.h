@@ -165,8 +165,19 @@ int nfc_get_state(nfc_ctx *ctx, nfc_state_header *hdr, float *ring, size_t ring_
                   size_t pending_cap);
 int nfc_set_state(nfc_ctx *ctx, const nfc_state_header *hdr, const float *ring, size_t ring_len,
                   const uint8_t *pending_bits, size_t pending_len);
+/* The same state written to DEVICE memory (16-byte aligned), asynchronously on the context's stream, for a
+ * boundary exchange that goes GPU to GPU (RCCL all-gather straight from this buffer):
+ *   [u32 len | 12 zero bytes | nfc_state_header | ring | pending bits]   len = bytes behind the 16-byte prefix.
+ * When 16 + len exceeds cap only the prefix is written (the reader sees len and can ask again with room).
+ * nfc_sync() before another stream or library reads the buffer. */
+int nfc_export_state(nfc_ctx *ctx, void *device_dst, size_t cap, size_t *len_out);
 /* Back to the state of a freshly created context (a new stream), keeping the device buffers. */
 int nfc_reset(nfc_ctx *ctx);
+/* Speculative start for a time shard that does not begin the stream (multi-GPU sharding): the
+ * window full of `level` (the unloaded-carrier estimate), its exact sum, idle state machines, decoders reset,
+ * n_seen = start_index.  Pushing an overlap that ends where the shard starts then converges to the true
+ * boundary state.  No host-side ring: the window is filled on the device. */
+int nfc_prime(nfc_ctx *ctx, uint64_t start_index, float level);
 
 int nfc_get_stats(nfc_ctx *ctx, nfc_stats *out);
 /* How much of nfc_stats' timing is collected.  Every HIP event recorded between two kernels costs the stream a

@@ -27,6 +27,10 @@ class OracleEngine(object):
         self.hi = hi_val
         self.reset()
 
+    @property
+    def av_window(self):
+        return self.ts.length
+
     def reset(self):
         self.sink = po.BitSink()
         self.router = po.Router(po.MillerDecoder(self.sink), po.ManchesterDecoder(self.sink))
@@ -175,3 +179,28 @@ def test_boundary_handoff_on_gpu():
         ctx.close()
     assert edges == o.transitions()
     assert packets == o.packets()
+
+
+@pytest.mark.gpu
+def test_export_state_matches_state_blob():
+    # the device-resident form of the boundary state (what goes into the RCCL all-gather) is byte for byte the
+    # host blob, behind a 16-byte length prefix; a slot that is too small gets the prefix only
+    from usrp_nfc_amd import api
+    _, iq = capture(1)
+    ctx = api.NfcContext(hi_val=1.1)
+    ctx.push(iq[:2 * 30011])          # ends inside a frame: pending packet bits are part of the state
+    blob = ctx.state_blob()
+    cap = sharding.slot_bytes(ctx.av_window)
+    buf = api.DeviceBuffer(np.zeros(cap, np.uint8), 0)
+    n = ctx.export_state(buf.ptr.value, cap)
+    ctx.sync()
+    assert n == blob.size
+    got = buf.download(cap)
+    assert int(got[:4].view('<u4')[0]) == blob.size and not got[4:16].any()
+    assert np.array_equal(got[16:16 + n], blob)
+    small = api.DeviceBuffer(np.full(64, 255, np.uint8), 0)
+    assert ctx.export_state(small.ptr.value, 64) == blob.size
+    ctx.sync()
+    got = small.download(64)
+    assert int(got[:4].view('<u4')[0]) == blob.size and (got[16:] == 255).all()
+    ctx.close()

@@ -47,7 +47,7 @@ PACKET_DTYPE = np.dtype([('idx', '<u8'), ('bit_off', '<u8'), ('n_bits', '<u4'), 
 # every symbol include/nfc_amd.h declares
 SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', 'nfc_last_error', 'nfc_push',
            'nfc_push_device', 'nfc_sync', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_symbols', 'nfc_read_packets',
-           'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_get_stats', 'nfc_set_timing',
+           'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_prime', 'nfc_export_state', 'nfc_get_stats', 'nfc_set_timing',
            'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_host_decode_lut']
 
 _lib = None
@@ -84,6 +84,9 @@ def load():
     L.nfc_get_state.argtypes = [vp, C.POINTER(StateHeader), vp, sz, vp, sz]
     L.nfc_set_state.argtypes = [vp, C.POINTER(StateHeader), vp, sz, vp, sz]
     L.nfc_reset.argtypes = [vp]
+    L.nfc_export_state.argtypes = [vp, vp, sz, psz]
+    L.nfc_sync.argtypes = [vp]
+    L.nfc_prime.argtypes = [vp, C.c_uint64, C.c_float]
     L.nfc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.nfc_set_timing.argtypes = [vp, C.c_int]
     L.nfc_device_alloc.argtypes = [C.c_int, sz, C.POINTER(vp)]

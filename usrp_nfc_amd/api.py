@@ -168,6 +168,15 @@ class NfcContext(object):
         h, ring, pend = self.get_state()
         return np.concatenate([np.frombuffer(bytes(h), np.uint8), ring.view(np.uint8), pend[0], pend[1]])
 
+    def export_state(self, dev_ptr, cap):
+        """Boundary state into device memory (16-byte aligned), asynchronously: [u32 len | 12 B | state_blob() bytes]."""
+        got = C.c_size_t(0)
+        self._chk(self.L.nfc_export_state(self.h, C.c_void_p(int(dev_ptr)), int(cap), C.byref(got)), 'nfc_export_state')
+        return got.value
+
+    def sync(self):
+        self._chk(self.L.nfc_sync(self.h), 'nfc_sync')
+
     def set_state_blob(self, blob):
         blob = np.ascontiguousarray(blob, np.uint8)
         hs = C.sizeof(_lib.StateHeader)
@@ -182,19 +191,8 @@ class NfcContext(object):
         """Speculative start for a time chunk that does not begin the stream: every ring slot at the
         estimated carrier level, idle state machine, decoders reset.  Pushing an overlap region that ends
         where the chunk starts then converges to the true boundary state (multi-GPU)."""
-        h = _lib.StateHeader()
-        L = self.av_window
-        ring = np.full(L, np.float32(level), np.float32)
-        h.n_seen = int(start_index)
-        h.ss = float(np.sum(ring.astype(np.float64)))
-        h.last_low = -1
-        h.filled = L
-        h.stable = 1
-        h.cur_state, h.last_bit, h.dur = 0, 0, 1
-        h.miller_state = 0
-        h.manch_state = 2
-        h.av_window = L
-        self.set_state(h, ring)
+        self._chk(self.L.nfc_prime(self.h, int(start_index), float(np.float32(level))), 'nfc_prime')
+
 
 class DeviceBuffer(object):
     """Input kept resident in HBM (nfc_device_alloc / nfc_device_upload) for NfcContext.push_device."""
@@ -209,6 +207,14 @@ class DeviceBuffer(object):
             raise NfcError('nfc_device_alloc: %s' % self.L.nfc_last_error(None).decode())
         if a.nbytes and self.L.nfc_device_upload(device, self.ptr, a.ctypes.data, a.nbytes) != 0:
             raise NfcError('nfc_device_upload failed')
+
+    def download(self, nbytes=None):
+        """The buffer's first nbytes (default: all) as a uint8 array (nfc_device_download)."""
+        n = self.nbytes if nbytes is None else int(nbytes)
+        out = np.zeros(n, np.uint8)
+        if n and self.L.nfc_device_download(self.device, out.ctypes.data, self.ptr, n) != 0:
+            raise NfcError('nfc_device_download failed')
+        return out
 
     def free(self):
         if getattr(self, 'ptr', None):

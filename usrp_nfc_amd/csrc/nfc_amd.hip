@@ -113,6 +113,8 @@ struct nfc_ctx {
     // carried state
     DevBuf d_state, d_ring[2];
     DevState *hs = nullptr;        // pinned host mirror of d_state
+    uint8_t *h_stage = nullptr;    // pinned staging for nfc_get_state
+    size_t h_stage_cap = 0;
     uint8_t *h_cflags = nullptr;   // pinned mirror of the per-chunk flag sections
     size_t h_cflags_cap = 0;
     int ring_cur = 0;
@@ -128,6 +130,7 @@ struct nfc_ctx {
     DevBuf d_starts, d_offs, d_edges, d_states, d_sym[2], d_src[2], d_started, d_bits[2], d_pending[2][2], d_close_end[2],
         d_close_idx[2];
     DevBuf d_partials, d_partials2, d_aggs;  // scan scratch
+    DevBuf d_pack;                           // nfc_get_state staging
     uint32_t cap_edges = 0, cap_sym[2] = {0, 0};   // capacity estimates of the edge / symbol buffers
     uint64_t cap_edges_floor = 0, cap_sym_floor[2] = {0, 0};   // raised when an estimate proved too small for this batch
     double edge_rate = 0.125;                      // entries per sample seen lately (peak-hold with slow decay)
@@ -177,9 +180,9 @@ inline void adopt_mirror(nfc_ctx *c) {
     c->h_dcarry = c->hs->dcarry;
 }
 // carried state set from the host without a copy engine round trip: the values travel as kernel arguments
-__global__ void k_set_state(DevState *d, Carry a, EdgeCarry b, DecCarry e, int zero_totals, float *zero_ring, int ring_len) {
-    if (zero_ring)
-        for (int i = threadIdx.x; i < ring_len; i += blockDim.x) zero_ring[i] = 0.f;
+__global__ void k_set_state(DevState *d, Carry a, EdgeCarry b, DecCarry e, int zero_totals, float *fill_ring, int ring_len, float fill) {
+    if (fill_ring)
+        for (int i = threadIdx.x; i < ring_len; i += blockDim.x) fill_ring[i] = fill;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     d->carry = a;
     d->ecarry = b;
@@ -187,9 +190,19 @@ __global__ void k_set_state(DevState *d, Carry a, EdgeCarry b, DecCarry e, int z
     if (zero_totals)
         for (int i = 0; i < TOT_BYTES; i++) d->totals[i] = 0;
 }
-inline void push_state(nfc_ctx *c, int zero_totals = 0, bool zero_ring = false) {
+inline void push_state(nfc_ctx *c, int zero_totals = 0, bool fill_ring = false, float fill = 0.f) {
     hipLaunchKernelGGL(k_set_state, dim3(1), dim3(256), 0, c->st, (DevState *)c->d_state.p, c->h_carry, c->h_ecarry, c->h_dcarry,
-                       zero_totals, zero_ring ? c->d_ring[c->ring_cur].as<float>() : (float *)nullptr, c->Lpad);
+                       zero_totals, fill_ring ? c->d_ring[c->ring_cur].as<float>() : (float *)nullptr, fill_ring && fill != 0.f ? c->L : c->Lpad,
+                       fill);
+}
+// ring | pending bits (type 0, type 1) as one contiguous byte vector (nfc_get_state)
+__global__ void k_pack_state(uint8_t *dst, const float *ring, int L, const uint8_t *p0, uint32_t n0, const uint8_t *p1, uint32_t n1) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    float *rd = (float *)dst;
+    for (uint32_t i = tid; i < (uint32_t)L; i += nth) rd[i] = ring[i];
+    uint8_t *pd = dst + (size_t)L * 4;
+    for (uint32_t i = tid; i < n0; i += nth) pd[i] = p0[i];
+    for (uint32_t i = tid; i < n1; i += nth) pd[n0 + i] = p1[i];
 }
 __global__ void k_set_ecarry(DevState *d, EdgeCarry b) {
     if (threadIdx.x == 0 && blockIdx.x == 0) d->ecarry = b;
@@ -305,6 +318,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
     HIPCHK(c, c->d_cflags.ensure((size_t)4 * nch));   // sections: cert | gflags | gmin | gmax
     if (c->h_cflags_cap < (size_t)4 * nch) {
         if (c->h_cflags) (void)hipHostFree(c->h_cflags);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
         c->h_cflags_cap = (size_t)4 * nch + 4096;
         HIPCHK(c, hipHostMalloc((void **)&c->h_cflags, c->h_cflags_cap, hipHostMallocDefault));
     }
@@ -895,7 +909,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     c->factor = 1e6 / p->samp_rate;
     c->Lpad = (c->L + 15) & ~15;
     c->twords = (c->L + 31) / 32;
-    int C = p->chunk_samples > 0 ? p->chunk_samples : 16384;
+    int C = p->chunk_samples > 0 ? p->chunk_samples : 4096;   // smallest chunk of the adaptive rule (run_threshold)
     C = std::max(C, 2 * c->L);
     C = std::max(C, c->mx + 2);
     c->rows_per_step = 4;
@@ -1030,7 +1044,7 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs};
+                     &c->d_partials, &c->d_aggs, &c->d_pack};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_cflags) (void)hipHostFree(c->h_cflags);
@@ -1173,9 +1187,20 @@ int nfc_reset(nfc_ctx *c) {
     return NFC_OK;
 }
 
-int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap, uint8_t *pending, size_t pending_cap) {
-    if (!c || !h) return NFC_ERR_ARG;
-    HIPCHK(c, hipStreamSynchronize(c->st));
+int nfc_prime(nfc_ctx *c, uint64_t start_index, float level) {
+    if (!c || !(level >= 0.f) || !std::isfinite(level)) return NFC_ERR_ARG;
+    if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
+    init_carried(c);
+    c->nseen = start_index;
+    c->h_carry.filled = c->L;
+    c->h_carry.stable = 1;
+    c->h_carry.ss = (double)level * (double)c->L;   // L equal addends: exact in any order (24 + 12 bits)
+    c->have_outputs = false;
+    push_state(c, 0, true, level);                  // the window itself is filled on the device
+    return NFC_OK;
+}
+
+static void fill_state_header(const nfc_ctx *c, nfc_state_header *h) {
     memset(h, 0, sizeof *h);
     h->n_seen = c->nseen;
     h->ss = c->h_carry.ss;
@@ -1192,16 +1217,66 @@ int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap,
         h->n_pending_bits[t] = c->h_dcarry.pending[t];
     }
     h->av_window = c->L;
-    if (ring) {
-        if (ring_cap < (size_t)c->L) return fail(c, NFC_ERR_ARG, "ring buffer too small");
-        HIPCHK(c, hipMemcpy(ring, c->d_ring[c->ring_cur].p, (size_t)c->L * 4, hipMemcpyDeviceToHost));
+}
+
+// [u32 length of what follows | 12 bytes zero | nfc_state_header | ring | pending bits]: the boundary state in device
+// memory, byte for byte what nfc_get_state returns, for an exchange that goes GPU to GPU (RCCL all-gather)
+__global__ void k_export_state(uint8_t *dst, uint32_t len, int fits, nfc_state_header h, const float *ring, int L, const uint8_t *p0,
+                               uint32_t n0, const uint8_t *p1, uint32_t n1) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (tid < 4) ((uint32_t *)dst)[tid] = tid == 0 ? len : 0u;
+    if (!fits) return;
+    uint8_t *b = dst + 16;
+    if (tid < sizeof(nfc_state_header)) b[tid] = ((const uint8_t *)&h)[tid];
+    float *rd = (float *)(b + sizeof(nfc_state_header));
+    for (uint32_t i = tid; i < (uint32_t)L; i += nth) rd[i] = ring[i];
+    uint8_t *pd = b + sizeof(nfc_state_header) + (size_t)L * 4;
+    for (uint32_t i = tid; i < n0; i += nth) pd[i] = p0[i];
+    for (uint32_t i = tid; i < n1; i += nth) pd[n0 + i] = p1[i];
+}
+
+int nfc_export_state(nfc_ctx *c, void *device_dst, size_t cap, size_t *len_out) {
+    if (!c || !device_dst || cap < 16 || ((uintptr_t)device_dst & 15u)) return NFC_ERR_ARG;
+    if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
+    nfc_state_header h;
+    fill_state_header(c, &h);   // the carried values are host-mirrored after every push: no wait needed here
+    const size_t p0 = h.n_pending_bits[0], p1 = h.n_pending_bits[1];
+    const size_t len = sizeof h + (size_t)c->L * 4 + p0 + p1;
+    static_assert(sizeof(nfc_state_header) % 4 == 0, "ring must stay 4-byte aligned behind the header");
+    hipLaunchKernelGGL(k_export_state, dim3(4), dim3(256), 0, c->st, (uint8_t *)device_dst, (uint32_t)len, (int)(16 + len <= cap), h,
+                       c->d_ring[c->ring_cur].as<float>(), c->L, c->d_pending[0][c->pend_cur].as<uint8_t>(), (uint32_t)p0,
+                       c->d_pending[1][c->pend_cur].as<uint8_t>(), (uint32_t)p1);
+    if (len_out) *len_out = len;
+    return NFC_OK;
+}
+
+int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap, uint8_t *pending, size_t pending_cap) {
+    if (!c || !h) return NFC_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    fill_state_header(c, h);
+    const size_t p0 = c->h_dcarry.pending[0], p1 = c->h_dcarry.pending[1];
+    if (ring && ring_cap < (size_t)c->L) return fail(c, NFC_ERR_ARG, "ring buffer too small");
+    if (pending && pending_cap < p0 + p1) return fail(c, NFC_ERR_ARG, "pending-bit buffer too small");
+    // through a pinned staging buffer: asynchronous copies and a single wait
+    const size_t need = (size_t)c->L * 4 + p0 + p1;
+    if (c->h_stage_cap < need) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        c->h_stage_cap = need + 4096;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_stage, c->h_stage_cap, hipHostMallocDefault));
     }
-    if (pending) {
-        const size_t p0 = c->h_dcarry.pending[0], p1 = c->h_dcarry.pending[1];
-        if (pending_cap < p0 + p1) return fail(c, NFC_ERR_ARG, "pending-bit buffer too small");
-        if (p0) HIPCHK(c, hipMemcpy(pending, c->d_pending[0][c->pend_cur].p, p0, hipMemcpyDeviceToHost));
-        if (p1) HIPCHK(c, hipMemcpy(pending + p0, c->d_pending[1][c->pend_cur].p, p1, hipMemcpyDeviceToHost));
+    uint8_t *st = c->h_stage;
+    if (ring || (pending && p0 + p1)) {
+        // gathered on the device (ring | pending bits of type 0 | of type 1), then one copy and one wait
+        HIPCHK(c, c->d_pack.ensure(need + 16));
+        hipLaunchKernelGGL(k_pack_state, dim3(4), dim3(256), 0, c->st, c->d_pack.as<uint8_t>(), c->d_ring[c->ring_cur].as<float>(), c->L,
+                           c->d_pending[0][c->pend_cur].as<uint8_t>(), (uint32_t)p0, c->d_pending[1][c->pend_cur].as<uint8_t>(),
+                           (uint32_t)p1);
+        HIPCHK(c, hipMemcpyAsync(st, c->d_pack.p, need, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
     }
+    if (ring) memcpy(ring, st, (size_t)c->L * 4);
+    if (pending && p0 + p1) memcpy(pending, st + (size_t)c->L * 4, p0 + p1);
     return NFC_OK;
 }
 

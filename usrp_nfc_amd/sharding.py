@@ -10,9 +10,10 @@ states, bits of a packet that straddles the boundary).  Protocol:
    samples, the edge / decoder / framing machines re-synchronise at the next frame gap, so at the
    chunk boundary the state is -- almost always -- exactly the true one;
 2. decode the own chunk from that state;
-3. exchange: all-gather of every rank's END state (about 8.2 KB: header + ring + pending packet bits;
-   RCCL over xGMI on a GPU node, gloo in the CPU tests);
-4. verify: rank r compares its speculated start state with rank r-1's true end state, bit for bit.
+3. exchange: ONE all-gather per round of every rank's (speculated START state, true END state) pair
+   (about 8.2 KB each: header + ring + pending packet bits; RCCL over xGMI on a GPU node, gloo in the
+   CPU tests), so that every rank can evaluate every comparison itself -- no second collective;
+4. verify: rank r's speculated start state must equal rank r-1's true end state, bit for bit.
    By induction from rank 0 (whose start is the stream start) all chunks are exact when every
    comparison holds.  Otherwise the first mismatching rank re-decodes its chunk from the true state and
    the exchange repeats (at most world-1 extra rounds).
@@ -33,36 +34,74 @@ def carrier_level(env_head):
     return float(sel.mean() if len(sel) else ca)
 
 
-class LocalComm(object):
-    """Single-process stand-in (world size 1)."""
-    world, rank = 1, 0
+_EMPTY = np.zeros(0, np.uint8)
+PREFIX = 16          # [u32 length | 12 zero bytes] in front of every state in an exchange slot (nfc_export_state)
+PENDING_ROOM = 65536  # bytes of open-packet bits a slot has room for
 
-    def all_gather(self, blob):
-        return [np.asarray(blob, np.uint8)]
+
+def slot_bytes(av_window, header_bytes=96):
+    n = PREFIX + header_bytes + 4 * int(av_window) + PENDING_ROOM
+    return (n + 15) // 16 * 16
+
+
+class LocalComm(object):
+    """Single-process stand-in (world size 1): nothing is ever exchanged."""
+    world, rank = 1, 0
+    device_slots = False
 
 
 class TorchDistComm(object):
-    """all_gather of byte blobs over torch.distributed (backend nccl == RCCL on ROCm, or gloo)."""
+    """The boundary exchange over torch.distributed (backend nccl == RCCL over xGMI on a GPU node, gloo in the
+    CPU tests): ONE all_gather per round of a two-slot frame (speculated start state | true end state), through
+    buffers allocated once.  On a GPU the engine writes its states straight into the send buffer in device
+    memory (nfc_export_state), so a state travels GPU -> GPU and reaches the host once, gathered."""
 
     def __init__(self, dist, device):
+        import torch
         self.dist = dist
         self.device = device
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        self.device_slots = device.type != 'cpu'
+        self._torch = torch
+        self.half = 0
 
-    def all_gather(self, blob):
-        import torch
-        blob = np.array(blob, np.uint8, copy=True)
-        ln = torch.tensor([blob.size], dtype=torch.int64, device=self.device)
-        lens = [torch.zeros_like(ln) for _ in range(self.world)]
-        self.dist.all_gather(lens, ln)
-        cap = max(int(x.item()) for x in lens)
-        buf = torch.zeros(max(cap, 1), dtype=torch.uint8, device=self.device)
-        if blob.size:
-            buf[:blob.size] = torch.from_numpy(blob).to(self.device)
-        out = [torch.zeros_like(buf) for _ in range(self.world)]
-        self.dist.all_gather(out, buf)
-        return [o[:int(l.item())].cpu().numpy() for o, l in zip(out, lens)]
+    def bind(self, av_window):
+        half = slot_bytes(av_window)
+        if half == self.half:
+            return
+        torch = self._torch
+        self.half = half
+        self._send = torch.zeros(2 * half, dtype=torch.uint8, device=self.device)
+        self._recv = torch.zeros(self.world * 2 * half, dtype=torch.uint8, device=self.device)
+        self._recv_parts = list(self._recv.chunk(self.world))
+
+    def slot_ptr(self, slot):
+        return self._send.data_ptr() + slot * self.half
+
+    def put(self, slot, blob):
+        """Host path (CPU engines, gloo): frame a state into a slot of the send buffer."""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        frame = np.zeros(self.half, np.uint8)
+        frame[:4] = np.array([blob.size], '<u4').view(np.uint8)
+        if PREFIX + blob.size <= self.half:
+            frame[PREFIX:PREFIX + blob.size] = blob
+        self._send[slot * self.half:(slot + 1) * self.half] = self._torch.from_numpy(frame).to(self.device)
+
+    def exchange(self):
+        """All ranks' (speculated start state, true end state) as byte vectors, in rank order."""
+        self.dist.all_gather(self._recv_parts, self._send)
+        got = self._recv.cpu().numpy().reshape(self.world, 2, self.half)
+        pairs = []
+        for r in range(self.world):
+            pair = []
+            for slot in range(2):
+                ln = int(got[r, slot, :4].view('<u4')[0])
+                if PREFIX + ln > self.half:   # every rank sees this and fails alike (no rank is left waiting)
+                    raise RuntimeError('rank %d: boundary state of %d bytes exceeds the %d-byte exchange slot' % (r, ln, self.half))
+                pair.append(got[r, slot, PREFIX:PREFIX + ln].copy())
+            pairs.append(tuple(pair))
+        return pairs
 
 
 def decode_shard(engine, comm, push_overlap, push_own, start_index, level):
@@ -74,28 +113,45 @@ def decode_shard(engine, comm, push_overlap, push_own, start_index, level):
     Returns the number of re-decodes this rank had to do.
     """
     rank, world = comm.rank, comm.world
+    on_device = world > 1 and comm.device_slots and hasattr(engine, 'export_state')
+    if world > 1:
+        comm.bind(engine.av_window)
+
+    def capture(slot):   # the engine's current state into an exchange slot
+        if world == 1:
+            return
+        if on_device:
+            engine.export_state(comm.slot_ptr(slot), comm.half)   # GPU -> the device send buffer, asynchronously
+        else:
+            comm.put(slot, engine.state_blob())
+
     if rank == 0:
         engine.reset()
-        spec = None
+        if world > 1 and not on_device:
+            comm.put(0, _EMPTY)   # (a device send buffer starts zeroed and rank 0 never writes its slot 0)
     else:
         engine.prime(start_index, level)
         push_overlap()
-        spec = engine.state_blob()
+        capture(0)
     push_own()
     redos = 0
     if world == 1:
         return redos
     for _ in range(world):
-        ends = comm.all_gather(engine.state_blob())
-        ok = rank == 0 or (spec.size == ends[rank - 1].size and np.array_equal(spec, ends[rank - 1]))
-        flags = comm.all_gather(np.array([1 if ok else 0], np.uint8))
-        bad = [r for r, f in enumerate(flags) if not int(f[0])]
+        # one collective per round: every rank sees every (speculated start, true end) pair and therefore
+        # reaches the same verdict without a second exchange
+        capture(1)
+        if on_device:
+            engine.sync()
+        pairs = comm.exchange()
+        bad = [r for r in range(1, world)
+               if not (pairs[r][0].size == pairs[r - 1][1].size and np.array_equal(pairs[r][0], pairs[r - 1][1]))]
         if not bad:
             break
         if rank == bad[0]:
             # this rank's predecessors are exact, so its predecessor's end state is the truth
-            spec = ends[rank - 1].copy()
-            engine.set_state_blob(spec)
+            engine.set_state_blob(pairs[rank - 1][1].copy())
+            capture(0)
             push_own()
             redos += 1
     return redos
