@@ -90,7 +90,8 @@ def main():
     n = int(a.samples)
     dist = None
     backend = os.environ.get('NFC_BENCH_BACKEND', 'nccl')   # 'gloo': plumbing test of the N>1 path on one GPU
-    if world > 1:
+    force_x = bool(os.environ.get('NFC_BENCH_FORCE_EXCHANGE')) and 'MASTER_ADDR' in os.environ   # 1-rank smoke of the RCCL path
+    if world > 1 or force_x:
         import torch
         import torch.distributed as dist
         ndev = max(1, torch.cuda.device_count())
@@ -127,7 +128,8 @@ def main():
     def one_step():
         nonlocal redo_count
         redo_count += sharding.decode_shard(ctx, comm, lambda: ctx.push_device(d_ov, len(ov) // 2),
-                                            lambda: ctx.push_device(d_own, n), g_lo - len(ov) // 2, level)
+                                            lambda: ctx.push_device(d_own, n), g_lo - len(ov) // 2, level,
+                                            force_exchange=bool(os.environ.get('NFC_BENCH_FORCE_EXCHANGE')))
         return ctx.stats()
 
     for _ in range(a.warmup):

@@ -27,6 +27,8 @@ class OracleEngine(object):
         self.hi = hi_val
         self.reset()
 
+    state_bytes = 65536   # room for the pickled state below in an exchange slot
+
     @property
     def av_window(self):
         return self.ts.length

@@ -877,10 +877,31 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
     __shared__ uint32_t s_mn[FIN_BLOCK / 64], s_mx[FIN_BLOCK / 64], s_fl[FIN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double part = 0;
-    for (int s = tid; s < A.L; s += FIN_BLOCK) {
-        const float v = resolve_slot(A, A.nchunks, s);
-        ring_next[s] = v;
-        part += (double)v;
+    // a thread's slots in rounds of eight: the common case (the last chunk accepted a sample into the slot) is two
+    // loads per slot, all sixteen in flight at once; only slots it left untouched walk further back
+    const int last = A.nchunks - 1;
+    const int vb = A.ver[last];
+    const uint32_t *tw = A.touched[vb] + (size_t)last * A.twords;
+    const float *ro = A.ring_out[vb] + (size_t)last * A.L;
+    for (int s0 = tid; s0 < A.L; s0 += 8 * FIN_BLOCK) {
+        uint32_t w[8];
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int s = s0 + k * FIN_BLOCK;
+            const bool in = s < A.L;
+            w[k] = in ? tw[s >> 5] : 0u;
+            v[k] = in ? ro[s] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int s = s0 + k * FIN_BLOCK;
+            if (s < A.L) {
+                if (!((w[k] >> (s & 31)) & 1u)) v[k] = resolve_slot(A, last, s);   // look further back
+                ring_next[s] = v[k];
+                part += (double)v[k];
+            }
+        }
     }
     uint32_t mn = 255u, mx = 0u, fl = 0u;
     if (sum)

@@ -36,7 +36,7 @@ def carrier_level(env_head):
 
 _EMPTY = np.zeros(0, np.uint8)
 PREFIX = 16          # [u32 length | 12 zero bytes] in front of every state in an exchange slot (nfc_export_state)
-PENDING_ROOM = 65536  # bytes of open-packet bits a slot has room for
+PENDING_ROOM = 4096  # bytes of open-packet bits a slot has room for (a frame is a few hundred bits)
 
 
 def slot_bytes(av_window, header_bytes=96):
@@ -66,8 +66,8 @@ class TorchDistComm(object):
         self._torch = torch
         self.half = 0
 
-    def bind(self, av_window):
-        half = slot_bytes(av_window)
+    def bind(self, av_window, state_bytes=None):
+        half = slot_bytes(av_window) if state_bytes is None else (PREFIX + int(state_bytes) + 15) // 16 * 16
         if half == self.half:
             return
         torch = self._torch
@@ -75,6 +75,9 @@ class TorchDistComm(object):
         self._send = torch.zeros(2 * half, dtype=torch.uint8, device=self.device)
         self._recv = torch.zeros(self.world * 2 * half, dtype=torch.uint8, device=self.device)
         self._recv_parts = list(self._recv.chunk(self.world))
+        self._recv_host = torch.zeros(self.world * 2 * half, dtype=torch.uint8)
+        if self.device_slots:
+            self._recv_host = self._recv_host.pin_memory()
 
     def slot_ptr(self, slot):
         return self._send.data_ptr() + slot * self.half
@@ -91,7 +94,12 @@ class TorchDistComm(object):
     def exchange(self):
         """All ranks' (speculated start state, true end state) as byte vectors, in rank order."""
         self.dist.all_gather(self._recv_parts, self._send)
-        got = self._recv.cpu().numpy().reshape(self.world, 2, self.half)
+        if self.device_slots:
+            self._recv_host.copy_(self._recv, non_blocking=True)   # one pinned copy of the gathered frames
+            self._torch.cuda.current_stream().synchronize()
+            got = self._recv_host.numpy().reshape(self.world, 2, self.half)
+        else:
+            got = self._recv.numpy().reshape(self.world, 2, self.half)
         pairs = []
         for r in range(self.world):
             pair = []
@@ -104,21 +112,23 @@ class TorchDistComm(object):
         return pairs
 
 
-def decode_shard(engine, comm, push_overlap, push_own, start_index, level):
+def decode_shard(engine, comm, push_overlap, push_own, start_index, level, force_exchange=False):
     """Run the protocol for this rank.
 
     engine: reset(), prime(start_index, level), state_blob(), set_state_blob(blob)
     push_overlap(): feeds the overlap samples (rank > 0) -- outputs are discarded
     push_own():     feeds the rank's own chunk; the engine then holds that chunk's outputs
+    force_exchange: run the exchange even with a single rank (exercises the collective path on one GPU).
     Returns the number of re-decodes this rank had to do.
     """
     rank, world = comm.rank, comm.world
-    on_device = world > 1 and comm.device_slots and hasattr(engine, 'export_state')
-    if world > 1:
-        comm.bind(engine.av_window)
+    exchanging = world > 1 or (force_exchange and hasattr(comm, 'exchange'))
+    on_device = exchanging and comm.device_slots and hasattr(engine, 'export_state')
+    if exchanging:
+        comm.bind(engine.av_window, getattr(engine, 'state_bytes', None))   # state_bytes: an engine with its own blob format
 
     def capture(slot):   # the engine's current state into an exchange slot
-        if world == 1:
+        if not exchanging:
             return
         if on_device:
             engine.export_state(comm.slot_ptr(slot), comm.half)   # GPU -> the device send buffer, asynchronously
@@ -127,7 +137,7 @@ def decode_shard(engine, comm, push_overlap, push_own, start_index, level):
 
     if rank == 0:
         engine.reset()
-        if world > 1 and not on_device:
+        if exchanging and not on_device:
             comm.put(0, _EMPTY)   # (a device send buffer starts zeroed and rank 0 never writes its slot 0)
     else:
         engine.prime(start_index, level)
@@ -135,7 +145,7 @@ def decode_shard(engine, comm, push_overlap, push_own, start_index, level):
         capture(0)
     push_own()
     redos = 0
-    if world == 1:
+    if not exchanging:
         return redos
     for _ in range(world):
         # one collective per round: every rank sees every (speculated start, true end) pair and therefore
