@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 from usrp_nfc_amd import api, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-OVERLAP = 65536         # samples of the predecessor's chunk each rank > 0 also holds (>= window + longest frames)
+OVERLAP = 8192          # samples of the predecessor's chunk each rank > 0 also holds: the 2000-sample window plus twice the longest
+                        # ISO 14443A frame at 2 Msps (163 bits ~ 3.1 k samples); a wrong guess costs a re-decode, never exactness
 
 
 def parse():

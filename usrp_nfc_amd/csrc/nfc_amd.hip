@@ -25,6 +25,7 @@
 #include "decoder_tables.h"
 #include "edges.hip.h"
 #include "scan.hip.h"
+#include "small.hip.h"
 #include "threshold.hip.h"
 #include "threshold_rr.hip.h"
 
@@ -95,6 +96,7 @@ struct nfc_ctx {
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, use_rr, rows_per_step, C_min, wave_slots, lds_per_slot;
+    int use_small = 1;   // short batches take the one-launch edge / decode / framing kernel (NFC_NO_SMALL=1 turns it off)
     uint64_t selmask;
     float eps;
     float i16_scale;
@@ -695,6 +697,77 @@ int run_decode(nfc_ctx *c) {
     return NFC_OK;   // totals and carries are mirrored by the caller's final copy
 }
 
+// ---------------------------------------------------------------------------
+// short batches: edges, decoders and framing in one launch (small.hip.h)
+// ---------------------------------------------------------------------------
+int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
+    uint8_t *tot = dT(c);
+    SmallArgs A;
+    memset(&A, 0, sizeof A);
+    A.E.neg = c->d_neg.as<uint64_t>();
+    A.E.pos = c->d_pos.as<uint64_t>();
+    A.E.n = n;
+    A.E.skip = skip;
+    A.E.mx = c->mx;
+    A.E.dur_in = c->h_ecarry.dur;
+    A.E.last_bit_in = c->h_ecarry.last_bit;
+    A.E.state_in = c->h_ecarry.state;
+    A.E.nd = c->mx + 1;
+    A.E.g0 = g0;
+    A.E.mx_magic = c->mx > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c->mx) : 0xFFFFFFFFu;
+    for (int b = 0; b < 64; b += c->mx) A.E.per_mask |= 1ull << b;
+    A.nwords = ((size_t)n + 63) / 64;
+    const uint32_t ce = c->cap_edges;
+    const uint32_t cs[2] = {c->cap_sym[0], c->cap_sym[1]};
+    HIPCHK(c, c->d_edges.ensure(((size_t)ce + 1) * sizeof(nfc_edge)));
+    HIPCHK(c, c->d_ecode.ensure(((size_t)ce + 8) * 2));
+    for (int t = 0; t < 2; t++) {
+        HIPCHK(c, c->d_sym[t].ensure((size_t)cs[t] + 16));
+        HIPCHK(c, c->d_src[t].ensure(((size_t)cs[t] + 16) * 4));
+    }
+    A.edges = c->d_edges.as<nfc_edge>();
+    A.ecode = c->d_ecode.as<uint16_t>();
+    A.cap_edges = ce;
+    A.T = c->T;
+    A.dec_state_in = (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4);
+    A.S = SymOut{{c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()}, {c->d_src[0].as<uint32_t>(), c->d_src[1].as<uint32_t>()}, {cs[0], cs[1]}};
+    const int pn = 1 - c->pend_cur;
+    for (int t = 0; t < 2; t++) {
+        SmallFraming &F = A.F[t];
+        F.enabled = (t == 0 ? c->T.tag : c->T.reader) ? 1 : 0;
+        if (!F.enabled) continue;
+        const uint32_t pend = c->h_dcarry.pending[t];
+        HIPCHK(c, c->d_bits[t].ensure((size_t)pend + cs[t] + 16));
+        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend + cs[t] + 16));
+        HIPCHK(c, c->d_close_end[t].ensure(((size_t)cs[t] + 4) * 4));
+        HIPCHK(c, c->d_close_idx[t].ensure(((size_t)cs[t] + 4) * 8));
+        if (pend) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t][c->pend_cur].p, pend, hipMemcpyDeviceToDevice, c->st));
+        F.start_bit = (t == 0) ? 1 : 0;   // packets.py:24-28
+        F.type = t;
+        F.started_in = (uint32_t)c->h_dcarry.pkt_started[t];
+        F.pend = pend;
+        F.cap_sym = cs[t];
+        F.sym = c->d_sym[t].as<uint8_t>();
+        F.src = c->d_src[t].as<uint32_t>();
+        F.bits = c->d_bits[t].as<uint8_t>();
+        F.pending_next = c->d_pending[t][pn].as<uint8_t>();
+        F.close_end = c->d_close_end[t].as<uint32_t>();
+        F.close_idx = c->d_close_idx[t].as<uint64_t>();
+        F.pending_cap = (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu);
+        F.maptot = (uint32_t *)(tot + (t ? TOT_PKTMAP1 : TOT_PKTMAP0));
+        F.pktot = (uint64_t *)(tot + (t ? TOT_PKT1 : TOT_PKT0));
+    }
+    A.tot_last2 = (Last2 *)(tot + TOT_LAST2);
+    A.tot_edges = (uint32_t *)(tot + TOT_EDGES);
+    A.tot_decmap = (DecMaps *)(tot + TOT_DECMAP);
+    A.tot_syms = (uint64_t *)(tot + TOT_SYMS);
+    A.tot_nsym = (uint32_t *)(tot + TOT_NSYM);
+    A.ecarry = dE(c);
+    A.dcarry = dD(c);
+    hipLaunchKernelGGL(k_small_stage, dim3(1), dim3(SM_BLOCK), 0, c->st, A);
+    return NFC_OK;
+}
+
 int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     c->have_outputs = false;
     c->pk_ready[0] = c->pk_ready[1] = false;
@@ -762,6 +835,14 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     auto edges_and_decode = [&]() -> int {
         size_caps();
         if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[2], c->st));
+        if (c->use_small && n <= SM_MAX_SAMPLES) {   // a short batch: one launch for the three stages
+            const int r = run_small(c, n, skip, g0);
+            if (r) return r;
+            if (!ev3_done && c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+            ev3_done = true;
+            HIPCHK(c, mirror_async(c));
+            return NFC_OK;
+        }
         int r = run_edges(c, n, skip, g0);
         if (r) return r;
         if (!ev3_done && c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
@@ -913,6 +994,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     C = std::max(C, 2 * c->L);
     C = std::max(C, c->mx + 2);
     c->rows_per_step = 4;
+    c->use_small = getenv("NFC_NO_SMALL") ? 0 : 1;
     c->use_rr = (c->L >= STEP && c->L <= 64 * RR_ROWS && getenv("NFC_RR")) ? 1 : 0;   // experimental: ring in registers
     if (c->use_rr) {
         C = std::max(2, (C + c->L / 2) / c->L) * c->L;   // whole ring periods

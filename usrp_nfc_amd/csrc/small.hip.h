@@ -1,0 +1,317 @@
+// small.hip.h -- edges, decoders and framing of a SHORT batch in one launch.
+//
+// The multi-launch stages (edges.hip.h, decode.hip.h) pay some twenty kernel boundaries per batch whatever
+// its length; a batch of a few tens of thousands of samples (a shard's warm-up overlap, a GNU Radio work()
+// call) is all boundary.  Here ONE workgroup walks the tiles of each stage in order, so every scan is a
+// single pass with the running prefix in registers -- no tile aggregates, no partials pass, no second read.
+// The per-item arithmetic is the same device code the large path runs (change_mask, event_mask,
+// event_entry, the LUT walk, pkt_map): only the orchestration differs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "decode.hip.h"
+#include "edges.hip.h"
+#include "scan.hip.h"
+
+namespace nfc {
+
+constexpr int SM_BLOCK = 256, SM_WAVES = SM_BLOCK / 64;   // four waves: room for registers (no scratch), short barriers
+constexpr int SM_EVCAP = 4096;              // entries listed per round of the edge writer
+constexpr uint32_t SM_MAX_SAMPLES = 1u << 18;   // batches up to this length take the one-launch path
+
+struct SmallFraming {   // one packet type
+    int32_t enabled, start_bit, type;
+    uint32_t started_in, pend, cap_sym;
+    const uint8_t *sym;
+    const uint32_t *src;
+    uint8_t *bits, *pending_next;
+    uint32_t *close_end;
+    uint64_t *close_idx;
+    uint32_t pending_cap;
+    uint32_t *maptot;
+    uint64_t *pktot;
+};
+struct SmallArgs {
+    EdgeArgs E;
+    size_t nwords;
+    nfc_edge *edges;
+    uint16_t *ecode;
+    uint32_t cap_edges;
+    DecTables T;
+    uint32_t dec_state_in;
+    SymOut S;
+    SmallFraming F[2];
+    Last2 *tot_last2;
+    uint32_t *tot_edges;
+    DecMaps *tot_decmap;
+    uint64_t *tot_syms;
+    uint32_t *tot_nsym;
+    EdgeCarry *ecarry;
+    DecCarry *dcarry;
+};
+
+__global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
+    // one LDS arena, carved per phase
+    __shared__ __attribute__((aligned(16))) unsigned char smem[36864];
+    __shared__ Last2 r_l2[SM_WAVES];
+    __shared__ uint32_t r_u32[SM_WAVES];
+    __shared__ uint64_t r_u64[SM_WAVES];
+    __shared__ DecMaps r_map[SM_WAVES];
+    const int tid = threadIdx.x;
+
+    // ================= edges: last-two-changes scan, event masks, entry offsets, entries =================
+    uint32_t n_edges_all = 0;
+    {
+        uint64_t *s_ng = (uint64_t *)smem, *s_ps = s_ng + SM_BLOCK, *s_m = s_ps + SM_BLOCK;
+        Last2 *s_ctx = (Last2 *)(s_m + SM_BLOCK);
+        uint16_t *s_ev = (uint16_t *)(s_ctx + SM_BLOCK);   // 8 KB + 8 KB
+        Last2 run_l2 = Last2Op::identity();
+        for (size_t w0 = 0; w0 < A.nwords; w0 += SM_BLOCK) {
+            const size_t w = w0 + tid;
+            uint64_t ng = 0, ps = 0, m = 0;
+            Last2 item = Last2Op::identity();
+            if (w < A.nwords) {
+                m = A.E.change_mask(w, ng, ps);
+                if (m) {
+                    const int b1 = 63 - __clzll((long long)m);
+                    const uint64_t m2 = m & ~(1ull << b1);
+                    item = Last2{(int32_t)(w * 64) + b1, m2 ? (int32_t)(w * 64) + (63 - __clzll((long long)m2)) : POS_NONE};
+                }
+            }
+            Last2 tot_l2;
+            const Last2 excl = block_exclusive<Last2Op, SM_WAVES>(item, r_l2, tot_l2);
+            const Last2 ctxw = Last2Op::op(run_l2, excl);
+            const uint64_t ev = (w < A.nwords) ? event_mask(A.E, w, ctxw, m) : 0ull;
+            uint32_t total;
+            const uint32_t off = block_exclusive<AddU32, SM_WAVES>((uint32_t)__popcll(ev), r_u32, total);
+            s_ng[tid] = ng;
+            s_ps[tid] = ps;
+            s_m[tid] = m;
+            s_ctx[tid] = ctxw;
+            for (uint32_t rbase = 0; rbase < total; rbase += SM_EVCAP) {
+                uint32_t k = off - rbase;   // wraps below the round: the unsigned compare drops those
+                uint64_t e = ev;
+                while (e) {
+                    if (k < (uint32_t)SM_EVCAP) s_ev[k] = (uint16_t)((tid << 6) | (__ffsll((long long)e) - 1));
+                    e &= e - 1;
+                    k++;
+                }
+                __syncthreads();
+                const uint32_t cnt = min((uint32_t)SM_EVCAP, total - rbase);
+                for (uint32_t j = tid; j < cnt; j += SM_BLOCK) {
+                    const uint32_t code = s_ev[j];
+                    const int wl = (int)(code >> 6), b = (int)(code & 63u);
+                    const int32_t p0 = (int32_t)((w0 + wl) * 64);
+                    int v, d, t;
+                    event_entry(A.E, p0, b, s_ng[wl], s_ps[wl], s_m[wl], s_ctx[wl], v, d, t);
+                    const uint32_t g = n_edges_all + rbase + j;
+                    if (g < A.cap_edges) {
+                        nfc_edge o;
+                        o.idx = A.E.g0 + (uint64_t)(p0 + b);
+                        o.d = d;
+                        o.v = (int8_t)v;
+                        o.t = (int8_t)t;
+                        o.pad = 0;
+                        A.edges[g] = o;
+                        A.ecode[g] = edge_code(v, d, t, A.E.nd);
+                    }
+                }
+                __syncthreads();
+            }
+            run_l2 = Last2Op::op(run_l2, tot_l2);
+            n_edges_all += total;
+        }
+        if (tid == 0) {
+            *A.tot_last2 = run_l2;
+            *A.tot_edges = n_edges_all;
+            if (A.E.skip < A.E.n) {   // (nothing but fill samples: unchanged)
+                int lb, dur, st;
+                A.E.state_before((int32_t)A.E.n, run_l2, lb, dur, st);
+                A.ecarry->last_bit = lb;
+                A.ecarry->dur = dur;
+                A.ecarry->state = st;
+            }
+        }
+    }
+    __syncthreads();
+    const size_t ne = min(n_edges_all, A.cap_edges);   // (an overflow makes the host repeat the batch with room)
+
+    // ================= decoders: state maps, walk, symbols =================
+    uint64_t n_sym_all = 0;
+    {
+        uint4 *s_mil = (uint4 *)smem;                      // 8 KB   maps for composing
+        uint2 *s_man = (uint2 *)(smem + 8192);             // 4 KB
+        uint16_t *s_mstep = (uint16_t *)(smem + 12288);    // 16 KB  next state | out byte, for walking
+        uint16_t *s_nstep = (uint16_t *)(smem + 28672);    // 8 KB
+        const bool lds_tab = 4 * A.T.nd <= DEC_LDS_ROWS;
+        if (lds_tab) {
+            const int rows = 4 * A.T.nd;
+            for (int i = tid; i < rows; i += SM_BLOCK) {
+                if (A.T.reader) s_mil[i] = A.T.mil_map[i];
+                if (A.T.tag) s_man[i] = A.T.man_map[i];
+            }
+            if (A.T.reader)
+                for (int i = tid; i < rows * 2; i += SM_BLOCK) ((uint4 *)s_mstep)[i] = ((const uint4 *)A.T.mil_step)[i];
+            if (A.T.tag)
+                for (int i = tid; i < rows; i += SM_BLOCK) ((uint4 *)s_nstep)[i] = ((const uint4 *)A.T.man_step)[i];
+            __syncthreads();
+        }
+        const uint4 *mil_map = lds_tab ? s_mil : A.T.mil_map;
+        const uint2 *man_map = lds_tab ? s_man : A.T.man_map;
+        const uint16_t *mil = lds_tab ? s_mstep : A.T.mil_step;
+        const uint16_t *man = lds_tab ? s_nstep : A.T.man_step;
+        DecMaps run_map = ComposeDec::identity();
+        for (size_t e0 = 0; e0 < ne; e0 += (size_t)SM_BLOCK * DEC_ITEMS) {
+            const size_t base = e0 + (size_t)tid * DEC_ITEMS;
+            uint32_t c[8];
+            load_codes(A.ecode, base, ne, c);
+            DecMaps agg = ComposeDec::identity();
+#pragma unroll
+            for (int k = 0; k < DEC_ITEMS; k++) {
+                const uint32_t code = (c[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const uint32_t li = code & 0x3FFFu, route = code >> 14;
+                if (route == 2u && A.T.reader) {
+                    const uint4 v = mil_map[li];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) agg.mil[q] = lookup16x4(v.x, v.y, v.z, v.w, agg.mil[q]);
+                } else if (route == 1u && A.T.tag) {
+                    const uint2 v = man_map[li];
+                    agg.man[0] = __builtin_amdgcn_perm(v.y, v.x, agg.man[0]);
+                    agg.man[1] = __builtin_amdgcn_perm(v.y, v.x, agg.man[1]);
+                }
+            }
+            DecMaps tot_map;
+            const DecMaps excl = block_exclusive<ComposeDec, SM_WAVES>(agg, r_map, tot_map);
+            uint32_t st = ComposeDec::step(ComposeDec::op(run_map, excl), A.dec_state_in);
+            uint32_t ow[4] = {0u, 0u, 0u, 0u};
+            uint32_t n_mil = 0, n_man = 0;
+#pragma unroll
+            for (int k = 0; k < DEC_ITEMS; k++) {
+                const uint32_t code = (c[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const uint32_t li = code & 0x3FFFu, route = code >> 14;
+                uint32_t w = 0;
+                if (route == 2u && A.T.reader) {
+                    const uint32_t e = mil[li * 16u + (st & 15u)];
+                    w = e >> 8;
+                    st = (st & ~15u) | (e & 15u);
+                    n_mil += w & 3u;
+                } else if (route == 1u && A.T.tag) {
+                    const uint32_t e = man[li * 8u + ((st >> 4) & 7u)];
+                    const uint32_t mo = e >> 8;
+                    w = (mo & 3u) ? ((mo & 0xFCu) | 3u) : 0u;
+                    st = (st & 15u) | ((e & 15u) << 4);
+                    n_man += (mo & 3u) ? 1u : 0u;
+                }
+                ow[k >> 2] |= w << (8 * (k & 3));
+            }
+            uint64_t tot_sym;
+            uint64_t run = n_sym_all + block_exclusive<AddU64, SM_WAVES>((uint64_t)n_mil | ((uint64_t)n_man << 32), r_u64, tot_sym);
+#pragma unroll
+            for (int k = 0; k < DEC_ITEMS; k++) {
+                const uint32_t w = (ow[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                const uint32_t q = w & 3u;
+                if (q == 0u) continue;
+                const int type = (q == 3u) ? 0 : 1;
+                const uint32_t off = type == 1 ? (uint32_t)run : (uint32_t)(run >> 32);
+                if (off + 1 < A.S.cap[type]) {
+                    A.S.sym[type][off] = (w >> 2) & 7u;
+                    A.S.src[type][off] = (uint32_t)(base + k);
+                    if (q == 2u) {
+                        A.S.sym[type][off + 1] = (w >> 5) & 7u;
+                        A.S.src[type][off + 1] = (uint32_t)(base + k);
+                    }
+                }
+                run += (q == 3u) ? (1ull << 32) : (uint64_t)q;
+            }
+            run_map = ComposeDec::op(run_map, tot_map);
+            n_sym_all += tot_sym;
+        }
+        if (tid == 0) {
+            *A.tot_decmap = run_map;
+            *A.tot_syms = n_sym_all;
+            const uint32_t st = ComposeDec::step(run_map, A.dec_state_in);
+            A.dcarry->mil_state = (int32_t)(st & 15u);
+            A.dcarry->man_state = (int32_t)(st >> 4);
+            A.tot_nsym[1] = (uint32_t)n_sym_all;           // Miller / reader
+            A.tot_nsym[0] = (uint32_t)(n_sym_all >> 32);    // Manchester / tag
+        }
+    }
+    __syncthreads();
+
+    // ================= framing, per decoder that exists =================
+    for (int t = 0; t < 2; t++) {
+        const SmallFraming &F = A.F[t];
+        if (!F.enabled) continue;
+        const uint32_t ns_all = t == 1 ? (uint32_t)n_sym_all : (uint32_t)(n_sym_all >> 32);
+        const size_t ns = min(ns_all, F.cap_sym);
+        uint32_t run_map = ComposePkt::identity();
+        uint64_t run_cnt = (uint64_t)F.pend;
+        for (size_t s0 = 0; s0 < ns; s0 += (size_t)SM_BLOCK * DEC_ITEMS) {
+            const size_t base = s0 + (size_t)tid * DEC_ITEMS;
+            uint32_t w[4];
+            load_bytes16(F.sym, base, ns, 0xFFu, w);
+            uint32_t agg = ComposePkt::identity();
+#pragma unroll
+            for (int k = 0; k < DEC_ITEMS; k++) {
+                if (base + k < ns) {
+                    const uint32_t m = pkt_map((w[k >> 2] >> (8 * (k & 3))) & 0xFFu, F.start_bit);
+                    agg = (m == 0x10u) ? agg : m;
+                }
+            }
+            uint32_t tot_map;
+            const uint32_t excl = block_exclusive<ComposePkt, SM_WAVES>(agg, r_u32, tot_map);
+            uint32_t started = ComposePkt::step(ComposePkt::op(run_map, excl), F.started_in);
+            uint32_t fw[4] = {0u, 0u, 0u, 0u};
+            uint32_t n_bits = 0, n_close = 0;
+#pragma unroll
+            for (int k = 0; k < DEC_ITEMS; k++) {
+                const uint32_t s = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                if (base + k < ns) {
+                    uint32_t f;
+                    if (s > 1u) {
+                        f = started ? 2u : 0u;
+                        started = 0u;
+                    } else {
+                        f = (!started && (int)s == F.start_bit) ? 0u : 1u;
+                        started = (started || (int)s == F.start_bit) ? 1u : 0u;
+                    }
+                    n_bits += f & 1u;
+                    n_close += f >> 1;
+                    fw[k >> 2] |= f << (8 * (k & 3));
+                }
+            }
+            uint64_t tot_cnt;
+            uint64_t run = run_cnt + block_exclusive<AddU64, SM_WAVES>((uint64_t)n_bits | ((uint64_t)n_close << 32), r_u64, tot_cnt);
+#pragma unroll
+            for (int k = 0; k < DEC_ITEMS; k++) {
+                const uint32_t f = (fw[k >> 2] >> (8 * (k & 3))) & 3u;
+                if (f & 2u) {
+                    const uint32_t j = (uint32_t)(run >> 32);
+                    F.close_end[j] = (uint32_t)run;
+                    F.close_idx[j] = A.edges[F.src[base + k]].idx;
+                    run += 1ull << 32;
+                } else if (f & 1u) {
+                    F.bits[(uint32_t)run] = (uint8_t)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                    run += 1ull;
+                }
+            }
+            run_map = ComposePkt::op(run_map, tot_map);
+            run_cnt += tot_cnt;
+        }
+        __syncthreads();   // the bits and close offsets of every thread
+        const uint32_t nbits = (uint32_t)run_cnt, ncl = (uint32_t)(run_cnt >> 32);
+        const uint32_t from = ncl ? F.close_end[ncl - 1] : 0u;
+        const uint32_t keep = nbits - from;
+        for (uint32_t i = tid; i < keep && i < F.pending_cap; i += SM_BLOCK) F.pending_next[i] = F.bits[from + i];
+        if (tid == 0) {
+            *F.maptot = run_map;
+            *F.pktot = run_cnt;
+            A.dcarry->pending[F.type] = keep;
+            A.dcarry->pkt_started[F.type] = (int32_t)((run_map >> (4 * F.started_in)) & 1u);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace nfc

@@ -958,11 +958,12 @@ __global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertI
     const float *ro = A.ring_out[vb] + (size_t)(c - 1) * L;
     float d = 0.f;
     bool differ = false;
-    for (int s0 = 0; s0 < L; s0 += 256) {
-        float t[4], u[4];
-        uint32_t w[4];
+    constexpr int CK = 16;   // slots per lane and round: every load of a round is in flight at once
+    for (int s0 = 0; s0 < L; s0 += 64 * CK) {
+        float t[CK], u[CK];
+        uint32_t w[CK];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < CK; k++) {
             const int s = s0 + 64 * k + lane;
             const bool in = s < L;
             t[k] = in ? ro[s] : 0.f;
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertI
             w[k] = in ? tw[s >> 5] : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < CK; k++) {
             const int s = s0 + 64 * k + lane;
             if (s < L) {
                 if (!((w[k] >> (s & 31)) & 1u)) t[k] = resolve_slot(A, (int)c, s);   // rare: look further back
