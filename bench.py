@@ -188,7 +188,7 @@ def main():
         }
         if not a.no_parity:
             out['parity'] = parity_check(a, own, flags, n)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
             out['cpu_baseline'] = cpu_baseline(own, flags)
         print(json.dumps(out))
         sys.stdout.flush()
