@@ -185,6 +185,51 @@ int nfc_get_stats(nfc_ctx *ctx, nfc_stats *out);
  * kernels' own launch durations (ms_threshold_kernel).  2: also the per-stage split. */
 int nfc_set_timing(nfc_ctx *ctx, int level);
 
+/* ---- "next" row f1: closed packets -> bytes -> commands, on the host -------------------------
+ * fsm.process_bits (fsm.py:218-238) without CRYPTO1: frame-end repair (fsm.py:49-66), odd-parity strip and
+ * check (fsm.py:28-47), command lookup by protocol stage and leading bytes with CRC_A / BCC checks
+ * (command.py:44-67,166-199; utilities.py:26-46), header / extra / CRC split (command.py:245-253), tag type and
+ * UID tracking (fsm.py:165-216).  No device work. */
+enum {
+    NFC_CMD_UNKNOWN = -1,       /* bytes that match no command: CommandStructure("UNKNOWN", [], bytes) */
+    NFC_CMD_PARITY_ERROR = -2   /* "PARITY ERROR" (fsm.py:225-227): no bytes, nothing dispatched */
+};
+enum {
+    NFC_FRAME_EXTRA_ERROR = 1,      /* "EXTRA ERROR" (fsm.py:61) */
+    NFC_FRAME_MANY_MORE_ERROR = 2,  /* "MANY MORE ERROR" (fsm.py:65) */
+    NFC_FRAME_UID_MISMATCH = 4,     /* "MISMATCH BETWEEN READER-TAG UID" (fsm.py:186,195) */
+    NFC_FRAME_ENCRYPTED = 8         /* a Classic authentication is in progress: the frame would need CRYPTO1 (row f3) */
+};
+typedef struct nfc_frame {
+    int32_t cmd;       /* index for nfc_command_info, or NFC_CMD_* */
+    int32_t type;      /* 0 tag -> reader, 1 reader -> tag */
+    uint32_t byte_off; /* nfc_fsm_process_packets: offset of the frame's bytes in the byte buffer */
+    uint16_t n_bytes, n_header, n_extra, n_crc; /* bytes = header | extra | crc */
+    uint32_t flags;    /* NFC_FRAME_* */
+} nfc_frame;
+typedef struct nfc_command_info {
+    char name[8];
+    int32_t stage, type, crc, n_header, n_extra, xor_check;
+    uint8_t header[2];
+    uint8_t pad[2];
+} nfc_command_info;
+typedef struct nfc_fsm nfc_fsm; /* protocol state across packets: previous command, tag type, UID */
+
+int nfc_fsm_create(nfc_fsm **out);
+void nfc_fsm_destroy(nfc_fsm *f);
+int nfc_fsm_reset(nfc_fsm *f);
+/* one packet's bits (as nfc_read_packet_bits returns them); bytes_out needs n_bits / 9 + 1 bytes */
+int nfc_fsm_process(nfc_fsm *f, const uint8_t *bits, size_t n_bits, int packet_type, nfc_frame *out, uint8_t *bytes_out,
+                    size_t bytes_cap);
+/* a batch of packets in stream order: the rows of nfc_read_packets (both types merged by idx) over their bit arrays */
+int nfc_fsm_process_packets(nfc_fsm *f, const nfc_packet *packets, size_t n_packets, const uint8_t *bits_type0,
+                            const uint8_t *bits_type1, nfc_frame *frames_out, uint8_t *bytes_out, size_t bytes_cap,
+                            size_t *bytes_used);
+int nfc_command_count(void);
+int nfc_command_get(int cmd, nfc_command_info *out);
+/* ISO 14443-3 type A CRC (utilities.py:30-41), low byte first */
+int nfc_crc_a(const uint8_t *data, size_t n, uint8_t out[2]);
+
 /* Device memory helpers so that a caller without HIP bindings (ctypes) can keep its input
  * resident in HBM and use nfc_push_device. */
 int nfc_device_alloc(int device, size_t bytes, void **out);

@@ -1,0 +1,98 @@
+"""Row f1: closed packets -> bytes -> commands.  Golden: the reference's own trace of the Ultralight
+transaction, outputs/ultralight.out (a data file of the reference, copied to tests/golden/), which fsm.process_bits
++ CommandStructure.display printed from these very packets."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden_util import Case
+from usrp_nfc_amd import command, fsm, utilities
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'ultralight.out')
+
+
+def trace_of(packets):
+    out = io.StringIO()
+    m = fsm.fsm(out=out)
+    for t, bits in packets:
+        m.process_bits(bits, t)
+    return out.getvalue()
+
+
+def test_crc_a_known_answers():
+    # CRC fields printed in the reference's trace
+    assert fsm.crc_a([0x93, 0x70, 0x88, 0x04, 0xBE, 0x6F, 0x5D]) == [0xA1, 0x8E]      # SEL1R
+    assert fsm.crc_a([0x04]) == [0xDA, 0x17]                                            # SEL1U
+    assert utilities.CRC.check_crc([0x50, 0x00, 0x57, 0xCD])                            # HALT (ISO 14443-3 annex B)
+    assert not utilities.CRC.check_crc([0x50, 0x00, 0x57, 0xCC])
+    assert fsm.crc_a([]) == [0x63, 0x63]
+
+
+def test_command_table_matches_reference_names():
+    names = [c.name() for c in command.CommandType.table()]
+    assert names[:6] == ['REQA', 'WUPA', 'ATQAUL', 'ATQA1K', 'ATQA1K', 'ATQADS']      # (the 4K answer is named ATQA1K, command.py:84)
+    assert command.CommandType.SEL1R.header() == [0x93, 0x70] and command.CommandType.SEL1R.total_len() == 9
+    assert command.CommandType.READT.total_len() == 18 and command.CommandType.HALT.stage() == 10
+    assert command.CommandType.ANTI1U.packet_type() == 0 and command.CommandType.REQA.packet_type() == 1
+
+
+def test_ultralight_trace_from_golden_packets():
+    c = Case('fx_ultralight_txn')
+    assert len(c.packets) == 19
+    # (the file lacks the last of the two blank lines display() prints after the final command)
+    assert trace_of(c.packets).rstrip('\n') == open(GOLD).read().rstrip('\n')
+
+
+def test_frame_end_repair_parity_and_unknown():
+    to_bits = utilities.Convert.to_bit_ar
+    out = io.StringIO()
+    m = fsm.fsm(out=out)
+    reqa = [0, 1, 1, 0, 0, 1, 0]                       # 0x26 as a 7-bit short frame
+    st = m.process_bits(reqa + [0], 1)                 # 8 bits: the missing ninth is assumed (fsm.py:56-57)
+    assert st.name() == 'REQA' and st.header() == [0x26]
+    st = m.process_bits(to_bits([0x44, 0x00], parity=True) + [1], 0)   # one extra bit equal to the start bit: dropped
+    assert st.name() == 'ATQAUL'
+    st = m.process_bits(to_bits([0x93, 0x20], parity=True) + [1], 1)   # extra bit that is NOT the start bit: reported
+    assert st.name() == 'ANTI1R' and 'EXTRA ERROR' in out.getvalue()
+    bad = to_bits([0x88, 0x04, 0xBE, 0x6F, 0x5D], parity=True)
+    bad[8] ^= 1
+    assert m.process_bits(bad, 0) is None and 'PARITY ERROR' in out.getvalue()
+    st = m.process_bits(to_bits([0x12, 0x34, 0x56], parity=True), 1)
+    assert st.name() == 'UNKNOWN' and st.extra() == [0x12, 0x34, 0x56]
+    st = m.process_bits(to_bits([0x26], parity=True)[:9] + [0, 1, 0], 1)   # 12 bits: "MANY MORE ERROR", cut to nine
+    assert st.name() == 'REQA' and 'MANY MORE ERROR' in out.getvalue()
+
+
+def test_bcc_and_crc_gate_the_lookup():
+    to_bits = utilities.Convert.to_bit_ar
+    m = fsm.fsm(out=io.StringIO())
+    m.process_bits(to_bits([0x26], parity=True)[:8], 1)
+    m.process_bits(to_bits([0x44, 0x00], parity=True), 0)
+    m.process_bits(to_bits([0x93, 0x20], parity=True), 1)
+    st = m.process_bits(to_bits([0x88, 0x04, 0xBE, 0x6F, 0x5C], parity=True), 0)   # wrong BCC: not ANTI1U, not ANTI1G
+    assert st.name() == 'UNKNOWN'
+    good = [0x93, 0x70, 0x88, 0x04, 0xBE, 0x6F, 0x5D, 0xA1, 0x8E]
+    assert m.process_bits(to_bits(good, parity=True), 1).name() == 'SEL1R'
+    good[-1] ^= 0x10
+    assert m.process_bits(to_bits(good, parity=True), 1).name() == 'UNKNOWN'
+
+
+@pytest.mark.gpu
+def test_ultralight_iq_to_trace_on_gpu():
+    # capture -> GPU decode -> batch protocol layer: the reference's printed trace, end to end
+    from usrp_nfc_amd import api
+    iq = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'fx_ultralight_iq.npz'))['iq']
+    ctx = api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32)
+    ctx.push(iq)
+    tabs = [ctx.packet_table(t) for t in (0, 1)]
+    bits = [ctx.packet_bits(t) for t in (0, 1)]
+    table = np.concatenate(tabs)
+    table = table[np.argsort(table['idx'], kind='stable')]
+    table = table[table['n_bits'] > 0]            # empty packets are discarded (packets.py:97)
+    out = io.StringIO()
+    frames, data = fsm.fsm(out=out).process_packets(table, bits[0], bits[1])
+    assert out.getvalue().rstrip('\n') == open(GOLD).read().rstrip('\n')
+    assert len(frames) == 19 and (frames['cmd'] >= 0).all()
+    ctx.close()

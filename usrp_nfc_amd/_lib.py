@@ -34,6 +34,17 @@ class Stats(C.Structure):
                 ('ms_threshold_kernel', C.c_double * 6), ('n_threshold_timed', C.c_uint32), ('chunk_samples', C.c_uint32)]
 
 
+class Frame(C.Structure):   # nfc_frame
+    _fields_ = [('cmd', C.c_int32), ('type', C.c_int32), ('byte_off', C.c_uint32), ('n_bytes', C.c_uint16),
+                ('n_header', C.c_uint16), ('n_extra', C.c_uint16), ('n_crc', C.c_uint16), ('flags', C.c_uint32)]
+
+
+class CommandInfo(C.Structure):   # nfc_command_info
+    _fields_ = [('name', C.c_char * 8), ('stage', C.c_int32), ('type', C.c_int32), ('crc', C.c_int32),
+                ('n_header', C.c_int32), ('n_extra', C.c_int32), ('xor_check', C.c_int32), ('header', C.c_uint8 * 2),
+                ('pad', C.c_uint8 * 2)]
+
+
 class StateHeader(C.Structure):
     _fields_ = [('n_seen', C.c_uint64), ('ss', C.c_double), ('last_low', C.c_int64), ('filled', C.c_int32),
                 ('stable', C.c_int32), ('cur_state', C.c_int32), ('last_bit', C.c_int32), ('dur', C.c_int32),
@@ -48,7 +59,9 @@ PACKET_DTYPE = np.dtype([('idx', '<u8'), ('bit_off', '<u8'), ('n_bits', '<u4'), 
 SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', 'nfc_last_error', 'nfc_push',
            'nfc_push_device', 'nfc_sync', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_symbols', 'nfc_read_packets',
            'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_prime', 'nfc_export_state', 'nfc_get_stats', 'nfc_set_timing',
-           'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_host_decode_lut']
+           'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_host_decode_lut',
+           'nfc_fsm_create', 'nfc_fsm_destroy', 'nfc_fsm_reset', 'nfc_fsm_process', 'nfc_fsm_process_packets',
+           'nfc_command_count', 'nfc_command_get', 'nfc_crc_a']
 
 _lib = None
 
@@ -94,6 +107,15 @@ def load():
     L.nfc_device_upload.argtypes = [C.c_int, vp, vp, sz]
     L.nfc_device_download.argtypes = [C.c_int, vp, vp, sz]
     L.nfc_host_decode_lut.argtypes = [C.POINTER(Params), C.c_int, vp, vp, sz, vp, sz, psz]
+    L.nfc_fsm_create.argtypes = [C.POINTER(vp)]
+    L.nfc_fsm_destroy.argtypes = [vp]
+    L.nfc_fsm_destroy.restype = None
+    L.nfc_fsm_reset.argtypes = [vp]
+    L.nfc_fsm_process.argtypes = [vp, vp, sz, C.c_int, C.POINTER(Frame), vp, sz]
+    L.nfc_fsm_process_packets.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz, psz]
+    L.nfc_command_count.restype = C.c_int
+    L.nfc_command_get.argtypes = [C.c_int, C.POINTER(CommandInfo)]
+    L.nfc_crc_a.argtypes = [vp, sz, vp]
     for name in SYMBOLS:
         getattr(L, name)
     _lib = L

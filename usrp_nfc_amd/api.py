@@ -119,6 +119,17 @@ class NfcContext(object):
             self._chk(self.L.nfc_read_packets(self.h, ptype, out.ctypes.data, out.size, C.byref(got)), 'nfc_read_packets')
         return out
 
+    def packet_bits(self, ptype):
+        """The per-type bit array the packet table's bit_off / n_bits index (nfc_read_packet_bits)."""
+        tab = self.packet_table(ptype)
+        if not len(tab):
+            return np.zeros(0, np.uint8)
+        bits = np.zeros(int((tab['bit_off'] + tab['n_bits']).max()), np.uint8)
+        got = C.c_size_t(0)
+        if bits.size:
+            self._chk(self.L.nfc_read_packet_bits(self.h, ptype, 0, bits.ctypes.data, bits.size, C.byref(got)), 'nfc_read_packet_bits')
+        return bits
+
     def packets(self):
         """Closed packets of both types in stream order: [(type, [bits]), ...] -- what
         CombinedPacketProcessor hands to fsm.process_bits (packets.py:96-98)."""

@@ -24,6 +24,7 @@
 #include "decode.hip.h"
 #include "decoder_tables.h"
 #include "edges.hip.h"
+#include "protocol.h"
 #include "scan.hip.h"
 #include "small.hip.h"
 #include "threshold.hip.h"
@@ -1395,6 +1396,65 @@ int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size
 int nfc_get_stats(nfc_ctx *c, nfc_stats *out) {
     if (!c || !out) return NFC_ERR_ARG;
     *out = c->stats;
+    return NFC_OK;
+}
+
+// ---- row f1: packets -> bytes -> commands (host only, protocol.h) ----
+int nfc_fsm_create(nfc_fsm **out) {
+    if (!out) return NFC_ERR_ARG;
+    *out = new nfc_fsm();
+    return NFC_OK;
+}
+void nfc_fsm_destroy(nfc_fsm *f) { delete f; }
+int nfc_fsm_reset(nfc_fsm *f) {
+    if (!f) return NFC_ERR_ARG;
+    *f = nfc_fsm();
+    return NFC_OK;
+}
+int nfc_fsm_process(nfc_fsm *f, const uint8_t *bits, size_t n_bits, int packet_type, nfc_frame *out, uint8_t *bytes_out, size_t bytes_cap) {
+    if (!f || !out || !bytes_out || (n_bits && !bits) || (packet_type != 0 && packet_type != 1)) return NFC_ERR_ARG;
+    if (bytes_cap < n_bits / 9 + 1) return NFC_ERR_ARG;
+    fsm_process(*f, bits, n_bits, packet_type, out, bytes_out);
+    return NFC_OK;
+}
+int nfc_fsm_process_packets(nfc_fsm *f, const nfc_packet *packets, size_t n_packets, const uint8_t *bits0, const uint8_t *bits1,
+                            nfc_frame *frames_out, uint8_t *bytes_out, size_t bytes_cap, size_t *bytes_used) {
+    if (!f || (n_packets && (!packets || !frames_out || !bytes_out))) return NFC_ERR_ARG;
+    size_t used = 0;
+    for (size_t i = 0; i < n_packets; i++) {
+        const nfc_packet &p = packets[i];
+        if (p.type != 0 && p.type != 1) return NFC_ERR_ARG;
+        const uint8_t *bits = p.type ? bits1 : bits0;
+        if (p.n_bits && !bits) return NFC_ERR_ARG;
+        if (used + p.n_bits / 9 + 1 > bytes_cap) return NFC_ERR_ARG;
+        fsm_process(*f, bits ? bits + p.bit_off : nullptr, p.n_bits, p.type, &frames_out[i], bytes_out + used);
+        frames_out[i].byte_off = (uint32_t)used;
+        used += frames_out[i].n_bytes;
+    }
+    if (bytes_used) *bytes_used = used;
+    return NFC_OK;
+}
+int nfc_command_count(void) { return CMD_COUNT; }
+int nfc_command_get(int cmd, nfc_command_info *out) {
+    if (cmd < 0 || cmd >= CMD_COUNT || !out) return NFC_ERR_ARG;
+    const CommandDef &c = COMMANDS[cmd];
+    memset(out, 0, sizeof *out);
+    strncpy(out->name, c.name, sizeof out->name - 1);
+    out->stage = c.stage;
+    out->type = c.type;
+    out->crc = c.crc;
+    out->n_header = c.n_header;
+    out->n_extra = c.n_extra;
+    out->xor_check = c.xor_check;
+    out->header[0] = c.header[0];
+    out->header[1] = c.header[1];
+    return NFC_OK;
+}
+int nfc_crc_a(const uint8_t *data, size_t n, uint8_t out[2]) {
+    if ((n && !data) || !out) return NFC_ERR_ARG;
+    const uint16_t c = crc_a(data, n);
+    out[0] = (uint8_t)(c & 0xFF);
+    out[1] = (uint8_t)(c >> 8);
     return NFC_OK;
 }
 
