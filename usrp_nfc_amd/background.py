@@ -10,8 +10,9 @@ with ``transition_sink.work`` / ``flush``.
 
 ``background(reader, tag, emulator)`` keeps the reference signature.  ``fsm`` may
 be passed explicitly (any object with ``process_bits``); by default the reference's
-own ``fsm`` module is used when it is importable (it is Python 2), else packets are
-only recorded in ``self.packets``.
+own ``fsm`` module is used when it is importable (it is Python 2), else this package's
+``fsm`` (row f1: it prints the reference's command trace); packets are also kept in
+``self.packets``.
 """
 from .packets import PacketType
 
@@ -37,7 +38,10 @@ class background(object):
                 else:
                     fsm = _ref_fsm.fsm()
             except Exception:
-                fsm = _Recorder()
+                # the reference's fsm is Python 2: use this package's (row f1: bytes, parity, CRC, commands; it prints
+                # the same trace; no CRYPTO1, no emulator encoder)
+                from . import fsm as _own_fsm
+                fsm = _own_fsm.fsm(emulator.process_packet) if emulator else _own_fsm.fsm()
         self._fsm = fsm
 
     # -- reference surface ---------------------------------------------------------
