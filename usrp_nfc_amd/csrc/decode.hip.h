@@ -170,7 +170,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
 // ---- symbols: placed by a scan of the emission counts ---------------------------------------
 struct SymOut {
     uint8_t *sym[2];   // [0] Manchester / tag, [1] Miller / reader
-    uint32_t *src[2];  // index of the producing edge
+    uint32_t *src[2];  // index of the producing edge -- written for error symbols only (the ones that can close a packet)
     uint32_t cap[2];   // buffer capacities (an overflow is detected by the host from the totals)
 };
 __global__ __launch_bounds__(SCAN_BLOCK) void k_sym_store(const uint8_t *outw, size_t n, const uint32_t *n_dev,
@@ -201,11 +201,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_sym_store(const uint8_t *outw, s
         const int type = (q == 3u) ? 0 : 1;
         const uint32_t off = type == 1 ? (uint32_t)run : (uint32_t)(run >> 32);
         if (off + 1 < S.cap[type]) {
-            S.sym[type][off] = (w >> 2) & 7u;
-            S.src[type][off] = (uint32_t)(base + k);
+            const uint32_t s0 = (w >> 2) & 7u;
+            S.sym[type][off] = (uint8_t)s0;
+            if (s0 > 1u) S.src[type][off] = (uint32_t)(base + k);   // only a symbol that can close a packet needs its edge
             if (q == 2u) {
-                S.sym[type][off + 1] = (w >> 5) & 7u;
-                S.src[type][off + 1] = (uint32_t)(base + k);
+                const uint32_t s1 = (w >> 5) & 7u;
+                S.sym[type][off + 1] = (uint8_t)s1;
+                if (s1 > 1u) S.src[type][off + 1] = (uint32_t)(base + k);
             }
         }
         run += (q == 3u) ? (1ull << 32) : (uint64_t)q;
