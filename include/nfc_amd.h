@@ -186,7 +186,8 @@ int nfc_get_stats(nfc_ctx *ctx, nfc_stats *out);
 int nfc_set_timing(nfc_ctx *ctx, int level);
 
 /* ---- "next" row f1: closed packets -> bytes -> commands, on the host -------------------------
- * fsm.process_bits (fsm.py:218-238) without CRYPTO1: frame-end repair (fsm.py:49-66), odd-parity strip and
+ * and row f3: the CRYPTO1 sessions of MIFARE Classic (cipher.py, lfsr.py, fsm.py:133-154).
+ * fsm.process_bits (fsm.py:218-238): frame-end repair (fsm.py:49-66), decryption while a session is up, odd-parity strip and
  * check (fsm.py:28-47), command lookup by protocol stage and leading bytes with CRC_A / BCC checks
  * (command.py:44-67,166-199; utilities.py:26-46), header / extra / CRC split (command.py:245-253), tag type and
  * UID tracking (fsm.py:165-216).  No device work. */
@@ -198,7 +199,9 @@ enum {
     NFC_FRAME_EXTRA_ERROR = 1,      /* "EXTRA ERROR" (fsm.py:61) */
     NFC_FRAME_MANY_MORE_ERROR = 2,  /* "MANY MORE ERROR" (fsm.py:65) */
     NFC_FRAME_UID_MISMATCH = 4,     /* "MISMATCH BETWEEN READER-TAG UID" (fsm.py:186,195) */
-    NFC_FRAME_ENCRYPTED = 8         /* a Classic authentication is in progress: the frame would need CRYPTO1 (row f3) */
+    NFC_FRAME_ENCRYPTED = 8,        /* a CRYPTO1 session was up: the frame was decrypted first (fsm.py:133-154) */
+    NFC_FRAME_AR_OK = 16, NFC_FRAME_AR_ERROR = 32,   /* reader answer vs suc64(nt): "AR OK" / "ERROR WITH AR" (fsm.py:203-208) */
+    NFC_FRAME_AT_OK = 64, NFC_FRAME_AT_ERROR = 128   /* tag answer vs suc96(nt) (fsm.py:209-214) */
 };
 typedef struct nfc_frame {
     int32_t cmd;       /* index for nfc_command_info, or NFC_CMD_* */
@@ -206,6 +209,8 @@ typedef struct nfc_frame {
     uint32_t byte_off; /* nfc_fsm_process_packets: offset of the frame's bytes in the byte buffer */
     uint16_t n_bytes, n_header, n_extra, n_crc; /* bytes = header | extra | crc */
     uint32_t flags;    /* NFC_FRAME_* */
+    uint16_t n_enc;    /* entries written to enc_out for this frame (what fsm._print_enc shows) */
+    uint16_t pad;
 } nfc_frame;
 typedef struct nfc_command_info {
     char name[8];
@@ -220,11 +225,13 @@ void nfc_fsm_destroy(nfc_fsm *f);
 int nfc_fsm_reset(nfc_fsm *f);
 /* one packet's bits (as nfc_read_packet_bits returns them); bytes_out needs n_bits / 9 + 1 bytes */
 int nfc_fsm_process(nfc_fsm *f, const uint8_t *bits, size_t n_bits, int packet_type, nfc_frame *out, uint8_t *bytes_out,
-                    size_t bytes_cap);
+                    size_t bytes_cap, uint16_t *enc_out /* NULL, or the same capacity: on-air byte | 0x100 if marked '!' */);
+/* MIFARE Classic sector keys A / B (fsm.set_keys, fsm.py:157-160; both default to FF FF FF FF FF FF) */
+int nfc_fsm_set_keys(nfc_fsm *f, const uint8_t key_a[6], const uint8_t key_b[6]);
 /* a batch of packets in stream order: the rows of nfc_read_packets (both types merged by idx) over their bit arrays */
 int nfc_fsm_process_packets(nfc_fsm *f, const nfc_packet *packets, size_t n_packets, const uint8_t *bits_type0,
                             const uint8_t *bits_type1, nfc_frame *frames_out, uint8_t *bytes_out, size_t bytes_cap,
-                            size_t *bytes_used);
+                            size_t *bytes_used, uint16_t *enc_out /* NULL, or bytes_cap entries, indexed like bytes_out */);
 int nfc_command_count(void);
 int nfc_command_get(int cmd, nfc_command_info *out);
 /* ISO 14443-3 type A CRC (utilities.py:30-41), low byte first */

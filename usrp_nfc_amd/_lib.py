@@ -36,7 +36,8 @@ class Stats(C.Structure):
 
 class Frame(C.Structure):   # nfc_frame
     _fields_ = [('cmd', C.c_int32), ('type', C.c_int32), ('byte_off', C.c_uint32), ('n_bytes', C.c_uint16),
-                ('n_header', C.c_uint16), ('n_extra', C.c_uint16), ('n_crc', C.c_uint16), ('flags', C.c_uint32)]
+                ('n_header', C.c_uint16), ('n_extra', C.c_uint16), ('n_crc', C.c_uint16), ('flags', C.c_uint32),
+                ('n_enc', C.c_uint16), ('pad', C.c_uint16)]
 
 
 class CommandInfo(C.Structure):   # nfc_command_info
@@ -60,7 +61,7 @@ SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', '
            'nfc_push_device', 'nfc_sync', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_symbols', 'nfc_read_packets',
            'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_prime', 'nfc_export_state', 'nfc_get_stats', 'nfc_set_timing',
            'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_host_decode_lut',
-           'nfc_fsm_create', 'nfc_fsm_destroy', 'nfc_fsm_reset', 'nfc_fsm_process', 'nfc_fsm_process_packets',
+           'nfc_fsm_create', 'nfc_fsm_destroy', 'nfc_fsm_reset', 'nfc_fsm_process', 'nfc_fsm_process_packets', 'nfc_fsm_set_keys',
            'nfc_command_count', 'nfc_command_get', 'nfc_crc_a']
 
 _lib = None
@@ -111,8 +112,9 @@ def load():
     L.nfc_fsm_destroy.argtypes = [vp]
     L.nfc_fsm_destroy.restype = None
     L.nfc_fsm_reset.argtypes = [vp]
-    L.nfc_fsm_process.argtypes = [vp, vp, sz, C.c_int, C.POINTER(Frame), vp, sz]
-    L.nfc_fsm_process_packets.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz, psz]
+    L.nfc_fsm_process.argtypes = [vp, vp, sz, C.c_int, C.POINTER(Frame), vp, sz, vp]
+    L.nfc_fsm_process_packets.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz, psz, vp]
+    L.nfc_fsm_set_keys.argtypes = [vp, vp, vp]
     L.nfc_command_count.restype = C.c_int
     L.nfc_command_get.argtypes = [C.c_int, C.POINTER(CommandInfo)]
     L.nfc_crc_a.argtypes = [vp, sz, vp]

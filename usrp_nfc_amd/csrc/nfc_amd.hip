@@ -1411,14 +1411,21 @@ int nfc_fsm_reset(nfc_fsm *f) {
     *f = nfc_fsm();
     return NFC_OK;
 }
-int nfc_fsm_process(nfc_fsm *f, const uint8_t *bits, size_t n_bits, int packet_type, nfc_frame *out, uint8_t *bytes_out, size_t bytes_cap) {
+int nfc_fsm_process(nfc_fsm *f, const uint8_t *bits, size_t n_bits, int packet_type, nfc_frame *out, uint8_t *bytes_out, size_t bytes_cap,
+                    uint16_t *enc_out) {
     if (!f || !out || !bytes_out || (n_bits && !bits) || (packet_type != 0 && packet_type != 1)) return NFC_ERR_ARG;
     if (bytes_cap < n_bits / 9 + 1) return NFC_ERR_ARG;
-    fsm_process(*f, bits, n_bits, packet_type, out, bytes_out);
+    fsm_process(*f, bits, n_bits, packet_type, out, bytes_out, enc_out);
+    return NFC_OK;
+}
+int nfc_fsm_set_keys(nfc_fsm *f, const uint8_t key_a[6], const uint8_t key_b[6]) {
+    if (!f || !key_a || !key_b) return NFC_ERR_ARG;
+    memcpy(f->key_a, key_a, 6);
+    memcpy(f->key_b, key_b, 6);
     return NFC_OK;
 }
 int nfc_fsm_process_packets(nfc_fsm *f, const nfc_packet *packets, size_t n_packets, const uint8_t *bits0, const uint8_t *bits1,
-                            nfc_frame *frames_out, uint8_t *bytes_out, size_t bytes_cap, size_t *bytes_used) {
+                            nfc_frame *frames_out, uint8_t *bytes_out, size_t bytes_cap, size_t *bytes_used, uint16_t *enc_out) {
     if (!f || (n_packets && (!packets || !frames_out || !bytes_out))) return NFC_ERR_ARG;
     size_t used = 0;
     for (size_t i = 0; i < n_packets; i++) {
@@ -1427,9 +1434,9 @@ int nfc_fsm_process_packets(nfc_fsm *f, const nfc_packet *packets, size_t n_pack
         const uint8_t *bits = p.type ? bits1 : bits0;
         if (p.n_bits && !bits) return NFC_ERR_ARG;
         if (used + p.n_bits / 9 + 1 > bytes_cap) return NFC_ERR_ARG;
-        fsm_process(*f, bits ? bits + p.bit_off : nullptr, p.n_bits, p.type, &frames_out[i], bytes_out + used);
+        fsm_process(*f, bits ? bits + p.bit_off : nullptr, p.n_bits, p.type, &frames_out[i], bytes_out + used, enc_out ? enc_out + used : nullptr);
         frames_out[i].byte_off = (uint32_t)used;
-        used += frames_out[i].n_bytes;
+        used += std::max<size_t>(frames_out[i].n_bytes, frames_out[i].n_enc);
     }
     if (bytes_used) *bytes_used = used;
     return NFC_OK;

@@ -4,8 +4,9 @@
 // (fsm.py:49-66), strip and check the odd parity of every ninth bit (fsm.py:28-47), find the command by the
 // protocol stage of the previous command and the leading bytes (command.py:166-199, with the ISO 14443-3
 // CRC_A of utilities.py:26-46 and the BCC xor check of command.py:44-67), split it into header / extra /
-// CRC (command.py:245-253) and track tag type and UID (fsm.py:165-216).  CRYPTO1 (fsm.py:133-154, row f3)
-// is not here: once a Classic authentication starts, frames are reported undecrypted (NFC_FRAME_ENCRYPTED).
+// CRC (command.py:245-253) and track tag type and UID (fsm.py:165-216).  Row f3, the CRYPTO1 stream cipher of
+// MIFARE Classic (cipher.py, lfsr.py; fsm.py:133-154,197-213), is here too: once a Classic authentication
+// starts, frames are decrypted before the parity check, nested authentications included.
 // Plain host C++, no device work: a packet is a few dozen bits and the machine is sequential.
 #pragma once
 #include <stdint.h>
@@ -157,15 +158,121 @@ inline int find_command(const uint8_t *b, int n, int type, int prev_cmd) {   // 
     return compatible(COMMANDS[option], b, n) ? option : -1;
 }
 
+// ---- CRYPTO1 (cipher.py) ----
+// 48-bit shift register; bit i of `st` is the i-th oldest bit (cipher.py keeps the whole bit history and looks
+// at its last 48).  One filter bit per clock; a clock shifts in L(st) ^ (input & feed_in) ^ (filter & feed_ks).
+struct Crypto1 {
+    uint64_t st = 0;
+    uint8_t ar[4] = {0, 0, 0, 0}, at[4] = {0, 0, 0, 0};   // the expected reader / tag answers (suc64, suc96 of the tag nonce)
+
+    void load_key(const uint8_t key[6]) {   // cipher.py:11-12: key bytes, least significant bit first
+        st = 0;
+        for (int i = 0; i < 48; i++) st |= (uint64_t)((key[i >> 3] >> (i & 7)) & 1) << i;
+    }
+    static int fa(int a, int b, int c, int d) { return ((a | b) ^ (a & d)) ^ (c & ((a ^ b) | d)); }   // cipher.py:97-99
+    static int fb(int a, int b, int c, int d) { return ((a & b) | c) ^ ((a ^ b) & (c | d)); }          // cipher.py:101-103
+    static int fc(int a, int b, int c, int d, int e) {                                                 // cipher.py:105-107
+        return (a | ((b | e) & (d ^ e))) ^ ((a ^ (b & d)) & ((c ^ d) | (b & e)));
+    }
+    int bit(int i) const { return (int)((st >> i) & 1); }
+    int filter() const {   // cipher.py:110-118
+        const int a = fa(bit(9), bit(11), bit(13), bit(15)), b = fb(bit(17), bit(19), bit(21), bit(23));
+        const int c = fb(bit(25), bit(27), bit(29), bit(31)), d = fa(bit(33), bit(35), bit(37), bit(39));
+        const int e = fb(bit(41), bit(43), bit(45), bit(47));
+        return fc(a, b, c, d, e);
+    }
+    int feedback() const {   // cipher.py:75-76
+        static const int taps[18] = {0, 5, 9, 10, 12, 14, 15, 17, 19, 24, 25, 27, 29, 35, 39, 41, 42, 43};
+        int l = 0;
+        for (int t : taps) l ^= bit(t);
+        return l;
+    }
+    // cipher.py:20-35: every bit is xored with the filter output; the ninth bit of a group (the parity, when
+    // has_parity) reuses the keystream bit of the next data bit -- the register does not move for it
+    void crypt(const uint8_t *in, size_t n, uint8_t *out, int feed_in, int feed_ks, int has_parity) {
+        int i = 0;
+        for (size_t k = 0; k < n; k++) {
+            const int f = filter();
+            const int b = in[k] & 1;
+            out[k] = (uint8_t)(f ^ b);
+            if (i < 8 || !has_parity) {
+                const uint64_t nx = (uint64_t)(feedback() ^ (b & feed_in) ^ (f & feed_ks));
+                st = (st >> 1) | (nx << 47);
+                i++;
+            } else {
+                i = 0;
+            }
+        }
+    }
+    // cipher.py:37-42 with lfsr.py: the 32-bit nonce register, taps 16 18 19 21; ar after 64 clocks, at after 96
+    void set_answers(const uint8_t nonce_bits[32]) {
+        uint8_t r[32];
+        memcpy(r, nonce_bits, 32);
+        int idx = 0;
+        auto advance = [&](int ticks) {
+            for (int t = 0; t < ticks; t++) {
+                const int b = r[(16 + idx) & 31] ^ r[(18 + idx) & 31] ^ r[(19 + idx) & 31] ^ r[(21 + idx) & 31];
+                r[idx] = (uint8_t)b;
+                idx = (idx + 1) & 31;
+            }
+        };
+        auto bytes = [&](uint8_t out[4]) {
+            for (int k = 0; k < 4; k++) {
+                int v = 0;
+                for (int i = 0; i < 8; i++) v |= (r[(idx + 8 * k + i) & 31] & 1) << i;
+                out[k] = (uint8_t)v;
+            }
+        };
+        advance(64);
+        bytes(ar);
+        advance(32);
+        bytes(at);
+    }
+    // cipher.py:62-72: mix uid ^ tag nonce into the register.  Plain nonce (first authentication): 32 bits in,
+    // nothing returned.  Encrypted nonce (nested authentication): 36 bits with parity in, the decrypted 36 out.
+    bool set_tag(const std::vector<uint8_t> &uid, const uint8_t *nonce, size_t n_nonce, bool encrypted, uint8_t *plain_out) {
+        uint8_t ub[64], xb[64], kb[64];
+        size_t ll = 0;
+        for (size_t k = 0; k < uid.size() && ll + 9 <= sizeof ub; k++) {
+            for (int i = 0; i < 8; i++) ub[ll++] = (uint8_t)((uid[k] >> i) & 1);
+            if (encrypted) ub[ll++] = 0;   // cipher.py:54-60: a zero where the parity bit sits
+        }
+        if (n_nonce < ll || ll == 0) return false;   // (IndexError in the reference)
+        for (size_t i = 0; i < ll; i++) xb[i] = ub[i] ^ (nonce[i] & 1);
+        crypt(xb, ll, kb, 1, encrypted ? 1 : 0, encrypted ? 1 : 0);
+        uint8_t nb[32];
+        size_t m = 0;
+        for (size_t i = 0; i < ll; i++) {
+            const uint8_t pb = encrypted ? (uint8_t)(ub[i] ^ kb[i]) : (uint8_t)(nonce[i] & 1);
+            if (plain_out) plain_out[i] = pb;
+            if ((!encrypted || i % 9 != 8) && m < 32) nb[m++] = pb;
+        }
+        if (m != 32) return false;
+        set_answers(nb);
+        return true;
+    }
+};
+
 }  // namespace nfc
 
 // ---- the machine (fsm.py) ----
 struct nfc_fsm {
+    nfc_fsm() = default;
+    nfc_fsm(const nfc_fsm &o) { *this = o; }
+    nfc_fsm &operator=(const nfc_fsm &o) {
+        cur_cmd = o.cur_cmd; tag_type = o.tag_type; encrypted = o.encrypted; cipher = o.cipher; uid = o.uid;
+        memcpy(key_a, o.key_a, 6); memcpy(key_b, o.key_b, 6);
+        cur_key = (o.cur_key == o.key_b) ? key_b : key_a;
+        return *this;
+    }
     int cur_cmd = nfc::CMD_REQA;
     int tag_type = -1;          // -1 none, 0 Ultralight, 1 Classic 1K, 2 Classic 4K, 3 DESFire (command.py:70-74)
-    int encrypted = 0;          // a Classic authentication has started: CRYPTO1 (row f3) would be needed from here on
+    int encrypted = 0;          // a CRYPTO1 session is up (fsm._encryption)
+    nfc::Crypto1 cipher;
+    uint8_t key_a[6] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF}, key_b[6] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};   // fsm.py:157-160
+    const uint8_t *cur_key = key_a;
     std::vector<uint8_t> uid;
-    void reset_tag() {
+    void reset_tag() {   // fsm.py:20-24
         uid.clear();
         tag_type = -1;
         encrypted = 0;
@@ -176,7 +283,10 @@ namespace nfc {
 
 // One packet (bits as PacketProcessor hands them over, packets.py:94-98).  Returns the frame record; bytes_out
 // receives the frame's bytes (capacity >= n_bits / 9 + 1).
-inline void fsm_process(nfc_fsm &F, const uint8_t *bits_in, size_t n_bits, int type, nfc_frame *out, uint8_t *bytes_out) {
+// enc_out (optional, same capacity): while a session is up, what was on the air -- one entry per nine bits, the byte in
+// the low half, bit 8 set when the parity bit equals the data parity (the '!' of fsm._print_enc, fsm.py:113-131).
+inline void fsm_process(nfc_fsm &F, const uint8_t *bits_in, size_t n_bits, int type, nfc_frame *out, uint8_t *bytes_out,
+                        uint16_t *enc_out = nullptr) {
     memset(out, 0, sizeof *out);
     out->type = type;
     out->cmd = NFC_CMD_UNKNOWN;
@@ -192,7 +302,44 @@ inline void fsm_process(nfc_fsm &F, const uint8_t *bits_in, size_t n_bits, int t
         out->flags |= NFC_FRAME_MANY_MORE_ERROR;
         bits.resize(n_bits - rem);
     }
-    if (F.encrypted) out->flags |= NFC_FRAME_ENCRYPTED;   // not decrypted here (fsm.py:133-154 is row f3)
+    if (F.encrypted) {   // fsm.py:133-154
+        out->flags |= NFC_FRAME_ENCRYPTED;
+        int ne = 0;
+        {
+            int cur = 0, ones = 0, k = 0;
+            for (uint8_t bit : bits) {
+                if (k < 8) {
+                    cur |= (bit & 1) << k;
+                    ones += bit & 1;
+                    k++;
+                } else {
+                    if (enc_out) enc_out[ne] = (uint16_t)(cur | (((ones & 1) == (bit & 1)) ? 0x100 : 0));
+                    ne++;
+                    cur = ones = k = 0;
+                }
+            }
+        }
+        out->n_enc = (uint16_t)ne;
+        std::vector<uint8_t> plain(bits.size());
+        const size_t ls = (bits.size() + 1) / 9;
+        if (F.cur_cmd == CMD_RANDTA && ls == (size_t)COMMANDS[CMD_RANDRB].total()) {
+            // {nr}{ar}: the reader nonce is fed back into the register while it is decrypted
+            const size_t ll = bits.size() / 2;
+            F.cipher.crypt(bits.data(), ll, plain.data(), 1, 1, 1);
+            F.cipher.crypt(bits.data() + ll, bits.size() - ll, plain.data() + ll, 0, 0, 1);
+        } else if (F.cur_cmd == CMD_AUTHA || F.cur_cmd == CMD_AUTHB) {
+            // nested authentication: a fresh register keyed for the new sector swallows the encrypted tag nonce
+            F.cipher = Crypto1();
+            F.cipher.load_key(F.cur_key);
+            plain.assign(bits.size(), 0);
+            size_t ll = F.uid.size() * 9;
+            if (!F.cipher.set_tag(F.uid, bits.data(), bits.size(), true, plain.data())) ll = 0;
+            plain.resize(ll);
+        } else {
+            F.cipher.crypt(bits.data(), bits.size(), plain.data(), 0, 0, 1);
+        }
+        bits.swap(plain);
+    }
     // fsm.py:28-47: eight data bits LSB first, then the odd-parity bit
     int nb = 0;
     {
@@ -258,7 +405,23 @@ inline void fsm_process(nfc_fsm &F, const uint8_t *bits_in, size_t n_bits, int t
             F.uid.insert(F.uid.end(), extra, extra + 4);
         }
         break;
-    case CMD_AUTHA: case CMD_AUTHB: F.encrypted = 1; break;   // everything after the plaintext request is CRYPTO1
+    case CMD_AUTHA: F.cur_key = F.key_a; break;
+    case CMD_AUTHB: F.cur_key = F.key_b; break;
+    case CMD_RANDTA:
+        if (!F.encrypted) {   // first authentication: the tag nonce came in the clear (fsm.py:197-202)
+            F.cipher = Crypto1();
+            F.cipher.load_key(F.cur_key);
+            uint8_t nb[32];
+            for (int i = 0; i < 32; i++) nb[i] = (uint8_t)((extra[i >> 3] >> (i & 7)) & 1);
+            if (out->n_extra >= 4 && F.cipher.set_tag(F.uid, nb, 32, false, nullptr)) F.encrypted = 1;
+        }
+        break;
+    case CMD_RANDRB:   // fsm.py:203-208
+        out->flags |= (F.encrypted && memcmp(extra + 4, F.cipher.ar, 4) == 0) ? NFC_FRAME_AR_OK : NFC_FRAME_AR_ERROR;
+        break;
+    case CMD_RANDTB:   // fsm.py:209-214
+        out->flags |= (F.encrypted && memcmp(extra, F.cipher.at, 4) == 0) ? NFC_FRAME_AT_OK : NFC_FRAME_AT_ERROR;
+        break;
     default: break;
     }
 }
