@@ -134,6 +134,7 @@ struct nfc_ctx {
         d_close_idx[2];
     DevBuf d_partials, d_partials2, d_aggs;  // scan scratch
     DevBuf d_pack;                           // nfc_get_state staging
+    DevBuf d_gvtop;                          // per chunk: bound of the ring values (guard of the fp64 sums)
     uint32_t cap_edges = 0, cap_sym[2] = {0, 0};   // capacity estimates of the edge / symbol buffers
     uint64_t cap_edges_floor = 0, cap_sym_floor[2] = {0, 0};   // raised when an estimate proved too small for this batch
     double edge_rate = 0.125;                      // entries per sample seen lately (peak-hold with slow decay)
@@ -179,6 +180,7 @@ inline hipError_t mirror_async(nfc_ctx *c) {
 }
 inline void adopt_mirror(nfc_ctx *c) {
     c->h_carry = c->hs->carry;
+    carry_apply_fin(c->h_carry);
     c->h_ecarry = c->hs->ecarry;
     c->h_dcarry = c->hs->dcarry;
 }
@@ -330,6 +332,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
     const uint8_t *h_cert = c->h_cflags, *h_gflags = c->h_cflags + nch, *h_gmin = c->h_cflags + 2 * (size_t)nch,
                   *h_gmax = c->h_cflags + 3 * (size_t)nch;
     HIPCHK(c, c->d_list.ensure((size_t)nch * 4));
+    HIPCHK(c, c->d_gvtop.ensure((size_t)nch * 4));
     c->h_ver.assign(nch, 0);
 
     // carried "HIGH ignored" bookkeeping from (_current_state, _last_bit, _dur) at the first stable sample
@@ -399,6 +402,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
     A.gmin = d_gmin;
     A.gmax = d_gmax;
     A.gflags = d_gflags;
+    A.gvtop = c->d_gvtop.as<uint32_t>();
     A.neg = c->d_neg.as<uint64_t>();
     A.pos = c->d_pos.as<uint64_t>();
     A.twords = c->twords;
@@ -503,25 +507,44 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
         // can every fp64 sum of this batch be proven exact?  (otherwise the summation order matters)
         int emin = 255, emax = 0;
         bool flagged = false;
+        uint32_t vtop = 0;
         if (have_summary && c->stats.threshold_passes == 1) {
             emin = (int)summary.emin;
             emax = (int)summary.emax;
             flagged = summary.flagged != 0;
+            vtop = summary.vtop;
         } else {
             HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
             HIPCHK(c, mirror_async(c));
             HIPCHK(c, hipStreamSynchronize(c->st));
+            std::vector<uint32_t> hv(nch);
+            HIPCHK(c, hipMemcpy(hv.data(), c->d_gvtop.p, (size_t)nch * 4, hipMemcpyDeviceToHost));
             for (uint32_t k = 0; k < nch; k++) {
                 emin = std::min(emin, (int)h_gmin[k]);
                 emax = std::max(emax, (int)h_gmax[k]);
                 if (h_gflags[k] & 1) flagged = true;
+                vtop = std::max(vtop, hv[k]);
             }
         }
         c->h_carry = c->hs->carry;
-        int low = emin - 23, high = emax + 2 + ceil_log2(L);
+        carry_apply_fin(c->h_carry);
+        // Every fp64 sum of the batch is exact -- hence independent of the order it was added in -- when all
+        // operands are multiples of 2^low and no sum reaches 2^(low + 53).  Operands: ring values (24-bit mantissas)
+        // and the carried ss / delta (their lowest set bits); sums: window sums, below av_window times the largest
+        // ring value, and the carried ss itself.
+        int low = emin - 23;
         if (c->h_carry.ss_emin != 255) low = std::min(low, c->h_carry.ss_emin);
+        float vtf;
+        memcpy(&vtf, &vtop, 4);
+        int high = 255 + 64;
+        if (std::isfinite(vtf) && vtf >= 0.f) {
+            const double top = (double)L * (double)vtf;
+            high = top > 0 ? std::ilogb(top) + 127 : 0;
+        }
         high = std::max(high, c->h_carry.ss_emax);
         const bool exact = (emax < 255) && (high - low <= 52);
+        if (dbg) fprintf(stderr, "[nfc] guard: emin %d emax %d ss_emin %d ss_emax %d low %d high %d flagged %d exact %d\n", emin, emax,
+                         c->h_carry.ss_emin, c->h_carry.ss_emax, low, high, (int)flagged, (int)exact);
         if (!exact || flagged) need_seq = true;
     }
 
@@ -1127,7 +1150,7 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs, &c->d_pack};
+                     &c->d_partials, &c->d_aggs, &c->d_pack, &c->d_gvtop};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_cflags) (void)hipHostFree(c->h_cflags);

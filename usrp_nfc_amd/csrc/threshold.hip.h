@@ -52,8 +52,16 @@ struct Carry {
     int32_t ring_emin; // guard over the carried ring values
     int32_t ring_emax;
     int32_t inexact;   // a sequential sum rounded at least once
-    int32_t pad;
+    int32_t fin_valid; // ss_fin holds the sum at the end of the last batch (applied by the next batch's preparation)
+    double ss_fin;     // The end-of-batch sum does NOT overwrite ss: a batch whose sums cannot be proven exact is replayed
+                       // by the sequential kernel from the batch-start ss after the parallel attempt has already finalized.
 };
+__host__ __device__ inline void carry_apply_fin(Carry &c) {
+    if (c.fin_valid) {
+        c.ss = c.ss_fin;
+        c.fin_valid = 0;
+    }
+}
 
 // "HIGH is ignored" (cur_state == 2, transition_sink.py:71) at sample n  <=>  the last LOW sample m < n
 // did not end on a run-length timeout (transition_sink.py:95-99 resets the state) and n - m <= max_len + 1.
@@ -105,6 +113,7 @@ struct ThrArgs {
     float *ring_in;        // [nchunks][L] the ring each chunk's latest evaluation started from
     RunMeta *meta;
     uint8_t *gmin, *gmax, *gflags;  // out: guard exponents / flags of the chunk's latest evaluation
+    uint32_t *gvtop;                // out: raw bits of an upper bound of every value the chunk's ring held (bounds the window sums)
     uint64_t *neg, *pos;   // classification bit planes, 64 samples per word: LOW / HIGH
     const uint32_t *list;  // chunks to run (nullptr: all)
     uint32_t nlist;
@@ -480,9 +489,11 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     float *rin = A.ring_in + (size_t)c * L;
     if constexpr (!SIGN_T)
         for (int s = lane; s < A.Lpad; s += 64) tch[s] = 0;
+    uint32_t vtop0 = 0u;   // raw bits of the largest incoming ring value (envelopes are >= 0: bits order like values)
     for (int s = lane; s < L; s += 64) {
         const float v = ring[s];
         rin[s] = v;
+        vtop0 = max(vtop0, __float_as_uint(v));
         if constexpr (SIGN_T) ring[s] = __uint_as_float(__float_as_uint(v) | 0x80000000u);
         if (v != 0.f) {
             const uint32_t e = max(f32_expfield(v), 1u);
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     uint32_t all_robust = 1;
     float min_ss = 3.0e38f;
     int chunk_nl = LL_NONE, chunk_kl = KEY_NONE;
-    uint32_t vmin = 0xFFFFFFFFu, vmax = 0u;   // accepted values as raw bits (positive floats order like uints)
+    uint32_t vmin = 0xFFFFFFFFu, vmax = vtop0;   // accepted values as raw bits (positive floats order like uints)
     uint32_t slot_step = (A.g0modL + m_chunk) % (uint32_t)L;
     const float etaD = 1.0f - 9.5367431640625e-07f;  // 1 - 2^-20
     // raw samples of the next two steps stay in flight while the current step is classified
@@ -768,6 +779,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 if (row_exact(A, lane, m, aj, xj, pj, ss0, w_nl, w_kl, emin, emax, flags, lm, pm)) {
                     ring[sj] = xj;
                     mark(sj);
+                    vmax = max(vmax, __float_as_uint(xj));
                 }
 #pragma unroll
                 for (int k = 0; k < NR; k++) {
@@ -824,6 +836,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     }
     emin = wave_min_u32(emin);
     emax = wave_max_u32(emax);
+    const uint32_t vtop = wave_max_u32(vmax);
     untouched = (uint32_t)wave_sum_f32((float)untouched);
     flags = wave_max_u32(flags);
     if (lane == 0) {
@@ -839,6 +852,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         A.gmin[c] = (uint8_t)emin;
         A.gmax[c] = (uint8_t)emax;
         A.gflags[c] = (uint8_t)(flags | (untouched ? 2u : 0u));
+        A.gvtop[c] = vtop;
         RunMeta mt;
         mt.min_ss = min_ss;
         mt.eps = eps;
@@ -868,13 +882,14 @@ struct CertSummary {
     uint32_t n_fail;            // chunks whose certification failed (atomic; zeroed by k_fill)
     uint32_t emin, emax;        // exponent fields over every chunk's accepted values
     uint32_t flagged;           // some chunk met a value it cannot vouch for
+    uint32_t vtop;              // raw bits of an upper bound of every ring value of the batch
 };
 constexpr int FIN_BLOCK = 256;
 // The ring at the end of the batch (look-back over all chunks) and its sum become the carried state; with
 // `sum` the guard summary of the batch is folded too.  One workgroup of FIN_BLOCK threads.
 __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_next, Carry *carry, CertSummary *sum) {
     __shared__ double s_part[FIN_BLOCK / 64];
-    __shared__ uint32_t s_mn[FIN_BLOCK / 64], s_mx[FIN_BLOCK / 64], s_fl[FIN_BLOCK / 64];
+    __shared__ uint32_t s_mn[FIN_BLOCK / 64], s_mx[FIN_BLOCK / 64], s_fl[FIN_BLOCK / 64], s_vt[FIN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double part = 0;
     // a thread's slots in rounds of eight: the common case (the last chunk accepted a sample into the slot) is two
@@ -903,18 +918,21 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
             }
         }
     }
-    uint32_t mn = 255u, mx = 0u, fl = 0u;
+    uint32_t mn = 255u, mx = 0u, fl = 0u, vt = 0u;
     if (sum)
         for (int k = tid; k < A.nchunks; k += FIN_BLOCK) {
             mn = min(mn, (uint32_t)A.gmin[k]);
             mx = max(mx, (uint32_t)A.gmax[k]);
             fl |= (uint32_t)A.gflags[k] & 1u;
+            vt = max(vt, A.gvtop[k]);
         }
     part = wave_sum_f64(part);
     mn = wave_min_u32(mn);
     mx = wave_max_u32(mx);
     fl = wave_max_u32(fl);
+    vt = wave_max_u32(vt);
     if (lane == 0) {
+        s_vt[wave] = vt;
         s_part[wave] = part;
         s_mn[wave] = mn;
         s_mx[wave] = mx;
@@ -928,12 +946,15 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
             mn = min(mn, s_mn[w]);
             mx = max(mx, s_mx[w]);
             fl |= s_fl[w];
+            vt = max(vt, s_vt[w]);
         }
-        carry->ss = S + carry->delta;
+        carry->ss_fin = S + carry->delta;
+        carry->fin_valid = 1;
         if (sum) {
             sum->emin = mn;
             sum->emax = mx;
             sum->flagged = fl;
+            sum->vtop = vt;
         }
     }
 }
@@ -1057,6 +1078,7 @@ __device__ __forceinline__ void prepare_batch(const float *ring, int L, Carry *c
     fill_reduce(red, part, emin, emax);
     if (tid == 0) {
         const double S = part;
+        carry_apply_fin(*carry);
         const double ss = carry->ss;
         const double delta = ss - S;
         carry->delta = delta;
@@ -1067,7 +1089,7 @@ __device__ __forceinline__ void prepare_batch(const float *ring, int L, Carry *c
         carry->ss_emax = max(eh, eh2);
         carry->ring_emin = (int)emin;
         carry->ring_emax = (int)emax;
-        if (sum) *sum = CertSummary{0u, 255u, 0u, 0u};
+        if (sum) *sum = CertSummary{0u, 255u, 0u, 0u, 0u};
     }
 }
 
@@ -1211,6 +1233,7 @@ __global__ __launch_bounds__(64) void k_threshold_seq(SeqArgs A) {
         }
     }
     A.carry->ss = ss;
+    A.carry->fin_valid = 0;   // (a parallel attempt at this batch may have left its end-of-batch sum: void)
     if (err != 0.0) A.carry->inexact = 1;
 }
 
