@@ -103,52 +103,11 @@ GOLD_1K = os.path.join(os.path.dirname(__file__), 'golden', '1k_with_enc.out')
 
 
 def packets_from_trace(path):
-    """Rebuild the on-air packets from the reference's own MIFARE Classic trace (outputs/1k_with_enc.out): a frame
-    of a CRYPTO1 session is printed as ciphertext first ('!' where the parity bit equals the data parity), any
-    other frame is its decoded bytes under odd parity.  Returns (packets, expected text)."""
-    to_bits = utilities.Convert.to_bit_ar
-    by_name = {}
-    for c in command.CommandType.table():
-        by_name.setdefault(c.name(), c.packet_type())
-    raw = open(path).read()
-    # the run's main thread printed "PROCESSING FINISHED" into the middle of one ciphertext line (usrp_nfc.py:172-173
-    # races the decoder thread): take it out again
-    raw = raw.replace(' PROCESSING FINISHED\n', ' ')
-    lines = raw.split('\n')
-    start = next(i for i, l in enumerate(lines) if l.startswith('COMMAND') or l.startswith('0x'))
-    text = '\n'.join(lines[start:])
-    packets, enc, cur = [], None, None
-
-    def flush():
-        if cur is None:
-            return
-        name, data = cur
-        if cur_enc is not None:
-            bits = []
-            for tok in cur_enc:
-                v = int(tok.rstrip('!'), 16)
-                byte = [(v >> i) & 1 for i in range(8)]
-                ones = sum(byte) & 1
-                bits += byte + [ones if tok.endswith('!') else 1 - ones]
-        elif name in ('REQA', 'WUPA'):
-            bits = to_bits(data)[:7] + [0]              # 7-bit short frame as the framing stage hands it over
-        else:
-            bits = to_bits(data, parity=True)
-        packets.append((by_name[name], bits))
-
-    cur_enc = None
-    for l in lines[start:]:
-        if l.startswith('0x'):
-            flush()
-            cur = None
-            enc = l.split()
-        elif l.startswith('COMMAND:'):
-            flush()
-            cur, cur_enc, enc = (l.split()[1], []), enc, None
-        elif l.startswith(('HEADER:', 'EXTRA:', 'CRC:')) and cur is not None:
-            cur[1].extend(int(t, 16) for t in l.split()[1:])
-    flush()
-    return packets, text
+    """The packets the framing stage would hand over for the frames of a printed trace (synth.frames_from_trace):
+    a short frame arrives as its seven bits and the end bit."""
+    from usrp_nfc_amd import synth
+    frames, text = synth.frames_from_trace(path)
+    return [(d, bits + [0] if len(bits) == 7 else bits) for d, bits in frames], text
 
 
 def test_classic_1k_trace_with_crypto1():
@@ -166,3 +125,27 @@ def test_crypto1_wrong_key_is_noticed():
     for t, bits in packets[:12]:
         m.process_bits(bits, t)
     assert 'AR OK' not in out.getvalue()
+
+
+@pytest.mark.gpu
+def test_classic_1k_capture_to_trace_on_gpu():
+    # BASELINE.json configs[3] in miniature: the MIFARE Classic 1K transaction of outputs/1k_with_enc.out, synthesised
+    # at 10 Msps from its on-air bits (ciphertext included), decoded on the GPU with the constructor arguments scaled
+    # to the rate (hard part 5), then through the protocol layer with CRYPTO1: the printed trace
+    from usrp_nfc_amd import api, synth
+    frames, text = synth.frames_from_trace(GOLD_1K)
+    m = synth.modulation_profile(frames, rate_msps=10.0, lead_in=15000, tail=2000)
+    iq = synth.iq_from_profile(m, seed=5)
+    ctx = api.NfcContext(samp_rate=10e6, hi_val=1.1, av_window=10000, max_len=250, input_kind=api.NFC_IN_IQ_F32)
+    ctx.push(iq)
+    assert ctx.stats().used_sequential == 0
+    tabs = [ctx.packet_table(t) for t in (0, 1)]
+    bits = [ctx.packet_bits(t) for t in (0, 1)]
+    table = np.concatenate(tabs)
+    table = table[np.argsort(table['idx'], kind='stable')]
+    table = table[table['n_bits'] > 0]
+    out = io.StringIO()
+    frames_out, _ = fsm.fsm(out=out).process_packets(table, bits[0], bits[1])
+    assert len(frames_out) == 202
+    assert out.getvalue().rstrip('\n') == text.rstrip('\n')
+    ctx.close()

@@ -69,6 +69,55 @@ def frame_bits(data, short_bits=0):
     return out
 
 
+# direction of every command name the reference's traces print (command.py:78-118)
+_TRACE_DIRECTION = dict(REQA=READER, WUPA=READER, ANTI1R=READER, SEL1R=READER, ANTI2R=READER, SEL2R=READER, AUTHA=READER,
+                        AUTHB=READER, RANDRB=READER, READR=READER, HALT=READER, WRITE=READER, COMPW1=READER, COMPW2=READER,
+                        ATQAUL=TAG, ATQA1K=TAG, ATQADS=TAG, ANTI1U=TAG, ANTI1G=TAG, SEL1U=TAG, SEL1K=TAG, ANTI2T=TAG, RANDTA=TAG,
+                        RANDTB=TAG, SEL2T=TAG, READT=TAG)
+
+
+def frames_from_trace(path):
+    """The on-air frames of one of the reference's printed traces (outputs/*.out), as (direction, data bits) for
+    modulation_profile, plus the trace text itself (banner lines dropped).
+
+    A frame of a CRYPTO1 session is printed as ciphertext first -- a byte per nine bits, '!' where the parity bit
+    equals the data parity (fsm._print_enc, fsm.py:113-131) -- so its bits are exactly recoverable; any other frame
+    is its decoded bytes under odd parity; REQA / WUPA are 7-bit short frames.  (One line of 1k_with_enc.out has the
+    run's "PROCESSING FINISHED" printed into it by the main thread: taken out again.)"""
+    raw = open(path).read().replace(' PROCESSING FINISHED\n', ' ')
+    lines = raw.split('\n')
+    start = next(i for i, l in enumerate(lines) if l.startswith('COMMAND') or l.startswith('0x'))
+    frames, pending_enc, cur = [], None, None
+
+    def flush():
+        if cur is None:
+            return
+        name, data, enc = cur
+        if enc is not None:
+            bits = []
+            for tok in enc:
+                v = int(tok.rstrip('!'), 16)
+                byte = [(v >> i) & 1 for i in range(8)]
+                ones = sum(byte) & 1
+                bits += byte + [ones if tok.endswith('!') else 1 - ones]
+        else:
+            bits = frame_bits(data, 7 if name in ('REQA', 'WUPA') else 0)
+        frames.append((_TRACE_DIRECTION[name], bits))
+
+    for l in lines[start:]:
+        if l.startswith('0x'):
+            flush()
+            cur = None
+            pending_enc = l.split()
+        elif l.startswith('COMMAND:'):
+            flush()
+            cur, pending_enc = (l.split()[1], [], pending_enc), None
+        elif l.startswith(('HEADER:', 'EXTRA:', 'CRC:')) and cur is not None:
+            cur[1].extend(int(t, 16) for t in l.split()[1:])
+    flush()
+    return frames, '\n'.join(lines[start:])
+
+
 def miller_pulses(bits):
     """Modified Miller (level, us) list: start-of-frame zero, the bits, end zero."""
     one = [(1, T_HALF), (0, T_ZERO), (1, T_ONE_REM)]
