@@ -35,7 +35,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--samples', type=float, default=1e8, help='samples per GPU')
-    ap.add_argument('--workload', default='miller', choices=['miller', 'manchester', 'all'])
+    ap.add_argument('--workload', default='miller', choices=['miller', 'manchester', 'all', 'classic1k'],
+                    help="BASELINE.json configs[1] / [2] / both decoders at 2 Msps, or configs[3] / [4]: the MIFARE Classic 1K "
+                         "transaction of outputs/1k_with_enc.out at 10 Msps (pass --samples 1e9)")
     ap.add_argument('--chunk', type=int, default=0, help='time-chunk samples of the threshold kernel (0: library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
@@ -43,7 +45,20 @@ def parse():
 
 
 def decoder_flags(workload):
-    return dict(reader=workload in ('miller', 'all'), tag=workload in ('manchester', 'all'))
+    return dict(reader=workload in ('miller', 'all', 'classic1k'), tag=workload in ('manchester', 'all', 'classic1k'))
+
+
+def stream_params(workload):
+    """Sample rate and the constructor arguments that go with it.  At 10 Msps the reference's fixed-sample defaults
+    (av_window 2000, max_len 50 samples) chop every bit period (hard part 5): they are scaled
+    with the rate, as its keyword arguments allow (transition_sink.py:12)."""
+    if workload == 'classic1k':
+        return dict(samp_rate=10e6, hi_val=1.1, av_window=10000, max_len=250)
+    return dict(samp_rate=2e6, hi_val=1.1)
+
+
+def shard_overlap(workload):
+    return OVERLAP * 5 if workload == 'classic1k' else OVERLAP   # the same time span at 10 Msps
 
 
 def make_capture_slice(workload, n_per_rank, rank, world):
@@ -52,10 +67,16 @@ def make_capture_slice(workload, n_per_rank, rank, world):
     The modulation profile is a pure function of the global sample index (a frame sequence tiled after a
     3000-sample idle lead-in); the noise comes from a per-rank PCG64 stream, the overlap region from the
     predecessor's stream, so neighbouring ranks agree on the samples they share."""
-    picks = {'miller': (0, 2, 4, 10), 'manchester': (1, 3, 5, 11), 'all': tuple(range(19))}[workload]
-    frames = [(d, synth.frame_bits(data, sb)) for d, _, data, sb in (synth.ULTRALIGHT_TXN[i] for i in picks)]
-    period = synth.modulation_profile(frames, rate_msps=2.0, lead_in=0, tail=0)
-    lead = 3000
+    if workload == 'classic1k':
+        frames, _ = synth.frames_from_trace(os.path.join(ROOT, 'tests', 'golden', '1k_with_enc.out'))
+        period = synth.modulation_profile(frames, rate_msps=10.0, lead_in=0, tail=0)
+        lead = 15000   # covers the 10000-sample window
+    else:
+        picks = {'miller': (0, 2, 4, 10), 'manchester': (1, 3, 5, 11), 'all': tuple(range(19))}[workload]
+        frames = [(d, synth.frame_bits(data, sb)) for d, _, data, sb in (synth.ULTRALIGHT_TXN[i] for i in picks)]
+        period = synth.modulation_profile(frames, rate_msps=2.0, lead_in=0, tail=0)
+        lead = 3000
+    overlap = shard_overlap(workload)
 
     def profile(g_lo, g_hi):
         g = np.arange(g_lo, g_hi, dtype=np.int64)
@@ -79,7 +100,7 @@ def make_capture_slice(workload, n_per_rank, rank, world):
     own = noisy(lo, lo + n_per_rank, rank)
     if rank == 0:
         return np.zeros(0, np.float32), own
-    ov = noisy(lo - OVERLAP, lo, rank - 1)
+    ov = noisy(lo - overlap, lo, rank - 1)
     return ov, own
 
 
@@ -107,7 +128,7 @@ def main():
     flags = decoder_flags(a.workload)
     d_own = api.DeviceBuffer(own, dev)
     d_ov = api.DeviceBuffer(ov, dev) if len(ov) else None
-    ctx = api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32, device=dev, chunk_samples=a.chunk, **flags)
+    ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, device=dev, chunk_samples=a.chunk, **stream_params(a.workload), **flags)
 
     def barrier():
         if dist is not None:
@@ -172,8 +193,11 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 envelope / f64 window sums / u8 symbols', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: Miller-only decode, synthetic IQ @2 Msps' if a.workload == 'miller'
-                       else 'workload=%s' % a.workload,
+            'config': {'workload': {'miller': 'configs[1]: Miller-only decode, synthetic IQ @2 Msps',
+                                    'manchester': 'configs[2]: Manchester-only decode, synthetic IQ @2 Msps',
+                                    'all': 'both decoders (-t all), Ultralight transaction, synthetic IQ @2 Msps',
+                                    'classic1k': 'configs[3]/[4]: -t all @10 Msps, MIFARE Classic 1K transaction tiled '
+                                                 '(av_window 10000, max_len 250)'}[a.workload],
                        'samples_per_gpu': n, 'time_chunk_samples': int(st.chunk_samples), 'time_chunks': int(st.n_chunks), 'parallelism': 'time-chunk x%d' % world,
                        'edges_per_gpu': n_edges, 'symbols_reader': int(cnt.n_symbols[1]),
                        'symbols_tag': int(cnt.n_symbols[0]), 'packets': int(cnt.n_packets[0] + cnt.n_packets[1]),
@@ -189,7 +213,7 @@ def main():
         if not a.no_parity:
             out['parity'] = parity_check(a, own, flags, n)
         if not a.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
-            out['cpu_baseline'] = cpu_baseline(own, flags)
+            out['cpu_baseline'] = cpu_baseline(own, flags, stream_params(a.workload))
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
@@ -213,9 +237,9 @@ def hbm_traffic(a, n):
 def parity_check(a, own, flags, n):
     """Rank 0's chunk decoded from a fresh stream, GPU vs the pinned C oracle, full size."""
     from oracle import c_oracle as co
-    ctx = api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32, **flags)
+    ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **stream_params(a.workload), **flags)
     ctx.push(own)
-    o = co.COracle(samp_rate=2e6, hi_val=1.1, **flags)
+    o = co.COracle(**stream_params(a.workload), **flags)
     o.push_iq(own)
     ge, oe = ctx.edges(), o.edges()
     ok_edges = len(ge) == len(oe) and np.array_equal(ge['idx'].astype(np.int64), oe['idx']) and \
@@ -228,11 +252,11 @@ def parity_check(a, own, flags, n):
             'symbols_equal': bool(ok_sym), 'packets_equal': bool(ok_pk), 'n_edges': int(len(oe)), 'n_packets': len(gp)}
 
 
-def cpu_baseline(own, flags):
+def cpu_baseline(own, flags, params):
     """The reference's CPU path timed on this host: the pinned C port of the per-sample loop (1 core),
     and -- for the reference's own language -- the line-for-line Python restatement on a prefix."""
     from oracle import c_oracle as co, py_oracle as po
-    o = co.COracle(samp_rate=2e6, hi_val=1.1, **flags)
+    o = co.COracle(**params, **flags)
     n = len(own) // 2
     t0 = time.perf_counter()
     o.push_iq(own)
@@ -240,7 +264,7 @@ def cpu_baseline(own, flags):
     npy = min(n, 4_000_000)
     x = synth.envelope_f32(own[:2 * npy])
     t0 = time.perf_counter()
-    po.run_path(x, samp_rate=2e6, hi_val=1.1, chunk=8192, **flags)
+    po.run_path(x, chunk=8192, **params, **flags)
     tp = time.perf_counter() - t0
     return {'value': n / tc / 1e6, 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
             'sample': 'oracle/nfc_oracle.c (C restatement of transition_sink+decoders), whole %d-sample workload, '
