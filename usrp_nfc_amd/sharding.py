@@ -93,7 +93,10 @@ class TorchDistComm(object):
 
     def exchange(self):
         """All ranks' (speculated start state, true end state) as byte vectors, in rank order."""
-        self.dist.all_gather(self._recv_parts, self._send)
+        if self.device_slots:
+            self.dist.all_gather_into_tensor(self._recv, self._send)   # RCCL's native form: one flat buffer
+        else:
+            self.dist.all_gather(self._recv_parts, self._send)
         if self.device_slots:
             self._recv_host.copy_(self._recv, non_blocking=True)   # one pinned copy of the gathered frames
             self._torch.cuda.current_stream().synchronize()
