@@ -163,3 +163,15 @@ def test_ragged_batch_end(n):
     st = r['stats']
     assert st.used_sequential == 0
     assert st.chunks_rerun == 0 and st.threshold_passes == 1, (st.threshold_passes, st.chunks_rerun)
+
+
+def test_stream_that_starts_inside_a_transaction():
+    # No idle lead-in: the fill phase stores pause-level samples, and while they sit in the window the reference's own
+    # running sum rounds (its order matters).  The sequential kernel replays a prefix of a few windows, the rest of the
+    # batch runs on the parallel path -- exact, and not at the one-lane rate
+    period = synth.modulation_profile(synth.txn_frames(), rate_msps=2.0, lead_in=0, tail=0)
+    iq = synth.iq_from_profile(synth.tiled_profile(period, 1_500_000, lead_in=0), seed=3)
+    r = check_vs_oracle(iq, dict(hi_val=1.1), kind=api.NFC_IN_IQ_F32)
+    st = r['stats']
+    assert st.used_sequential == 1            # the prefix
+    assert st.threshold_passes >= 2 and st.n_chunks > 100   # ... and a certified parallel attempt over the rest

@@ -135,6 +135,7 @@ struct nfc_ctx {
     DevBuf d_partials, d_partials2, d_aggs;  // scan scratch
     DevBuf d_pack;                           // nfc_get_state staging
     DevBuf d_gvtop;                          // per chunk: bound of the ring values (guard of the fp64 sums)
+    DevBuf d_seqout;                         // sequential kernel: edge-timing state after its last sample
     uint32_t cap_edges = 0, cap_sym[2] = {0, 0};   // capacity estimates of the edge / symbol buffers
     uint64_t cap_edges_floor = 0, cap_sym_floor[2] = {0, 0};   // raised when an estimate proved too small for this batch
     double edge_rate = 0.125;                      // entries per sample seen lately (peak-hold with slow decay)
@@ -291,10 +292,19 @@ double elapsed_ms(hipEvent_t a, hipEvent_t b) {
 // `ahead`, when given, enqueues the stages that follow (edges, decode) behind the first certification WITHOUT
 // waiting for its verdict: certification almost always succeeds, so the host round trip that reads the verdict
 // overlaps those stages instead of idling the GPU.  *clean reports that the verdict let that work stand.
-int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const std::function<int()> *ahead, bool *clean) {
+// One parallel attempt at the samples [base, n_all) of the batch (base a multiple of the step; the planes, the ring and
+// the carried sums already hold everything before base).  *need_seq: the attempt cannot vouch for its sums (or the
+// sequential kernel was asked for): nothing of it stands and the caller replays sequentially.
+static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint32_t skip_all, uint32_t base, const EdgeCarry &ec,
+                          const std::function<int()> *ahead, bool *clean, bool *need_seq_out) {
     bool ran_ahead = false;
     *clean = false;
     const int L = c->L;
+    const uint32_t n = n_all - base;
+    const uint32_t skip = skip_all > base ? skip_all - base : 0u;
+    const void *d_in = (const char *)d_in_all + (size_t)base * c->in_bytes_per_sample;
+    const uint64_t nseen = c->nseen + base;
+    uint32_t passes = 0;
     // Chunk length for this batch: one wave per chunk, and a chunk's latency is what the launch takes, so
     // aim at one full round of resident waves (no second, half-empty round), never below the configured size.
     if (!c->P.chunk_samples && !c->use_rr) {
@@ -305,11 +315,11 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
         c->C = (int)std::max<uint64_t>(want, (uint64_t)c->C_min);
     }
     // register-ring kernel: chunks are aligned to the ring (chunk c starts at sample c*C - off, slot 0)
-    const uint32_t off = c->use_rr ? (uint32_t)(c->nseen % (uint64_t)L) : 0u;
+    const uint32_t off = c->use_rr ? (uint32_t)(nseen % (uint64_t)L) : 0u;
     const uint32_t nch = (uint32_t)(((uint64_t)n + off + c->C - 1) / c->C);
     c->stats.n_chunks = nch;
     c->stats.chunk_samples = (uint32_t)c->C;
-    const size_t nwords = ((size_t)n + 63) / 64 + 8;
+    const size_t nwords = ((size_t)n_all + 63) / 64 + 8;
     HIPCHK(c, c->d_neg.ensure(nwords * 8));
     HIPCHK(c, c->d_pos.ensure(nwords * 8));
     for (int b = 0; b < 2; b++) {
@@ -323,7 +333,6 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
     HIPCHK(c, c->d_cflags.ensure((size_t)4 * nch));   // sections: cert | gflags | gmin | gmax
     if (c->h_cflags_cap < (size_t)4 * nch) {
         if (c->h_cflags) (void)hipHostFree(c->h_cflags);
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
         c->h_cflags_cap = (size_t)4 * nch + 4096;
         HIPCHK(c, hipHostMalloc((void **)&c->h_cflags, c->h_cflags_cap, hipHostMallocDefault));
     }
@@ -338,12 +347,12 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
     // carried "HIGH ignored" bookkeeping from (_current_state, _last_bit, _dur) at the first stable sample
     const int s0 = (int)skip;
     int nl0, kl0;
-    if (c->h_ecarry.last_bit == -1) {
-        nl0 = s0 - c->h_ecarry.dur - 1;
-        kl0 = 2 * (s0 - 1) + (c->h_ecarry.state == 2 ? 1 : 0);
-    } else if (c->h_ecarry.state == 2) {
+    if (ec.last_bit == -1) {
+        nl0 = s0 - ec.dur - 1;
+        kl0 = 2 * (s0 - 1) + (ec.state == 2 ? 1 : 0);
+    } else if (ec.state == 2) {
         nl0 = s0 - 1;
-        kl0 = 2 * (s0 - c->h_ecarry.dur - 1) + 1;
+        kl0 = 2 * (s0 - ec.dur - 1) + 1;
     } else {
         nl0 = s0 - 1;
         kl0 = KEY_NONE;
@@ -355,16 +364,12 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
     // a 256-sample step must not wrap the ring onto itself: short windows take the sequential kernel
     const bool force_seq = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0 || L < STEP;
     bool need_seq = force_seq;
-    c->stats.threshold_passes = 0;
-    c->stats.chunks_rerun = 0;
-    c->stats.used_sequential = 0;
-
     ThrArgs A;
     memset(&A, 0, sizeof A);
     A.in = d_in;
     A.n = n;
     A.skip = skip;
-    A.g0modL = (uint32_t)(c->nseen % (uint64_t)L);
+    A.g0modL = (uint32_t)(nseen % (uint64_t)L);
     A.L = L;
     A.Lpad = c->Lpad;
     A.mx = c->mx;
@@ -403,8 +408,8 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
     A.gmax = d_gmax;
     A.gflags = d_gflags;
     A.gvtop = c->d_gvtop.as<uint32_t>();
-    A.neg = c->d_neg.as<uint64_t>();
-    A.pos = c->d_pos.as<uint64_t>();
+    A.neg = c->d_neg.as<uint64_t>() + base / 64;
+    A.pos = c->d_pos.as<uint64_t>() + base / 64;
     A.twords = c->twords;
     A.off = (int32_t)off;
     A.nrows = (L + 63) / 64;
@@ -416,6 +421,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
         A.mode = 0;
         launch_threshold_kind(c, A, nch);
         c->stats.threshold_passes++;
+        passes++;
 
         // certify; re-run what cannot be proven from the exact (look-back) state; certify again what can
         // see a re-run chunk.  Every round makes at least the first pending chunk final.
@@ -483,6 +489,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
             A.mode = 1;
             launch_threshold_kind(c, A, A.nlist);
             c->stats.threshold_passes++;
+            passes++;
             c->stats.chunks_rerun += A.nlist;
             HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
             HIPCHK(c, hipStreamSynchronize(c->st));
@@ -508,7 +515,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
         int emin = 255, emax = 0;
         bool flagged = false;
         uint32_t vtop = 0;
-        if (have_summary && c->stats.threshold_passes == 1) {
+        if (have_summary && passes == 1) {
             emin = (int)summary.emin;
             emax = (int)summary.emax;
             flagged = summary.flagged != 0;
@@ -530,17 +537,14 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
         carry_apply_fin(c->h_carry);
         // Every fp64 sum of the batch is exact -- hence independent of the order it was added in -- when all
         // operands are multiples of 2^low and no sum reaches 2^(low + 53).  Operands: ring values (24-bit mantissas)
-        // and the carried ss / delta (their lowest set bits); sums: window sums, below av_window times the largest
-        // ring value, and the carried ss itself.
+        // and the carried ss / delta (their lowest set bits); sums: the window sums (bounded by the kernel from the sums
+        // it tracked) and the carried ss itself.
         int low = emin - 23;
         if (c->h_carry.ss_emin != 255) low = std::min(low, c->h_carry.ss_emin);
         float vtf;
         memcpy(&vtf, &vtop, 4);
-        int high = 255 + 64;
-        if (std::isfinite(vtf) && vtf >= 0.f) {
-            const double top = (double)L * (double)vtf;
-            high = top > 0 ? std::ilogb(top) + 127 : 0;
-        }
+        int high = 255 + 64;   // vtop: f32 bits of an upper bound of every window sum the batch saw
+        if (std::isfinite(vtf) && vtf >= 0.f) high = vtf > 0.f ? std::ilogb((double)vtf) + 127 : 0;
         high = std::max(high, c->h_carry.ss_emax);
         const bool exact = (emax < 255) && (high - low <= 52);
         if (dbg) fprintf(stderr, "[nfc] guard: emin %d emax %d ss_emin %d ss_emax %d low %d high %d flagged %d exact %d\n", emin, emax,
@@ -548,36 +552,82 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
         if (!exact || flagged) need_seq = true;
     }
 
-    if (need_seq) {
-        SeqArgs S;
-        memset(&S, 0, sizeof S);
-        S.in = d_in;
-        S.n = n;
-        S.skip = skip;
-        S.g0modL = (uint32_t)(c->nseen % (uint64_t)L);
-        S.L = L;
-        S.mx = c->mx;
-        S.lo = c->P.lo_val;
-        S.hi = c->P.hi_val;
-        S.hi_plus = c->hi_plus;
-        S.i16_scale = c->i16_scale;
-        S.ring = c->d_ring[c->ring_cur].as<float>();
-        S.carry = dC(c);
-        S.state = c->h_ecarry.state;
-        S.last_bit = c->h_ecarry.last_bit;
-        S.dur = c->h_ecarry.dur;
-        S.neg = c->d_neg.as<uint64_t>();
-        S.pos = c->d_pos.as<uint64_t>();
-        launch_seq_kind(c, S);
-        c->stats.used_sequential = 1;
-    } else {
+    *need_seq_out = need_seq;
+    if (!need_seq) {
         // the end-of-batch ring was resolved beside the last certification unless chunks were re-run after it
-        if (c->stats.threshold_passes > 1 || nch == 1)
+        if (passes > 1 || nch == 1)
             hipLaunchKernelGGL(k_finalize_state, dim3(1), dim3(FIN_BLOCK), 0, c->st, A, c->d_ring[1 - c->ring_cur].as<float>(), dC(c));
         c->ring_cur = 1 - c->ring_cur;
-        *clean = ran_ahead && c->stats.threshold_passes == 1;
+        *clean = ran_ahead && passes == 1;
     }
     return NFC_OK;
+}
+
+// The literal loop on one lane over the samples [base, base + len) of the batch (exact whatever the sums look like).
+// ec_out (optional): (_current_state, _last_bit, _dur) after the last of them, for the attempt that follows.
+static int sequential_span(nfc_ctx *c, const void *d_in_all, uint32_t skip_all, uint32_t base, uint32_t len, const EdgeCarry &ec,
+                           EdgeCarry *ec_out) {
+    SeqArgs S;
+    memset(&S, 0, sizeof S);
+    S.in = (const char *)d_in_all + (size_t)base * c->in_bytes_per_sample;
+    S.n = len;
+    S.skip = skip_all > base ? std::min(skip_all - base, len) : 0u;
+    S.g0modL = (uint32_t)((c->nseen + base) % (uint64_t)c->L);
+    S.L = c->L;
+    S.mx = c->mx;
+    S.lo = c->P.lo_val;
+    S.hi = c->P.hi_val;
+    S.hi_plus = c->hi_plus;
+    S.i16_scale = c->i16_scale;
+    S.ring = c->d_ring[c->ring_cur].as<float>();
+    S.carry = dC(c);
+    S.state = ec.state;
+    S.last_bit = ec.last_bit;
+    S.dur = ec.dur;
+    S.neg = c->d_neg.as<uint64_t>() + base / 64;
+    S.pos = c->d_pos.as<uint64_t>() + base / 64;
+    HIPCHK(c, c->d_seqout.ensure(64));
+    S.out = c->d_seqout.as<int32_t>();
+    launch_seq_kind(c, S);
+    c->stats.used_sequential = 1;
+    if (ec_out) {
+        int32_t o[3];
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        HIPCHK(c, hipMemcpy(o, c->d_seqout.p, sizeof o, hipMemcpyDeviceToHost));
+        ec_out->state = o[0];
+        ec_out->last_bit = o[1];
+        ec_out->dur = o[2];
+    }
+    return NFC_OK;
+}
+
+// The threshold stage of a batch.  Almost always one parallel attempt.  When an attempt cannot prove its fp64 sums
+// exact -- typically a stream that starts inside a transaction: the fill phase stored pause-level samples, and while
+// they sit in the window the reference's own running sum rounds -- the sequential kernel replays a PREFIX (a few
+// windows, until those values have been overwritten) and the rest of the batch gets another parallel attempt.
+int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const std::function<int()> *ahead, bool *clean) {
+    *clean = false;
+    c->stats.threshold_passes = 0;
+    c->stats.chunks_rerun = 0;
+    c->stats.used_sequential = 0;
+    const uint32_t span = (uint32_t)std::min<uint64_t>(((uint64_t)8 * c->L + STEP - 1) / STEP * STEP, 1u << 30);   // prefix per round
+    EdgeCarry ec = c->h_ecarry;
+    uint32_t base = 0;
+    for (int round = 0;; round++) {
+        bool need_seq = false, span_clean = false;
+        const int rc = threshold_span(c, d_in, n, skip, base, ec, base == 0 ? ahead : nullptr, &span_clean, &need_seq);
+        if (rc) return rc;
+        if (!need_seq) {
+            *clean = span_clean && base == 0;
+            return NFC_OK;
+        }
+        const bool forced = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0 || c->L < STEP;
+        const uint32_t left = n - base;
+        if (forced || round >= 6 || left <= 4 * span) return sequential_span(c, d_in, skip, base, left, ec, nullptr);
+        const int rs = sequential_span(c, d_in, skip, base, span, ec, &ec);
+        if (rs) return rs;
+        base += span;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1150,9 +1200,10 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs, &c->d_pack, &c->d_gvtop};
+                     &c->d_partials, &c->d_aggs, &c->d_pack, &c->d_gvtop, &c->d_seqout};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_cflags) (void)hipHostFree(c->h_cflags);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);

@@ -113,7 +113,7 @@ struct ThrArgs {
     float *ring_in;        // [nchunks][L] the ring each chunk's latest evaluation started from
     RunMeta *meta;
     uint8_t *gmin, *gmax, *gflags;  // out: guard exponents / flags of the chunk's latest evaluation
-    uint32_t *gvtop;                // out: raw bits of an upper bound of every value the chunk's ring held (bounds the window sums)
+    uint32_t *gvtop;                // out: raw bits (f32) of an upper bound of every window sum of the chunk
     uint64_t *neg, *pos;   // classification bit planes, 64 samples per word: LOW / HIGH
     const uint32_t *list;  // chunks to run (nullptr: all)
     uint32_t nlist;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     uint32_t all_robust = 1;
     float min_ss = 3.0e38f;
     int chunk_nl = LL_NONE, chunk_kl = KEY_NONE;
-    uint32_t vmin = 0xFFFFFFFFu, vmax = vtop0;   // accepted values as raw bits (positive floats order like uints)
+    uint32_t vmin = 0xFFFFFFFFu, vmax = vtop0;   // raw bits (positive floats order like uints): smallest accepted value; largest value OR window-sum bound
     uint32_t slot_step = (A.g0modL + m_chunk) % (uint32_t)L;
     const float etaD = 1.0f - 9.5367431640625e-07f;  // 1 - 2^-20
     // raw samples of the next two steps stay in flight while the current step is classified
@@ -632,6 +632,9 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 }
             }
             const float dn = (ssf - bt) * slD, up = (ssf + bt) * slU;
+            // every sum inside the step lies below ssf + bt (if the step commits on this path); vmax carries the bound of
+            // the window sums (which dominates every single value: they are non-negative)
+            vmax = max(vmax, __float_as_uint(up));
             const float tlo_dn = dn * loLf, tlo_up = up * loLf, thi_dn = dn * hiLf;
             unsigned long long him[NR], amb = 0, anyhi = 0, anylow = 0;
 #pragma unroll
@@ -683,7 +686,6 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                         posm[j] = 0ull;
                     }
                     vmin = min(vmin, __float_as_uint(tlo_dn));
-                    vmax = max(vmax, __float_as_uint(thi_up));
                 } else {
                     int before = (w_kl & 1) ? (w_kl >> 1) : LL_NONE;  // last LOW before the row (every key here is good)
 #pragma unroll
@@ -757,11 +759,14 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 steps_since_sync = 0;
             }
             float xs[NR], pv[NR];
+            float bx = 0.f;
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 xs[j] = x[j];
                 pv[j] = prev[j];
+                bx += fabsf(x[j] - prev[j]);
             }
+            vmax = max(vmax, __float_as_uint((float)ss0 * slU + wave_sum_f32(bx) * 1.001f));   // no sum inside the step can exceed this
 #pragma unroll 1
             for (int j = 0; j < NR; j++) {
                 const int m = (int)(base + 64u * j) + lane;
@@ -836,7 +841,9 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     }
     emin = wave_min_u32(emin);
     emax = wave_max_u32(emax);
-    const uint32_t vtop = wave_max_u32(vmax);
+    // every window sum of the chunk lies below this: each step folded its own bound (fast: tracked sum + margin, which
+    // covers drift, speculation and rounding; exact: sum + total variation of the step)
+    const uint32_t vtop = wave_max_u32(__float_as_uint(fmaxf(__uint_as_float(wave_max_u32(vmax)), ssf * (1.0f + eps + RND)) * 1.0009765625f));
     untouched = (uint32_t)wave_sum_f32((float)untouched);
     flags = wave_max_u32(flags);
     if (lane == 0) {
@@ -1190,6 +1197,7 @@ struct SeqArgs {
     Carry *carry;
     int32_t state, last_bit, dur;   // transition_sink._current_state/_last_bit/_dur at the batch start
     uint64_t *neg, *pos;
+    int32_t *out;                   // (state, last_bit, dur) after the last sample
 };
 template <int KIND>
 __global__ __launch_bounds__(64) void k_threshold_seq(SeqArgs A) {
@@ -1231,6 +1239,11 @@ __global__ __launch_bounds__(64) void k_threshold_seq(SeqArgs A) {
             A.pos[m >> 6] = wp;
             wn = wp = 0;
         }
+    }
+    if (A.out) {
+        A.out[0] = state;
+        A.out[1] = last_bit;
+        A.out[2] = dur;
     }
     A.carry->ss = ss;
     A.carry->fin_valid = 0;   // (a parallel attempt at this batch may have left its end-of-batch sum: void)
