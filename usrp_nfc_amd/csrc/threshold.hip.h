@@ -510,9 +510,9 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     uint32_t vmin = 0xFFFFFFFFu, vmax = vtop0;   // raw bits (positive floats order like uints): smallest accepted value; largest value OR window-sum bound
     uint32_t slot_step = (A.g0modL + m_chunk) % (uint32_t)L;
     const float etaD = 1.0f - 9.5367431640625e-07f;  // 1 - 2^-20
-    // raw samples of the next two steps stay in flight while the current step is classified
+    // the raw samples of the next step are in flight while the current step is classified
     using Raw = typename RawOf<KIND>::T;
-    Raw r1[NR], r2[NR];
+    Raw r1[NR];
     auto fetch = [&](uint32_t b, Raw (&r)[NR]) {
         if (b + STEPN <= A.n) {
 #pragma unroll
@@ -526,7 +526,6 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         }
     };
     fetch(m_chunk, r1);
-    fetch(m_chunk + STEPN, r2);
     // Every step of a chunk is whole except the batch's last one (masked, see `tail`) and the stretch before the
     // first stable sample, which takes the exact row path (chunk lengths are multiples of the step).
     const float loLf = (float)A.lo_L, hiLf = (float)A.hi_L;   // thresholds in f32 carry 2^-18 of slack (>> 4 roundings)
@@ -552,9 +551,8 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             x[j] = env_of<KIND>(r1[j], A.i16_scale);
-            r1[j] = r2[j];
         }
-        if (base + 2 * STEPN < n1) fetch(base + 2 * STEPN, r2);
+        if (base + STEPN < n1) fetch(base + STEPN, r1);   // one step (~3 us of work) ahead covers the HBM latency; two measured the same
         if (slot_step + STEPN <= (uint32_t)L) {   // the step does not wrap the ring: immediate offsets
             const float *rp = ring + slot_step + lane;
 #pragma unroll
