@@ -1,13 +1,16 @@
 // nfc_amd.hip -- context, batch orchestration and the C-ABI (include/nfc_amd.h) of the
 // MI355X-native ISO-14443A IQ -> bit path.  gfx950 only; no CPU fallback.
 //
-// One nfc_push = one batch:
+// One nfc_push = one batch, enqueued without a host round trip (process_batch):
 //   k_fill (first av_window samples, then the per-batch preparation)
-//   -> k_threshold pass 0 (speculate) -> k_certify (+ end-of-batch ring) [-> re-runs from the exact state | k_threshold_seq]
-//   -> run starts (scan) -> emission counts (scan) -> k_write_edges -> k_edge_carry
-//   -> decoder state maps (scan) -> symbols (scan) -> k_dec_carry
-//   -> per type: framing maps (scan) -> packet bits / closes (scan) -> k_pkt_finish
-// Outputs stay in HBM until read through nfc_read_*.
+//   -> k_threshold pass 0 (speculate) -> k_certify (+ end-of-batch state, verdict summary)
+//      [-> re-runs from the exact state | k_threshold_seq over a prefix, then another attempt]      (run_threshold)
+//   -> last-two-changes scan -> event masks + entry counts -> entry offsets -> k_write_edges        (run_edges)
+//   -> k_dec_reduce -> tile prefixes -> k_dec_apply -> symbol offsets -> k_sym_store
+//   -> per decoder that exists: k_pkt_reduce -> prefixes -> k_pkt_apply -> offsets -> k_pkt_store -> k_pkt_finish   (run_decode)
+//   (batches up to 2^18 samples: the three stages after the threshold stage in ONE launch, small.hip.h)
+// then one wait; the edge / decode stages are repeated if the certification failed or a capacity estimate was short.
+// Outputs stay in HBM until read through nfc_read_*.  Host-only: the protocol layer of protocol.h (nfc_fsm_*).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -130,7 +133,7 @@ struct nfc_ctx {
     DevBuf d_certinfo;
     DevBuf d_in, d_neg, d_pos, d_ringout[2], d_touched[2], d_info[2], d_ringin, d_meta, d_ver, d_cflags, d_list;
     DevBuf d_ctx, d_wcnt, d_ecode;
-    DevBuf d_starts, d_offs, d_edges, d_states, d_sym[2], d_src[2], d_started, d_bits[2], d_pending[2][2], d_close_end[2],
+    DevBuf d_edges, d_states, d_sym[2], d_src[2], d_started, d_bits[2], d_pending[2][2], d_close_end[2],
         d_close_idx[2];
     DevBuf d_partials, d_partials2, d_aggs;  // scan scratch
     DevBuf d_pack;                           // nfc_get_state staging
@@ -148,7 +151,7 @@ struct nfc_ctx {
     const void *last_in = nullptr;
     uint32_t last_n = 0, last_skip = 0;
     uint64_t last_g0 = 0;
-    uint32_t n_runs = 0, n_edges = 0;
+    uint32_t n_edges = 0;
     uint32_t n_sym[2] = {0, 0}, n_close[2] = {0, 0}, n_bits[2] = {0, 0};
     bool have_outputs = false;
     nfc_stats stats;
@@ -209,9 +212,6 @@ __global__ void k_pack_state(uint8_t *dst, const float *ring, int L, const uint8
     uint8_t *pd = dst + (size_t)L * 4;
     for (uint32_t i = tid; i < n0; i += nth) pd[i] = p0[i];
     for (uint32_t i = tid; i < n1; i += nth) pd[n0 + i] = p1[i];
-}
-__global__ void k_set_ecarry(DevState *d, EdgeCarry b) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) d->ecarry = b;
 }
 
 #define HIPCHK(c, call)                                                                              \
@@ -845,7 +845,7 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
 int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     c->have_outputs = false;
     c->pk_ready[0] = c->pk_ready[1] = false;
-    c->n_runs = c->n_edges = 0;
+    c->n_edges = 0;
     for (int t = 0; t < 2; t++) c->n_sym[t] = c->n_close[t] = c->n_bits[t] = 0;
     memset(&c->stats, 0, sizeof c->stats);
     c->n_kev = 0;
@@ -1197,7 +1197,7 @@ void nfc_destroy(nfc_ctx *c) {
     if (c->st) (void)hipStreamSynchronize(c->st);
     DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_state,
                      &c->d_ring[0], &c->d_ring[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
-                     &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_starts, &c->d_offs, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
+                     &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
                      &c->d_partials, &c->d_aggs, &c->d_pack, &c->d_gvtop, &c->d_seqout};
