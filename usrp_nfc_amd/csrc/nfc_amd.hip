@@ -31,7 +31,6 @@
 #include "scan.hip.h"
 #include "small.hip.h"
 #include "threshold.hip.h"
-#include "threshold_rr.hip.h"
 
 using namespace nfc;
 
@@ -99,7 +98,7 @@ struct nfc_ctx {
     int L, mx, C, Lpad, wpb, twords;
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
-    int bands_ok, fast_ok, nfold, use_rr, rows_per_step, C_min, wave_slots, lds_per_slot;
+    int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
     int use_small = 1;   // short batches take the one-launch edge / decode / framing kernel (NFC_NO_SMALL=1 turns it off)
     uint64_t selmask;
     float eps;
@@ -223,10 +222,6 @@ __global__ void k_pack_state(uint8_t *dst, const float *ring, int L, const uint8
 
 template <int KIND>
 void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
-    if (c->use_rr) {   // ring in registers: no LDS, four waves (chunks) per workgroup
-        hipLaunchKernelGGL((k_threshold_rr<KIND>), dim3((nwork + 3) / 4), dim3(256), 0, c->st, A);
-        return;
-    }
     const uint32_t blocks = (nwork + c->wpb - 1) / c->wpb;
     const size_t lds = (size_t)c->wpb * c->Lpad * c->lds_per_slot;
     if (c->rows_per_step == 8) hipLaunchKernelGGL((k_threshold<KIND, 8>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
@@ -307,15 +302,14 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     uint32_t passes = 0;
     // Chunk length for this batch: one wave per chunk, and a chunk's latency is what the launch takes, so
     // aim at one full round of resident waves (no second, half-empty round), never below the configured size.
-    if (!c->P.chunk_samples && !c->use_rr) {
+    if (!c->P.chunk_samples) {
         const uint64_t slots = (uint64_t)c->wave_slots;
         const int stp = 64 * c->rows_per_step;
         uint64_t want = ((uint64_t)n + slots - 1) / slots;
         want = (want + stp - 1) / stp * stp;
         c->C = (int)std::max<uint64_t>(want, (uint64_t)c->C_min);
     }
-    // register-ring kernel: chunks are aligned to the ring (chunk c starts at sample c*C - off, slot 0)
-    const uint32_t off = c->use_rr ? (uint32_t)(nseen % (uint64_t)L) : 0u;
+    const uint32_t off = 0u;   // (chunk c covers samples [c*C - off, (c+1)*C - off): the kernels here use off = 0)
     const uint32_t nch = (uint32_t)(((uint64_t)n + off + c->C - 1) / c->C);
     c->stats.n_chunks = nch;
     c->stats.chunk_samples = (uint32_t)c->C;
@@ -1069,12 +1063,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     C = std::max(C, c->mx + 2);
     c->rows_per_step = 4;
     c->use_small = getenv("NFC_NO_SMALL") ? 0 : 1;
-    c->use_rr = (c->L >= STEP && c->L <= 64 * RR_ROWS && getenv("NFC_RR")) ? 1 : 0;   // experimental: ring in registers
-    if (c->use_rr) {
-        C = std::max(2, (C + c->L / 2) / c->L) * c->L;   // whole ring periods
-        while (C < c->mx + 2) C += c->L;
-    } else {
-        c->rows_per_step = (c->L >= 512 && getenv("NFC_ROWS8")) ? 8 : 4;   // 8-row steps: measured no faster (register pressure)
+    {
+        c->rows_per_step = (c->L >= 512 && getenv("NFC_ROWS8")) ? 8 : 4;   // 8-row steps: measured slower (126 VGPRs: four waves per SIMD)
         const int stp = 64 * c->rows_per_step;
         C = (C + stp - 1) / stp * stp;
     }
