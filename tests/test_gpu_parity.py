@@ -175,3 +175,22 @@ def test_stream_that_starts_inside_a_transaction():
     st = r['stats']
     assert st.used_sequential == 1            # the prefix
     assert st.threshold_passes >= 2 and st.n_chunks > 100   # ... and a certified parallel attempt over the rest
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_parameters_many_chunks(seed):
+    # wider sweep: windows up to 12 000 samples, max_len up to 300 (LUT rows beyond the LDS-staged limit), batches of
+    # several hundred time chunks, streams that start inside modulation, pushes of very different lengths
+    rng = np.random.default_rng(900 + seed)
+    L = int(rng.choice([256, 500, 2000, 4096, 10000, 12000]))
+    mx = int(rng.choice([1, 2, 13, 50, 64, 127, 128, 250, 300]))
+    rate = float(rng.choice([2.0, 4.0, 10.0]))
+    n = int(rng.integers(3 * L + 1000, 900_000))
+    frames = synth.txn_frames()
+    period = synth.modulation_profile(frames, rate_msps=rate, lead_in=0, tail=0, depth=float(rng.choice([0.05, 0.08, 0.2])))
+    m = synth.tiled_profile(period, n, lead_in=int(rng.choice([0, L // 2, L + 500])))
+    iq = synth.iq_from_profile(m, seed=int(rng.integers(1, 1 << 30)), sigma=float(rng.choice([0.0005, 0.002, 0.01])))
+    params = dict(samp_rate=rate * 1e6, hi_val=float(rng.choice([1.05, 1.1])), av_window=L, max_len=mx)
+    check_vs_oracle(iq, params, kind=api.NFC_IN_IQ_F32)
+    cuts = sorted(set([0, n] + rng.integers(0, n, 4).tolist() + [int(rng.integers(0, min(n, 3000)))]))
+    check_vs_oracle(iq, params, kind=api.NFC_IN_IQ_F32, pushes=cuts)
