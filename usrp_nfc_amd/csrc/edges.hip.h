@@ -92,6 +92,11 @@ struct EdgeArgs {
     }
     // (_last_bit, _dur, _current_state) after sample p - 1, given the last two change positions before p
     __device__ __forceinline__ void state_before(int32_t p, Last2 c, int &lb, int &dur, int &st) const {
+        state_before(p, c, lb, dur, st, [this](int32_t q) { return val_at(q); });
+    }
+    // the same with the caller's way of reading val at a position (a tile's planes staged in LDS)
+    template <class Val>
+    __device__ __forceinline__ void state_before(int32_t p, Last2 c, int &lb, int &dur, int &st, Val val) const {
         if (c.s1 == POS_NONE) {                       // still in the run carried into the batch
             lb = last_bit_in;
             if (p <= (int32_t)skip) { dur = dur_in; st = state_in; return; }
@@ -101,13 +106,13 @@ struct EdgeArgs {
             else st = run_state(lb, len);
             return;
         }
-        lb = val_at(c.s1);
+        lb = val(c.s1);
         const int len = p - c.s1;
         dur = mod_mx(len - 1) + 1;
         if (lb != 0) { st = run_state(lb, len); return; }
         if (len >= mx + 1) { st = 0; return; }
         // a short val-0 run keeps what the previous (LOW / HIGH, possibly carried) run left
-        if (c.s2 != POS_NONE) { st = run_state(val_at(c.s2), c.s1 - c.s2); return; }
+        if (c.s2 != POS_NONE) { st = run_state(val(c.s2), c.s1 - c.s2); return; }
         if (c.s1 == (int32_t)skip) { st = state_in; return; }      // the carried run had no sample in this batch
         const int len0 = c.s1 - ((int32_t)skip - dur_in);
         if (last_bit_in == 0) st = (len0 >= mx + 1) ? 0 : state_in;
@@ -143,8 +148,9 @@ __device__ __forceinline__ uint64_t event_mask(const EdgeArgs &A, size_t w, Last
 }
 
 // The entry of the event at bit b of a word (ng / ps: its planes, m: its changes, ctx: the two changes before it).
+template <class Val>
 __device__ __forceinline__ void event_entry(const EdgeArgs &A, int32_t w0, int b, uint64_t ng, uint64_t ps, uint64_t m,
-                                            Last2 ctx, int &v, int &d, int &t) {
+                                            Last2 ctx, int &v, int &d, int &t, Val val) {
     const uint64_t mb = m & low_mask(b);
     Last2 c = ctx;
     if (mb) {
@@ -154,7 +160,7 @@ __device__ __forceinline__ void event_entry(const EdgeArgs &A, int32_t w0, int b
         c.s1 = w0 + b1;
     }
     int lb, dur, st;
-    A.state_before(w0 + b, c, lb, dur, st);
+    A.state_before(w0 + b, c, lb, dur, st, val);
     if ((m >> b) & 1ull) {   // val changes here (transition_sink.py:86-92)
         const int val = ((ng >> b) & 1ull) ? -1 : (int)((ps >> b) & 1ull);
         const int prev_st = st;
@@ -169,6 +175,11 @@ __device__ __forceinline__ void event_entry(const EdgeArgs &A, int32_t w0, int b
         d = A.mx;
         t = cs - 1;
     }
+}
+
+__device__ __forceinline__ void event_entry(const EdgeArgs &A, int32_t w0, int b, uint64_t ng, uint64_t ps, uint64_t m,
+                                            Last2 ctx, int &v, int &d, int &t) {
+    event_entry(A, w0, b, ng, ps, m, ctx, v, d, t, [&A](int32_t q) { return A.val_at(q); });
 }
 
 // ---- scan 1: last two change positions before every word; its apply also marks the word's events and
@@ -257,7 +268,17 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
             const int wl = (int)(code >> 6), b = (int)(code & 63u);
             const int32_t w0 = (int32_t)((wt + wl) * 64);
             int v, d, t;
-            event_entry(A, w0, b, s_ng[wl], s_ps[wl], s_m[wl], s_ctx[wl], v, d, t);
+            // val at an earlier change position: from the staged planes when it lies in this tile (nearly always)
+            auto val = [&](int32_t q) {
+                const long long ql = (long long)(q >> 6) - (long long)wt;
+                if (ql >= 0) {
+                    const int sh = q & 63;
+                    if ((s_ng[ql] >> sh) & 1ull) return -1;
+                    return (int)((s_ps[ql] >> sh) & 1ull);
+                }
+                return A.val_at(q);
+            };
+            event_entry(A, w0, b, s_ng[wl], s_ps[wl], s_m[wl], s_ctx[wl], v, d, t, val);
             const uint32_t g = gbase + rbase + j;
             if (g < cap) {
                 nfc_edge o;
