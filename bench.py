@@ -161,8 +161,8 @@ def main():
     kernel_ms = []
     n_pass = []
     for k in range(a.steps):
-        # HIP events bracket the k_threshold launch on every 4th step of the timed region: an event between two
-        # kernels costs the stream ~6 us, which the other steps do not pay (nfc_amd.h: nfc_set_timing)
+        # every 4th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
+        # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are)
         ctx.set_timing(1 if k % 4 == 0 else 0)
         st = one_step()
         kernel_ms += [st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed)]

@@ -180,9 +180,10 @@ int nfc_reset(nfc_ctx *ctx);
 int nfc_prime(nfc_ctx *ctx, uint64_t start_index, float level);
 
 int nfc_get_stats(nfc_ctx *ctx, nfc_stats *out);
-/* How much of nfc_stats' timing is collected.  Every HIP event recorded between two kernels costs the stream a
- * few microseconds, so the default is 0: no events (the ms_* fields stay 0).  1: ms_total and the threshold
- * kernels' own launch durations (ms_threshold_kernel).  2: also the per-stage split. */
+/* How much of nfc_stats' timing is collected.  Default 0: no events (the ms_* fields stay 0).  1: the threshold
+ * kernels' own launch durations (ms_threshold_kernel), from start / stop events attached to the launches themselves.
+ * 2: also ms_total and the per-stage split, from events recorded as markers between the kernels -- each marker costs
+ * the stream a few microseconds. */
 int nfc_set_timing(nfc_ctx *ctx, int level);
 
 /* ---- "next" row f1: closed packets -> bytes -> commands, on the host -------------------------

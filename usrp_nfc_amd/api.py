@@ -88,7 +88,7 @@ class NfcContext(object):
         return s
 
     def set_timing(self, level):
-        """0: no HIP events in the stream (default), 1: batch total + threshold kernel durations, 2: + per-stage split."""
+        """0: no HIP events (default), 1: threshold kernel durations (events attached to the launches), 2: + batch total and per-stage split (stream markers, a few us each)."""
         self._chk(self.L.nfc_set_timing(self.h, int(level)), 'nfc_set_timing')
 
     def _read(self, fn, total, dtype, *lead):

@@ -12,6 +12,7 @@
 // then one wait; the edge / decode stages are repeated if the certification failed or a capacity estimate was short.
 // Outputs stay in HBM until read through nfc_read_*.  Host-only: the protocol layer of protocol.h (nfc_fsm_*).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -106,7 +107,7 @@ struct nfc_ctx {
     size_t in_bytes_per_sample;
     hipStream_t st = nullptr;
     hipEvent_t ev[8] = {};
-    int timing = 0;   // 0: no events in the stream, 1: batch total + threshold kernels, 2: + stages (nfc_set_timing)
+    int timing = 0;   // 0: no events, 1: the threshold kernels' own start / stop events, 2: + batch total and stages as stream markers (nfc_set_timing)
     hipEvent_t kev[2 * 6] = {};  // start/stop pairs around the first k_threshold launches of a batch
     int n_kev = 0;
     std::string err;
@@ -220,31 +221,30 @@ __global__ void k_pack_state(uint8_t *dst, const float *ring, int L, const uint8
             return fail((c), NFC_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
     } while (0)
 
+// Timed launches (nfc_set_timing >= 1) hand the kernel its own start / stop events (hipExtLaunchKernelGGL): the
+// events take the kernel's begin and end, not the position of a marker in the stream, so they neither measure nor add
+// inter-launch gaps.
 template <int KIND>
-void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
+void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipEvent_t e1) {
     const uint32_t blocks = (nwork + c->wpb - 1) / c->wpb;
     const size_t lds = (size_t)c->wpb * c->Lpad * c->lds_per_slot;
+    if (e0) {
+        if (c->rows_per_step == 8) hipExtLaunchKernelGGL((k_threshold<KIND, 8>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, e0, e1, 0, A);
+        else hipExtLaunchKernelGGL((k_threshold<KIND, 4>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, e0, e1, 0, A);
+        return;
+    }
     if (c->rows_per_step == 8) hipLaunchKernelGGL((k_threshold<KIND, 8>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
     else hipLaunchKernelGGL((k_threshold<KIND, 4>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
 }
 void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
     const bool timed = c->timing >= 1 && c->n_kev < 6;
-    if (timed) (void)hipEventRecord(c->kev[2 * c->n_kev], c->st);
-    struct Stop {
-        nfc_ctx *c;
-        bool timed;
-        ~Stop() {
-            if (timed) {
-                (void)hipEventRecord(c->kev[2 * c->n_kev + 1], c->st);
-                c->n_kev++;
-            }
-        }
-    } stop{c, timed};
+    hipEvent_t e0 = timed ? c->kev[2 * c->n_kev] : nullptr, e1 = timed ? c->kev[2 * c->n_kev + 1] : nullptr;
+    if (timed) c->n_kev++;
     switch (c->P.input_kind) {
-    case NFC_IN_IQ_F32: launch_threshold<IN_IQ_F32>(c, A, nwork); break;
-    case NFC_IN_ENV_F32: launch_threshold<IN_ENV_F32>(c, A, nwork); break;
-    case NFC_IN_REAL_F32_SQ: launch_threshold<IN_REAL_F32_SQ>(c, A, nwork); break;
-    default: launch_threshold<IN_I16_SQ>(c, A, nwork); break;
+    case NFC_IN_IQ_F32: launch_threshold<IN_IQ_F32>(c, A, nwork, e0, e1); break;
+    case NFC_IN_ENV_F32: launch_threshold<IN_ENV_F32>(c, A, nwork, e0, e1); break;
+    case NFC_IN_REAL_F32_SQ: launch_threshold<IN_REAL_F32_SQ>(c, A, nwork, e0, e1); break;
+    default: launch_threshold<IN_I16_SQ>(c, A, nwork, e0, e1); break;
     }
 }
 void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n, int nchunks) {
@@ -854,7 +854,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         return NFC_OK;
     }
     if (((uintptr_t)d_in & 15u) != 0) return fail(c, NFC_ERR_ARG, "device input must be 16-byte aligned");
-    if (c->timing >= 1) HIPCHK(c, hipEventRecord(c->ev[0], c->st));
+    if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[0], c->st));
 
     uint32_t skip = 0;
     bool fills = false;
@@ -964,7 +964,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         HIPCHK(c, mirror_async(c));
         HIPCHK(c, hipStreamSynchronize(c->st));
     }
-    if (c->timing >= 1) {
+    if (c->timing >= 2) {
         HIPCHK(c, hipEventRecord(c->ev[4], c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
     }
@@ -981,8 +981,8 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
             }
         }
     }
-    if (c->timing >= 1) c->stats.ms_total = elapsed_ms(c->ev[0], c->ev[4]);
     if (c->timing >= 2) {
+        c->stats.ms_total = elapsed_ms(c->ev[0], c->ev[4]);
         c->stats.ms_threshold = elapsed_ms(c->ev[1], c->ev[2]);
         c->stats.ms_edges = elapsed_ms(c->ev[2], c->ev[3]);
         c->stats.ms_decode = elapsed_ms(c->ev[3], c->ev[4]);
