@@ -39,6 +39,27 @@ namespace {
 
 std::string g_create_error;
 
+// The first certification of a batch and the edge stage's counting pass both depend on k_threshold only, so they share
+// a launch: the first cert_blocks workgroups certify (the last of them resolves the end-of-batch state), the others
+// count the entries of their 512 words.  (Sequentially they were 22 + 23 us.)
+struct CertLaunch {
+    ThrArgs A;
+    uint8_t *cert;
+    float *ring_next;
+    Carry *carry;
+    CertSummary *sum;
+    uint32_t blocks;
+};
+__global__ __launch_bounds__(256) void k_certify_and_count(CertLaunch C, size_t nwords, LoadLast2 load, StoreCtxAndEvents store,
+                                                           const Last2 *partials, uint32_t *sums) {
+    if (blockIdx.x < C.blocks) {
+        certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, blockIdx.x, C.blocks);
+        return;
+    }
+    scan_apply_sum_block<Last2Op, EW_ITEMS, AddU32, LoadLast2, StoreCtxAndEvents>(nwords, nullptr, load, store, partials, sums,
+                                                                                    blockIdx.x - C.blocks);
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -107,6 +128,8 @@ struct nfc_ctx {
     size_t in_bytes_per_sample;
     hipStream_t st = nullptr;
     hipEvent_t ev[8] = {};
+    bool cert_pending = false;   // the first certification waits to share a launch with the edge stage (k_certify_and_count)
+    CertLaunch cert;
     int timing = 0;   // 0: no events, 1: the threshold kernels' own start / stop events, 2: + batch total and stages as stream markers (nfc_set_timing)
     hipEvent_t kev[2 * 6] = {};  // start/stop pairs around the first k_threshold launches of a batch
     int n_kev = 0;
@@ -440,15 +463,32 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             // the first round also resolves the end-of-batch state (last workgroup) and leaves its verdict as a
             // summary in the mirrored state block; later rounds (after re-runs) read the per-chunk flags
             CertSummary *d_sum = (CertSummary *)(tot + TOT_CERT);
-            hipLaunchKernelGGL(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, d_cert,
-                               dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[1 - c->ring_cur].as<float>(), dC(c),
-                               first_round ? d_sum : (CertSummary *)nullptr);
-            if (!first_round) HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
-            HIPCHK(c, mirror_async(c));
-            if (first_round && ahead) {
+            auto launch_certify = [&]() {
+                hipLaunchKernelGGL(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, d_cert,
+                                   dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[1 - c->ring_cur].as<float>(), dC(c),
+                                   first_round ? d_sum : (CertSummary *)nullptr);
+            };
+            if (first_round && ahead && !dbg) {
+                // the stages that follow are enqueued now; their first full-width kernel takes the certification along
+                c->cert = CertLaunch{A, d_cert, c->d_ring[1 - c->ring_cur].as<float>(), dC(c), d_sum, (np + 3) / 4 + 1};
+                c->cert_pending = true;
                 const int rc = (*ahead)();
+                if (c->cert_pending) {   // (a short batch's one-launch stage, or no edge stage at all: on its own then)
+                    c->cert_pending = false;
+                    launch_certify();
+                    HIPCHK(c, mirror_async(c));
+                }
                 if (rc) return rc;
                 ran_ahead = true;
+            } else {
+                launch_certify();
+                if (!first_round) HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
+                HIPCHK(c, mirror_async(c));
+                if (first_round && ahead) {
+                    const int rc = (*ahead)();
+                    if (rc) return rc;
+                    ran_ahead = true;
+                }
             }
             HIPCHK(c, hipStreamSynchronize(c->st));
             std::vector<uint32_t> failing;
@@ -660,8 +700,14 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     scan_reduce<Last2Op, EW_ITEMS>(c->st, nwords, nullptr, LoadLast2{E}, c->d_partials.as<Last2>());
     scan_partials<Last2Op>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials.as<Last2>(), Last2Op::identity(),
                            (Last2 *)(tot + TOT_LAST2));
-    scan_apply_sum<Last2Op, EW_ITEMS, AddU32>(c->st, nwords, nullptr, LoadLast2{E}, StoreCtxAndEvents{E, ctx, evm},
-                                              c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>());
+    if (c->cert_pending && tiles) {
+        c->cert_pending = false;
+        hipLaunchKernelGGL(k_certify_and_count, dim3((unsigned)(c->cert.blocks + tiles)), dim3(256), 0, c->st, c->cert, nwords, LoadLast2{E},
+                           StoreCtxAndEvents{E, ctx, evm}, c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>());
+    } else {
+        scan_apply_sum<Last2Op, EW_ITEMS, AddU32>(c->st, nwords, nullptr, LoadLast2{E}, StoreCtxAndEvents{E, ctx, evm},
+                                                  c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>());
+    }
     scan_partials<AddU32>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials2.as<uint32_t>(), 0u, (uint32_t *)(tot + TOT_EDGES),
                           EdgeCarryEpilogue{E, (const Last2 *)(tot + TOT_LAST2), dE(c)});
     const uint32_t cap = c->cap_edges;

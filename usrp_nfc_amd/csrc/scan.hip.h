@@ -294,15 +294,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(size_t n, const uint3
 // The same, with store() returning a count per item: the tile's sum of them lands in sums[tile] -- the
 // aggregates of the next scan (over the same tiling), which then needs no reduce launch of its own.
 template <class Tr, int ITEMS, class Tr2, class Load, class Store>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply_sum(size_t n, const uint32_t *n_dev, Load load, Store store,
-                                                              const typename Tr::T *partials, typename Tr2::T *sums) {
+__device__ __forceinline__ void scan_apply_sum_block(size_t n, const uint32_t *n_dev, const Load &load, const Store &store,
+                                                     const typename Tr::T *partials, typename Tr2::T *sums, uint32_t bid) {
     using T = typename Tr::T;
     using T2 = typename Tr2::T;
     if (n_dev) n = min(n, (size_t)*n_dev);
-    if ((size_t)blockIdx.x * SCAN_BLOCK * ITEMS >= n) return;
+    if ((size_t)bid * SCAN_BLOCK * ITEMS >= n) return;
     __shared__ T lds[SCAN_WAVES];
     __shared__ T2 lds2[SCAN_WAVES];
-    const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * ITEMS;
+    const size_t base = ((size_t)bid * SCAN_BLOCK + threadIdx.x) * ITEMS;
     T item[ITEMS];
     T agg = Tr::identity();
 #pragma unroll
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply_sum(size_t n, const u
     }
     T total;
     T excl = block_exclusive<Tr>(agg, lds, total);
-    T run = Tr::op(partials[blockIdx.x], excl);
+    T run = Tr::op(partials[bid], excl);
     T2 mine = Tr2::identity();
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
@@ -322,7 +322,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply_sum(size_t n, const u
         run = Tr::op(run, item[i]);
     }
     const T2 sum = block_sum<Tr2>(mine, lds2);
-    if (threadIdx.x == 0) sums[blockIdx.x] = sum;
+    if (threadIdx.x == 0) sums[bid] = sum;
+}
+template <class Tr, int ITEMS, class Tr2, class Load, class Store>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply_sum(size_t n, const uint32_t *n_dev, Load load, Store store,
+                                                              const typename Tr::T *partials, typename Tr2::T *sums) {
+    scan_apply_sum_block<Tr, ITEMS, Tr2, Load, Store>(n, n_dev, load, store, partials, sums, blockIdx.x);
 }
 
 // Host-side drivers.  `partials` must hold scan_num_tiles<ITEMS>(n) entries.

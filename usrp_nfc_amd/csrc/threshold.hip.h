@@ -966,14 +966,15 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
 
 // One extra workgroup (the last) resolves the end-of-batch ring meanwhile: if every chunk certifies, that is
 // the carried state of the next batch (otherwise k_finalize_state runs again after the re-runs).
-__global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertInfo *dbg, float *ring_next, Carry *carry,
-                                                 CertSummary *sum) {
+// (bid of nblocks: the certification may share a launch with another stage's workgroups, see k_certify_and_count)
+__device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, CertInfo *dbg, float *ring_next, Carry *carry,
+                                              CertSummary *sum, uint32_t bid, uint32_t nblocks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (ring_next && blockIdx.x == gridDim.x - 1) {
+    if (ring_next && bid == nblocks - 1) {
         finalize_state(A, ring_next, carry, sum);
         return;
     }
-    const uint32_t slotid = blockIdx.x * (blockDim.x >> 6) + wave;
+    const uint32_t slotid = bid * (blockDim.x >> 6) + wave;
     if (slotid >= A.nlist) return;
     const uint32_t c = A.list ? A.list[slotid] : slotid + 1;
     const int L = A.L;
@@ -1021,6 +1022,10 @@ __global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertI
         if (!ok && sum) atomicAdd(&sum->n_fail, 1u);
         if (dbg) dbg[c] = CertInfo{d, mt.eps * mt.min_ss, mt.all_robust, (uint32_t)low_ok};
     }
+}
+__global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertInfo *dbg, float *ring_next, Carry *carry,
+                                                 CertSummary *sum) {
+    certify_block(A, cert, dbg, ring_next, carry, sum, blockIdx.x, gridDim.x);
 }
 
 // Lowest / highest set bit of a double on the f32 exponent-field scale (bit value 2^(field-127)).
