@@ -212,6 +212,13 @@ def main():
         }
         if not a.no_parity:
             out['parity'] = parity_check(a, own, flags, n)
+            # the context the timed loop ran in must have produced the same decode (rank 0's shard starts the stream, so
+            # its outputs are those of the fresh decode the oracle was compared with): not only the side context is checked
+            out['parity']['timed_loop_counts_equal'] = bool(
+                n_edges == out['parity']['n_edges'] and int(cnt.n_packets[0] + cnt.n_packets[1]) == out['parity']['n_packets'])
+            if not out['parity']['timed_loop_counts_equal']:
+                raise SystemExit('bench: the timed loop decoded %d edges / %d packets, the oracle %d / %d' % (
+                    n_edges, int(cnt.n_packets[0] + cnt.n_packets[1]), out['parity']['n_edges'], out['parity']['n_packets']))
         if not a.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
             out['cpu_baseline'] = cpu_baseline(own, flags, stream_params(a.workload))
         print(json.dumps(out))

@@ -128,6 +128,11 @@ struct nfc_ctx {
     size_t in_bytes_per_sample;
     hipStream_t st = nullptr;
     hipEvent_t ev[8] = {};
+    bool state_dirty = false, dirty_fill_ring = false;   // host-side carried values not yet on the device (push_state)
+    float dirty_fill = 0.f;
+    Carry dirty_carry;
+    EdgeCarry dirty_ecarry;
+    DecCarry dirty_dcarry;
     bool cert_pending = false;   // the first certification waits to share a launch with the edge stage (k_certify_and_count)
     CertLaunch cert;
     int timing = 0;   // 0: no events, 1: the threshold kernels' own start / stop events, 2: + batch total and stages as stream markers (nfc_set_timing)
@@ -222,10 +227,33 @@ __global__ void k_set_state(DevState *d, Carry a, EdgeCarry b, DecCarry e, int z
     if (zero_totals)
         for (int i = 0; i < TOT_BYTES; i++) d->totals[i] = 0;
 }
-inline void push_state(nfc_ctx *c, int zero_totals = 0, bool fill_ring = false, float fill = 0.f) {
+inline void launch_set_state(nfc_ctx *c, int zero_totals, bool fill_ring, float fill) {
     hipLaunchKernelGGL(k_set_state, dim3(1), dim3(256), 0, c->st, (DevState *)c->d_state.p, c->h_carry, c->h_ecarry, c->h_dcarry,
                        zero_totals, fill_ring ? c->d_ring[c->ring_cur].as<float>() : (float *)nullptr, fill_ring && fill != 0.f ? c->L : c->Lpad,
                        fill);
+}
+// The host values become the device state lazily: with the next batch's first launch (k_fill takes them along), or
+// right away when something reads the device state first (flush_state).
+inline void push_state(nfc_ctx *c, int zero_totals = 0, bool fill_ring = false, float fill = 0.f) {
+    if (zero_totals) {
+        launch_set_state(c, zero_totals, fill_ring, fill);
+        c->state_dirty = false;
+        return;
+    }
+    c->state_dirty = true;
+    c->dirty_fill_ring = c->dirty_fill_ring || fill_ring;
+    if (fill_ring) c->dirty_fill = fill;
+    // the values as of NOW (process_batch advances the host mirrors before the batch's first launch)
+    c->dirty_carry = c->h_carry;
+    c->dirty_ecarry = c->h_ecarry;
+    c->dirty_dcarry = c->h_dcarry;
+}
+inline void flush_state(nfc_ctx *c) {
+    if (!c->state_dirty) return;
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(256), 0, c->st, (DevState *)c->d_state.p, c->dirty_carry, c->dirty_ecarry, c->dirty_dcarry, 0,
+                       c->dirty_fill_ring ? c->d_ring[c->ring_cur].as<float>() : (float *)nullptr,
+                       c->dirty_fill_ring && c->dirty_fill != 0.f ? c->L : c->Lpad, c->dirty_fill);
+    c->state_dirty = c->dirty_fill_ring = false;
 }
 // ring | pending bits (type 0, type 1) as one contiguous byte vector (nfc_get_state)
 __global__ void k_pack_state(uint8_t *dst, const float *ring, int L, const uint8_t *p0, uint32_t n0, const uint8_t *p1, uint32_t n1) {
@@ -276,11 +304,28 @@ void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n, int nchunks) {
     EdgeCarryInit eci{(int32_t *)dE(c), c->L % c->mx};
     uint8_t *ver = c->d_ver.as<uint8_t>();
     CertSummary *sum = (CertSummary *)(dT(c) + TOT_CERT);
+    StateInit init;
+    memset(&init, 0, sizeof init);
+    if (c->state_dirty) {
+        static_assert(offsetof(DevState, totals) <= sizeof init.words && offsetof(DevState, totals) % 4 == 0, "state head fits");
+        DevState h;
+        h.carry = c->dirty_carry;
+        h.ecarry = c->dirty_ecarry;
+        h.dcarry = c->dirty_dcarry;
+        init.apply = 1;
+        init.n_words = (int32_t)(offsetof(DevState, totals) / 4);
+        memcpy(init.words, &h, offsetof(DevState, totals));
+        init.dst = (uint32_t *)c->d_state.p;
+        init.fill_ring = c->dirty_fill_ring ? 1 : 0;
+        init.fill = c->dirty_fill;
+        init.ring_len = c->Lpad;
+        c->state_dirty = c->dirty_fill_ring = false;
+    }
     switch (c->P.input_kind) {
-    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum); break;
-    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum); break;
-    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum); break;
-    default: hipLaunchKernelGGL((k_fill<IN_I16_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum); break;
+    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init); break;
+    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init); break;
+    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init); break;
+    default: hipLaunchKernelGGL((k_fill<IN_I16_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init); break;
     }
 }
 void launch_seq_kind(nfc_ctx *c, const SeqArgs &A) {
@@ -1431,6 +1476,7 @@ __global__ void k_export_state(uint8_t *dst, uint32_t len, int fits, nfc_state_h
 int nfc_export_state(nfc_ctx *c, void *device_dst, size_t cap, size_t *len_out) {
     if (!c || !device_dst || cap < 16 || ((uintptr_t)device_dst & 15u)) return NFC_ERR_ARG;
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
+    flush_state(c);   // (a reset / prime that has not reached the device yet)
     nfc_state_header h;
     fill_state_header(c, &h);   // the carried values are host-mirrored after every push: no wait needed here
     const size_t p0 = h.n_pending_bits[0], p1 = h.n_pending_bits[1];
@@ -1445,6 +1491,7 @@ int nfc_export_state(nfc_ctx *c, void *device_dst, size_t cap, size_t *len_out) 
 
 int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap, uint8_t *pending, size_t pending_cap) {
     if (!c || !h) return NFC_ERR_ARG;
+    flush_state(c);
     HIPCHK(c, hipStreamSynchronize(c->st));
     fill_state_header(c, h);
     const size_t p0 = c->h_dcarry.pending[0], p1 = c->h_dcarry.pending[1];
@@ -1498,6 +1545,7 @@ int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size
     }
     if (p0) HIPCHK(c, hipMemcpy(c->d_pending[0][c->pend_cur].p, pending, p0, hipMemcpyHostToDevice));
     if (p1) HIPCHK(c, hipMemcpy(c->d_pending[1][c->pend_cur].p, pending + p0, p1, hipMemcpyHostToDevice));
+    c->dirty_fill_ring = false;   // (a pending reset / prime fill is superseded by the explicit window)
     HIPCHK(c, hipMemcpy(c->d_ring[c->ring_cur].p, ring, (size_t)c->L * 4, hipMemcpyHostToDevice));
     c->have_outputs = false;
     return upload_carried(c);

@@ -1113,13 +1113,28 @@ struct EdgeCarryInit {
 // then sum them in the reference's order.  One workgroup; the ordered sum, when the
 // exponent spread cannot prove every order equal, is one lane reading LDS.
 // ---------------------------------------------------------------------------
+// A reset / primed / restored stream state that has not reached the device yet rides along with the batch's first
+// launch: the head of the state block (carried values of all stages) by value, and the window's fill value.
+struct StateInit {
+    int32_t apply, fill_ring, ring_len, n_words;
+    float fill;
+    uint32_t *dst;        // the device state block
+    uint32_t words[32];
+};
+
 template <int KIND>
 __global__ __launch_bounds__(FILL_BLOCK) void k_fill(const void *in, uint32_t n, float i16_scale, int L, float *ring, Carry *carry,
-                                                     EdgeCarryInit eci, uint8_t *ver, int nchunks, CertSummary *sum) {
+                                                     EdgeCarryInit eci, uint8_t *ver, int nchunks, CertSummary *sum, StateInit init) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ FillRed red;
     float *lr = (float *)smem;
     const int tid = threadIdx.x;
+    if (init.apply) {
+        if (tid < init.n_words) init.dst[tid] = init.words[tid];
+        if (init.fill_ring)
+            for (int i = tid; i < init.ring_len; i += FILL_BLOCK) ring[i] = i < L ? init.fill : 0.f;
+        __syncthreads();
+    }
     if (carry->stable) {   // nothing to fill: only the per-batch preparation
         prepare_batch(ring, L, carry, ver, nchunks, sum, red);
         return;
