@@ -69,6 +69,78 @@ __device__ __forceinline__ void load_bytes16(const uint8_t *p, size_t base, size
     }
 }
 
+// ---- symbols and framing live in the EDGE domain ------------------------------------------------------
+// A symbol belongs to the edge that emitted it, and a thread's sixteen out-bytes hold its symbols in stream order.  So
+// PacketProcessor.append_bit (packets.py:67-79: two states per type, started or not) needs no scan over the symbol
+// arrays: the framing map of a span of symbols is the latest of its symbols that is not the identity (a start-bit value
+// starts, an error symbol stops, any other bit changes nothing), and it rides in the same aggregate as the symbol counts.
+constexpr uint32_t PM_STOP = 0u, PM_START = 1u, PM_ID = 2u;
+struct SymAgg {
+    uint32_t cnt[2];   // symbols: [0] Manchester / tag, [1] Miller / reader
+    uint32_t map[2];   // framing map over them: PM_*
+};
+struct SymAggOp {
+    using T = SymAgg;
+    static __host__ __device__ __forceinline__ T identity() { return T{{0u, 0u}, {PM_ID, PM_ID}}; }
+    static __device__ __forceinline__ T op(const T &a, const T &b) {
+        return T{{a.cnt[0] + b.cnt[0], a.cnt[1] + b.cnt[1]}, {b.map[0] == PM_ID ? a.map[0] : b.map[0], b.map[1] == PM_ID ? a.map[1] : b.map[1]}};
+    }
+    static __device__ __forceinline__ T shfl_up(const T &v, int d) {
+        return T{{(uint32_t)__shfl_up((int)v.cnt[0], d, 64), (uint32_t)__shfl_up((int)v.cnt[1], d, 64)},
+                 {(uint32_t)__shfl_up((int)v.map[0], d, 64), (uint32_t)__shfl_up((int)v.map[1], d, 64)}};
+    }
+};
+__device__ __forceinline__ uint32_t pm_apply(uint32_t map, uint32_t started) { return map == PM_ID ? started : map; }
+__device__ __forceinline__ uint32_t start_bit_of(int type) { return type == 0 ? 1u : 0u; }   // packets.py:24-28
+
+// f(type, symbol, k) for every symbol in a thread's sixteen out-bytes, in stream order (k: the edge within the thread)
+template <class F>
+__device__ __forceinline__ void for_each_symbol(const uint32_t (&ow)[4], F f) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t w = (ow[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        const uint32_t q = w & 3u;
+        if (q == 0u) continue;
+        if (q == 3u) {
+            f(0, (w >> 2) & 7u, k);
+        } else {
+            f(1, (w >> 2) & 7u, k);
+            if (q == 2u) f(1, (w >> 5) & 7u, k);
+        }
+    }
+}
+__device__ __forceinline__ SymAgg sym_agg_of(const uint32_t (&ow)[4]) {
+    SymAgg a = SymAggOp::identity();
+    for_each_symbol(ow, [&](int t, uint32_t s, int) {
+        a.cnt[t]++;
+        a.map[t] = s > 1u ? PM_STOP : (s == start_bit_of(t) ? PM_START : a.map[t]);
+    });
+    return a;
+}
+// per symbol: bit 0 = appended to the packet, bit 1 = closes a started packet (packets.py:67-79); updates `started`
+__device__ __forceinline__ uint32_t frame_symbol(int t, uint32_t s, uint32_t &started) {
+    uint32_t f;
+    if (s > 1u) {
+        f = started ? 2u : 0u;
+        started = 0u;
+    } else {
+        const bool sb = s == start_bit_of(t);
+        f = (!started && sb) ? 0u : 1u;
+        started = (started || sb) ? 1u : 0u;
+    }
+    return f;
+}
+// per type: appended bits in the low half, closes in the high half
+struct PktCnt {
+    uint64_t v[2];
+};
+struct PktCntOp {
+    using T = PktCnt;
+    static __host__ __device__ __forceinline__ T identity() { return T{{0ull, 0ull}}; }
+    static __device__ __forceinline__ T op(const T &a, const T &b) { return T{{a.v[0] + b.v[0], a.v[1] + b.v[1]}}; }
+    static __device__ __forceinline__ T shfl_up(const T &v, int d) { return T{{AddU64::shfl_up(v.v[0], d), AddU64::shfl_up(v.v[1], d)}}; }
+};
+
 // ---- pass 1: every edge is a pair of state maps (Miller, Manchester); a thread composes its sixteen ----
 // Each edge is routed as background.py:30-35 does: route 2 -> Miller, 1 -> Manchester, 0 dropped.
 template <bool LDS>
@@ -113,18 +185,18 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_reduce(const uint16_t *ecode
 
 // ---- pass 2: a thread walks its edges from its incoming states, one LUT look-up per edge ----
 // What an edge emits, one byte: bits 0-1 = 0 nothing, 1 / 2 Miller symbols, 3 one Manchester symbol;
-// bits 2-4 first symbol, bits 5-7 second symbol.  The tile's symbol counts (Miller low half, Manchester
-// high half) are the aggregates of the scan that places the symbols.
+// bits 2-4 first symbol, bits 5-7 second symbol.  The tile's symbol counts AND the framing maps over its symbols
+// (SymAgg) are the aggregates of the scan that places the symbols and hands every tile its framing state.
 template <bool LDS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode, size_t n, const uint32_t *n_dev, DecTables T,
                                                          const DecMaps *partials, const DecMaps *aggs, uint32_t state0,
-                                                         uint8_t *outw, uint64_t *sym_sums) {
+                                                         uint8_t *outw, SymAgg *sym_aggs) {
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
     __shared__ __attribute__((aligned(16))) uint16_t s_mil[LDS ? DEC_LDS_ROWS * 16 : 8];
     __shared__ __attribute__((aligned(16))) uint16_t s_man[LDS ? DEC_LDS_ROWS * 8 : 8];
     __shared__ DecMaps lds[SCAN_WAVES];
-    __shared__ uint64_t lds2[SCAN_WAVES];
+    __shared__ SymAgg lds2[SCAN_WAVES];
     if (LDS) {
         const int rows = 4 * T.nd;
         if (T.reader)
@@ -142,7 +214,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
     const uint16_t *mil = LDS ? s_mil : T.mil_step;
     const uint16_t *man = LDS ? s_man : T.man_step;
     uint32_t ow[4] = {0u, 0u, 0u, 0u};
-    uint32_t n_mil = 0, n_man = 0;
 #pragma unroll
     for (int k = 0; k < DEC_ITEMS; k++) {
         const uint32_t code = (c[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
@@ -152,215 +223,149 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
             const uint32_t e = mil[li * 16u + (st & 15u)];
             w = e >> 8;
             st = (st & ~15u) | (e & 15u);
-            n_mil += w & 3u;
         } else if (route == 1u && T.tag) {
             const uint32_t e = man[li * 8u + ((st >> 4) & 7u)];
             const uint32_t m = e >> 8;
             w = (m & 3u) ? ((m & 0xFCu) | 3u) : 0u;
             st = (st & 15u) | ((e & 15u) << 4);
-            n_man += (m & 3u) ? 1u : 0u;
         }
         ow[k >> 2] |= w << (8 * (k & 3));
     }
     if (base < n) *(uint4 *)(outw + base) = make_uint4(ow[0], ow[1], ow[2], ow[3]);   // outw has 16 bytes of slack
-    const uint64_t sum = block_sum<AddU64>((uint64_t)n_mil | ((uint64_t)n_man << 32), lds2);
-    if (threadIdx.x == 0) sym_sums[blockIdx.x] = sum;
+    SymAgg total_sa;
+    (void)block_exclusive<SymAggOp>(sym_agg_of(ow), lds2, total_sa);
+    if (threadIdx.x == 0) sym_aggs[blockIdx.x] = total_sa;
 }
 
-// ---- symbols: placed by a scan of the emission counts ---------------------------------------
+// ---- pass 3: symbols to their arrays; framing flags counted -------------------------------------------------
 struct SymOut {
     uint8_t *sym[2];   // [0] Manchester / tag, [1] Miller / reader
-    uint32_t *src[2];  // index of the producing edge -- written for error symbols only (the ones that can close a packet)
     uint32_t cap[2];   // buffer capacities (an overflow is detected by the host from the totals)
 };
-__global__ __launch_bounds__(SCAN_BLOCK) void k_sym_store(const uint8_t *outw, size_t n, const uint32_t *n_dev,
-                                                         const uint64_t *tile_base, SymOut S) {
+__global__ __launch_bounds__(SCAN_BLOCK) void k_sym_frame(const uint8_t *outw, size_t n, const uint32_t *n_dev, const SymAgg *tile_pre,
+                                                         uint32_t started0, uint32_t started1, SymOut S, PktCnt *pk_sums) {
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
-    __shared__ uint64_t lds[SCAN_WAVES];
+    __shared__ SymAgg lds[SCAN_WAVES];
+    __shared__ PktCnt lds2[SCAN_WAVES];
     const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_ITEMS;
     uint32_t ow[4] = {0u, 0u, 0u, 0u};
     if (base < n) {   // k_dec_apply wrote whole 16-byte groups, zero past n
         const uint4 a = *(const uint4 *)(outw + base);
         ow[0] = a.x; ow[1] = a.y; ow[2] = a.z; ow[3] = a.w;
     }
-    uint64_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < DEC_ITEMS; k++) {
-        const uint32_t q = (ow[k >> 2] >> (8 * (k & 3))) & 3u;
-        mine += (q == 3u) ? (1ull << 32) : (uint64_t)q;
-    }
-    uint64_t total;
-    uint64_t run = tile_base[blockIdx.x] + block_exclusive<AddU64>(mine, lds, total);
-    if (!mine) return;
-#pragma unroll
-    for (int k = 0; k < DEC_ITEMS; k++) {
-        const uint32_t w = (ow[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-        const uint32_t q = w & 3u;
-        if (q == 0u) continue;
-        const int type = (q == 3u) ? 0 : 1;
-        const uint32_t off = type == 1 ? (uint32_t)run : (uint32_t)(run >> 32);
-        if (off + 1 < S.cap[type]) {
-            const uint32_t s0 = (w >> 2) & 7u;
-            S.sym[type][off] = (uint8_t)s0;
-            if (s0 > 1u) S.src[type][off] = (uint32_t)(base + k);   // only a symbol that can close a packet needs its edge
-            if (q == 2u) {
-                const uint32_t s1 = (w >> 5) & 7u;
-                S.sym[type][off + 1] = (uint8_t)s1;
-                if (s1 > 1u) S.src[type][off + 1] = (uint32_t)(base + k);
-            }
-        }
-        run += (q == 3u) ? (1ull << 32) : (uint64_t)q;
-    }
+    SymAgg total;
+    const SymAgg pre = SymAggOp::op(tile_pre[blockIdx.x], block_exclusive<SymAggOp>(sym_agg_of(ow), lds, total));
+    uint32_t off[2] = {pre.cnt[0], pre.cnt[1]};
+    uint32_t started[2] = {pm_apply(pre.map[0], started0), pm_apply(pre.map[1], started1)};
+    uint32_t nb[2] = {0u, 0u}, nc[2] = {0u, 0u};
+    for_each_symbol(ow, [&](int t, uint32_t s, int) {
+        if (off[t] + 1 < S.cap[t]) S.sym[t][off[t]] = (uint8_t)s;
+        off[t]++;
+        const uint32_t f = frame_symbol(t, s, started[t]);
+        nb[t] += f & 1u;
+        nc[t] += f >> 1;
+    });
+    PktCnt tot_pk;
+    (void)block_exclusive<PktCntOp>(PktCnt{{(uint64_t)nb[0] | ((uint64_t)nc[0] << 32), (uint64_t)nb[1] | ((uint64_t)nc[1] << 32)}}, lds2, tot_pk);
+    if (threadIdx.x == 0) pk_sums[blockIdx.x] = tot_pk;
 }
 
-// ---- framing: PacketProcessor.append_bit (packets.py:67-79) ---------------------
-// state 0 = not started, 1 = started; nibble map
-__device__ __forceinline__ uint32_t pkt_map(uint32_t s, int start_bit) {
-    if (s > 1u) return 0x00u;                      // error symbol: started -> not started, not started stays
-    if ((int)s == start_bit) return 0x11u;         // start bit: not started -> started (dropped); started stays
-    return 0x10u;                                  // other bit: identity
-}
-__global__ __launch_bounds__(SCAN_BLOCK) void k_pkt_reduce(const uint8_t *sym, size_t n, const uint32_t *n_dev, int start_bit,
-                                                          uint32_t *partials, uint32_t *aggs) {
-    if (n_dev) n = min(n, (size_t)*n_dev);
-    if ((size_t)blockIdx.x * DEC_TILE >= n) return;
-    __shared__ uint32_t lds[SCAN_WAVES];
-    const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    uint32_t w[4];
-    load_bytes16(sym, tid * DEC_ITEMS, n, (uint32_t)(1 - start_bit), w);   // padding: a non-start bit is the identity
-    // the three maps (all -> 0, all -> 1, identity) compose to the latest one that is not the identity
-    uint32_t agg = ComposePkt::identity();
-#pragma unroll
-    for (int k = 0; k < DEC_ITEMS; k++) {
-        const uint32_t m = pkt_map((w[k >> 2] >> (8 * (k & 3))) & 0xFFu, start_bit);
-        agg = (m == 0x10u) ? agg : m;
-    }
-    aggs[tid] = agg;
-    uint32_t total;
-    (void)block_exclusive<ComposePkt>(agg, lds, total);
-    if (threadIdx.x == 0) partials[blockIdx.x] = total;
-}
-// per symbol: bit 0 = appended to the packet, bit 1 = closes a started packet; the tile sums of
-// (appended, closes << 32) are the aggregates of the placing scan
-__global__ __launch_bounds__(SCAN_BLOCK) void k_pkt_apply(const uint8_t *sym, size_t n, const uint32_t *n_dev, int start_bit,
-                                                         const uint32_t *partials, const uint32_t *aggs, uint32_t state0,
-                                                         uint8_t *pflags, uint64_t *sums) {
-    if (n_dev) n = min(n, (size_t)*n_dev);
-    if ((size_t)blockIdx.x * DEC_TILE >= n) return;
-    __shared__ uint32_t lds[SCAN_WAVES];
-    __shared__ uint64_t lds2[SCAN_WAVES];
-    const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    const size_t base = tid * DEC_ITEMS;
-    uint32_t w[4];
-    load_bytes16(sym, base, n, 0xFFu, w);
-    uint32_t total;
-    const uint32_t excl = block_exclusive<ComposePkt>(aggs[tid], lds, total);
-    uint32_t started = ComposePkt::step(ComposePkt::op(partials[blockIdx.x], excl), state0);
-    uint32_t fw[4] = {0u, 0u, 0u, 0u};
-    uint32_t n_bits = 0, n_close = 0;
-#pragma unroll
-    for (int k = 0; k < DEC_ITEMS; k++) {
-        const uint32_t s = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-        if (base + k < n) {
-            uint32_t f;
-            if (s > 1u) {
-                f = started ? 2u : 0u;
-                started = 0u;
-            } else {
-                f = (!started && (int)s == start_bit) ? 0u : 1u;
-                started = (started || (int)s == start_bit) ? 1u : 0u;
-            }
-            n_bits += f & 1u;
-            n_close += f >> 1;
-            fw[k >> 2] |= f << (8 * (k & 3));
-        }
-    }
-    if (base < n) *(uint4 *)(pflags + base) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
-    const uint64_t sum = block_sum<AddU64>((uint64_t)n_bits | ((uint64_t)n_close << 32), lds2);
-    if (threadIdx.x == 0) sums[blockIdx.x] = sum;
-}
+// ---- pass 4: packet bits and closes to their places ------------------------------------------------------------
 struct PktOut {
-    const uint32_t *src;
     const nfc_edge *edges;
-    uint8_t *bits;       // appended bits, starting with the pending ones of earlier batches
-    uint32_t *close_end; // per close: number of bits appended before it (= end offset of the packet)
-    uint64_t *close_idx; // per close: sample index of the closing edge
+    uint8_t *bits[2];       // appended bits per type, starting with the pending ones of earlier batches
+    uint32_t *close_end[2]; // per close: number of bits appended before it (= end offset of the packet)
+    uint64_t *close_idx[2]; // per close: sample index of the closing edge
+    uint32_t cap_bits[2], cap_close[2];   // more than estimated: dropped here, seen by the host in the totals, the stage repeated
 };
-__global__ __launch_bounds__(SCAN_BLOCK) void k_pkt_store(const uint8_t *sym, const uint8_t *pflags, size_t n, const uint32_t *n_dev,
-                                                         const uint64_t *tile_base, PktOut P) {
+__global__ __launch_bounds__(SCAN_BLOCK) void k_pkt_write(const uint8_t *outw, size_t n, const uint32_t *n_dev, const SymAgg *tile_pre,
+                                                         const PktCnt *pk_pre, uint32_t started0, uint32_t started1, PktOut P) {
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
-    __shared__ uint64_t lds[SCAN_WAVES];
+    __shared__ SymAgg lds[SCAN_WAVES];
+    __shared__ PktCnt lds2[SCAN_WAVES];
     const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_ITEMS;
-    uint32_t w[4], fw[4] = {0u, 0u, 0u, 0u};
-    load_bytes16(sym, base, n, 0u, w);
+    uint32_t ow[4] = {0u, 0u, 0u, 0u};
     if (base < n) {
-        const uint4 a = *(const uint4 *)(pflags + base);
-        fw[0] = a.x; fw[1] = a.y; fw[2] = a.z; fw[3] = a.w;
+        const uint4 a = *(const uint4 *)(outw + base);
+        ow[0] = a.x; ow[1] = a.y; ow[2] = a.z; ow[3] = a.w;
     }
-    uint64_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < DEC_ITEMS; k++) {
-        const uint32_t f = (fw[k >> 2] >> (8 * (k & 3))) & 3u;
-        mine += (uint64_t)(f & 1u) | ((uint64_t)(f >> 1) << 32);
-    }
-    uint64_t total;
-    uint64_t run = tile_base[blockIdx.x] + block_exclusive<AddU64>(mine, lds, total);
-    if (!mine) return;
-#pragma unroll
-    for (int k = 0; k < DEC_ITEMS; k++) {
-        const uint32_t f = (fw[k >> 2] >> (8 * (k & 3))) & 3u;
+    SymAgg total;
+    const SymAgg pre = SymAggOp::op(tile_pre[blockIdx.x], block_exclusive<SymAggOp>(sym_agg_of(ow), lds, total));
+    const uint32_t st0[2] = {pm_apply(pre.map[0], started0), pm_apply(pre.map[1], started1)};
+    uint32_t started[2] = {st0[0], st0[1]};
+    uint32_t nb[2] = {0u, 0u}, nc[2] = {0u, 0u};
+    for_each_symbol(ow, [&](int t, uint32_t s, int) {
+        const uint32_t f = frame_symbol(t, s, started[t]);
+        nb[t] += f & 1u;
+        nc[t] += f >> 1;
+    });
+    PktCnt tot_pk;
+    const PktCnt mine{{(uint64_t)nb[0] | ((uint64_t)nc[0] << 32), (uint64_t)nb[1] | ((uint64_t)nc[1] << 32)}};
+    const PktCnt run0 = PktCntOp::op(pk_pre[blockIdx.x], block_exclusive<PktCntOp>(mine, lds2, tot_pk));
+    if (!(mine.v[0] | mine.v[1])) return;
+    uint64_t run[2] = {run0.v[0], run0.v[1]};
+    started[0] = st0[0];
+    started[1] = st0[1];
+    for_each_symbol(ow, [&](int t, uint32_t s, int k) {
+        const uint32_t f = frame_symbol(t, s, started[t]);
         if (f & 2u) {
-            const uint32_t j = (uint32_t)(run >> 32);
-            P.close_end[j] = (uint32_t)run;
-            P.close_idx[j] = P.edges[P.src[base + k]].idx;
-            run += 1ull << 32;
+            const uint32_t j = (uint32_t)(run[t] >> 32);
+            if (j < P.cap_close[t]) {
+                P.close_end[t][j] = (uint32_t)run[t];
+                P.close_idx[t][j] = P.edges[base + k].idx;
+            }
+            run[t] += 1ull << 32;
         } else if (f & 1u) {
-            P.bits[(uint32_t)run] = (uint8_t)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-            run += 1ull;
+            if ((uint32_t)run[t] < P.cap_bits[t]) P.bits[t][(uint32_t)run[t]] = (uint8_t)s;
+            run[t] += 1ull;
         }
-    }
+    });
 }
 
-// After framing: keep the open packet's bits for the next batch and publish the carry.  Reads nothing that it
-// (or a sibling carry kernel) writes, so the edge / decode stages of a batch can be repeated as a whole.
+// After framing: keep the open packet's bits for the next batch and publish the carry.  Reads nothing that it (or a
+// sibling carry epilogue) writes, so the edge / decode stages of a batch can be repeated as a whole.  One workgroup
+// per packet type.
 struct PktFinish {
-    const uint8_t *bits;
-    uint8_t *pending_next;   // [cap]  (the other half of the double buffer)
-    const uint32_t *close_end;
-    const uint64_t *totals;  // (appended incl. pending) | closes << 32
-    const uint32_t *map_total;
+    const uint8_t *bits[2];
+    uint8_t *pending_next[2];   // (the other half of the double buffer)
+    const uint32_t *close_end[2];
+    const PktCnt *totals;       // per type: (appended incl. pending) | closes << 32
+    const SymAgg *sym_total;    // framing map over the batch's symbols
     DecCarry *carry;
-    int type;
-    int32_t started_in;
-    uint32_t pending_cap;
+    int32_t enabled[2], started_in[2];
+    uint32_t pending_cap[2];
+    uint32_t cap_bits[2], cap_close[2];
 };
 __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
-    const uint64_t tot = *F.totals;
+    const int t = blockIdx.x;
+    if (!F.enabled[t]) return;
+    const uint64_t tot = F.totals->v[t];
     const uint32_t nbits = (uint32_t)tot, ncl = (uint32_t)(tot >> 32);
-    const uint32_t from = ncl ? F.close_end[ncl - 1] : 0u;
+    if (nbits > F.cap_bits[t] || ncl > F.cap_close[t]) return;   // the host repeats the stage with room
+    const uint32_t from = ncl ? F.close_end[t][ncl - 1] : 0u;
     const uint32_t keep = nbits - from;
-    for (uint32_t i = threadIdx.x; i < keep && i < F.pending_cap; i += blockDim.x) F.pending_next[i] = F.bits[from + i];
+    for (uint32_t i = threadIdx.x; i < keep && i < F.pending_cap[t]; i += blockDim.x) F.pending_next[t][i] = F.bits[t][from + i];
     if (threadIdx.x == 0) {
-        F.carry->pending[F.type] = keep;
-        F.carry->pkt_started[F.type] = (int32_t)((*F.map_total >> (4 * F.started_in)) & 1u);
+        F.carry->pending[t] = keep;
+        F.carry->pkt_started[t] = (int32_t)pm_apply(F.sym_total->map[t], (uint32_t)F.started_in[t]);
     }
 }
 
-// Decoder states after the batch, from the total of the map scan; also splits the packed symbol totals into the
-// two per-type counts the framing scans read from the device.  Epilogue of the symbol-count partials pass.
+// Decoder states after the batch, from the total of the map scan; also publishes the per-type symbol counts the
+// host checks against the capacities.  Epilogue of the symbol scan's partials pass.
 struct DecCarryEpilogue {
     const DecMaps *total;
     uint32_t state_in;
     DecCarry *carry;
     uint32_t *nsym;
-    __device__ __forceinline__ void operator()(uint64_t sym_total) const {
+    __device__ __forceinline__ void operator()(const SymAgg &sym_total) const {
         const uint32_t st = ComposeDec::step(*total, state_in);
         carry->mil_state = (int32_t)(st & 15u);
         carry->man_state = (int32_t)(st >> 4);
-        nsym[1] = (uint32_t)sym_total;           // Miller / reader
-        nsym[0] = (uint32_t)(sym_total >> 32);   // Manchester / tag
+        nsym[1] = sym_total.cnt[1];   // Miller / reader
+        nsym[0] = sym_total.cnt[0];   // Manchester / tag
     }
 };
 

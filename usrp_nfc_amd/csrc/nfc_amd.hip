@@ -6,8 +6,8 @@
 //   -> k_threshold pass 0 (speculate) -> k_certify (+ end-of-batch state, verdict summary)
 //      [-> re-runs from the exact state | k_threshold_seq over a prefix, then another attempt]      (run_threshold)
 //   -> last-two-changes scan -> event masks + entry counts -> entry offsets -> k_write_edges        (run_edges)
-//   -> k_dec_reduce -> tile prefixes -> k_dec_apply -> symbol offsets -> k_sym_store
-//   -> per decoder that exists: k_pkt_reduce -> prefixes -> k_pkt_apply -> offsets -> k_pkt_store -> k_pkt_finish   (run_decode)
+//   -> k_dec_reduce -> tile prefixes -> k_dec_apply -> symbol offsets + framing states -> k_sym_frame
+//   -> bit / close offsets -> k_pkt_write -> k_pkt_finish (both packet types in each launch)        (run_decode)
 //   (batches up to 2^18 samples: the three stages after the threshold stage in ONE launch, small.hip.h)
 // then one wait; the edge / decode stages are repeated if the certification failed or a capacity estimate was short.
 // Outputs stay in HBM until read through nfc_read_*.  Host-only: the protocol layer of protocol.h (nfc_fsm_*).
@@ -96,10 +96,8 @@ enum : int {
     TOT_RUNS = 0,       // u32
     TOT_EDGES = 8,      // u32
     TOT_DECMAP = 16,    // DecMaps (24 bytes)
-    TOT_SYMS = 48,      // u64: miller | manchester << 32
-    TOT_PKTMAP0 = 56,   // u32
-    TOT_PKTMAP1 = 64,   // u32
-    TOT_PKT0 = 72,      // u64: bits | closes << 32
+    TOT_SYMAGG = 48,    // SymAgg (16 bytes): symbol counts and framing maps of the batch
+    TOT_PKT0 = 72,      // PktCnt: per type, bits | closes << 32
     TOT_PKT1 = 80,
     TOT_LAST2 = 88,     // Last2 (8 bytes)
     TOT_NSYM = 96,      // u32[2]: symbols per packet type
@@ -161,9 +159,9 @@ struct nfc_ctx {
     DevBuf d_certinfo;
     DevBuf d_in, d_neg, d_pos, d_ringout[2], d_touched[2], d_info[2], d_ringin, d_meta, d_ver, d_cflags, d_list;
     DevBuf d_ctx, d_wcnt, d_ecode;
-    DevBuf d_edges, d_states, d_sym[2], d_src[2], d_started, d_bits[2], d_pending[2][2], d_close_end[2],
+    DevBuf d_edges, d_states, d_sym[2], d_bits[2], d_pending[2][2], d_close_end[2],
         d_close_idx[2];
-    DevBuf d_partials, d_partials2, d_aggs;  // scan scratch
+    DevBuf d_partials, d_partials2, d_partials3, d_aggs;  // scan scratch
     DevBuf d_pack;                           // nfc_get_state staging
     DevBuf d_gvtop;                          // per chunk: bound of the ring values (guard of the fp64 sums)
     DevBuf d_seqout;                         // sequential kernel: edge-timing state after its last sample
@@ -771,26 +769,40 @@ int run_decode(nfc_ctx *c) {
     uint8_t *tot = dT(c);
     const uint32_t ce = c->cap_edges;                      // capacity; the count is on the device
     const uint32_t *ne_dev = (const uint32_t *)(tot + TOT_EDGES);
-    const nfc_edge *edges = c->d_edges.as<nfc_edge>();
     const uint32_t cs[2] = {c->cap_sym[0], c->cap_sym[1]};
     const size_t tiles = dec_num_tiles(ce);
-    HIPCHK(c, c->d_states.ensure((size_t)ce + 16));   // one out-word per edge
+    HIPCHK(c, c->d_states.ensure((size_t)ce + 16));   // one out-byte per edge
+    HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(DecMaps)));
+    HIPCHK(c, c->d_partials2.ensure((tiles + 1) * sizeof(SymAgg)));
+    HIPCHK(c, c->d_partials3.ensure((tiles + 1) * sizeof(PktCnt)));
+    HIPCHK(c, c->d_aggs.ensure((tiles * SCAN_BLOCK + 1) * sizeof(DecMaps)));
+    const int pn = 1 - c->pend_cur;   // the open packets' bits go to the other half of the double buffer
+    const bool enabled[2] = {c->T.tag != 0, c->T.reader != 0};   // background.py:17-25
+    uint32_t pend[2] = {0u, 0u};
     for (int t = 0; t < 2; t++) {
         HIPCHK(c, c->d_sym[t].ensure((size_t)cs[t] + 16));
-        HIPCHK(c, c->d_src[t].ensure(((size_t)cs[t] + 16) * 4));
+        if (!enabled[t]) continue;   // no symbols of this type; its carry stays
+        pend[t] = c->h_dcarry.pending[t];
+        HIPCHK(c, c->d_bits[t].ensure((size_t)pend[t] + cs[t] + 16));
+        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend[t] + cs[t] + 16));
+        HIPCHK(c, c->d_close_end[t].ensure(((size_t)cs[t] + 4) * 4));
+        HIPCHK(c, c->d_close_idx[t].ensure(((size_t)cs[t] + 4) * 8));
+        if (pend[t]) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t][c->pend_cur].p, pend[t], hipMemcpyDeviceToDevice, c->st));
     }
-    HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(DecMaps)));
-    HIPCHK(c, c->d_partials2.ensure((tiles + 1) * sizeof(uint64_t)));
-    HIPCHK(c, c->d_aggs.ensure((tiles * SCAN_BLOCK + 1) * sizeof(DecMaps)));
 
-    // decoder states: tile maps -> tile prefixes -> every thread walks its edges; the walk's symbol counts per
-    // tile feed the scan that places the symbols
+    // decoder states: tile maps -> tile prefixes -> every thread walks its edges.  What the walk emits stays per edge
+    // (one byte); a tile's symbol counts and the framing map over its symbols are the aggregates of the next scan,
+    // which places the symbols and hands every tile the packet state it starts in.
     const uint16_t *ecode = c->d_ecode.as<uint16_t>();
     uint8_t *outw = c->d_states.as<uint8_t>();
     const uint32_t dec_state_in = (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4);
+    const uint32_t started0 = (uint32_t)c->h_dcarry.pkt_started[0], started1 = (uint32_t)c->h_dcarry.pkt_started[1];
     const bool lds_tables = 4 * c->T.nd <= DEC_LDS_ROWS;
     DecMaps *dparts = c->d_partials.as<DecMaps>(), *daggs = c->d_aggs.as<DecMaps>();
-    uint64_t *sums = c->d_partials2.as<uint64_t>();
+    SymAgg *sparts = c->d_partials2.as<SymAgg>();
+    PktCnt *pparts = c->d_partials3.as<PktCnt>();
+    SymAgg *sym_total = (SymAgg *)(tot + TOT_SYMAGG);
+    PktCnt *pk_total = (PktCnt *)(tot + TOT_PKT0);
     if (tiles) {
         if (lds_tables)
             hipLaunchKernelGGL(k_dec_reduce<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
@@ -801,58 +813,47 @@ int run_decode(nfc_ctx *c) {
     if (tiles) {
         if (lds_tables)
             hipLaunchKernelGGL(k_dec_apply<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
-                               dec_state_in, outw, sums);
+                               dec_state_in, outw, sparts);
         else
             hipLaunchKernelGGL(k_dec_apply<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
-                               dec_state_in, outw, sums);
+                               dec_state_in, outw, sparts);
     }
-    scan_partials<AddU64>(c->st, tiles, ne_dev, DEC_TILE, sums, 0ull, (uint64_t *)(tot + TOT_SYMS),
-                          DecCarryEpilogue{(const DecMaps *)(tot + TOT_DECMAP), dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM)});
+    scan_partials<SymAggOp>(c->st, tiles, ne_dev, DEC_TILE, sparts, SymAggOp::identity(), sym_total,
+                            DecCarryEpilogue{(const DecMaps *)(tot + TOT_DECMAP), dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM)});
+    // framing in the same (edge) domain: flags counted per tile -> offsets -> bits and closes to their places
     if (tiles) {
-        SymOut so{{c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()}, {c->d_src[0].as<uint32_t>(), c->d_src[1].as<uint32_t>()}, {cs[0], cs[1]}};
-        hipLaunchKernelGGL(k_sym_store, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, sums, so);
+        SymOut so{{c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()}, {cs[0], cs[1]}};
+        hipLaunchKernelGGL(k_sym_frame, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, sparts, started0, started1, so,
+                           pparts);
     }
-
-    // framing, per decoder that exists (background.py:17-25); the other type has no symbols and keeps its carry
-    const int pn = 1 - c->pend_cur;   // the open packets' bits go to the other half of the double buffer
+    scan_partials<PktCntOp>(c->st, tiles, ne_dev, DEC_TILE, pparts, PktCnt{{(uint64_t)pend[0], (uint64_t)pend[1]}}, pk_total);
+    const uint32_t cap_bits[2] = {pend[0] + cs[0], pend[1] + cs[1]};
+    if (tiles) {
+        PktOut po{c->d_edges.as<nfc_edge>(),
+                  {c->d_bits[0].as<uint8_t>(), c->d_bits[1].as<uint8_t>()},
+                  {c->d_close_end[0].as<uint32_t>(), c->d_close_end[1].as<uint32_t>()},
+                  {c->d_close_idx[0].as<uint64_t>(), c->d_close_idx[1].as<uint64_t>()},
+                  {enabled[0] ? cap_bits[0] : 0u, enabled[1] ? cap_bits[1] : 0u},
+                  {enabled[0] ? cs[0] : 0u, enabled[1] ? cs[1] : 0u}};
+        hipLaunchKernelGGL(k_pkt_write, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, sparts, pparts, started0,
+                           started1, po);
+    }
+    PktFinish F;
+    memset(&F, 0, sizeof F);
     for (int t = 0; t < 2; t++) {
-        if (!(t == 0 ? c->T.tag : c->T.reader)) continue;
-        const uint32_t ns = cs[t];   // capacity
-        const size_t ptiles = dec_num_tiles(ns);
-        const uint32_t *ns_dev = (const uint32_t *)(tot + TOT_NSYM) + t;
-        const uint32_t pend = c->h_dcarry.pending[t];
-        const int start_bit = (t == 0) ? 1 : 0;  // packets.py:24-28
-        HIPCHK(c, c->d_started.ensure((size_t)ns + 16));
-        HIPCHK(c, c->d_bits[t].ensure((size_t)pend + ns + 16));
-        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend + ns + 16));
-        HIPCHK(c, c->d_close_end[t].ensure(((size_t)ns + 4) * 4));
-        HIPCHK(c, c->d_close_idx[t].ensure(((size_t)ns + 4) * 8));
-        HIPCHK(c, c->d_partials.ensure((ptiles + 1) * sizeof(uint64_t)));
-        HIPCHK(c, c->d_partials2.ensure((ptiles + 1) * sizeof(uint64_t)));
-        HIPCHK(c, c->d_aggs.ensure((ptiles * SCAN_BLOCK + 1) * sizeof(uint32_t)));
-        if (pend) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t][c->pend_cur].p, pend, hipMemcpyDeviceToDevice, c->st));
-        const uint8_t *sym = c->d_sym[t].as<uint8_t>();
-        uint8_t *pflags = c->d_started.as<uint8_t>();
-        uint32_t *maptot = (uint32_t *)(tot + (t ? TOT_PKTMAP1 : TOT_PKTMAP0));
-        uint64_t *pktot = (uint64_t *)(tot + (t ? TOT_PKT1 : TOT_PKT0));
-        uint32_t *pparts = c->d_partials.as<uint32_t>(), *paggs = c->d_aggs.as<uint32_t>();
-        uint64_t *psums = c->d_partials2.as<uint64_t>();
-        if (ptiles)
-            hipLaunchKernelGGL(k_pkt_reduce, dim3((unsigned)ptiles), dim3(SCAN_BLOCK), 0, c->st, sym, (size_t)ns, ns_dev, start_bit, pparts, paggs);
-        scan_partials<ComposePkt>(c->st, ptiles, ns_dev, DEC_TILE, pparts, ComposePkt::identity_host(), maptot);
-        if (ptiles)
-            hipLaunchKernelGGL(k_pkt_apply, dim3((unsigned)ptiles), dim3(SCAN_BLOCK), 0, c->st, sym, (size_t)ns, ns_dev, start_bit, pparts, paggs,
-                               (uint32_t)c->h_dcarry.pkt_started[t], pflags, psums);
-        scan_partials<AddU64>(c->st, ptiles, ns_dev, DEC_TILE, psums, (uint64_t)pend, pktot);
-        if (ptiles) {
-            PktOut po{c->d_src[t].as<uint32_t>(), edges, c->d_bits[t].as<uint8_t>(), c->d_close_end[t].as<uint32_t>(),
-                      c->d_close_idx[t].as<uint64_t>()};
-            hipLaunchKernelGGL(k_pkt_store, dim3((unsigned)ptiles), dim3(SCAN_BLOCK), 0, c->st, sym, pflags, (size_t)ns, ns_dev, psums, po);
-        }
-        PktFinish F{c->d_bits[t].as<uint8_t>(), c->d_pending[t][pn].as<uint8_t>(), c->d_close_end[t].as<uint32_t>(), pktot, maptot,
-                    dD(c), t, c->h_dcarry.pkt_started[t], (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu)};
-        hipLaunchKernelGGL(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
+        F.enabled[t] = enabled[t] ? 1 : 0;
+        F.bits[t] = c->d_bits[t].as<uint8_t>();
+        F.pending_next[t] = c->d_pending[t][pn].as<uint8_t>();
+        F.close_end[t] = c->d_close_end[t].as<uint32_t>();
+        F.started_in[t] = c->h_dcarry.pkt_started[t];
+        F.pending_cap[t] = (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu);
+        F.cap_bits[t] = cap_bits[t];
+        F.cap_close[t] = cs[t];
     }
+    F.totals = pk_total;
+    F.sym_total = sym_total;
+    F.carry = dD(c);
+    hipLaunchKernelGGL(k_pkt_finish, dim3(2), dim3(256), 0, c->st, F);
     return NFC_OK;   // totals and carries are mirrored by the caller's final copy
 }
 
@@ -880,16 +881,13 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     const uint32_t cs[2] = {c->cap_sym[0], c->cap_sym[1]};
     HIPCHK(c, c->d_edges.ensure(((size_t)ce + 1) * sizeof(nfc_edge)));
     HIPCHK(c, c->d_ecode.ensure(((size_t)ce + 8) * 2));
-    for (int t = 0; t < 2; t++) {
-        HIPCHK(c, c->d_sym[t].ensure((size_t)cs[t] + 16));
-        HIPCHK(c, c->d_src[t].ensure(((size_t)cs[t] + 16) * 4));
-    }
+    for (int t = 0; t < 2; t++) HIPCHK(c, c->d_sym[t].ensure((size_t)cs[t] + 16));
     A.edges = c->d_edges.as<nfc_edge>();
     A.ecode = c->d_ecode.as<uint16_t>();
     A.cap_edges = ce;
     A.T = c->T;
     A.dec_state_in = (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4);
-    A.S = SymOut{{c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()}, {c->d_src[0].as<uint32_t>(), c->d_src[1].as<uint32_t>()}, {cs[0], cs[1]}};
+    A.S = SymOut{{c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()}, {cs[0], cs[1]}};
     const int pn = 1 - c->pend_cur;
     for (int t = 0; t < 2; t++) {
         SmallFraming &F = A.F[t];
@@ -901,25 +899,21 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
         HIPCHK(c, c->d_close_end[t].ensure(((size_t)cs[t] + 4) * 4));
         HIPCHK(c, c->d_close_idx[t].ensure(((size_t)cs[t] + 4) * 8));
         if (pend) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t][c->pend_cur].p, pend, hipMemcpyDeviceToDevice, c->st));
-        F.start_bit = (t == 0) ? 1 : 0;   // packets.py:24-28
-        F.type = t;
         F.started_in = (uint32_t)c->h_dcarry.pkt_started[t];
         F.pend = pend;
-        F.cap_sym = cs[t];
-        F.sym = c->d_sym[t].as<uint8_t>();
-        F.src = c->d_src[t].as<uint32_t>();
+        F.cap_bits = pend + cs[t];
+        F.cap_close = cs[t];
         F.bits = c->d_bits[t].as<uint8_t>();
         F.pending_next = c->d_pending[t][pn].as<uint8_t>();
         F.close_end = c->d_close_end[t].as<uint32_t>();
         F.close_idx = c->d_close_idx[t].as<uint64_t>();
         F.pending_cap = (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu);
-        F.maptot = (uint32_t *)(tot + (t ? TOT_PKTMAP1 : TOT_PKTMAP0));
-        F.pktot = (uint64_t *)(tot + (t ? TOT_PKT1 : TOT_PKT0));
     }
     A.tot_last2 = (Last2 *)(tot + TOT_LAST2);
     A.tot_edges = (uint32_t *)(tot + TOT_EDGES);
     A.tot_decmap = (DecMaps *)(tot + TOT_DECMAP);
-    A.tot_syms = (uint64_t *)(tot + TOT_SYMS);
+    A.tot_symagg = (SymAgg *)(tot + TOT_SYMAGG);
+    A.tot_pk = (PktCnt *)(tot + TOT_PKT0);
     A.tot_nsym = (uint32_t *)(tot + TOT_NSYM);
     A.ecarry = dE(c);
     A.dcarry = dD(c);
@@ -1279,9 +1273,9 @@ void nfc_destroy(nfc_ctx *c) {
     DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_state,
                      &c->d_ring[0], &c->d_ring[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
-                     &c->d_src[0], &c->d_src[1], &c->d_started, &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
+                     &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs, &c->d_pack, &c->d_gvtop, &c->d_seqout};
+                     &c->d_partials, &c->d_partials3, &c->d_aggs, &c->d_pack, &c->d_gvtop, &c->d_seqout};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

@@ -5,7 +5,7 @@
 // call) is all boundary.  Here ONE workgroup walks the tiles of each stage in order, so every scan is a
 // single pass with the running prefix in registers -- no tile aggregates, no partials pass, no second read.
 // The per-item arithmetic is the same device code the large path runs (change_mask, event_mask,
-// event_entry, the LUT walk, pkt_map): only the orchestration differs.
+// event_entry, the LUT walk, frame_symbol): only the orchestration differs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,16 +21,12 @@ constexpr int SM_EVCAP = 4096;              // entries listed per round of the e
 constexpr uint32_t SM_MAX_SAMPLES = 1u << 18;   // batches up to this length take the one-launch path
 
 struct SmallFraming {   // one packet type
-    int32_t enabled, start_bit, type;
-    uint32_t started_in, pend, cap_sym;
-    const uint8_t *sym;
-    const uint32_t *src;
+    int32_t enabled;
+    uint32_t started_in, pend;
     uint8_t *bits, *pending_next;
     uint32_t *close_end;
     uint64_t *close_idx;
-    uint32_t pending_cap;
-    uint32_t *maptot;
-    uint64_t *pktot;
+    uint32_t pending_cap, cap_bits, cap_close;
 };
 struct SmallArgs {
     EdgeArgs E;
@@ -45,7 +41,8 @@ struct SmallArgs {
     Last2 *tot_last2;
     uint32_t *tot_edges;
     DecMaps *tot_decmap;
-    uint64_t *tot_syms;
+    SymAgg *tot_symagg;
+    PktCnt *tot_pk;
     uint32_t *tot_nsym;
     EdgeCarry *ecarry;
     DecCarry *dcarry;
@@ -56,7 +53,8 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[36864];
     __shared__ Last2 r_l2[SM_WAVES];
     __shared__ uint32_t r_u32[SM_WAVES];
-    __shared__ uint64_t r_u64[SM_WAVES];
+    __shared__ SymAgg r_sa[SM_WAVES];
+    __shared__ PktCnt r_pk[SM_WAVES];
     __shared__ DecMaps r_map[SM_WAVES];
     const int tid = threadIdx.x;
 
@@ -137,8 +135,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
     __syncthreads();
     const size_t ne = min(n_edges_all, A.cap_edges);   // (an overflow makes the host repeat the batch with room)
 
-    // ================= decoders: state maps, walk, symbols =================
-    uint64_t n_sym_all = 0;
+    // ================= decoders: state maps, walk, symbols; framing in the same pass (decode.hip.h: edge domain) =================
     {
         uint4 *s_mil = (uint4 *)smem;                      // 8 KB   maps for composing
         uint2 *s_man = (uint2 *)(smem + 8192);             // 4 KB
@@ -162,6 +159,8 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
         const uint16_t *mil = lds_tab ? s_mstep : A.T.mil_step;
         const uint16_t *man = lds_tab ? s_nstep : A.T.man_step;
         DecMaps run_map = ComposeDec::identity();
+        SymAgg run_sa = SymAggOp::identity();
+        PktCnt run_pk{{(uint64_t)A.F[0].pend, (uint64_t)A.F[1].pend}};
         for (size_t e0 = 0; e0 < ne; e0 += (size_t)SM_BLOCK * DEC_ITEMS) {
             const size_t base = e0 + (size_t)tid * DEC_ITEMS;
             uint32_t c[8];
@@ -185,7 +184,6 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
             const DecMaps excl = block_exclusive<ComposeDec, SM_WAVES>(agg, r_map, tot_map);
             uint32_t st = ComposeDec::step(ComposeDec::op(run_map, excl), A.dec_state_in);
             uint32_t ow[4] = {0u, 0u, 0u, 0u};
-            uint32_t n_mil = 0, n_man = 0;
 #pragma unroll
             for (int k = 0; k < DEC_ITEMS; k++) {
                 const uint32_t code = (c[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
@@ -195,122 +193,76 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
                     const uint32_t e = mil[li * 16u + (st & 15u)];
                     w = e >> 8;
                     st = (st & ~15u) | (e & 15u);
-                    n_mil += w & 3u;
                 } else if (route == 1u && A.T.tag) {
                     const uint32_t e = man[li * 8u + ((st >> 4) & 7u)];
                     const uint32_t mo = e >> 8;
                     w = (mo & 3u) ? ((mo & 0xFCu) | 3u) : 0u;
                     st = (st & 15u) | ((e & 15u) << 4);
-                    n_man += (mo & 3u) ? 1u : 0u;
                 }
                 ow[k >> 2] |= w << (8 * (k & 3));
             }
-            uint64_t tot_sym;
-            uint64_t run = n_sym_all + block_exclusive<AddU64, SM_WAVES>((uint64_t)n_mil | ((uint64_t)n_man << 32), r_u64, tot_sym);
-#pragma unroll
-            for (int k = 0; k < DEC_ITEMS; k++) {
-                const uint32_t w = (ow[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                const uint32_t q = w & 3u;
-                if (q == 0u) continue;
-                const int type = (q == 3u) ? 0 : 1;
-                const uint32_t off = type == 1 ? (uint32_t)run : (uint32_t)(run >> 32);
-                if (off + 1 < A.S.cap[type]) {
-                    A.S.sym[type][off] = (w >> 2) & 7u;
-                    A.S.src[type][off] = (uint32_t)(base + k);
-                    if (q == 2u) {
-                        A.S.sym[type][off + 1] = (w >> 5) & 7u;
-                        A.S.src[type][off + 1] = (uint32_t)(base + k);
+            // symbols to their arrays, framing flags counted (k_sym_frame), bits and closes to theirs (k_pkt_write)
+            SymAgg tot_sa;
+            const SymAgg pre = SymAggOp::op(run_sa, block_exclusive<SymAggOp, SM_WAVES>(sym_agg_of(ow), r_sa, tot_sa));
+            uint32_t off[2] = {pre.cnt[0], pre.cnt[1]};
+            const uint32_t st0[2] = {pm_apply(pre.map[0], A.F[0].started_in), pm_apply(pre.map[1], A.F[1].started_in)};
+            uint32_t started[2] = {st0[0], st0[1]};
+            uint32_t nb[2] = {0u, 0u}, nc[2] = {0u, 0u};
+            for_each_symbol(ow, [&](int t, uint32_t s, int) {
+                if (off[t] + 1 < A.S.cap[t]) A.S.sym[t][off[t]] = (uint8_t)s;
+                off[t]++;
+                const uint32_t f = frame_symbol(t, s, started[t]);
+                nb[t] += f & 1u;
+                nc[t] += f >> 1;
+            });
+            PktCnt tot_pk;
+            const PktCnt mine{{(uint64_t)nb[0] | ((uint64_t)nc[0] << 32), (uint64_t)nb[1] | ((uint64_t)nc[1] << 32)}};
+            const PktCnt run0 = PktCntOp::op(run_pk, block_exclusive<PktCntOp, SM_WAVES>(mine, r_pk, tot_pk));
+            uint64_t run[2] = {run0.v[0], run0.v[1]};
+            started[0] = st0[0];
+            started[1] = st0[1];
+            for_each_symbol(ow, [&](int t, uint32_t s, int k) {
+                const uint32_t f = frame_symbol(t, s, started[t]);
+                if (f & 2u) {
+                    const uint32_t j = (uint32_t)(run[t] >> 32);
+                    if (j < A.F[t].cap_close) {
+                        A.F[t].close_end[j] = (uint32_t)run[t];
+                        A.F[t].close_idx[j] = A.edges[base + k].idx;
                     }
+                    run[t] += 1ull << 32;
+                } else if (f & 1u) {
+                    if ((uint32_t)run[t] < A.F[t].cap_bits) A.F[t].bits[(uint32_t)run[t]] = (uint8_t)s;
+                    run[t] += 1ull;
                 }
-                run += (q == 3u) ? (1ull << 32) : (uint64_t)q;
-            }
+            });
             run_map = ComposeDec::op(run_map, tot_map);
-            n_sym_all += tot_sym;
+            run_sa = SymAggOp::op(run_sa, tot_sa);
+            run_pk = PktCntOp::op(run_pk, tot_pk);
         }
+        __syncthreads();   // the bits and close offsets of every thread
         if (tid == 0) {
             *A.tot_decmap = run_map;
-            *A.tot_syms = n_sym_all;
+            *A.tot_symagg = run_sa;
+            *A.tot_pk = run_pk;
             const uint32_t st = ComposeDec::step(run_map, A.dec_state_in);
             A.dcarry->mil_state = (int32_t)(st & 15u);
             A.dcarry->man_state = (int32_t)(st >> 4);
-            A.tot_nsym[1] = (uint32_t)n_sym_all;           // Miller / reader
-            A.tot_nsym[0] = (uint32_t)(n_sym_all >> 32);    // Manchester / tag
+            A.tot_nsym[1] = run_sa.cnt[1];   // Miller / reader
+            A.tot_nsym[0] = run_sa.cnt[0];   // Manchester / tag
         }
-    }
-    __syncthreads();
-
-    // ================= framing, per decoder that exists =================
-    for (int t = 0; t < 2; t++) {
-        const SmallFraming &F = A.F[t];
-        if (!F.enabled) continue;
-        const uint32_t ns_all = t == 1 ? (uint32_t)n_sym_all : (uint32_t)(n_sym_all >> 32);
-        const size_t ns = min(ns_all, F.cap_sym);
-        uint32_t run_map = ComposePkt::identity();
-        uint64_t run_cnt = (uint64_t)F.pend;
-        for (size_t s0 = 0; s0 < ns; s0 += (size_t)SM_BLOCK * DEC_ITEMS) {
-            const size_t base = s0 + (size_t)tid * DEC_ITEMS;
-            uint32_t w[4];
-            load_bytes16(F.sym, base, ns, 0xFFu, w);
-            uint32_t agg = ComposePkt::identity();
-#pragma unroll
-            for (int k = 0; k < DEC_ITEMS; k++) {
-                if (base + k < ns) {
-                    const uint32_t m = pkt_map((w[k >> 2] >> (8 * (k & 3))) & 0xFFu, F.start_bit);
-                    agg = (m == 0x10u) ? agg : m;
-                }
+        for (int t = 0; t < 2; t++) {
+            const SmallFraming &F = A.F[t];
+            if (!F.enabled) continue;
+            const uint32_t nbits = (uint32_t)run_pk.v[t], ncl = (uint32_t)(run_pk.v[t] >> 32);
+            if (nbits > F.cap_bits || ncl > F.cap_close) continue;   // the host repeats the stage with room
+            const uint32_t from = ncl ? F.close_end[ncl - 1] : 0u;
+            const uint32_t keep = nbits - from;
+            for (uint32_t i = tid; i < keep && i < F.pending_cap; i += SM_BLOCK) F.pending_next[i] = F.bits[from + i];
+            if (tid == 0) {
+                A.dcarry->pending[t] = keep;
+                A.dcarry->pkt_started[t] = (int32_t)pm_apply(run_sa.map[t], F.started_in);
             }
-            uint32_t tot_map;
-            const uint32_t excl = block_exclusive<ComposePkt, SM_WAVES>(agg, r_u32, tot_map);
-            uint32_t started = ComposePkt::step(ComposePkt::op(run_map, excl), F.started_in);
-            uint32_t fw[4] = {0u, 0u, 0u, 0u};
-            uint32_t n_bits = 0, n_close = 0;
-#pragma unroll
-            for (int k = 0; k < DEC_ITEMS; k++) {
-                const uint32_t s = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                if (base + k < ns) {
-                    uint32_t f;
-                    if (s > 1u) {
-                        f = started ? 2u : 0u;
-                        started = 0u;
-                    } else {
-                        f = (!started && (int)s == F.start_bit) ? 0u : 1u;
-                        started = (started || (int)s == F.start_bit) ? 1u : 0u;
-                    }
-                    n_bits += f & 1u;
-                    n_close += f >> 1;
-                    fw[k >> 2] |= f << (8 * (k & 3));
-                }
-            }
-            uint64_t tot_cnt;
-            uint64_t run = run_cnt + block_exclusive<AddU64, SM_WAVES>((uint64_t)n_bits | ((uint64_t)n_close << 32), r_u64, tot_cnt);
-#pragma unroll
-            for (int k = 0; k < DEC_ITEMS; k++) {
-                const uint32_t f = (fw[k >> 2] >> (8 * (k & 3))) & 3u;
-                if (f & 2u) {
-                    const uint32_t j = (uint32_t)(run >> 32);
-                    F.close_end[j] = (uint32_t)run;
-                    F.close_idx[j] = A.edges[F.src[base + k]].idx;
-                    run += 1ull << 32;
-                } else if (f & 1u) {
-                    F.bits[(uint32_t)run] = (uint8_t)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-                    run += 1ull;
-                }
-            }
-            run_map = ComposePkt::op(run_map, tot_map);
-            run_cnt += tot_cnt;
         }
-        __syncthreads();   // the bits and close offsets of every thread
-        const uint32_t nbits = (uint32_t)run_cnt, ncl = (uint32_t)(run_cnt >> 32);
-        const uint32_t from = ncl ? F.close_end[ncl - 1] : 0u;
-        const uint32_t keep = nbits - from;
-        for (uint32_t i = tid; i < keep && i < F.pending_cap; i += SM_BLOCK) F.pending_next[i] = F.bits[from + i];
-        if (tid == 0) {
-            *F.maptot = run_map;
-            *F.pktot = run_cnt;
-            A.dcarry->pending[F.type] = keep;
-            A.dcarry->pkt_started[F.type] = (int32_t)((run_map >> (4 * F.started_in)) & 1u);
-        }
-        __syncthreads();
     }
 }
 
