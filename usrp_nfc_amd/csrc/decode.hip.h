@@ -72,25 +72,84 @@ __device__ __forceinline__ void load_bytes16(const uint8_t *p, size_t base, size
 // ---- symbols and framing live in the EDGE domain ------------------------------------------------------
 // A symbol belongs to the edge that emitted it, and a thread's sixteen out-bytes hold its symbols in stream order.  So
 // PacketProcessor.append_bit (packets.py:67-79: two states per type, started or not) needs no scan over the symbol
-// arrays: the framing map of a span of symbols is the latest of its symbols that is not the identity (a start-bit value
-// starts, an error symbol stops, any other bit changes nothing), and it rides in the same aggregate as the symbol counts.
-constexpr uint32_t PM_STOP = 0u, PM_START = 1u, PM_ID = 2u;
-struct SymAgg {
-    uint32_t cnt[2];   // symbols: [0] Manchester / tag, [1] Miller / reader
-    uint32_t map[2];   // framing map over them: PM_*
+// arrays, and no scan of its own: ONE aggregate per span of edges carries, per packet type,
+//   cnt  symbols emitted (places the symbols),
+//   map  the framing map over them: the latest symbol that is not the identity decides (a start-bit value starts, an
+//        error symbol stops, any other bit changes nothing),
+//   nb / nc  bits appended / packets closed if the span is entered in state "started", and
+//   db / dc  whether entering it "not started" gives one fewer: the two hypotheses merge at the span's first symbol
+//        that is not the identity -- a start bit (dropped instead of appended) or an error symbol (nothing to close).
+constexpr uint32_t PM_STOP = 0u, PM_START = 1u, PM_ID = 2u;   // map, FrameAgg.fl bits 0-1
+constexpr uint32_t FA_DB = 4u, FA_DC = 8u;                    // FrameAgg.fl bits 2, 3
+struct FrameAgg {
+    uint32_t cnt[2];   // [0] Manchester / tag, [1] Miller / reader
+    uint32_t nb[2], nc[2];
+    uint32_t fl[2];
 };
-struct SymAggOp {
-    using T = SymAgg;
-    static __host__ __device__ __forceinline__ T identity() { return T{{0u, 0u}, {PM_ID, PM_ID}}; }
+struct FrameAggOp {
+    using T = FrameAgg;
+    static __host__ __device__ __forceinline__ T identity() { return T{{0u, 0u}, {0u, 0u}, {0u, 0u}, {PM_ID, PM_ID}}; }
     static __device__ __forceinline__ T op(const T &a, const T &b) {
-        return T{{a.cnt[0] + b.cnt[0], a.cnt[1] + b.cnt[1]}, {b.map[0] == PM_ID ? a.map[0] : b.map[0], b.map[1] == PM_ID ? a.map[1] : b.map[1]}};
+        T r;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint32_t ma = a.fl[t] & 3u, mb = b.fl[t] & 3u;
+            const bool into_stopped = ma == PM_STOP;   // b is entered "not started" whatever a was entered in
+            r.cnt[t] = a.cnt[t] + b.cnt[t];
+            r.nb[t] = a.nb[t] + b.nb[t] - (into_stopped ? (b.fl[t] >> 2) & 1u : 0u);
+            r.nc[t] = a.nc[t] + b.nc[t] - (into_stopped ? (b.fl[t] >> 3) & 1u : 0u);
+            r.fl[t] = (mb == PM_ID ? ma : mb) | ((ma == PM_ID ? b.fl[t] : a.fl[t]) & (FA_DB | FA_DC));
+        }
+        return r;
     }
     static __device__ __forceinline__ T shfl_up(const T &v, int d) {
-        return T{{(uint32_t)__shfl_up((int)v.cnt[0], d, 64), (uint32_t)__shfl_up((int)v.cnt[1], d, 64)},
-                 {(uint32_t)__shfl_up((int)v.map[0], d, 64), (uint32_t)__shfl_up((int)v.map[1], d, 64)}};
+        T r;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            r.cnt[t] = (uint32_t)__shfl_up((int)v.cnt[t], d, 64);
+            r.nb[t] = (uint32_t)__shfl_up((int)v.nb[t], d, 64);
+            r.nc[t] = (uint32_t)__shfl_up((int)v.nc[t], d, 64);
+            r.fl[t] = (uint32_t)__shfl_up((int)v.fl[t], d, 64);
+        }
+        return r;
     }
 };
-__device__ __forceinline__ uint32_t pm_apply(uint32_t map, uint32_t started) { return map == PM_ID ? started : map; }
+// Inside a tile (<= 2 * DEC_TILE = 8192 symbols of a type) the counts fit 16 bits: the block scans run on this packed
+// form, half the words to shuffle.  a = cnt | nb << 16, b = nc | fl << 16.
+struct FramePk {
+    uint32_t a[2], b[2];
+};
+struct FramePkOp {
+    using T = FramePk;
+    static __device__ __forceinline__ T pack(const FrameAgg &f) {
+        return T{{f.cnt[0] | (f.nb[0] << 16), f.cnt[1] | (f.nb[1] << 16)}, {f.nc[0] | (f.fl[0] << 16), f.nc[1] | (f.fl[1] << 16)}};
+    }
+    static __device__ __forceinline__ FrameAgg unpack(const T &p) {
+        return FrameAgg{{p.a[0] & 0xFFFFu, p.a[1] & 0xFFFFu}, {p.a[0] >> 16, p.a[1] >> 16}, {p.b[0] & 0xFFFFu, p.b[1] & 0xFFFFu}, {p.b[0] >> 16, p.b[1] >> 16}};
+    }
+    static __device__ __forceinline__ T identity() { return T{{0u, 0u}, {PM_ID << 16, PM_ID << 16}}; }
+    static __device__ __forceinline__ T op(const T &x, const T &y) {
+        T r;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint32_t ma = (x.b[t] >> 16) & 3u, mb = (y.b[t] >> 16) & 3u;
+            const uint32_t stopped = ma == PM_STOP ? 1u : 0u;
+            r.a[t] = x.a[t] + y.a[t] - ((stopped & (y.b[t] >> 18)) << 16);
+            const uint32_t nc = (x.b[t] & 0xFFFFu) + (y.b[t] & 0xFFFFu) - (stopped & (y.b[t] >> 19));
+            const uint32_t fl = (mb == PM_ID ? ma : mb) | (((ma == PM_ID ? y.b[t] : x.b[t]) >> 16) & (FA_DB | FA_DC));
+            r.b[t] = nc | (fl << 16);
+        }
+        return r;
+    }
+    static __device__ __forceinline__ T shfl_up(const T &v, int d) {
+        return T{{(uint32_t)__shfl_up((int)v.a[0], d, 64), (uint32_t)__shfl_up((int)v.a[1], d, 64)},
+                 {(uint32_t)__shfl_up((int)v.b[0], d, 64), (uint32_t)__shfl_up((int)v.b[1], d, 64)}};
+    }
+};
+__device__ __forceinline__ uint32_t pm_apply(uint32_t fl, uint32_t started) { return (fl & 3u) == PM_ID ? started : (fl & 3u); }
+// bits appended / packets closed over a span entered in state `started`
+__device__ __forceinline__ uint32_t fa_bits(const FrameAgg &a, int t, uint32_t started) { return a.nb[t] - (started ? 0u : (a.fl[t] >> 2) & 1u); }
+__device__ __forceinline__ uint32_t fa_closes(const FrameAgg &a, int t, uint32_t started) { return a.nc[t] - (started ? 0u : (a.fl[t] >> 3) & 1u); }
 __device__ __forceinline__ uint32_t start_bit_of(int type) { return type == 0 ? 1u : 0u; }   // packets.py:24-28
 
 // f(type, symbol, k) for every symbol in a thread's sixteen out-bytes, in stream order (k: the edge within the thread)
@@ -109,14 +168,6 @@ __device__ __forceinline__ void for_each_symbol(const uint32_t (&ow)[4], F f) {
         }
     }
 }
-__device__ __forceinline__ SymAgg sym_agg_of(const uint32_t (&ow)[4]) {
-    SymAgg a = SymAggOp::identity();
-    for_each_symbol(ow, [&](int t, uint32_t s, int) {
-        a.cnt[t]++;
-        a.map[t] = s > 1u ? PM_STOP : (s == start_bit_of(t) ? PM_START : a.map[t]);
-    });
-    return a;
-}
 // per symbol: bit 0 = appended to the packet, bit 1 = closes a started packet (packets.py:67-79); updates `started`
 __device__ __forceinline__ uint32_t frame_symbol(int t, uint32_t s, uint32_t &started) {
     uint32_t f;
@@ -130,15 +181,28 @@ __device__ __forceinline__ uint32_t frame_symbol(int t, uint32_t s, uint32_t &st
     }
     return f;
 }
+__device__ __forceinline__ FrameAgg frame_agg_of(const uint32_t (&ow)[4]) {
+    FrameAgg a = FrameAggOp::identity();
+    uint32_t st1[2] = {1u, 1u};   // the "entered started" hypothesis
+    for_each_symbol(ow, [&](int t, uint32_t s, int) {
+        a.cnt[t]++;
+        const uint32_t f = frame_symbol(t, s, st1[t]);
+        a.nb[t] += f & 1u;
+        a.nc[t] += f >> 1;
+        if ((a.fl[t] & 3u) == PM_ID) {   // the first symbol that is not the identity: the hypotheses merge here
+            if (s > 1u) a.fl[t] = PM_STOP | FA_DC;
+            else if (s == start_bit_of(t)) a.fl[t] = PM_START | FA_DB;
+        } else if (s > 1u) {
+            a.fl[t] = (a.fl[t] & ~3u) | PM_STOP;
+        } else if (s == start_bit_of(t)) {
+            a.fl[t] = (a.fl[t] & ~3u) | PM_START;
+        }
+    });
+    return a;
+}
 // per type: appended bits in the low half, closes in the high half
 struct PktCnt {
     uint64_t v[2];
-};
-struct PktCntOp {
-    using T = PktCnt;
-    static __host__ __device__ __forceinline__ T identity() { return T{{0ull, 0ull}}; }
-    static __device__ __forceinline__ T op(const T &a, const T &b) { return T{{a.v[0] + b.v[0], a.v[1] + b.v[1]}}; }
-    static __device__ __forceinline__ T shfl_up(const T &v, int d) { return T{{AddU64::shfl_up(v.v[0], d), AddU64::shfl_up(v.v[1], d)}}; }
 };
 
 // ---- pass 1: every edge is a pair of state maps (Miller, Manchester); a thread composes its sixteen ----
@@ -186,17 +250,17 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_reduce(const uint16_t *ecode
 // ---- pass 2: a thread walks its edges from its incoming states, one LUT look-up per edge ----
 // What an edge emits, one byte: bits 0-1 = 0 nothing, 1 / 2 Miller symbols, 3 one Manchester symbol;
 // bits 2-4 first symbol, bits 5-7 second symbol.  The tile's symbol counts AND the framing maps over its symbols
-// (SymAgg) are the aggregates of the scan that places the symbols and hands every tile its framing state.
+// (FrameAgg) are the aggregates of the ONE scan that places symbols, packet bits and packet ends.
 template <bool LDS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode, size_t n, const uint32_t *n_dev, DecTables T,
                                                          const DecMaps *partials, const DecMaps *aggs, uint32_t state0,
-                                                         uint8_t *outw, SymAgg *sym_aggs) {
+                                                         uint8_t *outw, FrameAgg *frame_aggs) {
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
     __shared__ __attribute__((aligned(16))) uint16_t s_mil[LDS ? DEC_LDS_ROWS * 16 : 8];
     __shared__ __attribute__((aligned(16))) uint16_t s_man[LDS ? DEC_LDS_ROWS * 8 : 8];
     __shared__ DecMaps lds[SCAN_WAVES];
-    __shared__ SymAgg lds2[SCAN_WAVES];
+    __shared__ FramePk lds2[SCAN_WAVES];
     if (LDS) {
         const int rows = 4 * T.nd;
         if (T.reader)
@@ -232,96 +296,70 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
         ow[k >> 2] |= w << (8 * (k & 3));
     }
     if (base < n) *(uint4 *)(outw + base) = make_uint4(ow[0], ow[1], ow[2], ow[3]);   // outw has 16 bytes of slack
-    SymAgg total_sa;
-    (void)block_exclusive<SymAggOp>(sym_agg_of(ow), lds2, total_sa);
-    if (threadIdx.x == 0) sym_aggs[blockIdx.x] = total_sa;
+    FramePk total_fa;
+    (void)block_exclusive<FramePkOp>(FramePkOp::pack(frame_agg_of(ow)), lds2, total_fa);
+    if (threadIdx.x == 0) frame_aggs[blockIdx.x] = FramePkOp::unpack(total_fa);
 }
 
-// ---- pass 3: symbols to their arrays; framing flags counted -------------------------------------------------
-struct SymOut {
-    uint8_t *sym[2];   // [0] Manchester / tag, [1] Miller / reader
-    uint32_t cap[2];   // buffer capacities (an overflow is detected by the host from the totals)
+// ---- pass 3: symbols, packet bits and packet ends to their places ------------------------------------------------
+struct FrameOut {
+    uint8_t *sym[2];        // [0] Manchester / tag, [1] Miller / reader
+    uint32_t cap_sym[2];    // buffer capacities (an overflow is seen by the host in the totals, the stage repeated)
+    const nfc_edge *edges;
+    uint8_t *bits[2];       // appended bits per type, starting with the pending ones of earlier batches
+    uint32_t *close_end[2]; // per close: number of bits appended before it (= end offset of the packet)
+    uint64_t *close_idx[2]; // per close: sample index of the closing edge
+    uint32_t cap_bits[2], cap_close[2];
+    const uint8_t *pending[2];   // the open packets' bits of earlier batches (workgroup 0 puts them in front)
+    uint32_t pend[2], started_in[2];
 };
-__global__ __launch_bounds__(SCAN_BLOCK) void k_sym_frame(const uint8_t *outw, size_t n, const uint32_t *n_dev, const SymAgg *tile_pre,
-                                                         uint32_t started0, uint32_t started1, SymOut S, PktCnt *pk_sums) {
+__device__ __forceinline__ void copy_pending(const FrameOut &P, int tid, int nthreads) {
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+        for (uint32_t i = tid; i < P.pend[t] && i < P.cap_bits[t]; i += nthreads) P.bits[t][i] = P.pending[t][i];
+}
+// a thread's symbols, given the aggregate of everything before them
+__device__ __forceinline__ void frame_write(const FrameOut &P, const FrameAgg &pre, const uint32_t (&ow)[4], size_t base) {
+    uint32_t off[2], started[2], bo[2], co[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        off[t] = pre.cnt[t];
+        started[t] = pm_apply(pre.fl[t], P.started_in[t]);
+        bo[t] = P.pend[t] + fa_bits(pre, t, P.started_in[t]);
+        co[t] = fa_closes(pre, t, P.started_in[t]);
+    }
+    for_each_symbol(ow, [&](int t, uint32_t s, int k) {
+        if (off[t] + 1 < P.cap_sym[t]) P.sym[t][off[t]] = (uint8_t)s;
+        off[t]++;
+        const uint32_t f = frame_symbol(t, s, started[t]);
+        if (f & 2u) {
+            if (co[t] < P.cap_close[t]) {
+                P.close_end[t][co[t]] = bo[t];
+                P.close_idx[t][co[t]] = P.edges[base + k].idx;
+            }
+            co[t]++;
+        } else if (f & 1u) {
+            if (bo[t] < P.cap_bits[t]) P.bits[t][bo[t]] = (uint8_t)s;
+            bo[t]++;
+        }
+    });
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw, size_t n, const uint32_t *n_dev, const FrameAgg *tile_pre,
+                                                           FrameOut P) {
+    if (blockIdx.x == 0) copy_pending(P, threadIdx.x, SCAN_BLOCK);
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
-    __shared__ SymAgg lds[SCAN_WAVES];
-    __shared__ PktCnt lds2[SCAN_WAVES];
+    __shared__ FramePk lds[SCAN_WAVES];
     const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_ITEMS;
     uint32_t ow[4] = {0u, 0u, 0u, 0u};
     if (base < n) {   // k_dec_apply wrote whole 16-byte groups, zero past n
         const uint4 a = *(const uint4 *)(outw + base);
         ow[0] = a.x; ow[1] = a.y; ow[2] = a.z; ow[3] = a.w;
     }
-    SymAgg total;
-    const SymAgg pre = SymAggOp::op(tile_pre[blockIdx.x], block_exclusive<SymAggOp>(sym_agg_of(ow), lds, total));
-    uint32_t off[2] = {pre.cnt[0], pre.cnt[1]};
-    uint32_t started[2] = {pm_apply(pre.map[0], started0), pm_apply(pre.map[1], started1)};
-    uint32_t nb[2] = {0u, 0u}, nc[2] = {0u, 0u};
-    for_each_symbol(ow, [&](int t, uint32_t s, int) {
-        if (off[t] + 1 < S.cap[t]) S.sym[t][off[t]] = (uint8_t)s;
-        off[t]++;
-        const uint32_t f = frame_symbol(t, s, started[t]);
-        nb[t] += f & 1u;
-        nc[t] += f >> 1;
-    });
-    PktCnt tot_pk;
-    (void)block_exclusive<PktCntOp>(PktCnt{{(uint64_t)nb[0] | ((uint64_t)nc[0] << 32), (uint64_t)nb[1] | ((uint64_t)nc[1] << 32)}}, lds2, tot_pk);
-    if (threadIdx.x == 0) pk_sums[blockIdx.x] = tot_pk;
-}
-
-// ---- pass 4: packet bits and closes to their places ------------------------------------------------------------
-struct PktOut {
-    const nfc_edge *edges;
-    uint8_t *bits[2];       // appended bits per type, starting with the pending ones of earlier batches
-    uint32_t *close_end[2]; // per close: number of bits appended before it (= end offset of the packet)
-    uint64_t *close_idx[2]; // per close: sample index of the closing edge
-    uint32_t cap_bits[2], cap_close[2];   // more than estimated: dropped here, seen by the host in the totals, the stage repeated
-};
-__global__ __launch_bounds__(SCAN_BLOCK) void k_pkt_write(const uint8_t *outw, size_t n, const uint32_t *n_dev, const SymAgg *tile_pre,
-                                                         const PktCnt *pk_pre, uint32_t started0, uint32_t started1, PktOut P) {
-    if (n_dev) n = min(n, (size_t)*n_dev);
-    if ((size_t)blockIdx.x * DEC_TILE >= n) return;
-    __shared__ SymAgg lds[SCAN_WAVES];
-    __shared__ PktCnt lds2[SCAN_WAVES];
-    const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_ITEMS;
-    uint32_t ow[4] = {0u, 0u, 0u, 0u};
-    if (base < n) {
-        const uint4 a = *(const uint4 *)(outw + base);
-        ow[0] = a.x; ow[1] = a.y; ow[2] = a.z; ow[3] = a.w;
-    }
-    SymAgg total;
-    const SymAgg pre = SymAggOp::op(tile_pre[blockIdx.x], block_exclusive<SymAggOp>(sym_agg_of(ow), lds, total));
-    const uint32_t st0[2] = {pm_apply(pre.map[0], started0), pm_apply(pre.map[1], started1)};
-    uint32_t started[2] = {st0[0], st0[1]};
-    uint32_t nb[2] = {0u, 0u}, nc[2] = {0u, 0u};
-    for_each_symbol(ow, [&](int t, uint32_t s, int) {
-        const uint32_t f = frame_symbol(t, s, started[t]);
-        nb[t] += f & 1u;
-        nc[t] += f >> 1;
-    });
-    PktCnt tot_pk;
-    const PktCnt mine{{(uint64_t)nb[0] | ((uint64_t)nc[0] << 32), (uint64_t)nb[1] | ((uint64_t)nc[1] << 32)}};
-    const PktCnt run0 = PktCntOp::op(pk_pre[blockIdx.x], block_exclusive<PktCntOp>(mine, lds2, tot_pk));
-    if (!(mine.v[0] | mine.v[1])) return;
-    uint64_t run[2] = {run0.v[0], run0.v[1]};
-    started[0] = st0[0];
-    started[1] = st0[1];
-    for_each_symbol(ow, [&](int t, uint32_t s, int k) {
-        const uint32_t f = frame_symbol(t, s, started[t]);
-        if (f & 2u) {
-            const uint32_t j = (uint32_t)(run[t] >> 32);
-            if (j < P.cap_close[t]) {
-                P.close_end[t][j] = (uint32_t)run[t];
-                P.close_idx[t][j] = P.edges[base + k].idx;
-            }
-            run[t] += 1ull << 32;
-        } else if (f & 1u) {
-            if ((uint32_t)run[t] < P.cap_bits[t]) P.bits[t][(uint32_t)run[t]] = (uint8_t)s;
-            run[t] += 1ull;
-        }
-    });
+    FramePk total;
+    const FramePk in_tile = block_exclusive<FramePkOp>(FramePkOp::pack(frame_agg_of(ow)), lds, total);
+    // (staging the tile's symbols and bits in LDS to store whole words measured slower: 32 vs 26 us)
+    if (ow[0] | ow[1] | ow[2] | ow[3]) frame_write(P, FrameAggOp::op(tile_pre[blockIdx.x], FramePkOp::unpack(in_tile)), ow, base);
 }
 
 // After framing: keep the open packet's bits for the next batch and publish the carry.  Reads nothing that it (or a
@@ -332,7 +370,7 @@ struct PktFinish {
     uint8_t *pending_next[2];   // (the other half of the double buffer)
     const uint32_t *close_end[2];
     const PktCnt *totals;       // per type: (appended incl. pending) | closes << 32
-    const SymAgg *sym_total;    // framing map over the batch's symbols
+    const FrameAgg *frame_total;   // framing map over the batch's symbols
     DecCarry *carry;
     int32_t enabled[2], started_in[2];
     uint32_t pending_cap[2];
@@ -349,23 +387,28 @@ __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
     for (uint32_t i = threadIdx.x; i < keep && i < F.pending_cap[t]; i += blockDim.x) F.pending_next[t][i] = F.bits[t][from + i];
     if (threadIdx.x == 0) {
         F.carry->pending[t] = keep;
-        F.carry->pkt_started[t] = (int32_t)pm_apply(F.sym_total->map[t], (uint32_t)F.started_in[t]);
+        F.carry->pkt_started[t] = (int32_t)pm_apply(F.frame_total->fl[t], (uint32_t)F.started_in[t]);
     }
 }
 
 // Decoder states after the batch, from the total of the map scan; also publishes the per-type symbol counts the
-// host checks against the capacities.  Epilogue of the symbol scan's partials pass.
+// host checks against the capacities and the per-type bit / close totals.  Epilogue of the framing scan's partials pass.
 struct DecCarryEpilogue {
     const DecMaps *total;
     uint32_t state_in;
     DecCarry *carry;
     uint32_t *nsym;
-    __device__ __forceinline__ void operator()(const SymAgg &sym_total) const {
+    PktCnt *pk_total;
+    uint32_t pend[2], started_in[2];
+    __device__ __forceinline__ void operator()(const FrameAgg &ft) const {
         const uint32_t st = ComposeDec::step(*total, state_in);
         carry->mil_state = (int32_t)(st & 15u);
         carry->man_state = (int32_t)(st >> 4);
-        nsym[1] = sym_total.cnt[1];   // Miller / reader
-        nsym[0] = sym_total.cnt[0];   // Manchester / tag
+        nsym[1] = ft.cnt[1];   // Miller / reader
+        nsym[0] = ft.cnt[0];   // Manchester / tag
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            pk_total->v[t] = (uint64_t)(pend[t] + fa_bits(ft, t, started_in[t])) | ((uint64_t)fa_closes(ft, t, started_in[t]) << 32);
     }
 };
 

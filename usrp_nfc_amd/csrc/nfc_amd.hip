@@ -6,8 +6,8 @@
 //   -> k_threshold pass 0 (speculate) -> k_certify (+ end-of-batch state, verdict summary)
 //      [-> re-runs from the exact state | k_threshold_seq over a prefix, then another attempt]      (run_threshold)
 //   -> last-two-changes scan -> event masks + entry counts -> entry offsets -> k_write_edges        (run_edges)
-//   -> k_dec_reduce -> tile prefixes -> k_dec_apply -> symbol offsets + framing states -> k_sym_frame
-//   -> bit / close offsets -> k_pkt_write -> k_pkt_finish (both packet types in each launch)        (run_decode)
+//   -> k_dec_reduce -> tile prefixes -> k_dec_apply -> symbol / bit / close offsets and framing states (one scan)
+//   -> k_frame_write -> k_pkt_finish (both packet types in each launch)                             (run_decode)
 //   (batches up to 2^18 samples: the three stages after the threshold stage in ONE launch, small.hip.h)
 // then one wait; the edge / decode stages are repeated if the certification failed or a capacity estimate was short.
 // Outputs stay in HBM until read through nfc_read_*.  Host-only: the protocol layer of protocol.h (nfc_fsm_*).
@@ -96,13 +96,13 @@ enum : int {
     TOT_RUNS = 0,       // u32
     TOT_EDGES = 8,      // u32
     TOT_DECMAP = 16,    // DecMaps (24 bytes)
-    TOT_SYMAGG = 48,    // SymAgg (16 bytes): symbol counts and framing maps of the batch
     TOT_PKT0 = 72,      // PktCnt: per type, bits | closes << 32
     TOT_PKT1 = 80,
     TOT_LAST2 = 88,     // Last2 (8 bytes)
     TOT_NSYM = 96,      // u32[2]: symbols per packet type
     TOT_CERT = 104,     // CertSummary (16 bytes)
-    TOT_BYTES = 128
+    TOT_FRAME = 128,    // FrameAgg (32 bytes): symbol counts, framing maps, bit / close counts of the batch
+    TOT_BYTES = 160
 };
 
 // Everything the host mirrors after a batch, in one block so that one copy fetches it.
@@ -161,7 +161,7 @@ struct nfc_ctx {
     DevBuf d_ctx, d_wcnt, d_ecode;
     DevBuf d_edges, d_states, d_sym[2], d_bits[2], d_pending[2][2], d_close_end[2],
         d_close_idx[2];
-    DevBuf d_partials, d_partials2, d_partials3, d_aggs;  // scan scratch
+    DevBuf d_partials, d_partials2, d_aggs;  // scan scratch
     DevBuf d_pack;                           // nfc_get_state staging
     DevBuf d_gvtop;                          // per chunk: bound of the ring values (guard of the fp64 sums)
     DevBuf d_seqout;                         // sequential kernel: edge-timing state after its last sample
@@ -765,43 +765,59 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
 // ---------------------------------------------------------------------------
 // decode + framing
 // ---------------------------------------------------------------------------
+// what both forms of the stage write through: symbol, bit and close arrays sized from the estimates; the open packets'
+// bits of earlier batches go in front of this batch's (the other half of the double buffer takes the next ones)
+int frame_out(nfc_ctx *c, FrameOut &P, const bool (&enabled)[2]) {
+    memset(&P, 0, sizeof P);
+    const int pn = 1 - c->pend_cur;
+    P.edges = c->d_edges.as<nfc_edge>();
+    for (int t = 0; t < 2; t++) {
+        const uint32_t cs = c->cap_sym[t];
+        HIPCHK(c, c->d_sym[t].ensure((size_t)cs + 16));
+        P.sym[t] = c->d_sym[t].as<uint8_t>();
+        P.cap_sym[t] = cs;
+        P.started_in[t] = (uint32_t)c->h_dcarry.pkt_started[t];
+        if (!enabled[t]) continue;   // no symbols of this type (background.py:17-25); its carry stays
+        const uint32_t pend = c->h_dcarry.pending[t];
+        HIPCHK(c, c->d_bits[t].ensure((size_t)pend + cs + 16));
+        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend + cs + 16));
+        HIPCHK(c, c->d_close_end[t].ensure(((size_t)cs + 4) * 4));
+        HIPCHK(c, c->d_close_idx[t].ensure(((size_t)cs + 4) * 8));
+        P.bits[t] = c->d_bits[t].as<uint8_t>();
+        P.close_end[t] = c->d_close_end[t].as<uint32_t>();
+        P.close_idx[t] = c->d_close_idx[t].as<uint64_t>();
+        P.cap_bits[t] = pend + cs;
+        P.cap_close[t] = cs;
+        P.pending[t] = c->d_pending[t][c->pend_cur].as<uint8_t>();
+        P.pend[t] = pend;
+    }
+    return NFC_OK;
+}
+
 int run_decode(nfc_ctx *c) {
     uint8_t *tot = dT(c);
     const uint32_t ce = c->cap_edges;                      // capacity; the count is on the device
     const uint32_t *ne_dev = (const uint32_t *)(tot + TOT_EDGES);
-    const uint32_t cs[2] = {c->cap_sym[0], c->cap_sym[1]};
     const size_t tiles = dec_num_tiles(ce);
     HIPCHK(c, c->d_states.ensure((size_t)ce + 16));   // one out-byte per edge
     HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(DecMaps)));
-    HIPCHK(c, c->d_partials2.ensure((tiles + 1) * sizeof(SymAgg)));
-    HIPCHK(c, c->d_partials3.ensure((tiles + 1) * sizeof(PktCnt)));
+    HIPCHK(c, c->d_partials2.ensure((tiles + 1) * sizeof(FrameAgg)));
     HIPCHK(c, c->d_aggs.ensure((tiles * SCAN_BLOCK + 1) * sizeof(DecMaps)));
-    const int pn = 1 - c->pend_cur;   // the open packets' bits go to the other half of the double buffer
-    const bool enabled[2] = {c->T.tag != 0, c->T.reader != 0};   // background.py:17-25
-    uint32_t pend[2] = {0u, 0u};
-    for (int t = 0; t < 2; t++) {
-        HIPCHK(c, c->d_sym[t].ensure((size_t)cs[t] + 16));
-        if (!enabled[t]) continue;   // no symbols of this type; its carry stays
-        pend[t] = c->h_dcarry.pending[t];
-        HIPCHK(c, c->d_bits[t].ensure((size_t)pend[t] + cs[t] + 16));
-        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend[t] + cs[t] + 16));
-        HIPCHK(c, c->d_close_end[t].ensure(((size_t)cs[t] + 4) * 4));
-        HIPCHK(c, c->d_close_idx[t].ensure(((size_t)cs[t] + 4) * 8));
-        if (pend[t]) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t][c->pend_cur].p, pend[t], hipMemcpyDeviceToDevice, c->st));
-    }
+    const bool enabled[2] = {c->T.tag != 0, c->T.reader != 0};
+    FrameOut P;
+    const int rf = frame_out(c, P, enabled);
+    if (rf) return rf;
 
     // decoder states: tile maps -> tile prefixes -> every thread walks its edges.  What the walk emits stays per edge
-    // (one byte); a tile's symbol counts and the framing map over its symbols are the aggregates of the next scan,
-    // which places the symbols and hands every tile the packet state it starts in.
+    // (one byte); a tile's symbol counts, framing map and bit / close counts are the aggregates of ONE more scan, whose
+    // prefixes place the symbols, the packet bits and the packet ends in a single pass.
     const uint16_t *ecode = c->d_ecode.as<uint16_t>();
     uint8_t *outw = c->d_states.as<uint8_t>();
     const uint32_t dec_state_in = (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4);
-    const uint32_t started0 = (uint32_t)c->h_dcarry.pkt_started[0], started1 = (uint32_t)c->h_dcarry.pkt_started[1];
     const bool lds_tables = 4 * c->T.nd <= DEC_LDS_ROWS;
     DecMaps *dparts = c->d_partials.as<DecMaps>(), *daggs = c->d_aggs.as<DecMaps>();
-    SymAgg *sparts = c->d_partials2.as<SymAgg>();
-    PktCnt *pparts = c->d_partials3.as<PktCnt>();
-    SymAgg *sym_total = (SymAgg *)(tot + TOT_SYMAGG);
+    FrameAgg *fparts = c->d_partials2.as<FrameAgg>();
+    FrameAgg *frame_total = (FrameAgg *)(tot + TOT_FRAME);
     PktCnt *pk_total = (PktCnt *)(tot + TOT_PKT0);
     if (tiles) {
         if (lds_tables)
@@ -813,45 +829,30 @@ int run_decode(nfc_ctx *c) {
     if (tiles) {
         if (lds_tables)
             hipLaunchKernelGGL(k_dec_apply<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
-                               dec_state_in, outw, sparts);
+                               dec_state_in, outw, fparts);
         else
             hipLaunchKernelGGL(k_dec_apply<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
-                               dec_state_in, outw, sparts);
+                               dec_state_in, outw, fparts);
     }
-    scan_partials<SymAggOp>(c->st, tiles, ne_dev, DEC_TILE, sparts, SymAggOp::identity(), sym_total,
-                            DecCarryEpilogue{(const DecMaps *)(tot + TOT_DECMAP), dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM)});
-    // framing in the same (edge) domain: flags counted per tile -> offsets -> bits and closes to their places
-    if (tiles) {
-        SymOut so{{c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()}, {cs[0], cs[1]}};
-        hipLaunchKernelGGL(k_sym_frame, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, sparts, started0, started1, so,
-                           pparts);
-    }
-    scan_partials<PktCntOp>(c->st, tiles, ne_dev, DEC_TILE, pparts, PktCnt{{(uint64_t)pend[0], (uint64_t)pend[1]}}, pk_total);
-    const uint32_t cap_bits[2] = {pend[0] + cs[0], pend[1] + cs[1]};
-    if (tiles) {
-        PktOut po{c->d_edges.as<nfc_edge>(),
-                  {c->d_bits[0].as<uint8_t>(), c->d_bits[1].as<uint8_t>()},
-                  {c->d_close_end[0].as<uint32_t>(), c->d_close_end[1].as<uint32_t>()},
-                  {c->d_close_idx[0].as<uint64_t>(), c->d_close_idx[1].as<uint64_t>()},
-                  {enabled[0] ? cap_bits[0] : 0u, enabled[1] ? cap_bits[1] : 0u},
-                  {enabled[0] ? cs[0] : 0u, enabled[1] ? cs[1] : 0u}};
-        hipLaunchKernelGGL(k_pkt_write, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, sparts, pparts, started0,
-                           started1, po);
-    }
+    scan_partials<FrameAggOp>(c->st, tiles, ne_dev, DEC_TILE, fparts, FrameAggOp::identity(), frame_total,
+                              DecCarryEpilogue{(const DecMaps *)(tot + TOT_DECMAP), dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM), pk_total,
+                                               {P.pend[0], P.pend[1]}, {P.started_in[0], P.started_in[1]}});
+    hipLaunchKernelGGL(k_frame_write, dim3((unsigned)std::max<size_t>(tiles, 1)), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts, P);
+    const int pn = 1 - c->pend_cur;
     PktFinish F;
     memset(&F, 0, sizeof F);
     for (int t = 0; t < 2; t++) {
         F.enabled[t] = enabled[t] ? 1 : 0;
-        F.bits[t] = c->d_bits[t].as<uint8_t>();
+        F.bits[t] = P.bits[t];
         F.pending_next[t] = c->d_pending[t][pn].as<uint8_t>();
-        F.close_end[t] = c->d_close_end[t].as<uint32_t>();
-        F.started_in[t] = c->h_dcarry.pkt_started[t];
+        F.close_end[t] = P.close_end[t];
+        F.started_in[t] = (int32_t)P.started_in[t];
         F.pending_cap[t] = (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu);
-        F.cap_bits[t] = cap_bits[t];
-        F.cap_close[t] = cs[t];
+        F.cap_bits[t] = P.cap_bits[t];
+        F.cap_close[t] = P.cap_close[t];
     }
     F.totals = pk_total;
-    F.sym_total = sym_total;
+    F.frame_total = frame_total;
     F.carry = dD(c);
     hipLaunchKernelGGL(k_pkt_finish, dim3(2), dim3(256), 0, c->st, F);
     return NFC_OK;   // totals and carries are mirrored by the caller's final copy
@@ -878,41 +879,26 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     for (int b = 0; b < 64; b += c->mx) A.E.per_mask |= 1ull << b;
     A.nwords = ((size_t)n + 63) / 64;
     const uint32_t ce = c->cap_edges;
-    const uint32_t cs[2] = {c->cap_sym[0], c->cap_sym[1]};
     HIPCHK(c, c->d_edges.ensure(((size_t)ce + 1) * sizeof(nfc_edge)));
     HIPCHK(c, c->d_ecode.ensure(((size_t)ce + 8) * 2));
-    for (int t = 0; t < 2; t++) HIPCHK(c, c->d_sym[t].ensure((size_t)cs[t] + 16));
     A.edges = c->d_edges.as<nfc_edge>();
     A.ecode = c->d_ecode.as<uint16_t>();
     A.cap_edges = ce;
     A.T = c->T;
     A.dec_state_in = (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4);
-    A.S = SymOut{{c->d_sym[0].as<uint8_t>(), c->d_sym[1].as<uint8_t>()}, {cs[0], cs[1]}};
+    const bool enabled[2] = {c->T.tag != 0, c->T.reader != 0};
+    const int rf = frame_out(c, A.P, enabled);
+    if (rf) return rf;
     const int pn = 1 - c->pend_cur;
     for (int t = 0; t < 2; t++) {
-        SmallFraming &F = A.F[t];
-        F.enabled = (t == 0 ? c->T.tag : c->T.reader) ? 1 : 0;
-        if (!F.enabled) continue;
-        const uint32_t pend = c->h_dcarry.pending[t];
-        HIPCHK(c, c->d_bits[t].ensure((size_t)pend + cs[t] + 16));
-        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend + cs[t] + 16));
-        HIPCHK(c, c->d_close_end[t].ensure(((size_t)cs[t] + 4) * 4));
-        HIPCHK(c, c->d_close_idx[t].ensure(((size_t)cs[t] + 4) * 8));
-        if (pend) HIPCHK(c, hipMemcpyAsync(c->d_bits[t].p, c->d_pending[t][c->pend_cur].p, pend, hipMemcpyDeviceToDevice, c->st));
-        F.started_in = (uint32_t)c->h_dcarry.pkt_started[t];
-        F.pend = pend;
-        F.cap_bits = pend + cs[t];
-        F.cap_close = cs[t];
-        F.bits = c->d_bits[t].as<uint8_t>();
-        F.pending_next = c->d_pending[t][pn].as<uint8_t>();
-        F.close_end = c->d_close_end[t].as<uint32_t>();
-        F.close_idx = c->d_close_idx[t].as<uint64_t>();
-        F.pending_cap = (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu);
+        A.enabled[t] = enabled[t] ? 1 : 0;
+        A.pending_next[t] = c->d_pending[t][pn].as<uint8_t>();
+        A.pending_cap[t] = (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu);
     }
     A.tot_last2 = (Last2 *)(tot + TOT_LAST2);
     A.tot_edges = (uint32_t *)(tot + TOT_EDGES);
     A.tot_decmap = (DecMaps *)(tot + TOT_DECMAP);
-    A.tot_symagg = (SymAgg *)(tot + TOT_SYMAGG);
+    A.tot_frame = (FrameAgg *)(tot + TOT_FRAME);
     A.tot_pk = (PktCnt *)(tot + TOT_PKT0);
     A.tot_nsym = (uint32_t *)(tot + TOT_NSYM);
     A.ecarry = dE(c);
@@ -1275,7 +1261,7 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_partials3, &c->d_aggs, &c->d_pack, &c->d_gvtop, &c->d_seqout};
+                     &c->d_partials, &c->d_aggs, &c->d_pack, &c->d_gvtop, &c->d_seqout};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

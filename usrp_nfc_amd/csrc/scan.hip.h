@@ -50,21 +50,6 @@ struct AddU64 {  // also used as two packed u32 counters (no carry between halve
 // ---- finite-state maps ---------------------------------------------------------
 // A map sends every state to its successor; "f then g" is h[s] = g[f[s]].
 // Decoder maps are stored one byte per state so that v_perm_b32 does four look-ups at once.
-__host__ __device__ constexpr uint64_t identity_map(int nstates) {   // nibble form (framing machine, host tables)
-    uint64_t m = 0;
-    for (int s = 0; s < nstates; s++) m |= (uint64_t)s << (4 * s);
-    return m;
-}
-template <int NSTATES>
-__device__ __forceinline__ uint64_t compose_map(uint64_t f, uint64_t g) {
-    uint64_t h = 0;
-#pragma unroll
-    for (int s = 0; s < NSTATES; s++) {
-        const uint32_t fs = (uint32_t)(f >> (4 * s)) & 15u;
-        h |= ((g >> (4 * fs)) & 15ull) << (4 * s);
-    }
-    return h;
-}
 // four look-ups into a 16-byte table g0..g3; sel holds four indices 0..15
 __device__ __forceinline__ uint32_t lookup16x4(uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3, uint32_t sel) {
     const uint32_t s7 = sel & 0x07070707u;
@@ -107,16 +92,6 @@ struct ComposeDec {
         const uint32_t b = __builtin_amdgcn_perm(m.man[1], m.man[0], (st >> 4) & 7u) & 15u;
         return a | (b << 4);
     }
-};
-
-// Packet framing: 2 states (started or not) -> 8-bit nibble map, kept in a u32.
-struct ComposePkt {
-    using T = uint32_t;
-    static __host__ __device__ __forceinline__ T identity() { return (uint32_t)identity_map(2); }
-    static T identity_host() { return identity(); }
-    static __device__ __forceinline__ T op(T a, T b) { return (uint32_t)compose_map<2>(a, b); }
-    static __device__ __forceinline__ T shfl_up(T v, int d) { return (T)__shfl_up((int)v, d, 64); }
-    static __device__ __forceinline__ uint32_t step(T m, uint32_t st) { return (m >> (4 * st)) & 1u; }
 };
 
 // ---- block-level helpers ----------------------------------------------------

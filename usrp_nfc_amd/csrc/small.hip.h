@@ -20,14 +20,6 @@ constexpr int SM_BLOCK = 256, SM_WAVES = SM_BLOCK / 64;   // four waves: room fo
 constexpr int SM_EVCAP = 4096;              // entries listed per round of the edge writer
 constexpr uint32_t SM_MAX_SAMPLES = 1u << 18;   // batches up to this length take the one-launch path
 
-struct SmallFraming {   // one packet type
-    int32_t enabled;
-    uint32_t started_in, pend;
-    uint8_t *bits, *pending_next;
-    uint32_t *close_end;
-    uint64_t *close_idx;
-    uint32_t pending_cap, cap_bits, cap_close;
-};
 struct SmallArgs {
     EdgeArgs E;
     size_t nwords;
@@ -36,12 +28,14 @@ struct SmallArgs {
     uint32_t cap_edges;
     DecTables T;
     uint32_t dec_state_in;
-    SymOut S;
-    SmallFraming F[2];
+    FrameOut P;             // (edges: the array this launch writes)
+    int32_t enabled[2];
+    uint8_t *pending_next[2];
+    uint32_t pending_cap[2];
     Last2 *tot_last2;
     uint32_t *tot_edges;
     DecMaps *tot_decmap;
-    SymAgg *tot_symagg;
+    FrameAgg *tot_frame;
     PktCnt *tot_pk;
     uint32_t *tot_nsym;
     EdgeCarry *ecarry;
@@ -53,8 +47,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[36864];
     __shared__ Last2 r_l2[SM_WAVES];
     __shared__ uint32_t r_u32[SM_WAVES];
-    __shared__ SymAgg r_sa[SM_WAVES];
-    __shared__ PktCnt r_pk[SM_WAVES];
+    __shared__ FramePk r_fa[SM_WAVES];
     __shared__ DecMaps r_map[SM_WAVES];
     const int tid = threadIdx.x;
 
@@ -159,8 +152,8 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
         const uint16_t *mil = lds_tab ? s_mstep : A.T.mil_step;
         const uint16_t *man = lds_tab ? s_nstep : A.T.man_step;
         DecMaps run_map = ComposeDec::identity();
-        SymAgg run_sa = SymAggOp::identity();
-        PktCnt run_pk{{(uint64_t)A.F[0].pend, (uint64_t)A.F[1].pend}};
+        FrameAgg run_fa = FrameAggOp::identity();
+        copy_pending(A.P, tid, SM_BLOCK);
         for (size_t e0 = 0; e0 < ne; e0 += (size_t)SM_BLOCK * DEC_ITEMS) {
             const size_t base = e0 + (size_t)tid * DEC_ITEMS;
             uint32_t c[8];
@@ -201,66 +194,34 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
                 }
                 ow[k >> 2] |= w << (8 * (k & 3));
             }
-            // symbols to their arrays, framing flags counted (k_sym_frame), bits and closes to theirs (k_pkt_write)
-            SymAgg tot_sa;
-            const SymAgg pre = SymAggOp::op(run_sa, block_exclusive<SymAggOp, SM_WAVES>(sym_agg_of(ow), r_sa, tot_sa));
-            uint32_t off[2] = {pre.cnt[0], pre.cnt[1]};
-            const uint32_t st0[2] = {pm_apply(pre.map[0], A.F[0].started_in), pm_apply(pre.map[1], A.F[1].started_in)};
-            uint32_t started[2] = {st0[0], st0[1]};
-            uint32_t nb[2] = {0u, 0u}, nc[2] = {0u, 0u};
-            for_each_symbol(ow, [&](int t, uint32_t s, int) {
-                if (off[t] + 1 < A.S.cap[t]) A.S.sym[t][off[t]] = (uint8_t)s;
-                off[t]++;
-                const uint32_t f = frame_symbol(t, s, started[t]);
-                nb[t] += f & 1u;
-                nc[t] += f >> 1;
-            });
-            PktCnt tot_pk;
-            const PktCnt mine{{(uint64_t)nb[0] | ((uint64_t)nc[0] << 32), (uint64_t)nb[1] | ((uint64_t)nc[1] << 32)}};
-            const PktCnt run0 = PktCntOp::op(run_pk, block_exclusive<PktCntOp, SM_WAVES>(mine, r_pk, tot_pk));
-            uint64_t run[2] = {run0.v[0], run0.v[1]};
-            started[0] = st0[0];
-            started[1] = st0[1];
-            for_each_symbol(ow, [&](int t, uint32_t s, int k) {
-                const uint32_t f = frame_symbol(t, s, started[t]);
-                if (f & 2u) {
-                    const uint32_t j = (uint32_t)(run[t] >> 32);
-                    if (j < A.F[t].cap_close) {
-                        A.F[t].close_end[j] = (uint32_t)run[t];
-                        A.F[t].close_idx[j] = A.edges[base + k].idx;
-                    }
-                    run[t] += 1ull << 32;
-                } else if (f & 1u) {
-                    if ((uint32_t)run[t] < A.F[t].cap_bits) A.F[t].bits[(uint32_t)run[t]] = (uint8_t)s;
-                    run[t] += 1ull;
-                }
-            });
+            // symbols, packet bits and packet ends to their places (decode.hip.h: one aggregate carries all three offsets)
+            FramePk tot_fa;
+            const FramePk in_tile = block_exclusive<FramePkOp, SM_WAVES>(FramePkOp::pack(frame_agg_of(ow)), r_fa, tot_fa);
+            if (ow[0] | ow[1] | ow[2] | ow[3]) frame_write(A.P, FrameAggOp::op(run_fa, FramePkOp::unpack(in_tile)), ow, base);
             run_map = ComposeDec::op(run_map, tot_map);
-            run_sa = SymAggOp::op(run_sa, tot_sa);
-            run_pk = PktCntOp::op(run_pk, tot_pk);
+            run_fa = FrameAggOp::op(run_fa, FramePkOp::unpack(tot_fa));
         }
         __syncthreads();   // the bits and close offsets of every thread
         if (tid == 0) {
             *A.tot_decmap = run_map;
-            *A.tot_symagg = run_sa;
-            *A.tot_pk = run_pk;
+            *A.tot_frame = run_fa;
             const uint32_t st = ComposeDec::step(run_map, A.dec_state_in);
             A.dcarry->mil_state = (int32_t)(st & 15u);
             A.dcarry->man_state = (int32_t)(st >> 4);
-            A.tot_nsym[1] = run_sa.cnt[1];   // Miller / reader
-            A.tot_nsym[0] = run_sa.cnt[0];   // Manchester / tag
+            A.tot_nsym[1] = run_fa.cnt[1];   // Miller / reader
+            A.tot_nsym[0] = run_fa.cnt[0];   // Manchester / tag
         }
         for (int t = 0; t < 2; t++) {
-            const SmallFraming &F = A.F[t];
-            if (!F.enabled) continue;
-            const uint32_t nbits = (uint32_t)run_pk.v[t], ncl = (uint32_t)(run_pk.v[t] >> 32);
-            if (nbits > F.cap_bits || ncl > F.cap_close) continue;   // the host repeats the stage with room
-            const uint32_t from = ncl ? F.close_end[ncl - 1] : 0u;
+            const uint32_t nbits = A.P.pend[t] + fa_bits(run_fa, t, A.P.started_in[t]), ncl = fa_closes(run_fa, t, A.P.started_in[t]);
+            if (tid == 0) A.tot_pk->v[t] = (uint64_t)nbits | ((uint64_t)ncl << 32);
+            if (!A.enabled[t]) continue;
+            if (nbits > A.P.cap_bits[t] || ncl > A.P.cap_close[t]) continue;   // the host repeats the stage with room
+            const uint32_t from = ncl ? A.P.close_end[t][ncl - 1] : 0u;
             const uint32_t keep = nbits - from;
-            for (uint32_t i = tid; i < keep && i < F.pending_cap; i += SM_BLOCK) F.pending_next[i] = F.bits[from + i];
+            for (uint32_t i = tid; i < keep && i < A.pending_cap[t]; i += SM_BLOCK) A.pending_next[t][i] = A.P.bits[t][from + i];
             if (tid == 0) {
                 A.dcarry->pending[t] = keep;
-                A.dcarry->pkt_started[t] = (int32_t)pm_apply(run_sa.map[t], F.started_in);
+                A.dcarry->pkt_started[t] = (int32_t)pm_apply(run_fa.fl[t], A.P.started_in[t]);
             }
         }
     }
