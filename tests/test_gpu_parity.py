@@ -154,6 +154,16 @@ def test_synthetic_workloads_2M(name, kw):
     assert len(r['packets']) > 100
 
 
+@pytest.mark.parametrize('own_prefix_max', ['0', '3'])
+def test_prefix_launch_path(monkeypatch, own_prefix_max):
+    # Few tiles: every tile's workgroup folds its predecessors' aggregates itself; long batches keep the single-workgroup
+    # prefix launches.  The library reads the switch-over at nfc_create: force the long-batch form on a short batch
+    # (and a mixed case: the decode stage's tiles exceed the limit, later pushes of 300k samples do not).
+    monkeypatch.setenv('NFC_OWN_PREFIX_MAX', own_prefix_max)
+    iq = synth.workload('all', 2_300_000)
+    check_vs_oracle(iq, dict(hi_val=1.1), kind=api.NFC_IN_IQ_F32, pushes=[0, 1_400_000, 1_700_000, 2_300_000])
+
+
 @pytest.mark.parametrize('n', [2_000_001, 2_000_063, 2_000_064, 2_000_191, 1_999_999])
 def test_ragged_batch_end(n):
     # a batch that does not end on a 256-sample step: its last step runs with the lanes past the end masked,

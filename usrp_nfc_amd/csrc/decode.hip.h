@@ -254,13 +254,16 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_reduce(const uint16_t *ecode
 template <bool LDS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode, size_t n, const uint32_t *n_dev, DecTables T,
                                                          const DecMaps *partials, const DecMaps *aggs, uint32_t state0,
-                                                         uint8_t *outw, FrameAgg *frame_aggs) {
+                                                         uint8_t *outw, FrameAgg *frame_aggs, FramePk *thread_aggs, bool own_prefix, DecMaps *total_out) {
     if (n_dev) n = min(n, (size_t)*n_dev);
+    if (own_prefix && n == 0 && blockIdx.x == 0 && threadIdx.x == 0) *total_out = ComposeDec::identity();
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
     __shared__ __attribute__((aligned(16))) uint16_t s_mil[LDS ? DEC_LDS_ROWS * 16 : 8];
     __shared__ __attribute__((aligned(16))) uint16_t s_man[LDS ? DEC_LDS_ROWS * 8 : 8];
     __shared__ DecMaps lds[SCAN_WAVES];
     __shared__ FramePk lds2[SCAN_WAVES];
+    // own_prefix: `partials` still holds the tiles' maps (scan.hip.h: tile_prefix; first, while few registers are live)
+    const DecMaps pre = own_prefix ? tile_prefix<ComposeDec, SCAN_BLOCK>(partials, blockIdx.x, lds) : partials[blockIdx.x];
     if (LDS) {
         const int rows = 4 * T.nd;
         if (T.reader)
@@ -274,7 +277,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
     load_codes(ecode, base, n, c);
     DecMaps total;
     const DecMaps excl = block_exclusive<ComposeDec>(aggs[tid], lds, total);
-    uint32_t st = ComposeDec::step(ComposeDec::op(partials[blockIdx.x], excl), state0);
+    // (own_prefix: the last tile publishes the total)
+    if (own_prefix && threadIdx.x == 0 && ((size_t)blockIdx.x + 1) * DEC_TILE >= n) *total_out = ComposeDec::op(pre, total);
+    uint32_t st = ComposeDec::step(ComposeDec::op(pre, excl), state0);
     const uint16_t *mil = LDS ? s_mil : T.mil_step;
     const uint16_t *man = LDS ? s_man : T.man_step;
     uint32_t ow[4] = {0u, 0u, 0u, 0u};
@@ -297,7 +302,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
     }
     if (base < n) *(uint4 *)(outw + base) = make_uint4(ow[0], ow[1], ow[2], ow[3]);   // outw has 16 bytes of slack
     FramePk total_fa;
-    (void)block_exclusive<FramePkOp>(FramePkOp::pack(frame_agg_of(ow)), lds2, total_fa);
+    const FramePk mine = FramePkOp::pack(frame_agg_of(ow));
+    *(uint4 *)(thread_aggs + tid) = make_uint4(mine.a[0], mine.a[1], mine.b[0], mine.b[1]);   // (k_frame_write scans them again)
+    (void)block_exclusive<FramePkOp>(mine, lds2, total_fa);
     if (threadIdx.x == 0) frame_aggs[blockIdx.x] = FramePkOp::unpack(total_fa);
 }
 
@@ -344,22 +351,58 @@ __device__ __forceinline__ void frame_write(const FrameOut &P, const FrameAgg &p
         }
     });
 }
+// Decoder states after the batch, from the total of the map scan; also publishes the per-type symbol counts the
+// host checks against the capacities and the per-type bit / close totals.  Epilogue of the framing scan's partials pass.
+struct DecCarryEpilogue {
+    const DecMaps *total;
+    uint32_t state_in;
+    DecCarry *carry;
+    uint32_t *nsym;
+    PktCnt *pk_total;
+    uint32_t pend[2], started_in[2];
+    __device__ __forceinline__ void operator()(const FrameAgg &ft) const {
+        const uint32_t st = ComposeDec::step(*total, state_in);
+        carry->mil_state = (int32_t)(st & 15u);
+        carry->man_state = (int32_t)(st >> 4);
+        nsym[1] = ft.cnt[1];   // Miller / reader
+        nsym[0] = ft.cnt[0];   // Manchester / tag
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            pk_total->v[t] = (uint64_t)(pend[t] + fa_bits(ft, t, started_in[t])) | ((uint64_t)fa_closes(ft, t, started_in[t]) << 32);
+    }
+};
+
 __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw, size_t n, const uint32_t *n_dev, const FrameAgg *tile_pre,
-                                                           FrameOut P) {
+                                                           const FramePk *thread_aggs, FrameOut P, bool own_prefix, FrameAgg *total_out,
+                                                           DecCarryEpilogue epi) {
     if (blockIdx.x == 0) copy_pending(P, threadIdx.x, SCAN_BLOCK);
     if (n_dev) n = min(n, (size_t)*n_dev);
+    if (own_prefix && n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        *total_out = FrameAggOp::identity();
+        epi(FrameAggOp::identity());
+    }
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
     __shared__ FramePk lds[SCAN_WAVES];
+    __shared__ FrameAgg lds_pre[SCAN_WAVES];
+    // own_prefix: tile_pre still holds the tiles' aggregates (scan.hip.h: tile_prefix; first, while few registers are live)
+    const FrameAgg pre = own_prefix ? tile_prefix<FrameAggOp, SCAN_BLOCK>(tile_pre, blockIdx.x, lds_pre) : tile_pre[blockIdx.x];
     const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_ITEMS;
     uint32_t ow[4] = {0u, 0u, 0u, 0u};
     if (base < n) {   // k_dec_apply wrote whole 16-byte groups, zero past n
         const uint4 a = *(const uint4 *)(outw + base);
         ow[0] = a.x; ow[1] = a.y; ow[2] = a.z; ow[3] = a.w;
     }
+    const uint4 m4 = *(const uint4 *)(thread_aggs + (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x);
     FramePk total;
-    const FramePk in_tile = block_exclusive<FramePkOp>(FramePkOp::pack(frame_agg_of(ow)), lds, total);
+    const FramePk in_tile = block_exclusive<FramePkOp>(FramePk{{m4.x, m4.y}, {m4.z, m4.w}}, lds, total);
     // (staging the tile's symbols and bits in LDS to store whole words measured slower: 32 vs 26 us)
-    if (ow[0] | ow[1] | ow[2] | ow[3]) frame_write(P, FrameAggOp::op(tile_pre[blockIdx.x], FramePkOp::unpack(in_tile)), ow, base);
+    // (own_prefix: the last tile publishes the total and the carries)
+    if (own_prefix && threadIdx.x == 0 && ((size_t)blockIdx.x + 1) * DEC_TILE >= n) {
+        const FrameAgg all = FrameAggOp::op(pre, FramePkOp::unpack(total));
+        *total_out = all;
+        epi(all);
+    }
+    if (ow[0] | ow[1] | ow[2] | ow[3]) frame_write(P, FrameAggOp::op(pre, FramePkOp::unpack(in_tile)), ow, base);
 }
 
 // After framing: keep the open packet's bits for the next batch and publish the carry.  Reads nothing that it (or a
@@ -390,26 +433,5 @@ __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
         F.carry->pkt_started[t] = (int32_t)pm_apply(F.frame_total->fl[t], (uint32_t)F.started_in[t]);
     }
 }
-
-// Decoder states after the batch, from the total of the map scan; also publishes the per-type symbol counts the
-// host checks against the capacities and the per-type bit / close totals.  Epilogue of the framing scan's partials pass.
-struct DecCarryEpilogue {
-    const DecMaps *total;
-    uint32_t state_in;
-    DecCarry *carry;
-    uint32_t *nsym;
-    PktCnt *pk_total;
-    uint32_t pend[2], started_in[2];
-    __device__ __forceinline__ void operator()(const FrameAgg &ft) const {
-        const uint32_t st = ComposeDec::step(*total, state_in);
-        carry->mil_state = (int32_t)(st & 15u);
-        carry->man_state = (int32_t)(st >> 4);
-        nsym[1] = ft.cnt[1];   // Miller / reader
-        nsym[0] = ft.cnt[0];   // Manchester / tag
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-            pk_total->v[t] = (uint64_t)(pend[t] + fa_bits(ft, t, started_in[t])) | ((uint64_t)fa_closes(ft, t, started_in[t]) << 32);
-    }
-};
 
 }  // namespace nfc

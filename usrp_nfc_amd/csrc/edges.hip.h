@@ -216,6 +216,22 @@ __device__ __forceinline__ uint16_t edge_code(int v, int d, int t, int nd) {
     return (uint16_t)(((v + 1) * nd + dd) | ((t + 1) << 14));
 }
 
+// carried (_last_bit, _dur, _current_state) after the batch, from the scan-1 total; runs once after the entry-count
+// scan: as the epilogue of its prefix launch, or in the workgroup of the last tile of k_write_edges
+struct EdgeCarryEpilogue {
+    EdgeArgs A;
+    const Last2 *total;
+    EdgeCarry *carry;
+    __device__ __forceinline__ void operator()(uint32_t) const {
+        if (A.skip >= A.n) return;  // nothing but fill samples: unchanged
+        int lb, dur, st;
+        A.state_before((int32_t)A.n, *total, lb, dur, st);
+        carry->last_bit = lb;
+        carry->dur = dur;
+        carry->state = st;
+    }
+};
+
 // The writer: a workgroup owns 512 consecutive words (two per thread).  It places its entries with a block
 // scan, lists them as (word, bit) in LDS, and then works one thread per entry, so that consecutive lanes
 // store consecutive 16-byte entries.
@@ -224,7 +240,8 @@ constexpr int EW_WORDS = SCAN_BLOCK * EW_ITEMS;
 constexpr int EW_CAP = 4096;   // entries listed per round (a tile holds 2150 on the bench workloads, 32768 at most)
 __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const Last2 *ctx, const uint64_t *evm,
                                                            const uint32_t *tile_base, nfc_edge *edges, uint16_t *ecode,
-                                                           uint32_t cap) {
+                                                           uint32_t cap, bool own_prefix, uint32_t *total_out, const Last2 *last2_total,
+                                                           EdgeCarry *carry_out) {
     __shared__ uint64_t s_ng[EW_WORDS], s_ps[EW_WORDS], s_m[EW_WORDS];
     __shared__ Last2 s_ctx[EW_WORDS];
     __shared__ uint16_t s_ev[EW_CAP];
@@ -249,7 +266,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
     }
     uint32_t total;
     const uint32_t off = block_exclusive<AddU32>(mine, s_scan, total);
-    const uint32_t gbase = tile_base[blockIdx.x];
+    // own_prefix: tile_base still holds the tiles' entry counts; the last tile publishes the total and the carry
+    const uint32_t gbase = own_prefix ? tile_prefix<AddU32, SCAN_BLOCK>(tile_base, blockIdx.x, s_scan) : tile_base[blockIdx.x];
+    if (own_prefix && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        *total_out = gbase + total;
+        EdgeCarryEpilogue{A, last2_total, carry_out}(gbase + total);
+    }
     for (uint32_t rbase = 0; rbase < total; rbase += EW_CAP) {
         uint32_t k = off - rbase;   // wraps below the round: the unsigned compare drops those
 #pragma unroll
@@ -294,21 +316,5 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
         __syncthreads();
     }
 }
-
-// carried (_last_bit, _dur, _current_state) after the batch, from the scan-1 total; runs as the epilogue of the
-// entry-count scan's partials pass
-struct EdgeCarryEpilogue {
-    EdgeArgs A;
-    const Last2 *total;
-    EdgeCarry *carry;
-    __device__ __forceinline__ void operator()(uint32_t) const {
-        if (A.skip >= A.n) return;  // nothing but fill samples: unchanged
-        int lb, dur, st;
-        A.state_before((int32_t)A.n, *total, lb, dur, st);
-        carry->last_bit = lb;
-        carry->dur = dur;
-        carry->state = st;
-    }
-};
 
 }  // namespace nfc

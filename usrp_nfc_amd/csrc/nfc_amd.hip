@@ -51,13 +51,13 @@ struct CertLaunch {
     uint32_t blocks;
 };
 __global__ __launch_bounds__(256) void k_certify_and_count(CertLaunch C, size_t nwords, LoadLast2 load, StoreCtxAndEvents store,
-                                                           const Last2 *partials, uint32_t *sums) {
+                                                           const Last2 *partials, uint32_t *sums, bool own_prefix, Last2 *total_out) {
     if (blockIdx.x < C.blocks) {
         certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, blockIdx.x, C.blocks);
         return;
     }
     scan_apply_sum_block<Last2Op, EW_ITEMS, AddU32, LoadLast2, StoreCtxAndEvents>(nwords, nullptr, load, store, partials, sums,
-                                                                                    blockIdx.x - C.blocks);
+                                                                                    blockIdx.x - C.blocks, own_prefix, total_out);
 }
 
 struct DevBuf {
@@ -119,6 +119,7 @@ struct nfc_ctx {
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
+    uint32_t own_prefix_max = OWN_PREFIX_MAX_TILES;   // tile counts up to this need no prefix launches (NFC_OWN_PREFIX_MAX overrides)
     int use_small = 1;   // short batches take the one-launch edge / decode / framing kernel (NFC_NO_SMALL=1 turns it off)
     uint64_t selmask;
     float eps;
@@ -161,7 +162,7 @@ struct nfc_ctx {
     DevBuf d_ctx, d_wcnt, d_ecode;
     DevBuf d_edges, d_states, d_sym[2], d_bits[2], d_pending[2][2], d_close_end[2],
         d_close_idx[2];
-    DevBuf d_partials, d_partials2, d_aggs;  // scan scratch
+    DevBuf d_partials, d_partials2, d_aggs, d_faggs;  // scan scratch
     DevBuf d_pack;                           // nfc_get_state staging
     DevBuf d_gvtop;                          // per chunk: bound of the ring values (guard of the fp64 sums)
     DevBuf d_seqout;                         // sequential kernel: edge-timing state after its last sample
@@ -740,25 +741,32 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     uint64_t *evm = c->d_wcnt.as<uint64_t>();   // event masks
     // scan 1: the two latest val changes before every 64-sample word; each word then marks its entries, and the
     // tiles' entry counts are the aggregates of scan 2 (entry offsets per tile)
+    // While the tiles are few, each tile's workgroup folds its predecessors' aggregates itself (scan.hip.h: tile_prefix)
+    // and the two single-workgroup prefix launches of the stage are not needed.
+    const bool own = tiles <= c->own_prefix_max;
+    Last2 *last2_total = (Last2 *)(tot + TOT_LAST2);
+    uint32_t *edges_total = (uint32_t *)(tot + TOT_EDGES);
     scan_reduce<Last2Op, EW_ITEMS>(c->st, nwords, nullptr, LoadLast2{E}, c->d_partials.as<Last2>());
-    scan_partials<Last2Op>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials.as<Last2>(), Last2Op::identity(),
-                           (Last2 *)(tot + TOT_LAST2));
+    if (!own)
+        scan_partials<Last2Op>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials.as<Last2>(), Last2Op::identity(), last2_total);
     if (c->cert_pending && tiles) {
         c->cert_pending = false;
         hipLaunchKernelGGL(k_certify_and_count, dim3((unsigned)(c->cert.blocks + tiles)), dim3(256), 0, c->st, c->cert, nwords, LoadLast2{E},
-                           StoreCtxAndEvents{E, ctx, evm}, c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>());
+                           StoreCtxAndEvents{E, ctx, evm}, c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>(), own, last2_total);
     } else {
         scan_apply_sum<Last2Op, EW_ITEMS, AddU32>(c->st, nwords, nullptr, LoadLast2{E}, StoreCtxAndEvents{E, ctx, evm},
-                                                  c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>());
+                                                  c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>(), own, last2_total);
     }
-    scan_partials<AddU32>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials2.as<uint32_t>(), 0u, (uint32_t *)(tot + TOT_EDGES),
-                          EdgeCarryEpilogue{E, (const Last2 *)(tot + TOT_LAST2), dE(c)});
+    if (!own)
+        scan_partials<AddU32>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials2.as<uint32_t>(), 0u, edges_total,
+                              EdgeCarryEpilogue{E, last2_total, dE(c)});
     const uint32_t cap = c->cap_edges;
     HIPCHK(c, c->d_edges.ensure(((size_t)cap + 1) * sizeof(nfc_edge)));
     HIPCHK(c, c->d_ecode.ensure(((size_t)cap + 8) * 2));
     if (nwords)
         hipLaunchKernelGGL(k_write_edges, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, ctx, evm,
-                           c->d_partials2.as<uint32_t>(), c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), cap);
+                           c->d_partials2.as<uint32_t>(), c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), cap, own, edges_total,
+                           last2_total, dE(c));
     return NFC_OK;
 }
 
@@ -803,6 +811,7 @@ int run_decode(nfc_ctx *c) {
     HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(DecMaps)));
     HIPCHK(c, c->d_partials2.ensure((tiles + 1) * sizeof(FrameAgg)));
     HIPCHK(c, c->d_aggs.ensure((tiles * SCAN_BLOCK + 1) * sizeof(DecMaps)));
+    HIPCHK(c, c->d_faggs.ensure((tiles * SCAN_BLOCK + 1) * sizeof(FramePk)));
     const bool enabled[2] = {c->T.tag != 0, c->T.reader != 0};
     FrameOut P;
     const int rf = frame_out(c, P, enabled);
@@ -825,19 +834,22 @@ int run_decode(nfc_ctx *c) {
         else
             hipLaunchKernelGGL(k_dec_reduce<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
     }
-    scan_partials<ComposeDec>(c->st, tiles, ne_dev, DEC_TILE, dparts, ComposeDec::identity_host(), (DecMaps *)(tot + TOT_DECMAP));
+    const bool own = tiles <= c->own_prefix_max;   // (scan.hip.h: tile_prefix -- no prefix launches while the tiles are few)
+    DecMaps *map_total = (DecMaps *)(tot + TOT_DECMAP);
+    const DecCarryEpilogue epi{map_total, dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM), pk_total,
+                               {P.pend[0], P.pend[1]}, {P.started_in[0], P.started_in[1]}};
+    if (!own) scan_partials<ComposeDec>(c->st, tiles, ne_dev, DEC_TILE, dparts, ComposeDec::identity_host(), map_total);
     if (tiles) {
         if (lds_tables)
             hipLaunchKernelGGL(k_dec_apply<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
-                               dec_state_in, outw, fparts);
+                               dec_state_in, outw, fparts, c->d_faggs.as<FramePk>(), own, map_total);
         else
             hipLaunchKernelGGL(k_dec_apply<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
-                               dec_state_in, outw, fparts);
+                               dec_state_in, outw, fparts, c->d_faggs.as<FramePk>(), own, map_total);
     }
-    scan_partials<FrameAggOp>(c->st, tiles, ne_dev, DEC_TILE, fparts, FrameAggOp::identity(), frame_total,
-                              DecCarryEpilogue{(const DecMaps *)(tot + TOT_DECMAP), dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM), pk_total,
-                                               {P.pend[0], P.pend[1]}, {P.started_in[0], P.started_in[1]}});
-    hipLaunchKernelGGL(k_frame_write, dim3((unsigned)std::max<size_t>(tiles, 1)), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts, P);
+    if (!own) scan_partials<FrameAggOp>(c->st, tiles, ne_dev, DEC_TILE, fparts, FrameAggOp::identity(), frame_total, epi);
+    hipLaunchKernelGGL(k_frame_write, dim3((unsigned)std::max<size_t>(tiles, 1)), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts,
+                       c->d_faggs.as<FramePk>(), P, own, frame_total, epi);
     const int pn = 1 - c->pend_cur;
     PktFinish F;
     memset(&F, 0, sizeof F);
@@ -1134,6 +1146,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     C = std::max(C, c->mx + 2);
     c->rows_per_step = 4;
     c->use_small = getenv("NFC_NO_SMALL") ? 0 : 1;
+    if (const char *e = getenv("NFC_OWN_PREFIX_MAX")) c->own_prefix_max = (uint32_t)strtoul(e, nullptr, 10);
     {
         c->rows_per_step = (c->L >= 512 && getenv("NFC_ROWS8")) ? 8 : 4;   // 8-row steps: measured slower (126 VGPRs: four waves per SIMD)
         const int stp = 64 * c->rows_per_step;
@@ -1261,7 +1274,7 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs, &c->d_pack, &c->d_gvtop, &c->d_seqout};
+                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_pack, &c->d_gvtop, &c->d_seqout};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

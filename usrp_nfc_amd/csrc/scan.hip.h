@@ -140,6 +140,31 @@ __device__ __forceinline__ typename Tr::T block_sum(typename Tr::T v, typename T
     return total;
 }
 
+// A tile's exclusive prefix from the aggregates of its predecessors, computed by the tile's OWN workgroup: every
+// thread folds a contiguous share of aggs[0 .. b), one ordered block reduction joins the shares.  The aggregates
+// are a few tens of KB and stay in L2, so while there are only a few thousand tiles this is cheaper than a
+// single-workgroup prefix launch between two passes (5-10 us each, plus the boundary); the total traffic is
+// quadratic in the tile count, so long batches keep the launch (OWN_PREFIX_MAX_TILES).
+constexpr uint32_t OWN_PREFIX_MAX_TILES = 4096;
+template <class Tr, int BLOCK = 256>
+__device__ __forceinline__ typename Tr::T tile_prefix(const typename Tr::T *aggs, uint32_t b, typename Tr::T *lds) {
+    using T = typename Tr::T;
+    const uint32_t per = (b + BLOCK - 1) / BLOCK;
+    const uint32_t lo = min(b, (uint32_t)threadIdx.x * per), hi = min(b, lo + per);
+    T acc = Tr::identity();
+    constexpr int G = sizeof(T) <= 8 ? 8 : 4;   // loads in flight per thread: the fold must not wait for them one by one
+    for (uint32_t i = lo; i < hi; i += G) {
+        T v[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) v[k] = (i + k < hi) ? aggs[i + k] : Tr::identity();
+#pragma unroll
+        for (int k = 0; k < G; k++) acc = Tr::op(acc, v[k]);
+    }
+    T total;
+    (void)block_exclusive<Tr, BLOCK / 64>(acc, lds, total);
+    return total;
+}
+
 // tiles of BLOCK*ITEMS items
 template <int ITEMS>
 inline size_t scan_num_tiles(size_t n) {
@@ -270,7 +295,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(size_t n, const uint3
 // aggregates of the next scan (over the same tiling), which then needs no reduce launch of its own.
 template <class Tr, int ITEMS, class Tr2, class Load, class Store>
 __device__ __forceinline__ void scan_apply_sum_block(size_t n, const uint32_t *n_dev, const Load &load, const Store &store,
-                                                     const typename Tr::T *partials, typename Tr2::T *sums, uint32_t bid) {
+                                                     const typename Tr::T *partials, typename Tr2::T *sums, uint32_t bid,
+                                                     bool own_prefix = false, typename Tr::T *total_out = nullptr) {
     using T = typename Tr::T;
     using T2 = typename Tr2::T;
     if (n_dev) n = min(n, (size_t)*n_dev);
@@ -288,7 +314,10 @@ __device__ __forceinline__ void scan_apply_sum_block(size_t n, const uint32_t *n
     }
     T total;
     T excl = block_exclusive<Tr>(agg, lds, total);
-    T run = Tr::op(partials[bid], excl);
+    // own_prefix: `partials` still holds the tiles' aggregates (no prefix launch ran); the last tile publishes the total
+    const T pre = own_prefix ? tile_prefix<Tr, SCAN_BLOCK>(partials, bid, lds) : partials[bid];
+    if (own_prefix && total_out && threadIdx.x == 0 && ((size_t)bid + 1) * SCAN_BLOCK * ITEMS >= n) *total_out = Tr::op(pre, total);
+    T run = Tr::op(pre, excl);
     T2 mine = Tr2::identity();
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
@@ -301,8 +330,9 @@ __device__ __forceinline__ void scan_apply_sum_block(size_t n, const uint32_t *n
 }
 template <class Tr, int ITEMS, class Tr2, class Load, class Store>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply_sum(size_t n, const uint32_t *n_dev, Load load, Store store,
-                                                              const typename Tr::T *partials, typename Tr2::T *sums) {
-    scan_apply_sum_block<Tr, ITEMS, Tr2, Load, Store>(n, n_dev, load, store, partials, sums, blockIdx.x);
+                                                              const typename Tr::T *partials, typename Tr2::T *sums, bool own_prefix,
+                                                              typename Tr::T *total_out) {
+    scan_apply_sum_block<Tr, ITEMS, Tr2, Load, Store>(n, n_dev, load, store, partials, sums, blockIdx.x, own_prefix, total_out);
 }
 
 // Host-side drivers.  `partials` must hold scan_num_tiles<ITEMS>(n) entries.
@@ -322,11 +352,11 @@ inline void scan_apply(hipStream_t st, size_t n, const uint32_t *n_dev, Load loa
 }
 template <class Tr, int ITEMS, class Tr2, class Load, class Store>
 inline void scan_apply_sum(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, const typename Tr::T *partials,
-                           typename Tr2::T *sums) {
+                           typename Tr2::T *sums, bool own_prefix = false, typename Tr::T *total_out = nullptr) {
     const size_t tiles = scan_num_tiles<ITEMS>(n);
     if (tiles)
         hipLaunchKernelGGL((k_scan_apply_sum<Tr, ITEMS, Tr2, Load, Store>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev,
-                           load, store, partials, sums);
+                           load, store, partials, sums, own_prefix, total_out);
 }
 
 }  // namespace nfc
