@@ -94,6 +94,41 @@ struct ComposeDec {
     }
 };
 
+// ---- wave-level scan on DPP -----------------------------------------------------
+// An ordered inclusive scan across the 64 lanes with data-parallel-primitive moves (one VALU instruction per word and
+// step; a __shfl_up is an address computation plus an LDS permute per word).  Lanes a move does not reach keep `old`,
+// which is the operator's identity, so every step is an unconditional op(up, x).
+template <int CTRL, int ROWMASK, class T>
+__device__ __forceinline__ T dpp_move(const T &old, const T &v) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    constexpr int W = sizeof(T) / 4;
+    uint32_t o[W], x[W], r[W];
+    __builtin_memcpy(o, &old, sizeof(T));
+    __builtin_memcpy(x, &v, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < W; i++) r[i] = (uint32_t)__builtin_amdgcn_update_dpp((int)o[i], (int)x[i], CTRL, ROWMASK, 0xF, false);
+    T out;
+    __builtin_memcpy(&out, r, sizeof(T));
+    return out;
+}
+template <class Tr>
+__device__ __forceinline__ typename Tr::T wave_inclusive(typename Tr::T x) {
+    using T = typename Tr::T;
+    const T id = Tr::identity();
+    x = Tr::op(dpp_move<0x111, 0xF>(id, x), x);   // row_shr:1   (rows of 16 lanes)
+    x = Tr::op(dpp_move<0x112, 0xF>(id, x), x);   // row_shr:2
+    x = Tr::op(dpp_move<0x114, 0xF>(id, x), x);   // row_shr:4
+    x = Tr::op(dpp_move<0x118, 0xF>(id, x), x);   // row_shr:8
+    x = Tr::op(dpp_move<0x142, 0xA>(id, x), x);   // row_bcast:15 -> rows 1 and 3
+    x = Tr::op(dpp_move<0x143, 0xC>(id, x), x);   // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+// the inclusive value of the lane below (identity in lane 0)
+template <class Tr>
+__device__ __forceinline__ typename Tr::T wave_shift_up1(const typename Tr::T &inc) {
+    return dpp_move<0x138, 0xF>(Tr::identity(), inc);   // wave_shr:1
+}
+
 // ---- block-level helpers ----------------------------------------------------
 // Inclusive scan of one value per thread across the block; returns the exclusive
 // prefix of this thread and the block total.  lds must hold WAVES entries.
@@ -102,12 +137,7 @@ __device__ __forceinline__ typename Tr::T block_exclusive(typename Tr::T v, type
                                                           typename Tr::T &block_total) {
     using T = typename Tr::T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        T up = Tr::shfl_up(inc, d);
-        if (lane >= d) inc = Tr::op(up, inc);
-    }
+    const T inc = wave_inclusive<Tr>(v);
     if (lane == 63) lds[wave] = inc;
     __syncthreads();
     T wave_prefix = Tr::identity();
@@ -120,9 +150,7 @@ __device__ __forceinline__ typename Tr::T block_exclusive(typename Tr::T v, type
     }
     __syncthreads();
     block_total = total;
-    T excl = Tr::shfl_up(inc, 1);
-    if (lane == 0) excl = Tr::identity();
-    return Tr::op(wave_prefix, excl);
+    return Tr::op(wave_prefix, wave_shift_up1<Tr>(inc));
 }
 // Block total of a commutative sum, valid in every thread.
 template <class Tr, int WAVES = SCAN_WAVES>
@@ -218,13 +246,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan_partials(size_t nparts, const ui
         T inc = v[0];
 #pragma unroll
         for (int k = 1; k < PART_ITEMS; k++) inc = Tr::op(inc, v[k]);
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            T up = Tr::shfl_up(inc, d);
-            if (lane >= d) inc = Tr::op(up, inc);
-        }
-        T excl = Tr::shfl_up(inc, 1);
-        if (lane == 0) excl = Tr::identity();
+        inc = wave_inclusive<Tr>(inc);
+        const T excl = wave_shift_up1<Tr>(inc);
         if (lane == 63) lds[wave] = inc;
         __syncthreads();
         if (wave == 0) {   // scan of the wave totals
