@@ -181,23 +181,59 @@ __device__ __forceinline__ uint32_t frame_symbol(int t, uint32_t s, uint32_t &st
     }
     return f;
 }
+// The same aggregate without walking the symbols: a thread's 16 out-bytes are 32 symbol slots (slot 2k + j: symbol j of
+// edge k); per packet type three 32-bit masks say which slots hold a symbol, an error symbol, a start-bit value, and
+// the started / not-started latch over them is the carry chain of ONE addition (a start generates, an error kills,
+// everything else propagates).
+__device__ __forceinline__ uint32_t transpose_pairs(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3) {
+    // m_i: bits 0-1 of byte j = the slot pair of edge 4 i + j.  Returns the pairs in stream order (pair 4 i + j at bits 8 i + 2 j).
+    uint32_t x = m0 | (m1 << 2) | (m2 << 4) | (m3 << 6);   // byte j: [m0.j, m1.j, m2.j, m3.j] -- a 4 x 4 matrix of pairs, transposed:
+    uint32_t t = (x ^ (x >> 6)) & 0x00CC00CCu;
+    x ^= t ^ (t << 6);
+    t = (x ^ (x >> 12)) & 0x0000F0F0u;
+    x ^= t ^ (t << 12);
+    return x;
+}
 __device__ __forceinline__ FrameAgg frame_agg_of(const uint32_t (&ow)[4]) {
-    FrameAgg a = FrameAggOp::identity();
-    uint32_t st1[2] = {1u, 1u};   // the "entered started" hypothesis
-    for_each_symbol(ow, [&](int t, uint32_t s, int) {
-        a.cnt[t]++;
-        const uint32_t f = frame_symbol(t, s, st1[t]);
-        a.nb[t] += f & 1u;
-        a.nc[t] += f >> 1;
-        if ((a.fl[t] & 3u) == PM_ID) {   // the first symbol that is not the identity: the hypotheses merge here
-            if (s > 1u) a.fl[t] = PM_STOP | FA_DC;
-            else if (s == start_bit_of(t)) a.fl[t] = PM_START | FA_DB;
-        } else if (s > 1u) {
-            a.fl[t] = (a.fl[t] & ~3u) | PM_STOP;
-        } else if (s == start_bit_of(t)) {
-            a.fl[t] = (a.fl[t] & ~3u) | PM_START;
-        }
-    });
+    constexpr uint32_t M = 0x01010101u;
+    uint32_t V1[4], ST1[4], SA1[4], V0[4], ST0[4], SA0[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t w = ow[i];
+        const uint32_t b0 = w & M, b1 = (w >> 1) & M;
+        const uint32_t v0 = b0 & b1;            // q == 3: one Manchester symbol
+        const uint32_t v1e = b0 ^ b1;           // q == 1 or 2: a first Miller symbol
+        const uint32_t v1o = b1 & ~b0;          // q == 2: a second one
+        const uint32_t c2 = (w >> 2) & M, hi0 = ((w >> 3) | (w >> 4)) & M;   // first symbol: bit 0; > 1
+        const uint32_t c5 = (w >> 5) & M, hi1 = ((w >> 6) | (w >> 7)) & M;   // second symbol
+        const uint32_t z0 = M ^ (c2 | hi0), z1 = M ^ (c5 | hi1);             // == 0 (Miller's start-bit value, packets.py:24-28)
+        const uint32_t o0 = c2 & ~hi0;                                       // == 1 (Manchester's)
+        V1[i] = v1e | (v1o << 1);
+        ST1[i] = (hi0 & v1e) | ((hi1 & v1o) << 1);
+        SA1[i] = (z0 & v1e) | ((z1 & v1o) << 1);
+        V0[i] = v0;
+        ST0[i] = hi0 & v0;
+        SA0[i] = o0 & v0;
+    }
+    const uint32_t V[2] = {transpose_pairs(V0[0], V0[1], V0[2], V0[3]), transpose_pairs(V1[0], V1[1], V1[2], V1[3])};
+    const uint32_t ST[2] = {transpose_pairs(ST0[0], ST0[1], ST0[2], ST0[3]), transpose_pairs(ST1[0], ST1[1], ST1[2], ST1[3])};
+    const uint32_t SA[2] = {transpose_pairs(SA0[0], SA0[1], SA0[2], SA0[3]), transpose_pairs(SA1[0], SA1[1], SA1[2], SA1[3])};
+    FrameAgg a;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint32_t nonid = ST[t] | SA[t];
+        // entered "started": state before every slot = carry into it of (SA | keep) + SA + 1, keep = neither start nor error
+        const uint32_t x = SA[t] | ~nonid, y = SA[t];
+        const uint32_t before = (x + y + 1u) ^ x ^ y;
+        const uint32_t appended = V[t] & ~ST[t] & (before | ~SA[t]);
+        const uint32_t closes = ST[t] & before;
+        const uint32_t first = nonid & (0u - nonid);
+        a.cnt[t] = (uint32_t)__popc(V[t]);
+        a.nb[t] = (uint32_t)__popc(appended);
+        a.nc[t] = (uint32_t)__popc(closes);
+        a.fl[t] = nonid == 0u ? PM_ID
+                              : ((ST[t] > SA[t] ? PM_STOP : PM_START) | ((first & SA[t]) ? FA_DB : 0u) | ((first & ST[t]) ? FA_DC : 0u));
+    }
     return a;
 }
 // per type: appended bits in the low half, closes in the high half
