@@ -152,36 +152,10 @@ __device__ __forceinline__ uint32_t fa_bits(const FrameAgg &a, int t, uint32_t s
 __device__ __forceinline__ uint32_t fa_closes(const FrameAgg &a, int t, uint32_t started) { return a.nc[t] - (started ? 0u : (a.fl[t] >> 3) & 1u); }
 __device__ __forceinline__ uint32_t start_bit_of(int type) { return type == 0 ? 1u : 0u; }   // packets.py:24-28
 
-// f(type, symbol, k) for every symbol in a thread's sixteen out-bytes, in stream order (k: the edge within the thread)
-template <class F>
-__device__ __forceinline__ void for_each_symbol(const uint32_t (&ow)[4], F f) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint32_t w = (ow[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-        const uint32_t q = w & 3u;
-        if (q == 0u) continue;
-        if (q == 3u) {
-            f(0, (w >> 2) & 7u, k);
-        } else {
-            f(1, (w >> 2) & 7u, k);
-            if (q == 2u) f(1, (w >> 5) & 7u, k);
-        }
-    }
-}
-// per symbol: bit 0 = appended to the packet, bit 1 = closes a started packet (packets.py:67-79); updates `started`
-__device__ __forceinline__ uint32_t frame_symbol(int t, uint32_t s, uint32_t &started) {
-    uint32_t f;
-    if (s > 1u) {
-        f = started ? 2u : 0u;
-        started = 0u;
-    } else {
-        const bool sb = s == start_bit_of(t);
-        f = (!started && sb) ? 0u : 1u;
-        started = (started || sb) ? 1u : 0u;
-    }
-    return f;
-}
-// The same aggregate without walking the symbols: a thread's 16 out-bytes are 32 symbol slots (slot 2k + j: symbol j of
+// PacketProcessor.append_bit per symbol (packets.py:67-79): an error symbol (> 1) closes a started packet and leaves the
+// state "not started"; a bit is appended unless it is the start-bit value arriving while not started (it starts the
+// packet and is dropped); the start-bit value leaves the state "started".
+// A thread never walks its symbols to apply this: a thread's 16 out-bytes are 32 symbol slots (slot 2k + j: symbol j of
 // edge k); per packet type three 32-bit masks say which slots hold a symbol, an error symbol, a start-bit value, and
 // the started / not-started latch over them is the carry chain of ONE addition (a start generates, an error kills,
 // everything else propagates).
@@ -194,7 +168,10 @@ __device__ __forceinline__ uint32_t transpose_pairs(uint32_t m0, uint32_t m1, ui
     x ^= t ^ (t << 12);
     return x;
 }
-__device__ __forceinline__ FrameAgg frame_agg_of(const uint32_t (&ow)[4]) {
+struct SlotMasks {
+    uint32_t V[2], ST[2], SA[2];   // per type: slots that hold a symbol / an error symbol / a start-bit value
+};
+__device__ __forceinline__ SlotMasks slot_masks(const uint32_t (&ow)[4]) {
     constexpr uint32_t M = 0x01010101u;
     uint32_t V1[4], ST1[4], SA1[4], V0[4], ST0[4], SA0[4];
 #pragma unroll
@@ -215,24 +192,31 @@ __device__ __forceinline__ FrameAgg frame_agg_of(const uint32_t (&ow)[4]) {
         ST0[i] = hi0 & v0;
         SA0[i] = o0 & v0;
     }
-    const uint32_t V[2] = {transpose_pairs(V0[0], V0[1], V0[2], V0[3]), transpose_pairs(V1[0], V1[1], V1[2], V1[3])};
-    const uint32_t ST[2] = {transpose_pairs(ST0[0], ST0[1], ST0[2], ST0[3]), transpose_pairs(ST1[0], ST1[1], ST1[2], ST1[3])};
-    const uint32_t SA[2] = {transpose_pairs(SA0[0], SA0[1], SA0[2], SA0[3]), transpose_pairs(SA1[0], SA1[1], SA1[2], SA1[3])};
+    return SlotMasks{{transpose_pairs(V0[0], V0[1], V0[2], V0[3]), transpose_pairs(V1[0], V1[1], V1[2], V1[3])},
+                     {transpose_pairs(ST0[0], ST0[1], ST0[2], ST0[3]), transpose_pairs(ST1[0], ST1[1], ST1[2], ST1[3])},
+                     {transpose_pairs(SA0[0], SA0[1], SA0[2], SA0[3]), transpose_pairs(SA1[0], SA1[1], SA1[2], SA1[3])}};
+}
+// started / not started before every slot, entered in state `started`: the carry into the slot of (SA | keep) + SA + started,
+// keep = slots that are neither a start nor an error (a start generates a carry, an error kills it, the rest propagate)
+__device__ __forceinline__ uint32_t started_before(const SlotMasks &m, int t, uint32_t started) {
+    const uint32_t x = m.SA[t] | ~(m.ST[t] | m.SA[t]), y = m.SA[t];
+    return (x + y + started) ^ x ^ y;
+}
+__device__ __forceinline__ FrameAgg frame_agg_of(const uint32_t (&ow)[4]) {
+    const SlotMasks m = slot_masks(ow);
     FrameAgg a;
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-        const uint32_t nonid = ST[t] | SA[t];
-        // entered "started": state before every slot = carry into it of (SA | keep) + SA + 1, keep = neither start nor error
-        const uint32_t x = SA[t] | ~nonid, y = SA[t];
-        const uint32_t before = (x + y + 1u) ^ x ^ y;
-        const uint32_t appended = V[t] & ~ST[t] & (before | ~SA[t]);
-        const uint32_t closes = ST[t] & before;
+        const uint32_t nonid = m.ST[t] | m.SA[t];
+        const uint32_t before = started_before(m, t, 1u);
+        const uint32_t appended = m.V[t] & ~m.ST[t] & (before | ~m.SA[t]);
+        const uint32_t closes = m.ST[t] & before;
         const uint32_t first = nonid & (0u - nonid);
-        a.cnt[t] = (uint32_t)__popc(V[t]);
+        a.cnt[t] = (uint32_t)__popc(m.V[t]);
         a.nb[t] = (uint32_t)__popc(appended);
         a.nc[t] = (uint32_t)__popc(closes);
         a.fl[t] = nonid == 0u ? PM_ID
-                              : ((ST[t] > SA[t] ? PM_STOP : PM_START) | ((first & SA[t]) ? FA_DB : 0u) | ((first & ST[t]) ? FA_DC : 0u));
+                              : ((m.ST[t] > m.SA[t] ? PM_STOP : PM_START) | ((first & m.SA[t]) ? FA_DB : 0u) | ((first & m.ST[t]) ? FA_DC : 0u));
     }
     return a;
 }
@@ -361,31 +345,40 @@ __device__ __forceinline__ void copy_pending(const FrameOut &P, int tid, int nth
     for (int t = 0; t < 2; t++)
         for (uint32_t i = tid; i < P.pend[t] && i < P.cap_bits[t]; i += nthreads) P.bits[t][i] = P.pending[t][i];
 }
-// a thread's symbols, given the aggregate of everything before them
+// a thread's symbols, given the aggregate of everything before them: one round per symbol it holds
 __device__ __forceinline__ void frame_write(const FrameOut &P, const FrameAgg &pre, const uint32_t (&ow)[4], size_t base) {
-    uint32_t off[2], started[2], bo[2], co[2];
+    const SlotMasks m = slot_masks(ow);
+    const uint64_t lo = (uint64_t)ow[0] | ((uint64_t)ow[1] << 32), hi = (uint64_t)ow[2] | ((uint64_t)ow[3] << 32);
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-        off[t] = pre.cnt[t];
-        started[t] = pm_apply(pre.fl[t], P.started_in[t]);
-        bo[t] = P.pend[t] + fa_bits(pre, t, P.started_in[t]);
-        co[t] = fa_closes(pre, t, P.started_in[t]);
-    }
-    for_each_symbol(ow, [&](int t, uint32_t s, int k) {
-        if (off[t] + 1 < P.cap_sym[t]) P.sym[t][off[t]] = (uint8_t)s;
-        off[t]++;
-        const uint32_t f = frame_symbol(t, s, started[t]);
-        if (f & 2u) {
-            if (co[t] < P.cap_close[t]) {
-                P.close_end[t][co[t]] = bo[t];
-                P.close_idx[t][co[t]] = P.edges[base + k].idx;
+        uint32_t v = m.V[t];
+        if (!v) continue;
+        const uint32_t started = pm_apply(pre.fl[t], P.started_in[t]);
+        const uint32_t before = started_before(m, t, started);
+        const uint32_t appended = v & ~m.ST[t] & (before | ~m.SA[t]);
+        const uint32_t closes = m.ST[t] & before;
+        uint32_t off = pre.cnt[t];
+        const uint32_t bo = P.pend[t] + fa_bits(pre, t, P.started_in[t]), co = fa_closes(pre, t, P.started_in[t]);
+        while (v) {
+            const uint32_t low = v & (0u - v);
+            const int slot = __ffs((int)v) - 1, k = slot >> 1;
+            v ^= low;
+            const uint32_t byte = (uint32_t)((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFFu;
+            const uint32_t s = (byte >> ((slot & 1) ? 5 : 2)) & 7u;
+            if (off + 1 < P.cap_sym[t]) P.sym[t][off] = (uint8_t)s;
+            off++;
+            if (appended & low) {
+                const uint32_t i = bo + (uint32_t)__popc(appended & (low - 1u));
+                if (i < P.cap_bits[t]) P.bits[t][i] = (uint8_t)s;
+            } else if (closes & low) {
+                const uint32_t j = co + (uint32_t)__popc(closes & (low - 1u));
+                if (j < P.cap_close[t]) {
+                    P.close_end[t][j] = bo + (uint32_t)__popc(appended & (low - 1u));
+                    P.close_idx[t][j] = P.edges[base + k].idx;
+                }
             }
-            co[t]++;
-        } else if (f & 1u) {
-            if (bo[t] < P.cap_bits[t]) P.bits[t][bo[t]] = (uint8_t)s;
-            bo[t]++;
         }
-    });
+    }
 }
 // Decoder states after the batch, from the total of the map scan; also publishes the per-type symbol counts the
 // host checks against the capacities and the per-type bit / close totals.  Epilogue of the framing scan's partials pass.

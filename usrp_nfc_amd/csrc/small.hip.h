@@ -5,7 +5,7 @@
 // call) is all boundary.  Here ONE workgroup walks the tiles of each stage in order, so every scan is a
 // single pass with the running prefix in registers -- no tile aggregates, no partials pass, no second read.
 // The per-item arithmetic is the same device code the large path runs (change_mask, event_mask,
-// event_entry, the LUT walk, frame_symbol): only the orchestration differs.
+// event_entry, the LUT walk, frame_agg_of / frame_write): only the orchestration differs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
