@@ -5,9 +5,10 @@
 // Every edge is routed by its type exactly as background.py:30-35 does (t == 1 ->
 // Miller, t == 0 -> Manchester, t == -1 dropped).  An edge is a state map looked
 // up in a host-built LUT (decoder_tables.h); an ordered scan of map compositions
-// gives each edge its incoming decoder state; a second scan of emission counts
-// places the 0-2 symbols it produces.  Framing is the same pattern with a
-// two-state machine (started / not started) over the symbol stream.
+// gives each edge its incoming decoder state.  What an edge emits (0-2 symbols)
+// stays with the edge; ONE more scan, of an aggregate that carries symbol counts,
+// the framing map and bit / close counts under both entry states, places the
+// symbols, the packet bits and the packet ends of both packet types.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
