@@ -238,6 +238,25 @@ int nfc_command_get(int cmd, nfc_command_info *out);
 /* ISO 14443-3 type A CRC (utilities.py:30-41), low byte first */
 int nfc_crc_a(const uint8_t *data, size_t n, uint8_t out[2]);
 
+/* ---- "next" row f4: the transmit side as a device-side signal generator -------------------------
+ * encode_bits of miller_encoder / manchester_encoder / binary_src.encoder (miller.py:200-233, manchester.py:64-79,
+ * binary_src.py:17-20) on the host; binary_src.work (binary_src.py:64-103: int(dur * samp_rate / 1e6) samples per run,
+ * complex64 level + 0j) and multiplier (multiplier.py:18-22: times A exp(j 2 pi f k / samp_rate)) as one kernel. */
+typedef struct {
+    int32_t level;  /* 0 / 1; 2 = binary_src's "temporary pause" marker (no samples) */
+    int32_t pad;
+    double dur_us;
+} nfc_tx_run;
+enum { NFC_TX_SAME = 0, NFC_TX_MANCHESTER = 1, NFC_TX_MILLER = 2 };
+int nfc_tx_encode(int encoding, const uint8_t *bits, size_t n_bits, nfc_tx_run *out, size_t cap, size_t *n_out);
+/* samples binary_src.work produces for the runs */
+int nfc_tx_sample_count(const nfc_tx_run *runs, size_t n_runs, double samp_rate, uint64_t *n_samples);
+/* renders the runs into dev_out (complex64, 32-byte aligned, cap_samples entries); carrier != 0 multiplies by the carrier,
+ * sample k of this call having carrier index first_index + k.  kernel_ms (may be NULL): the kernel's duration by HIP events. */
+int nfc_tx_render_device(int device, const nfc_tx_run *runs, size_t n_runs, double samp_rate, int carrier, double freq,
+                         float amp, uint64_t first_index, void *dev_out, size_t cap_samples, size_t *n_samples,
+                         float *kernel_ms);
+
 /* Device memory helpers so that a caller without HIP bindings (ctypes) can keep its input
  * resident in HBM and use nfc_push_device. */
 int nfc_device_alloc(int device, size_t bytes, void **out);

@@ -53,6 +53,8 @@ class StateHeader(C.Structure):
                 ('n_pending_bits', C.c_uint32 * 2), ('av_window', C.c_int32), ('reserved', C.c_int32)]
 
 
+TX_RUN_DTYPE = np.dtype([('level', '<i4'), ('pad', '<i4'), ('dur_us', '<f8')])   # nfc_tx_run
+NFC_TX_SAME, NFC_TX_MANCHESTER, NFC_TX_MILLER = 0, 1, 2
 EDGE_DTYPE = np.dtype([('idx', '<u8'), ('d', '<i4'), ('v', 'i1'), ('t', 'i1'), ('pad', '<i2')])
 PACKET_DTYPE = np.dtype([('idx', '<u8'), ('bit_off', '<u8'), ('n_bits', '<u4'), ('type', '<i4')])
 
@@ -62,7 +64,7 @@ SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', '
            'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_prime', 'nfc_export_state', 'nfc_get_stats', 'nfc_set_timing',
            'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_host_decode_lut',
            'nfc_fsm_create', 'nfc_fsm_destroy', 'nfc_fsm_reset', 'nfc_fsm_process', 'nfc_fsm_process_packets', 'nfc_fsm_set_keys',
-           'nfc_command_count', 'nfc_command_get', 'nfc_crc_a']
+           'nfc_command_count', 'nfc_command_get', 'nfc_crc_a', 'nfc_tx_encode', 'nfc_tx_sample_count', 'nfc_tx_render_device']
 
 _lib = None
 
@@ -118,6 +120,10 @@ def load():
     L.nfc_command_count.restype = C.c_int
     L.nfc_command_get.argtypes = [C.c_int, C.POINTER(CommandInfo)]
     L.nfc_crc_a.argtypes = [vp, sz, vp]
+    L.nfc_tx_encode.argtypes = [C.c_int, vp, sz, vp, sz, psz]
+    L.nfc_tx_sample_count.argtypes = [vp, sz, C.c_double, C.POINTER(C.c_uint64)]
+    L.nfc_tx_render_device.argtypes = [C.c_int, vp, sz, C.c_double, C.c_int, C.c_double, C.c_float, C.c_uint64, vp, sz, psz,
+                                       C.POINTER(C.c_float)]
     for name in SYMBOLS:
         getattr(L, name)
     _lib = L

@@ -208,13 +208,14 @@ class NfcContext(object):
 class DeviceBuffer(object):
     """Input kept resident in HBM (nfc_device_alloc / nfc_device_upload) for NfcContext.push_device."""
 
-    def __init__(self, host_array, device=0):
+    def __init__(self, host_array, device=0, nbytes=None):
+        """nbytes: allocate that much (at least the array's size) -- room for a kernel to write into."""
         self.L = _lib.load()
         self.device = device
         a = np.ascontiguousarray(host_array)
-        self.nbytes = a.nbytes
+        self.nbytes = max(a.nbytes, int(nbytes or 0))
         self.ptr = C.c_void_p()
-        if self.L.nfc_device_alloc(device, a.nbytes, C.byref(self.ptr)) != 0:
+        if self.L.nfc_device_alloc(device, self.nbytes, C.byref(self.ptr)) != 0:
             raise NfcError('nfc_device_alloc: %s' % self.L.nfc_last_error(None).decode())
         if a.nbytes and self.L.nfc_device_upload(device, self.ptr, a.ctypes.data, a.nbytes) != 0:
             raise NfcError('nfc_device_upload failed')

@@ -32,6 +32,7 @@
 #include "scan.hip.h"
 #include "small.hip.h"
 #include "threshold.hip.h"
+#include "tx.hip.h"
 
 using namespace nfc;
 
@@ -1614,6 +1615,134 @@ int nfc_crc_a(const uint8_t *data, size_t n, uint8_t out[2]) {
     out[0] = (uint8_t)(c & 0xFF);
     out[1] = (uint8_t)(c >> 8);
     return NFC_OK;
+}
+
+// ---- row f4: transmit side ---------------------------------------------------------------------------------------
+int nfc_tx_encode(int encoding, const uint8_t *bits, size_t n_bits, nfc_tx_run *out, size_t cap, size_t *n_out) {
+    if ((!bits && n_bits) || !n_out) return fail(nullptr, NFC_ERR_ARG, "nfc_tx_encode: null argument");
+    for (size_t i = 0; i < n_bits; i++)
+        if (bits[i] > 1) return fail(nullptr, NFC_ERR_ARG, "nfc_tx_encode: bit %zu is %u", i, (unsigned)bits[i]);
+    std::vector<nfc_tx_run> v;
+    v.reserve(3 * n_bits + 8);
+    switch (encoding) {
+    case NFC_TX_SAME: tx_encode_same(bits, n_bits, v); break;
+    case NFC_TX_MANCHESTER: tx_encode_manchester(bits, n_bits, v); break;
+    case NFC_TX_MILLER: tx_encode_miller(bits, n_bits, v); break;
+    default: return fail(nullptr, NFC_ERR_ARG, "nfc_tx_encode: unknown encoding %d", encoding);
+    }
+    *n_out = v.size();
+    if (v.size() > cap) return fail(nullptr, NFC_ERR_ARG, "nfc_tx_encode: %zu runs do not fit %zu", v.size(), cap);
+    if (out) memcpy(out, v.data(), v.size() * sizeof(nfc_tx_run));
+    return NFC_OK;
+}
+
+namespace {
+// binary_src.py:83 -- dur = int(dur * mult) with mult = samp_rate / 1e6, in double; the marker level 2 produces nothing
+int tx_run_samples(const nfc_tx_run &r, double mult, uint64_t *n) {
+    *n = 0;
+    if (r.level == 2) return NFC_OK;
+    if (r.level != 0 && r.level != 1) return fail(nullptr, NFC_ERR_ARG, "tx run level %d", r.level);
+    const double d = r.dur_us * mult;
+    if (!(d >= 0) || d > 1e15) return fail(nullptr, NFC_ERR_ARG, "tx run duration %g us", r.dur_us);
+    *n = (uint64_t)d;   // truncation, as int() does
+    return NFC_OK;
+}
+}  // namespace
+
+int nfc_tx_sample_count(const nfc_tx_run *runs, size_t n_runs, double samp_rate, uint64_t *n_samples) {
+    if ((!runs && n_runs) || !n_samples || !(samp_rate > 0)) return fail(nullptr, NFC_ERR_ARG, "nfc_tx_sample_count: bad argument");
+    const double mult = samp_rate / 1e6;   // binary_src.py:38
+    uint64_t tot = 0;
+    for (size_t i = 0; i < n_runs; i++) {
+        uint64_t k;
+        const int r = tx_run_samples(runs[i], mult, &k);
+        if (r) return r;
+        tot += k;
+    }
+    *n_samples = tot;
+    return NFC_OK;
+}
+
+int nfc_tx_render_device(int device, const nfc_tx_run *runs, size_t n_runs, double samp_rate, int carrier, double freq, float amp,
+                         uint64_t first_index, void *dev_out, size_t cap_samples, size_t *n_samples, float *kernel_ms) {
+    if ((!runs && n_runs) || !n_samples || !(samp_rate > 0) || (!dev_out && cap_samples)) return fail(nullptr, NFC_ERR_ARG, "nfc_tx_render_device: bad argument");
+    if (n_runs > 0xFFFFFFF0ull) return fail(nullptr, NFC_ERR_ARG, "nfc_tx_render_device: too many runs");
+    if (((uintptr_t)dev_out & 31u) != 0) return fail(nullptr, NFC_ERR_ARG, "nfc_tx_render_device: output must be 32-byte aligned");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, NFC_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    const double mult = samp_rate / 1e6;
+    std::vector<uint64_t> ends(n_runs);
+    std::vector<int8_t> levels(n_runs);
+    uint64_t tot = 0;
+    for (size_t i = 0; i < n_runs; i++) {
+        uint64_t k;
+        const int r = tx_run_samples(runs[i], mult, &k);
+        if (r) return r;
+        tot += k;
+        ends[i] = tot;
+        levels[i] = (int8_t)runs[i].level;
+    }
+    *n_samples = (size_t)tot;
+    if (tot > cap_samples) return fail(nullptr, NFC_ERR_ARG, "nfc_tx_render_device: %llu samples do not fit %zu", (unsigned long long)tot, cap_samples);
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (tot == 0) return NFC_OK;
+    TxArgs A;
+    memset(&A, 0, sizeof A);
+    void *d_ends = nullptr, *d_levels = nullptr, *d_first = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    // per tile of the output, the run its first sample falls in (one walk over the runs; the last entry closes the last tile)
+    const size_t n_tiles = (size_t)((tot + TX_TILE - 1) / TX_TILE);
+    std::vector<uint32_t> first(n_tiles + 1);
+    {
+        size_t r = 0;
+        for (size_t t = 0; t < n_tiles; t++) {
+            const uint64_t s = (uint64_t)t * TX_TILE;
+            while (ends[r] <= s) r++;
+            first[t] = (uint32_t)r;
+        }
+        while (ends[r] <= tot - 1) r++;
+        first[n_tiles] = (uint32_t)r;
+    }
+    int rc = NFC_OK;
+    auto bad = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess) return false;
+        rc = fail(nullptr, NFC_ERR_DEVICE, "nfc_tx_render_device: %s: %s", what, hipGetErrorString(e));
+        return true;
+    };
+    do {
+        if (bad(hipMalloc(&d_ends, n_runs * 8), "hipMalloc")) break;
+        if (bad(hipMalloc(&d_levels, n_runs), "hipMalloc")) break;
+        if (bad(hipMemcpy(d_ends, ends.data(), n_runs * 8, hipMemcpyHostToDevice), "upload")) break;
+        if (bad(hipMemcpy(d_levels, levels.data(), n_runs, hipMemcpyHostToDevice), "upload")) break;
+        if (bad(hipMalloc(&d_first, first.size() * 4), "hipMalloc")) break;
+        if (bad(hipMemcpy(d_first, first.data(), first.size() * 4, hipMemcpyHostToDevice), "upload")) break;
+        A.tile_first = (const uint32_t *)d_first;
+        A.ends = (const uint64_t *)d_ends;
+        A.levels = (const int8_t *)d_levels;
+        A.n_runs = (uint32_t)n_runs;
+        A.n_samples = tot;
+        A.first_index = first_index;
+        A.carrier = carrier ? 1 : 0;
+        const double turns = freq / samp_rate, fr = turns - std::floor(turns);
+        A.phase_inc = (uint64_t)(fr * 18446744073709551616.0);   // floor(frac(f / fs) * 2^64)
+        A.amp = amp;
+        A.out = (float2 *)dev_out;
+        const unsigned blocks = (unsigned)n_tiles;
+        if (kernel_ms) {
+            if (bad(hipEventCreate(&e0), "event") || bad(hipEventCreate(&e1), "event")) break;
+            hipExtLaunchKernelGGL(k_tx_render, dim3(blocks), dim3(TX_BLOCK), 0, nullptr, e0, e1, 0, A);
+        } else {
+            hipLaunchKernelGGL(k_tx_render, dim3(blocks), dim3(TX_BLOCK), 0, nullptr, A);
+        }
+        if (bad(hipGetLastError(), "launch")) break;
+        if (bad(hipDeviceSynchronize(), "kernel")) break;
+        if (kernel_ms && bad(hipEventElapsedTime(kernel_ms, e0, e1), "event")) break;
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d_ends) (void)hipFree(d_ends);
+    if (d_levels) (void)hipFree(d_levels);
+    if (d_first) (void)hipFree(d_first);
+    return rc;
 }
 
 int nfc_device_alloc(int device, size_t bytes, void **out) {
