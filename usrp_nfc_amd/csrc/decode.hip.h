@@ -435,9 +435,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
     if (ow[0] | ow[1] | ow[2] | ow[3]) frame_write(P, FrameAggOp::op(pre, FramePkOp::unpack(in_tile)), ow, base);
 }
 
-// After framing: keep the open packet's bits for the next batch and publish the carry.  Reads nothing that it (or a
-// sibling carry epilogue) writes, so the edge / decode stages of a batch can be repeated as a whole.  One workgroup
-// per packet type.
+// After framing: keep the open packets' bits for the next batch and publish the carry.  Reads nothing that it (or a
+// sibling carry epilogue) writes, so the edge / decode stages of a batch can be repeated as a whole.  One workgroup,
+// the batch's last: it also copies the stream state block into the host's pinned mirror (mapped memory), which saves
+// the copy-engine launch that would otherwise follow.
 struct PktFinish {
     const uint8_t *bits[2];
     uint8_t *pending_next[2];   // (the other half of the double buffer)
@@ -448,19 +449,28 @@ struct PktFinish {
     int32_t enabled[2], started_in[2];
     uint32_t pending_cap[2];
     uint32_t cap_bits[2], cap_close[2];
+    const uint32_t *mirror_src;   // the device state block, or NULL
+    uint32_t *mirror_dst;         // the host mirror as the device sees it
+    uint32_t mirror_words;
 };
 __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
-    const int t = blockIdx.x;
-    if (!F.enabled[t]) return;
-    const uint64_t tot = F.totals->v[t];
-    const uint32_t nbits = (uint32_t)tot, ncl = (uint32_t)(tot >> 32);
-    if (nbits > F.cap_bits[t] || ncl > F.cap_close[t]) return;   // the host repeats the stage with room
-    const uint32_t from = ncl ? F.close_end[t][ncl - 1] : 0u;
-    const uint32_t keep = nbits - from;
-    for (uint32_t i = threadIdx.x; i < keep && i < F.pending_cap[t]; i += blockDim.x) F.pending_next[t][i] = F.bits[t][from + i];
-    if (threadIdx.x == 0) {
-        F.carry->pending[t] = keep;
-        F.carry->pkt_started[t] = (int32_t)pm_apply(F.frame_total->fl[t], (uint32_t)F.started_in[t]);
+    for (int t = 0; t < 2; t++) {
+        if (!F.enabled[t]) continue;
+        const uint64_t tot = F.totals->v[t];
+        const uint32_t nbits = (uint32_t)tot, ncl = (uint32_t)(tot >> 32);
+        if (nbits > F.cap_bits[t] || ncl > F.cap_close[t]) continue;   // the host repeats the stage with room
+        const uint32_t from = ncl ? F.close_end[t][ncl - 1] : 0u;
+        const uint32_t keep = nbits - from;
+        for (uint32_t i = threadIdx.x; i < keep && i < F.pending_cap[t]; i += blockDim.x) F.pending_next[t][i] = F.bits[t][from + i];
+        if (threadIdx.x == 0) {
+            F.carry->pending[t] = keep;
+            F.carry->pkt_started[t] = (int32_t)pm_apply(F.frame_total->fl[t], (uint32_t)F.started_in[t]);
+        }
+    }
+    if (F.mirror_src) {
+        __threadfence();
+        __syncthreads();   // thread 0's carry words are part of the block
+        for (uint32_t i = threadIdx.x; i < F.mirror_words; i += blockDim.x) F.mirror_dst[i] = F.mirror_src[i];
     }
 }
 

@@ -147,6 +147,7 @@ struct nfc_ctx {
     // carried state
     DevBuf d_state, d_ring[2];
     DevState *hs = nullptr;        // pinned host mirror of d_state
+    void *hs_dev = nullptr;        // the same memory as the device addresses it (kernels may fill the mirror themselves)
     uint8_t *h_stage = nullptr;    // pinned staging for nfc_get_state
     size_t h_stage_cap = 0;
     uint8_t *h_cflags = nullptr;   // pinned mirror of the per-chunk flag sections
@@ -867,8 +868,12 @@ int run_decode(nfc_ctx *c) {
     F.totals = pk_total;
     F.frame_total = frame_total;
     F.carry = dD(c);
-    hipLaunchKernelGGL(k_pkt_finish, dim3(2), dim3(256), 0, c->st, F);
-    return NFC_OK;   // totals and carries are mirrored by the caller's final copy
+    static_assert(sizeof(DevState) % 4 == 0, "whole words");
+    F.mirror_src = (const uint32_t *)c->d_state.p;   // the stage's last launch also fills the host's mirror of the state block
+    F.mirror_dst = (uint32_t *)c->hs_dev;
+    F.mirror_words = (uint32_t)(sizeof(DevState) / 4);
+    hipLaunchKernelGGL(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
+    return NFC_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -999,10 +1004,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         if (r) return r;
         if (!ev3_done && c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
         ev3_done = true;
-        r = run_decode(c);
-        if (r) return r;
-        HIPCHK(c, mirror_async(c));
-        return NFC_OK;
+        return run_decode(c);   // (its last launch mirrors the state block)
     };
     const std::function<int()> ahead = edges_and_decode;
     bool clean = false;
@@ -1251,8 +1253,9 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     c->T.tag = p->enable_tag ? 1 : 0;
     // carried state
     CRT(c->d_state.ensure(sizeof(DevState)));
-    CRT(hipHostMalloc((void **)&c->hs, sizeof(DevState), hipHostMallocDefault));
+    CRT(hipHostMalloc((void **)&c->hs, sizeof(DevState), hipHostMallocMapped));
     memset(c->hs, 0, sizeof(DevState));
+    CRT(hipHostGetDevicePointer(&c->hs_dev, c->hs, 0));
     for (int b = 0; b < 2; b++) {
         CRT(c->d_ring[b].ensure((size_t)c->Lpad * 4));
         CRT(hipMemset(c->d_ring[b].p, 0, (size_t)c->Lpad * 4));
