@@ -985,7 +985,7 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     const float *ro = A.ring_out[vb] + (size_t)(c - 1) * L;
     float d = 0.f;
     bool differ = false;
-    constexpr int CK = 16;   // slots per lane and round: every load of a round is in flight at once
+    constexpr int CK = 8;    // slots per lane and round: every load of a round is in flight at once (16 costs the fused launch its occupancy)
     for (int s0 = 0; s0 < L; s0 += 64 * CK) {
         float t[CK], u[CK];
         uint32_t w[CK];
