@@ -142,10 +142,6 @@ struct FramePkOp {
         }
         return r;
     }
-    static __device__ __forceinline__ T shfl_up(const T &v, int d) {
-        return T{{(uint32_t)__shfl_up((int)v.a[0], d, 64), (uint32_t)__shfl_up((int)v.a[1], d, 64)},
-                 {(uint32_t)__shfl_up((int)v.b[0], d, 64), (uint32_t)__shfl_up((int)v.b[1], d, 64)}};
-    }
 };
 __device__ __forceinline__ uint32_t pm_apply(uint32_t fl, uint32_t started) { return (fl & 3u) == PM_ID ? started : (fl & 3u); }
 // bits appended / packets closed over a span entered in state `started`

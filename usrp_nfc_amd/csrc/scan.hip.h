@@ -1,8 +1,9 @@
 // scan.hip.h -- device-wide ordered exclusive scan for gfx950 (wave64), generic in
-// the (possibly non-commutative) operator.  Reduce-then-scan in three launches:
+// the (possibly non-commutative) operator.  Reduce-then-scan:
 //   k_scan_reduce   : one aggregate per tile of BLOCK*ITEMS items
-//   k_scan_partials : one workgroup turns the tile aggregates into exclusive prefixes
-//   k_scan_apply    : re-reads the items, hands each its exclusive prefix
+//   tile prefixes   : while the tiles are few, every tile's workgroup folds its predecessors' aggregates itself
+//                     (tile_prefix); beyond OWN_PREFIX_MAX_TILES one workgroup does it in a launch (k_scan_partials)
+//   k_scan_apply_sum: re-reads the items, hands each its exclusive prefix
 // Items are produced by a Load functor (so a stage can compute its item on the
 // fly from whatever it reads) and consumed by a Store functor.  A blocked
 // arrangement (thread t owns ITEMS consecutive items) keeps the order, which the
@@ -288,34 +289,8 @@ inline void scan_partials(hipStream_t st, size_t tiles, const uint32_t *n_dev, u
         hipLaunchKernelGGL((k_scan_partials<Tr, 1024, Epi>), dim3(1), dim3(1024), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
 }
 
-template <class Tr, int ITEMS, class Load, class Store>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(size_t n, const uint32_t *n_dev, Load load, Store store,
-                                                          const typename Tr::T *partials) {
-    using T = typename Tr::T;
-    if (n_dev) n = min(n, (size_t)*n_dev);
-    if ((size_t)blockIdx.x * SCAN_BLOCK * ITEMS >= n) return;
-    __shared__ T lds[SCAN_WAVES];
-    const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * ITEMS;
-    T item[ITEMS];
-    T agg = Tr::identity();
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const size_t idx = base + i;
-        item[i] = (idx < n) ? load(idx) : Tr::identity();
-        agg = Tr::op(agg, item[i]);
-    }
-    T total;
-    T excl = block_exclusive<Tr>(agg, lds, total);
-    T run = Tr::op(partials[blockIdx.x], excl);
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const size_t idx = base + i;
-        if (idx < n) store(idx, run, item[i]);
-        run = Tr::op(run, item[i]);
-    }
-}
-// The same, with store() returning a count per item: the tile's sum of them lands in sums[tile] -- the
-// aggregates of the next scan (over the same tiling), which then needs no reduce launch of its own.
+// The apply pass: every item gets its exclusive prefix; store() returns a count per item and the tile's sum of them
+// lands in sums[tile] -- the aggregates of the next scan (over the same tiling), which then needs no reduce launch of its own.
 template <class Tr, int ITEMS, class Tr2, class Load, class Store>
 __device__ __forceinline__ void scan_apply_sum_block(size_t n, const uint32_t *n_dev, const Load &load, const Store &store,
                                                      const typename Tr::T *partials, typename Tr2::T *sums, uint32_t bid,
@@ -365,13 +340,6 @@ inline void scan_reduce(hipStream_t st, size_t n, const uint32_t *n_dev, Load lo
     const size_t tiles = scan_num_tiles<ITEMS>(n);
     if (tiles)
         hipLaunchKernelGGL((k_scan_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load, partials);
-}
-template <class Tr, int ITEMS, class Load, class Store>
-inline void scan_apply(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, const typename Tr::T *partials) {
-    const size_t tiles = scan_num_tiles<ITEMS>(n);
-    if (tiles)
-        hipLaunchKernelGGL((k_scan_apply<Tr, ITEMS, Load, Store>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load,
-                           store, partials);
 }
 template <class Tr, int ITEMS, class Tr2, class Load, class Store>
 inline void scan_apply_sum(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, const typename Tr::T *partials,
