@@ -141,6 +141,10 @@ def main():
     if dist is not None:
         import torch
         comm = sharding.TorchDistComm(dist, torch.device('cuda', local) if backend == 'nccl' else torch.device('cpu'))   # nccl == RCCL over xGMI
+        if backend == 'nccl':
+            # a stream of its own as torch's current one: the decode context joins it (nfc_set_stream), so the exported
+            # boundary states are ordered before the all-gather on the device, without a host wait
+            torch.cuda.set_stream(torch.cuda.Stream(device=local))
     else:
         comm = sharding.LocalComm()
     level = sharding.carrier_level(synth.envelope_f32(ov[:2 * 4096])) if len(ov) else 0.0

@@ -146,6 +146,9 @@ int nfc_push(nfc_ctx *ctx, const void *host_samples, size_t n);
 int nfc_push_device(nfc_ctx *ctx, const void *dev_samples, size_t n);
 /* Wait for the device; outputs of the last push are complete after it. */
 int nfc_sync(nfc_ctx *ctx);
+/* Enqueue this context's work on the caller's HIP stream (hipStream_t; NULL: back to the context's own), so that what the
+ * caller enqueues there next -- a collective on the exported boundary states -- needs no host wait in between. */
+int nfc_set_stream(nfc_ctx *ctx, void *stream);
 
 /* Outputs of the LAST push (valid until the next push). */
 int nfc_get_counts(nfc_ctx *ctx, nfc_counts *out);

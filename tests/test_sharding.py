@@ -206,3 +206,52 @@ def test_export_state_matches_state_blob():
     got = small.download(64)
     assert int(got[:4].view('<u4')[0]) == blob.size and (got[16:] == 255).all()
     ctx.close()
+
+
+_CALLERS_STREAM = r"""
+import sys
+import numpy as np
+import torch
+torch.cuda.init()            # torch's HIP runtime first: it cannot start after another one has claimed the device
+sys.path.insert(0, %r)
+from oracle import c_oracle as co
+from tests.test_sharding import capture
+from usrp_nfc_amd import api, sharding
+_, iq = capture(1)
+o = co.COracle(hi_val=1.1)
+o.push_iq(iq)
+side = torch.cuda.Stream(device=0)
+ctx = api.NfcContext(hi_val=1.1)
+cap = sharding.slot_bytes(ctx.av_window)
+slot = torch.zeros(cap, dtype=torch.uint8, device='cuda:0')
+torch.cuda.synchronize()
+with torch.cuda.stream(side):
+    ctx.set_stream(side.cuda_stream)
+    ctx.push(iq)
+    tr, pk = ctx.transitions(), ctx.packets()
+    n = ctx.export_state(slot.data_ptr(), cap)     # asynchronous, on `side`
+    got = slot.clone()                             # ordered behind it by the stream alone
+side.synchronize()
+assert tr == o.transitions() and pk == o.packets()
+blob = ctx.state_blob()
+got = got.cpu().numpy()
+assert n == blob.size and np.array_equal(got[16:16 + n], blob)
+ctx.set_stream(None)   # back on its own stream
+ctx.reset()
+ctx.push(iq)
+assert ctx.transitions() == o.transitions()
+ctx.close()
+print('caller-stream ok')
+"""
+
+
+@pytest.mark.gpu
+def test_context_on_the_callers_stream():
+    # nfc_set_stream: the context enqueues on the caller's HIP stream, so a consumer the caller puts on that stream next
+    # (here a torch copy of the exported boundary state; in bench.py the RCCL all-gather) needs no host wait in between.
+    # In a process of its own: torch brings its own HIP runtime, which has to be the first to open the device.
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', _CALLERS_STREAM % root], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and 'caller-stream ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

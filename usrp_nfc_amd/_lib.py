@@ -60,7 +60,7 @@ PACKET_DTYPE = np.dtype([('idx', '<u8'), ('bit_off', '<u8'), ('n_bits', '<u4'), 
 
 # every symbol include/nfc_amd.h declares
 SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', 'nfc_last_error', 'nfc_push',
-           'nfc_push_device', 'nfc_sync', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_symbols', 'nfc_read_packets',
+           'nfc_push_device', 'nfc_sync', 'nfc_set_stream', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_symbols', 'nfc_read_packets',
            'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_prime', 'nfc_export_state', 'nfc_get_stats', 'nfc_set_timing',
            'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_host_decode_lut',
            'nfc_fsm_create', 'nfc_fsm_destroy', 'nfc_fsm_reset', 'nfc_fsm_process', 'nfc_fsm_process_packets', 'nfc_fsm_set_keys',
@@ -91,6 +91,7 @@ def load():
     L.nfc_push.argtypes = [vp, vp, sz]
     L.nfc_push_device.argtypes = [vp, vp, sz]
     L.nfc_sync.argtypes = [vp]
+    L.nfc_set_stream.argtypes = [vp, vp]
     L.nfc_get_counts.argtypes = [vp, C.POINTER(Counts)]
     L.nfc_read_edges.argtypes = [vp, sz, vp, sz, psz]
     L.nfc_read_symbols.argtypes = [vp, C.c_int, sz, vp, sz, psz]

@@ -188,6 +188,11 @@ class NfcContext(object):
     def sync(self):
         self._chk(self.L.nfc_sync(self.h), 'nfc_sync')
 
+    def set_stream(self, stream):
+        """Run on the caller's HIP stream (an integer hipStream_t, e.g. torch.cuda.current_stream().cuda_stream; 0 / None:
+        the context's own again)."""
+        self._chk(self.L.nfc_set_stream(self.h, C.c_void_p(int(stream or 0))), 'nfc_set_stream')
+
     def set_state_blob(self, blob):
         blob = np.ascontiguousarray(blob, np.uint8)
         hs = C.sizeof(_lib.StateHeader)

@@ -127,6 +127,7 @@ struct nfc_ctx {
     float i16_scale;
     size_t in_bytes_per_sample;
     hipStream_t st = nullptr;
+    hipStream_t own_st = nullptr;   // the stream the context created (st may be the caller's: nfc_set_stream)
     hipEvent_t ev[8] = {};
     bool state_dirty = false, dirty_fill_ring = false;   // host-side carried values not yet on the device (push_state)
     float dirty_fill = 0.f;
@@ -1207,7 +1208,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         int per_cu = (int)std::min<size_t>(20, (size_t)(160 * 1024) / (lds_wave * c->wpb) * c->wpb);   // LDS- and VGPR-bound
         c->wave_slots = std::max(1, prop.multiProcessorCount * std::max(1, per_cu));
     }
-    CRT(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    CRT(hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking));
+    c->st = c->own_st;
     for (auto &e : c->ev) CRT(hipEventCreate(&e));
     for (auto &e : c->kev) CRT(hipEventCreate(&e));
     const size_t lds = (size_t)c->wpb * c->Lpad * c->lds_per_slot;
@@ -1287,7 +1289,7 @@ void nfc_destroy(nfc_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->kev)
         if (e) (void)hipEventDestroy(e);
-    if (c->st) (void)hipStreamDestroy(c->st);
+    if (c->own_st) (void)hipStreamDestroy(c->own_st);
     delete c;
 }
 
@@ -1311,6 +1313,13 @@ int nfc_push(nfc_ctx *c, const void *host_samples, size_t n) {
 int nfc_sync(nfc_ctx *c) {
     if (!c) return NFC_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->st));
+    return NFC_OK;
+}
+
+int nfc_set_stream(nfc_ctx *c, void *stream) {
+    if (!c) return NFC_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->st));   // nothing of this context is left on the stream it leaves
+    c->st = stream ? (hipStream_t)stream : c->own_st;
     return NFC_OK;
 }
 

@@ -82,6 +82,10 @@ class TorchDistComm(object):
     def slot_ptr(self, slot):
         return self._send.data_ptr() + slot * self.half
 
+    def stream_handle(self):
+        """The HIP stream the collective is enqueued on (hipStream_t as an integer), or None on the CPU."""
+        return int(self._torch.cuda.current_stream(self.device).cuda_stream) if self.device_slots else None
+
     def put(self, slot, blob):
         """Host path (CPU engines, gloo): frame a state into a slot of the send buffer."""
         blob = np.ascontiguousarray(blob, np.uint8)
@@ -129,6 +133,11 @@ def decode_shard(engine, comm, push_overlap, push_own, start_index, level, force
     on_device = exchanging and comm.device_slots and hasattr(engine, 'export_state')
     if exchanging:
         comm.bind(engine.av_window, getattr(engine, 'state_bytes', None))   # state_bytes: an engine with its own blob format
+    # the engine works on the collective's stream: its exported states are ordered before the all-gather without a host wait
+    # (needs a stream of its own as torch's current one: the default stream has no handle to share)
+    same_stream = bool(on_device and hasattr(engine, 'set_stream') and comm.stream_handle())
+    if same_stream:
+        engine.set_stream(comm.stream_handle())
 
     def capture(slot):   # the engine's current state into an exchange slot
         if not exchanging:
@@ -154,7 +163,7 @@ def decode_shard(engine, comm, push_overlap, push_own, start_index, level, force
         # one collective per round: every rank sees every (speculated start, true end) pair and therefore
         # reaches the same verdict without a second exchange
         capture(1)
-        if on_device:
+        if on_device and not same_stream:
             engine.sync()
         pairs = comm.exchange()
         bad = [r for r in range(1, world)
