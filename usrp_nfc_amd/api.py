@@ -191,7 +191,11 @@ class NfcContext(object):
     def set_stream(self, stream):
         """Run on the caller's HIP stream (an integer hipStream_t, e.g. torch.cuda.current_stream().cuda_stream; 0 / None:
         the context's own again)."""
-        self._chk(self.L.nfc_set_stream(self.h, C.c_void_p(int(stream or 0))), 'nfc_set_stream')
+        h = int(stream or 0)
+        if h == getattr(self, '_stream', 0):
+            return   # (the switch waits for the stream it leaves: not something to repeat per batch)
+        self._chk(self.L.nfc_set_stream(self.h, C.c_void_p(h)), 'nfc_set_stream')
+        self._stream = h
 
     def set_state_blob(self, blob):
         blob = np.ascontiguousarray(blob, np.uint8)
