@@ -922,6 +922,9 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     A.tot_nsym = (uint32_t *)(tot + TOT_NSYM);
     A.ecarry = dE(c);
     A.dcarry = dD(c);
+    A.mirror_src = (const uint32_t *)c->d_state.p;
+    A.mirror_dst = (uint32_t *)c->hs_dev;
+    A.mirror_words = (uint32_t)(sizeof(DevState) / 4);
     hipLaunchKernelGGL(k_small_stage, dim3(1), dim3(SM_BLOCK), 0, c->st, A);
     return NFC_OK;
 }
@@ -994,11 +997,15 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         size_caps();
         if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[2], c->st));
         if (c->use_small && n <= SM_MAX_SAMPLES) {   // a short batch: one launch for the three stages
+            if (c->cert_pending) {   // the certification (and the end-of-batch state) first: the stage's launch is the last, and mirrors the state
+                c->cert_pending = false;
+                hipLaunchKernelGGL(k_certify, dim3(c->cert.blocks), dim3(256), 0, c->st, c->cert.A, c->cert.cert, (CertInfo *)nullptr,
+                                   c->cert.ring_next, c->cert.carry, c->cert.sum);
+            }
             const int r = run_small(c, n, skip, g0);
             if (r) return r;
             if (!ev3_done && c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
             ev3_done = true;
-            HIPCHK(c, mirror_async(c));
             return NFC_OK;
         }
         int r = run_edges(c, n, skip, g0);

@@ -40,6 +40,9 @@ struct SmallArgs {
     uint32_t *tot_nsym;
     EdgeCarry *ecarry;
     DecCarry *dcarry;
+    const uint32_t *mirror_src;   // the device state block -> the host's mapped mirror (decode.hip.h: PktFinish), or NULL
+    uint32_t *mirror_dst;
+    uint32_t mirror_words;
 };
 
 __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
@@ -224,6 +227,11 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
                 A.dcarry->pkt_started[t] = (int32_t)pm_apply(run_fa.fl[t], A.P.started_in[t]);
             }
         }
+    }
+    if (A.mirror_src) {   // the batch's last launch: the state block goes to the host's mirror from here
+        __threadfence();
+        __syncthreads();
+        for (uint32_t i = tid; i < A.mirror_words; i += SM_BLOCK) A.mirror_dst[i] = A.mirror_src[i];
     }
 }
 
