@@ -378,7 +378,8 @@ __device__ __forceinline__ void frame_write(const FrameOut &P, const FrameAgg &p
     }
 }
 // Decoder states after the batch, from the total of the map scan; also publishes the per-type symbol counts the
-// host checks against the capacities and the per-type bit / close totals.  Epilogue of the framing scan's partials pass.
+// host checks against the capacities and the per-type bit / close totals.  Runs once after the framing scan: in the last
+// tile's workgroup of k_frame_write, or as the epilogue of the scan's prefix launch (long batches).
 struct DecCarryEpilogue {
     const DecMaps *total;
     uint32_t state_in;

@@ -7,10 +7,12 @@
 //      [-> re-runs from the exact state | k_threshold_seq over a prefix, then another attempt]      (run_threshold)
 //   -> last-two-changes scan -> event masks + entry counts -> entry offsets -> k_write_edges        (run_edges)
 //   -> k_dec_reduce -> tile prefixes -> k_dec_apply -> symbol / bit / close offsets and framing states (one scan)
-//   -> k_frame_write -> k_pkt_finish (both packet types in each launch)                             (run_decode)
+//   -> k_frame_write -> k_pkt_finish (both packet types in each launch; fills the host's mirror of the state) (run_decode)
 //   (batches up to 2^18 samples: the three stages after the threshold stage in ONE launch, small.hip.h)
 // then one wait; the edge / decode stages are repeated if the certification failed or a capacity estimate was short.
-// Outputs stay in HBM until read through nfc_read_*.  Host-only: the protocol layer of protocol.h (nfc_fsm_*).
+// Tile prefixes: folded by every tile's own workgroup while the tiles are few, by a prefix launch beyond (scan.hip.h).
+// Outputs stay in HBM until read through nfc_read_*.  Host-only: the protocol layer of protocol.h (nfc_fsm_*), the
+// encoders of tx.hip.h; its renderer (row f4) is a kernel of its own outside the batch.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
