@@ -73,7 +73,7 @@ inline void tx_encode_miller(const uint8_t *bits, size_t n, std::vector<nfc_tx_r
 
 // ---- renderer (device) -------------------------------------------------------------------------------------------
 constexpr int TX_BLOCK = 256;
-constexpr int TX_PER_THREAD = 8;                     // complex samples per thread: four 16-byte stores
+constexpr int TX_PER_THREAD = 4;                     // complex samples per thread: 32 contiguous bytes (64 per thread measured half the store rate)
 constexpr int TX_TILE = TX_BLOCK * TX_PER_THREAD;
 constexpr int TX_LDS_RUNS = 1024;
 
