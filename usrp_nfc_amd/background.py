@@ -38,8 +38,8 @@ class background(object):
                 else:
                     fsm = _ref_fsm.fsm()
             except Exception:
-                # the reference's fsm is Python 2: use this package's (row f1: bytes, parity, CRC, commands; it prints
-                # the same trace; no CRYPTO1, no emulator encoder)
+                # the reference's fsm is Python 2: use this package's (rows f1 / f3: bytes, parity, CRC, commands, CRYPTO1
+                # sessions; it prints the same trace; the outgoing half for an emulator -- process_outgoing -- is out of scope)
                 from . import fsm as _own_fsm
                 fsm = _own_fsm.fsm(emulator.process_packet) if emulator else _own_fsm.fsm()
         self._fsm = fsm
