@@ -164,6 +164,18 @@ def test_prefix_launch_path(monkeypatch, own_prefix_max):
     check_vs_oracle(iq, dict(hi_val=1.1), kind=api.NFC_IN_IQ_F32, pushes=[0, 1_400_000, 1_700_000, 2_300_000])
 
 
+@pytest.mark.parametrize('window,max_len,rate', [(2000, 50, 2.0), (4000, 100, 4.0), (10000, 250, 10.0)])
+def test_ring_in_global_memory(monkeypatch, window, max_len, rate):
+    # Long windows keep a chunk's ring in global memory when the batch is long enough to fill the machine that way
+    # (nfc_amd.hip: threshold_span); NFC_RING=global forces that kernel on batches of test size, for every window
+    monkeypatch.setenv('NFC_RING', 'global')
+    period = synth.modulation_profile(synth.txn_frames(), rate_msps=rate, lead_in=0, tail=0)
+    iq = synth.iq_from_profile(synth.tiled_profile(period, 1_300_000, lead_in=window + 700), seed=11)
+    r = check_vs_oracle(iq, dict(samp_rate=rate * 1e6, hi_val=1.1, av_window=window, max_len=max_len), kind=api.NFC_IN_IQ_F32,
+                        pushes=[0, 400_001, 1_300_000])
+    assert r['stats'].used_sequential == 0
+
+
 @pytest.mark.parametrize('n', [2_000_001, 2_000_063, 2_000_064, 2_000_191, 1_999_999])
 def test_ragged_batch_end(n):
     # a batch that does not end on a 256-sample step: its last step runs with the lanes past the end masked,

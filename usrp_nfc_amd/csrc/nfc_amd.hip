@@ -122,6 +122,9 @@ struct nfc_ctx {
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
+    int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
+    int gring_ok = 0, gring_force = 0, wave_slots_g = 0;   // long windows qualify (NFC_RING=lds|global overrides the choice)
+    DevBuf d_gring;
     uint32_t own_prefix_max = OWN_PREFIX_MAX_TILES;   // tile counts up to this need no prefix launches (NFC_OWN_PREFIX_MAX overrides)
     int use_small = 1;   // short batches take the one-launch edge / decode / framing kernel (NFC_NO_SMALL=1 turns it off)
     uint64_t selmask;
@@ -281,15 +284,16 @@ __global__ void k_pack_state(uint8_t *dst, const float *ring, int L, const uint8
 // inter-launch gaps.
 template <int KIND>
 void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipEvent_t e1) {
-    const uint32_t blocks = (nwork + c->wpb - 1) / c->wpb;
-    const size_t lds = (size_t)c->wpb * c->Lpad * c->lds_per_slot;
+    const uint32_t wpb = c->gring ? 4u : (uint32_t)c->wpb;
+    const uint32_t blocks = (nwork + wpb - 1) / wpb;
+    const size_t lds = c->gring ? 0 : (size_t)wpb * c->Lpad * c->lds_per_slot;
     if (e0) {
-        if (c->rows_per_step == 8) hipExtLaunchKernelGGL((k_threshold<KIND, 8>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, e0, e1, 0, A);
-        else hipExtLaunchKernelGGL((k_threshold<KIND, 4>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, e0, e1, 0, A);
+        if (c->gring) hipExtLaunchKernelGGL((k_threshold<KIND, 4, true>), dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
+        else hipExtLaunchKernelGGL((k_threshold<KIND, 4, false>), dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
         return;
     }
-    if (c->rows_per_step == 8) hipLaunchKernelGGL((k_threshold<KIND, 8>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
-    else hipLaunchKernelGGL((k_threshold<KIND, 4>), dim3(blocks), dim3(64 * c->wpb), lds, c->st, A);
+    if (c->gring) hipLaunchKernelGGL((k_threshold<KIND, 4, true>), dim3(blocks), dim3(64 * wpb), lds, c->st, A);
+    else hipLaunchKernelGGL((k_threshold<KIND, 4, false>), dim3(blocks), dim3(64 * wpb), lds, c->st, A);
 }
 void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
     const bool timed = c->timing >= 1 && c->n_kev < 6;
@@ -374,8 +378,12 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     uint32_t passes = 0;
     // Chunk length for this batch: one wave per chunk, and a chunk's latency is what the launch takes, so
     // aim at one full round of resident waves (no second, half-empty round), never below the configured size.
+    // Long windows: the ring of a chunk in global memory frees the LDS and brings the occupancy back to what the registers
+    // allow -- worth it when the batch then fills the machine with chunks of many windows each (a chunk pays one window
+    // of speculation and two windows of certification traffic): otherwise the LDS ring, with its fewer, longer chunks.
+    c->gring = c->gring_ok && (c->gring_force || (uint64_t)n >= (uint64_t)c->wave_slots_g * 8u * (uint64_t)c->L);
     if (!c->P.chunk_samples) {
-        const uint64_t slots = (uint64_t)c->wave_slots;
+        const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : c->wave_slots);
         const int stp = 64 * c->rows_per_step;
         uint64_t want = ((uint64_t)n + slots - 1) / slots;
         want = (want + stp - 1) / stp * stp;
@@ -408,6 +416,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                   *h_gmax = c->h_cflags + 3 * (size_t)nch;
     HIPCHK(c, c->d_list.ensure((size_t)nch * 4));
     HIPCHK(c, c->d_gvtop.ensure((size_t)nch * 4));
+    if (c->gring) HIPCHK(c, c->d_gring.ensure((size_t)nch * c->Lpad * c->lds_per_slot));
     c->h_ver.assign(nch, 0);
 
     // carried "HIGH ignored" bookkeeping from (_current_state, _last_bit, _dur) at the first stable sample
@@ -432,6 +441,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     bool need_seq = force_seq;
     ThrArgs A;
     memset(&A, 0, sizeof A);
+    A.gring = c->d_gring.p;
     A.in = d_in;
     A.n = n;
     A.skip = skip;
@@ -1161,7 +1171,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     c->use_small = getenv("NFC_NO_SMALL") ? 0 : 1;
     if (const char *e = getenv("NFC_OWN_PREFIX_MAX")) c->own_prefix_max = (uint32_t)strtoul(e, nullptr, 10);
     {
-        c->rows_per_step = (c->L >= 512 && getenv("NFC_ROWS8")) ? 8 : 4;   // 8-row steps: measured slower (126 VGPRs: four waves per SIMD)
+        c->rows_per_step = 4;   // (8-row steps measured slower: 126 VGPRs, four waves per SIMD)
         const int stp = 64 * c->rows_per_step;
         C = (C + stp - 1) / stp * stp;
     }
@@ -1169,6 +1179,13 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     c->C_min = C;
     c->lds_per_slot = (p->input_kind == NFC_IN_ENV_F32) ? 5 : 4;   // ring (+ touched byte map for raw envelopes)
     c->wpb = std::max(1, std::min(4, (int)(65536 / ((size_t)c->Lpad * c->lds_per_slot))));
+    // An LDS ring beyond 12 KB leaves a SIMD with fewer than four waves: such windows keep the ring in global memory
+    // (a delay line read one step ahead), and the registers set the occupancy again.
+    c->gring_ok = (size_t)c->Lpad * c->lds_per_slot > 12 * 1024 && c->L >= 2 * STEP;
+    if (const char *e = getenv("NFC_RING")) {
+        if (strcmp(e, "global") == 0 && c->L >= 2 * STEP) c->gring_ok = c->gring_force = 1;
+        else if (strcmp(e, "lds") == 0) c->gring_ok = 0;
+    }
     c->hi_plus = p->hi_val + 0.1;  // transition_sink.py:63
     const double eps = std::ldexp(1.0, -48);
     auto band = [&](double v, double &a, double &b) {
@@ -1216,6 +1233,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         const size_t lds_wave = (size_t)c->Lpad * c->lds_per_slot;
         int per_cu = (int)std::min<size_t>(20, (size_t)(160 * 1024) / (lds_wave * c->wpb) * c->wpb);   // LDS- and VGPR-bound
         c->wave_slots = std::max(1, prop.multiProcessorCount * std::max(1, per_cu));
+        c->wave_slots_g = prop.multiProcessorCount * 20;   // VGPR-bound: five waves per SIMD
     }
     CRT(hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking));
     c->st = c->own_st;
@@ -1227,14 +1245,10 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         return fail(nullptr, NFC_ERR_ARG, "av_window too large for one wave's LDS ring");
     }
     if (lds > 64 * 1024) {
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_IQ_F32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_IQ_F32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_IQ_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // decoder LUTs
     DecoderTables t = build_tables(p->samp_rate, c->mx);
@@ -1289,7 +1303,7 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_pack, &c->d_gvtop, &c->d_seqout};
+                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_gring, &c->d_pack, &c->d_gvtop, &c->d_seqout};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

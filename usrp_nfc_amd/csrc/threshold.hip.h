@@ -89,6 +89,7 @@ struct RunMeta {
 };
 
 struct ThrArgs {
+    void *gring;                // GRING kernels: per chunk a ring row (Lpad floats, + Lpad touched bytes for raw envelopes)
     const void *in;
     uint32_t n;       // samples in the batch
     uint32_t skip;    // leading samples consumed by the fill phase
@@ -370,7 +371,9 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
     return acc;   // the caller stores x into the ring slot
 }
 
-template <int KIND, int NR>
+// GRING: the ring lives in global memory (one row of A.gring per chunk) instead of LDS -- for windows whose LDS ring would
+// leave a SIMD with one or two waves; its old values are then asked for one step ahead, like the input.
+template <int KIND, int NR, bool GRING>
 __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     constexpr uint32_t STEPN = 64u * NR;   // samples per step: NR rows of 64
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     // kind keeps a byte map after the ring.)
     constexpr bool SIGN_T = (KIND != IN_ENV_F32);
     const size_t lds_wave = SIGN_T ? (size_t)A.Lpad * 4 : (size_t)A.Lpad * 5;
-    float *ring = (float *)(smem + (size_t)wave * lds_wave);
+    float *ring = GRING ? (float *)((unsigned char *)A.gring + (size_t)c * lds_wave) : (float *)(smem + (size_t)wave * lds_wave);
     unsigned char *tch = (unsigned char *)(ring + A.Lpad);
     auto mark = [&](uint32_t sl) { if constexpr (!SIGN_T) tch[sl] = 1; };
     const int L = A.L;
@@ -408,6 +411,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
 
     // ---------------- incoming state ----------------
     if (c == 0) {
+        #pragma unroll 8
         for (int s = lane; s < L; s += 64) ring[s] = A.ring_carry[s];
         ss0 = cr.ss;
         w_nl = A.nl0;
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     } else if (A.mode == 1) {
         for (int s = lane; s < L; s += 64) ring[s] = resolve_slot(A, (int)c, s);
         double part = 0;
+        #pragma unroll 8
         for (int s = lane; s < L; s += 64) part += (double)ring[s];
         ss0 = wave_sum_f64(part) + cr.delta;
         resolve_low_state(A, (int)c, w_nl, w_kl);
@@ -446,6 +451,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         mxv = wave_max_f32(mxv);
         const float half = 0.5f * mxv;
         float sa = 0.f, na = 0.f;
+        #pragma unroll 8
         for (int s = lane; s < L; s += 64) {
             const float x = ring[s];
             if (x >= half) { sa += x; na += 1.f; }
@@ -454,6 +460,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         na = wave_sum_f32(na);
         const float ca = (na > 0.f) ? sa / na : mxv;
         float sb = 0.f, nb = 0.f;
+        #pragma unroll 8
         for (int s = lane; s < L; s += 64) {
             const float x = ring[s];
             if (x >= half && x <= ca) { sb += x; nb += 1.f; }
@@ -465,6 +472,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         // ring slot s last saw sample m = w0 + ((s - slot0) mod L)
         int ll = LL_NONE, nl = LL_NONE;
         double part = 0;
+        #pragma unroll 8
         for (int s = lane; s < L; s += 64) {
             const int rel = (s >= (int)slot0) ? s - (int)slot0 : s - (int)slot0 + L;
             const int m = (int)w0 + rel;
@@ -490,6 +498,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     if constexpr (!SIGN_T)
         for (int s = lane; s < A.Lpad; s += 64) tch[s] = 0;
     uint32_t vtop0 = 0u;   // raw bits of the largest incoming ring value (envelopes are >= 0: bits order like values)
+    #pragma unroll 8
     for (int s = lane; s < L; s += 64) {
         const float v = ring[s];
         rin[s] = v;
@@ -539,10 +548,13 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     int steps_since_sync = 0;
     auto exact_sum = [&]() {
         double part = 0;
+        #pragma unroll 8
         for (int s2 = lane; s2 < L; s2 += 64) part += (double)(SIGN_T ? fabsf(ring[s2]) : ring[s2]);
         return rfl(wave_sum_f64(part) + cr.delta);
     };
     const float slD = 1.0f - 3.814697265625e-06f, slU = 1.0f + 3.814697265625e-06f;
+    float pn[NR];   // GRING: the next step's old ring values, in flight
+    bool have_pn = false;
     for (uint32_t base = m_chunk; base < n1; base += STEPN) {
         float x[NR], prev[NR];
         uint32_t slot[NR];
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 slot[j] = slot_step + 64u * j + lane;
-                prev[j] = SIGN_T ? fabsf(rp[64 * j]) : rp[64 * j];
+                if (!GRING || !have_pn) prev[j] = SIGN_T ? fabsf(rp[64 * j]) : rp[64 * j];
             }
         } else {
 #pragma unroll
@@ -566,7 +578,26 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 uint32_t s = slot_step + 64u * j + lane;
                 s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
                 slot[j] = s;
-                prev[j] = SIGN_T ? fabsf(ring[s]) : ring[s];
+                if (!GRING || !have_pn) prev[j] = SIGN_T ? fabsf(ring[s]) : ring[s];
+            }
+        }
+        if constexpr (GRING) {
+            // the ring is in global memory: this step's old values were asked for a step ago, the next step's are asked for
+            // now (slots no step in between writes: the window holds at least two steps)
+            if (have_pn) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) prev[j] = SIGN_T ? fabsf(pn[j]) : pn[j];
+            }
+            have_pn = base + STEPN < n1;
+            if (have_pn) {
+                uint32_t ns = slot_step + STEPN;
+                ns = (ns >= (uint32_t)L) ? ns - (uint32_t)L : ns;
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    uint32_t s = ns + 64u * j + lane;
+                    s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
+                    pn[j] = ring[s];
+                }
             }
         }
         unsigned long long unt[NR];   // tail only: lanes past the end whose slot had not been touched
