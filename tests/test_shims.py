@@ -89,3 +89,20 @@ def test_decoder_reads_16bit_wav(tmp_path):
     o.push_real_sq((pcm.astype(np.float32) * sc).astype(np.float32))
     assert f.got == o.packets()
     assert len(f.got) >= 17
+
+
+@pytest.mark.gpu
+def test_decoder_reads_raw_iq_file(tmp_path):
+    # a raw interleaved complex64 capture (what a UHD file sink writes) takes the UHD branch: |IQ|^2, hi_val 1.1
+    from usrp_nfc_amd import synth
+    from usrp_nfc_amd.decoder import decoder
+    iq = synth.workload('all', 400_000)
+    path = str(tmp_path / 'capture.fc32')
+    iq.tofile(path)
+    f = _Fsm()
+    decoder(src=path, reader=True, tag=True, samp_rate=2e6, fsm=f, batch=150_000).run()
+    from oracle import c_oracle as co
+    o = co.COracle(samp_rate=2e6, hi_val=1.1)
+    o.push_iq(iq)
+    assert f.got == o.packets() and len(f.got) > 50
+

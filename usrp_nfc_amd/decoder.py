@@ -7,7 +7,8 @@ wiring: source -> envelope -> ``transition_sink(samp_rate, background.append, hi
 * With GNU Radio importable it is a ``gr.hier_block2`` built from the same blocks as the reference
   (``usrp_src`` / ``wavfile_source -> float_to_complex -> complex_to_mag_squared``), so
   ``usrp_nfc.py`` can ``self.connect(decoder(...))`` unchanged.
-* Without GNU Radio (this image) ``src`` may be a 16-bit mono WAV path, a raw float32 file, or a numpy
+* Without GNU Radio (this image) ``src`` may be a 16-bit mono WAV path, a raw float32 file, a raw complex64 IQ
+  file (``.fc32`` / ``.cfile`` / ``.iq``), or a numpy
   array, and ``run()`` streams it through the GPU path offline: a real recording is squared like the
   reference's WAV branch (float_to_complex with Q = 0, then |.|^2), complex64 / interleaved IQ takes
   the UHD branch's |IQ|^2.
@@ -45,6 +46,8 @@ def _load_source(src, wav_scale):
         finally:
             w.close()
         return pcm, api.NFC_IN_I16_SQ, wav_scale
+    if str(src).lower().endswith(('.fc32', '.cfile', '.iq', '.c64')):   # raw interleaved complex64, as a UHD / file sink writes
+        return numpy.fromfile(src, dtype=numpy.float32), api.NFC_IN_IQ_F32, 0.0
     return numpy.fromfile(src, dtype=numpy.float32), api.NFC_IN_REAL_F32_SQ, 0.0
 
 
