@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Row f4 measurement: k_tx_render on a 1e8-sample TX stream (reader frames, Miller), with and without the carrier.
+"""Row f4 measurement (kept under tests/: it uses the oracle as its checker): k_tx_render on a 1e8-sample TX stream (reader frames, Miller), with and without the carrier.
 Algorithmic bytes: 8 B per complex64 sample written (the run table is a few hundred KB).  Prints one JSON line."""
 import json
+import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import tx_oracle as txo   # the checker (a sample of the output is compared)
 from usrp_nfc_amd import api, synth, tx
 
@@ -15,8 +16,8 @@ rate = 2e6
 frames = [synth.frame_bits([0x26], 7), synth.frame_bits([0x93, 0x20]), synth.frame_bits([0x30, 0x04, 0x26, 0xEE])]
 period = []
 for b in frames:
-    period += [(1, 150.0)] + txo.miller_encode(b)
-per_samples = len(txo.render(period, rate))
+    period += [(1, 150.0)] + tx.encode_bits(tx.NFC_TX_MILLER, b)   # the product's encoder builds the stream
+per_samples = tx.sample_count(tx.as_runs(period), rate)
 reps = n_target // per_samples
 pulses = period * reps
 runs = tx.as_runs(pulses)
