@@ -228,6 +228,7 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
+        ctx.set_stream(None)   # back on its own stream before torch's streams go away
         dist.barrier()
         dist.destroy_process_group()
 

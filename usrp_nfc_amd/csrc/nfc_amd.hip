@@ -1297,7 +1297,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
 void nfc_destroy(nfc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->P.device);
-    if (c->st) (void)hipStreamSynchronize(c->st);
+    if (c->st && c->st == c->own_st) (void)hipStreamSynchronize(c->st);
+    else (void)hipDeviceSynchronize();   // on a caller's stream (nfc_set_stream): the handle may be gone by now
     DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_state,
                      &c->d_ring[0], &c->d_ring[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
