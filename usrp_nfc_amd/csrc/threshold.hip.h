@@ -825,18 +825,20 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
             }
             ssf = (float)ss0;
         }
-        {   // one coalesced store of the step's NR words per plane
-            unsigned long long lo4 = lowm[0], po4 = posm[0];
+        {   // the step's NR words per plane: the masks are scalar pairs, v_writelane puts their halves into lanes 0 .. 2 NR - 1
+            // (neg) and 2 NR .. 4 NR - 1 (pos) of ONE register, and those lanes store a dword each
+            int pk = 0;
 #pragma unroll
-            for (int k = 1; k < NR; k++) {
-                lo4 = (lane == k) ? lowm[k] : lo4;
-                po4 = (lane == k) ? posm[k] : po4;
+            for (int k = 0; k < NR; k++) {
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)lowm[k]), "n"(2 * k));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)(lowm[k] >> 32)), "n"(2 * k + 1));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)posm[k]), "n"(2 * NR + 2 * k));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)(posm[k] >> 32)), "n"(2 * NR + 2 * k + 1));
             }
-            const uint32_t w = (base >> 6) + lane;
-            if (lane < NR && (size_t)w * 64 < A.n) {
-                A.neg[w] = lo4;
-                A.pos[w] = po4;
-            }
+            const int h = lane & (2 * NR - 1);                      // dword within the plane's NR words
+            const uint32_t w = (base >> 6) + (uint32_t)(h >> 1);    // its word
+            uint32_t *dst = (uint32_t *)(lane < 2 * NR ? A.neg : A.pos) + 2 * (size_t)(base >> 6) + h;
+            if (lane < 4 * NR && (size_t)w * 64 < A.n) *dst = (uint32_t)pk;
         }
         slot_step += STEPN;
         slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
