@@ -32,8 +32,8 @@ OVERLAP = 8192          # samples of the predecessor's chunk each rank > 0 also 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=100)   # 0.45 ms each: the device reaches its steady clocks within the first few dozen
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--samples', type=float, default=1e8, help='samples per GPU')
     ap.add_argument('--workload', default='miller', choices=['miller', 'manchester', 'all', 'classic1k'],
                     help="BASELINE.json configs[1] / [2] / both decoders at 2 Msps, or configs[3] / [4]: the MIFARE Classic 1K "

@@ -5,7 +5,7 @@ tag=${1:-r01}
 out=gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o $tag -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity > $out/${tag}_bench_under_rocprof.json 2> $out/stats.log
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o $tag -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity > $out/${tag}_bench_under_rocprof.json 2> $out/stats.log
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2> $out/fetch.log
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2> $out/write.log
 timeout 400 python3 bench.py > $out/${tag}_bench.json 2> $out/bench.log
