@@ -151,12 +151,18 @@ def main():
     g_lo = rank * n
     redo_count = 0
 
+    force_exchange = bool(os.environ.get('NFC_BENCH_FORCE_EXCHANGE'))
+    n_ov = len(ov) // 2
+
+    def push_overlap():
+        ctx.push_device(d_ov, n_ov)
+
+    def push_own():
+        ctx.push_device(d_own, n)
+
     def one_step():
         nonlocal redo_count
-        redo_count += sharding.decode_shard(ctx, comm, lambda: ctx.push_device(d_ov, len(ov) // 2),
-                                            lambda: ctx.push_device(d_own, n), g_lo - len(ov) // 2, level,
-                                            force_exchange=bool(os.environ.get('NFC_BENCH_FORCE_EXCHANGE')))
-        return ctx.stats()
+        redo_count += sharding.decode_shard(ctx, comm, push_overlap, push_own, g_lo - n_ov, level, force_exchange=force_exchange)
 
     for _ in range(a.warmup):
         one_step()
@@ -166,15 +172,21 @@ def main():
     n_pass = []
     for k in range(a.steps):
         # every 4th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
-        # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are)
-        ctx.set_timing(1 if k % 4 == 0 else 0)
-        st = one_step()
-        kernel_ms += [st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed)]
-        n_pass.append(st.threshold_passes)
+        # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are); the host reads the statistics
+        # of those steps only (the device idles while the host is between two pushes)
+        timed = k % 4 == 0
+        if timed or k % 4 == 1:
+            ctx.set_timing(1 if timed else 0)
+        one_step()
+        if timed:
+            st = ctx.stats()
+            kernel_ms += [st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed)]
+            n_pass.append(st.threshold_passes)
     barrier()
     dt = time.perf_counter() - t0
     ctx.set_timing(2)   # one more, untimed, step for the per-stage split reported beside the headline
     one_step()
+    st = ctx.stats()
     if dist is not None:
         import torch
         tmax = torch.tensor([dt], device='cuda' if backend == 'nccl' else 'cpu', dtype=torch.float64)
