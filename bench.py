@@ -171,11 +171,11 @@ def main():
     kernel_ms = []
     n_pass = []
     for k in range(a.steps):
-        # every 4th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
+        # every 8th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
         # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are); the host reads the statistics
         # of those steps only (the device idles while the host is between two pushes)
-        timed = k % 4 == 0
-        if timed or k % 4 == 1:
+        timed = k % 8 == 0
+        if timed or k % 8 == 1:
             ctx.set_timing(1 if timed else 0)
         one_step()
         if timed:
