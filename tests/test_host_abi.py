@@ -65,3 +65,15 @@ def test_no_gpu_means_loud_failure():
         pytest.skip('a GPU is present')
     with pytest.raises(api.NfcError):
         api.NfcContext()
+
+
+def test_no_gpu_means_loud_failure_for_the_tx_renderer():
+    # the transmit-side renderer has no CPU path either (the encoders are host code by design: test_tx.py)
+    L = _lib.load()
+    if L.nfc_device_count() > 0:
+        pytest.skip('a GPU is present')
+    from usrp_nfc_amd import tx
+    runs = tx.as_runs([(1, 9.44), (0, 3.0)])
+    assert tx.sample_count(runs, 2e6) == 24
+    with pytest.raises(RuntimeError):
+        tx.render_device(runs, 2e6, 32, 24)   # (any pointer: the call must fail before touching it)
