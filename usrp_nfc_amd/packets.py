@@ -3,14 +3,12 @@
 
 
 class PacketType:
-    TAG_TO_READER = 0
-    READER_TO_TAG = 1
-    NUM_TYPES = 2
+    TAG_TO_READER, READER_TO_TAG, NUM_TYPES = 0, 1, 2
+    _START_BIT = {0: 1, 1: 0}   # the first bit of a frame: Manchester frames open with 1, Modified-Miller frames with 0
 
     @staticmethod
     def start_bit(t):
-        if t == PacketType.TAG_TO_READER:
-            return 1
-        elif t == PacketType.READER_TO_TAG:
-            return 0
-        raise ValueError('Unknown Packet Type', str(t))
+        try:
+            return PacketType._START_BIT[t]
+        except KeyError:
+            raise ValueError('Unknown Packet Type', str(t))
