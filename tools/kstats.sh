@@ -1,5 +1,5 @@
 #!/bin/bash
-# Per-kernel time per step of one bench workload under rocprofv3 (kernel trace + stats).  usage: tools_kstats.sh <workload> [tag]
+# Per-kernel time per step of one bench workload under rocprofv3 (kernel trace + stats).  usage: tools/kstats.sh <workload> [tag]
 w=${1:-miller}; tag=${2:-k}
 out=gpurun_out/kstats_$tag
 mkdir -p $out
@@ -8,7 +8,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o $tag
 python3 - <<PY
 import csv
 rows = list(csv.DictReader(open("$out/${tag}_kernel_stats.csv")))
-thr = [r for r in rows if "k_threshold<" in r["Name"]]
+thr = [r for r in rows if "k_threshold" in r["Name"]]
 nstep = int(thr[0]["Calls"]) if thr else 1
 tot = 0
 for r in rows:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <outdir> <counters...> -- bench args
+# usage: tools/pmc.sh <outdir> <counters...> -- bench args
 out=$1; shift
 ctrs=()
 while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift

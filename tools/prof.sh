@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage: tools_prof.sh <outdir> bench args...   -> per-kernel per-step table
+# usage: tools/prof.sh <outdir> bench args...   -> per-kernel per-step table
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$out -o p -- python3 bench.py "$@" > gpurun_out/$out.log 2>&1
 python3 - <<PY
 import csv,sys
 rows=list(csv.DictReader(open("gpurun_out/$out/p_kernel_stats.csv")))
-thr=[r for r in rows if "k_threshold<" in r["Name"]]
+thr=[r for r in rows if "k_threshold" in r["Name"]]
 nstep=int(thr[0]["Calls"]) if thr else 1
 tot=0
 for r in rows:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the files under profiles/ on the GPU box (outputs land in gpurun_out/prof, copy what is judged).
-# usage: tools_profiles.sh <round-tag>
+# usage: tools/profiles.sh <round-tag>
 tag=${1:-r01}
 out=gpurun_out/prof
 mkdir -p $out
@@ -13,7 +13,7 @@ python3 - <<PY
 import csv, json, collections
 out = "$out"; tag = "$tag"
 rows = list(csv.DictReader(open(f"{out}/stats/{tag}_kernel_stats.csv")))
-thr = [r for r in rows if "k_threshold<" in r["Name"]]
+thr = [r for r in rows if "k_threshold" in r["Name"]]
 nstep = int(thr[0]["Calls"]) if thr else 1
 lines = []; tot = 0
 for r in rows:
@@ -22,7 +22,7 @@ for r in rows:
 lines.append("total per step %.1f us over %d steps (incl. warm-up and the untimed extra step)" % (tot, nstep))
 open(f"{out}/{tag}_kernel_stats_per_step.txt", "w").write("\n".join(lines) + "\n")
 def pmc(d, name):
-    rs = [r for r in csv.DictReader(open(f"{out}/{d}/p_counter_collection.csv")) if "k_threshold<" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    rs = [r for r in csv.DictReader(open(f"{out}/{d}/p_counter_collection.csv")) if "k_threshold" in r["Kernel_Name"] and r["Counter_Name"] == name]
     byd = collections.defaultdict(float)
     for r in rs: byd[r["Dispatch_Id"]] += float(r["Counter_Value"])
     v = sorted(byd.values()); return v[len(v) // 2]

@@ -34,6 +34,7 @@
 #include "scan.hip.h"
 #include "small.hip.h"
 #include "threshold.hip.h"
+#include "threshold_lean.hip.h"
 #include "tx.hip.h"
 
 using namespace nfc;
@@ -122,6 +123,8 @@ struct nfc_ctx {
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
+    int lean = 1, lean_k = 2;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
+    float lean_gfac = 1.5f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
     int gring_ok = 0, gring_force = 0, wave_slots_g = 0;   // long windows qualify (NFC_RING=lds|global overrides the choice)
     DevBuf d_gring;
@@ -295,10 +298,35 @@ void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e
     if (c->gring) hipLaunchKernelGGL((k_threshold<KIND, 4, true>), dim3(blocks), dim3(64 * wpb), lds, c->st, A);
     else hipLaunchKernelGGL((k_threshold<KIND, 4, false>), dim3(blocks), dim3(64 * wpb), lds, c->st, A);
 }
-void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork) {
+// Pass 0 with the LDS ring: the lean optimistic kernel (threshold_lean.hip.h); chunks it gives up on are re-run by k_threshold.
+template <int KIND>
+void launch_lean(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipEvent_t e1) {
+    const uint32_t wpb = (uint32_t)c->wpb;
+    const uint32_t blocks = (nwork + wpb - 1) / wpb;
+    const size_t lds = (size_t)wpb * c->Lpad * c->lds_per_slot;
+    auto go = [&](auto kern) {
+        if (e0) hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
+        else hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, A);
+    };
+    switch (c->lean_k) {
+    case 2: go(k_threshold_lean<KIND, 4, 2>); break;
+    case 3: go(k_threshold_lean<KIND, 4, 3>); break;
+    default: go(k_threshold_lean<KIND, 4, 4>); break;
+    }
+}
+void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, bool lean = false) {
     const bool timed = c->timing >= 1 && c->n_kev < 6;
     hipEvent_t e0 = timed ? c->kev[2 * c->n_kev] : nullptr, e1 = timed ? c->kev[2 * c->n_kev + 1] : nullptr;
     if (timed) c->n_kev++;
+    if (lean) {
+        switch (c->P.input_kind) {
+        case NFC_IN_IQ_F32: launch_lean<IN_IQ_F32>(c, A, nwork, e0, e1); break;
+        case NFC_IN_ENV_F32: launch_lean<IN_ENV_F32>(c, A, nwork, e0, e1); break;
+        case NFC_IN_REAL_F32_SQ: launch_lean<IN_REAL_F32_SQ>(c, A, nwork, e0, e1); break;
+        default: launch_lean<IN_I16_SQ>(c, A, nwork, e0, e1); break;
+        }
+        return;
+    }
     switch (c->P.input_kind) {
     case NFC_IN_IQ_F32: launch_threshold<IN_IQ_F32>(c, A, nwork, e0, e1); break;
     case NFC_IN_ENV_F32: launch_threshold<IN_ENV_F32>(c, A, nwork, e0, e1); break;
@@ -495,7 +523,14 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
         A.list = nullptr;
         A.nlist = 0;
         A.mode = 0;
-        launch_threshold_kind(c, A, nch);
+        // the lean kernel wherever it applies (LDS ring, more than one chunk: chunk 0's verdict travels with the certification)
+        const bool lean = c->lean && !c->gring && nch > 1;
+        A.cert = d_cert;
+        A.sum = (CertSummary *)(dT(c) + TOT_CERT);
+        A.ksteps = c->lean_k;
+        A.gfac = c->lean_gfac;
+        A.gfloor = c->lean_gmin;
+        launch_threshold_kind(c, A, nch, lean);
         c->stats.threshold_passes++;
         passes++;
 
@@ -559,8 +594,14 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 }
                 HIPCHK(c, hipMemcpy(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost));
             }
+            if (first_round && lean && !h_cert[0]) failing.push_back(0);   // chunk 0 gave up: re-run from the carried state
             for (uint32_t k : c->h_list)
                 if (!h_cert[k]) failing.push_back(k);
+            if (getenv("NFC_TRACE")) {
+                fprintf(stderr, "[nfc] round %d: n_fail %u, %zu failing of %u pending (cert[0] %d):", rounds, summary.n_fail, failing.size(), np, (int)h_cert[0]);
+                for (size_t i = 0; i < failing.size() && i < 12; i++) fprintf(stderr, " %u", failing[i]);
+                fprintf(stderr, "\n");
+            }
             if (dbg) {
                 std::vector<CertInfo> ci(nch);
                 HIPCHK(c, hipMemcpy(ci.data(), c->d_certinfo.p, (size_t)nch * sizeof(CertInfo), hipMemcpyDeviceToHost));
@@ -568,6 +609,14 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 for (uint32_t k : c->h_list) worst = std::max(worst, (double)ci[k].d / std::max(1e-30f, ci[k].allowed));
                 fprintf(stderr, "[nfc] certify round %d: %u pending, %zu failing, worst d/allowed %.3f\n", rounds, np,
                         failing.size(), worst);
+                if (first_round && lean) {
+                    std::vector<ChunkInfo> inf(nch);
+                    HIPCHK(c, hipMemcpy(inf.data(), c->d_info[0].p, (size_t)nch * sizeof(ChunkInfo), hipMemcpyDeviceToHost));
+                    int why[8] = {0};
+                    for (uint32_t k : failing) why[(inf[k].flags >> 4) & 7]++;
+                    fprintf(stderr, "[nfc]   lean gave up: range %d, band %d, low run %d, allowance %d, first sample %d; not lean %d\n", why[1], why[2],
+                            why[3], why[4], why[5], why[0]);
+                }
                 for (size_t i = 0; i < failing.size() && i < 8; i++) {
                     const CertInfo &x = ci[failing[i]];
                     fprintf(stderr, "[nfc]   chunk %u: d %.6g allowed %.6g all_robust %u low_ok %u\n", failing[i], x.d,
@@ -1169,6 +1218,10 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     C = std::max(C, c->mx + 2);
     c->rows_per_step = 4;
     c->use_small = getenv("NFC_NO_SMALL") ? 0 : 1;
+    if (const char *e = getenv("NFC_LEAN")) c->lean = atoi(e) != 0;
+    if (const char *e = getenv("NFC_LEAN_K")) c->lean_k = std::min(4, std::max(2, atoi(e)));   // (one step ahead does not survive the compiler: tools/audit_lean_isa.py)
+    if (const char *e = getenv("NFC_LEAN_GFAC")) c->lean_gfac = (float)atof(e);
+    if (const char *e = getenv("NFC_LEAN_GMIN")) c->lean_gmin = (float)atof(e);
     if (const char *e = getenv("NFC_OWN_PREFIX_MAX")) c->own_prefix_max = (uint32_t)strtoul(e, nullptr, 10);
     {
         c->rows_per_step = 4;   // (8-row steps measured slower: 126 VGPRs, four waves per SIMD)
@@ -1249,6 +1302,18 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // decoder LUTs
     DecoderTables t = build_tables(p->samp_rate, c->mx);

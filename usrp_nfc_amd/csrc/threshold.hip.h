@@ -38,6 +38,7 @@ namespace nfc {
 constexpr int STEP = 256;            // smallest step (4 rows of 64 samples); the wide variant walks 512
 constexpr int LL_NONE = -(1 << 30);  // "no such sample" (batch-local index)
 constexpr int MAX_FIX_ITERS = 80;
+constexpr float RND_SUM = 2.44140625e-04f;   // 2^-12: margin for the accumulated rounding of the f32 running sum
 
 enum : int { IN_IQ_F32 = 0, IN_ENV_F32 = 1, IN_REAL_F32_SQ = 2, IN_I16_SQ = 3 };
 
@@ -88,6 +89,7 @@ struct RunMeta {
     uint32_t pad;
 };
 
+struct CertSummary;
 struct ThrArgs {
     void *gring;                // GRING kernels: per chunk a ring row (Lpad floats, + Lpad touched bytes for raw envelopes)
     const void *in;
@@ -122,6 +124,11 @@ struct ThrArgs {
     int32_t twords;        // u32 words per touched bitmap
     int32_t off;           // chunk c covers samples [c*C - off, (c+1)*C - off)  (register-ring kernel: ring-aligned)
     int32_t nrows;         // ceil(L / 64)
+    // k_threshold_lean (threshold_lean.hip.h)
+    uint8_t *cert;         // per-chunk verdict bytes: chunk 0's is written by the threshold kernel itself
+    CertSummary *sum;      // n_fail takes chunk 0's failure
+    int32_t ksteps;        // steps per superstep
+    float gfac, gfloor;    // next drift allowance = max(gfac * B, gfloor * ss)
 };
 
 // ---------------------------------------------------------------------------
@@ -371,45 +378,12 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
     return acc;   // the caller stores x into the ring slot
 }
 
-// GRING: the ring lives in global memory (one row of A.gring per chunk) instead of LDS -- for windows whose LDS ring would
-// leave a SIMD with one or two waves; its old values are then asked for one step ahead, like the input.
-template <int KIND, int NR, bool GRING>
-__global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
-    constexpr uint32_t STEPN = 64u * NR;   // samples per step: NR rows of 64
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
-    const int wpb = blockDim.x >> 6;
-    const uint32_t slotid = blockIdx.x * wpb + wave;
-    uint32_t c;
-    if (A.list) {
-        if (slotid >= A.nlist) return;
-        c = rfl(A.list[slotid]);
-    } else {
-        if (slotid >= (uint32_t)A.nchunks) return;
-        c = slotid;
-    }
-    // Envelopes are >= 0, so the ring keeps "not yet accepted into during this chunk" in the SIGN bit of a slot
-    // (-|v|: untouched); the first accepted sample stores +x.  (A raw-envelope input may be negative: that
-    // kind keeps a byte map after the ring.)
-    constexpr bool SIGN_T = (KIND != IN_ENV_F32);
-    const size_t lds_wave = SIGN_T ? (size_t)A.Lpad * 4 : (size_t)A.Lpad * 5;
-    float *ring = GRING ? (float *)((unsigned char *)A.gring + (size_t)c * lds_wave) : (float *)(smem + (size_t)wave * lds_wave);
-    unsigned char *tch = (unsigned char *)(ring + A.Lpad);
-    auto mark = [&](uint32_t sl) { if constexpr (!SIGN_T) tch[sl] = 1; };
+// The state a chunk starts from: chunk 0 the carried (exact) one; mode 1 the exact one resolved from the predecessors'
+// summaries; otherwise speculated from the L samples before the chunk.
+template <int KIND>
+__device__ __forceinline__ void chunk_incoming(const ThrArgs &A, uint32_t c, int lane, float *ring, const Carry &cr, uint32_t m_chunk,
+                                               double &ss0, int &w_nl, int &w_kl, float &eps) {
     const int L = A.L;
-    const int mx = A.mx;
-    const uint32_t m_chunk = c * (uint32_t)A.C;   // this kernel runs with A.off == 0
-    const uint32_t n1 = min(A.n, m_chunk + (uint32_t)A.C);
-    const uint32_t m_start = max(m_chunk, A.skip);
-    const Carry cr = *A.carry;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
-
-    uint32_t emin = 255u, emax = 0u;
-    int w_nl, w_kl;  // last non-LOW index / key of the last LOW sample, before the current row
-    double ss0;
-    float eps = 0.f;  // margin of this evaluation
-
-    // ---------------- incoming state ----------------
     if (c == 0) {
         #pragma unroll 8
         for (int s = lane; s < L; s += 64) ring[s] = A.ring_carry[s];
@@ -490,10 +464,14 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         w_kl = (ll == LL_NONE) ? KEY_NONE : 2 * ll + 1;
         ss0 = wave_sum_f64(part) + cr.delta;
     }
-    ss0 = rfl(ss0);
-    w_nl = rfl(w_nl);
-    w_kl = rfl(w_kl);
-    const int nl_in = w_nl, kl_in = w_kl;
+}
+
+// Keeps the ring the evaluation starts from (for k_certify), marks every slot untouched, folds the exponent guard;
+// returns the raw bits of the largest incoming value.
+template <bool SIGN_T>
+__device__ __forceinline__ uint32_t chunk_save_in(const ThrArgs &A, uint32_t c, int lane, float *ring, unsigned char *tch, uint32_t &emin,
+                                                  uint32_t &emax) {
+    const int L = A.L;
     float *rin = A.ring_in + (size_t)c * L;
     if constexpr (!SIGN_T)
         for (int s = lane; s < A.Lpad; s += 64) tch[s] = 0;
@@ -510,6 +488,120 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
             emax = max(emax, e);
         }
     }
+
+    return vtop0;
+}
+
+// The chunk's summary: ring at its end + touched map, LOW bookkeeping, guard, what the evaluation assumed.
+template <bool SIGN_T>
+__device__ __forceinline__ void chunk_publish(const ThrArgs &A, uint32_t c, int lane, const float *ring, const unsigned char *tch, uint32_t emin,
+                                              uint32_t emax, uint32_t vmin, uint32_t vmax, float ssf, float eps, uint32_t flags, int chunk_kl,
+                                              int chunk_nl, double ss_out, float min_ss, int nl_in, int kl_in, uint32_t all_robust) {
+    const int L = A.L;
+    // fold the raw-bit extremes of the fast path into the exponent guard
+    if (vmax != 0u) {
+        emax = max(emax, (vmax >> 31) ? 255u : max((vmax >> 23) & 0xFFu, 1u));
+        if (vmin != 0xFFFFFFFFu) emin = min(emin, max((vmin >> 23) & 0xFFu, 1u));
+    }
+
+    // ---------------- publish the summary ----------------
+    const int vb_old = A.ver[c];
+    const int vb_new = (A.mode == 1) ? (1 - vb_old) : vb_old;  // pass 0 fills buffer ver[c] directly
+    float *ro = A.ring_out[vb_new] + (size_t)c * L;
+    uint32_t *to = A.touched[vb_new] + (size_t)c * A.twords;
+    uint32_t untouched = 0;
+    for (int sbase = 0; sbase < A.twords * 32; sbase += 64) {
+        const int s = sbase + lane;
+        const float rv = (s < L) ? ring[s] : 0.f;
+        const bool t = (s < L) && (SIGN_T ? !(__float_as_uint(rv) >> 31) : (tch[s] != 0));
+        const unsigned long long bal = __ballot(t);
+        if (s < L) {
+            ro[s] = SIGN_T ? fabsf(rv) : rv;
+            if (!t) untouched++;
+        }
+        const int w = sbase >> 5;
+        if (lane == 0) {
+            to[w] = (uint32_t)bal;
+            if (w + 1 < A.twords) to[w + 1] = (uint32_t)(bal >> 32);
+        }
+    }
+    emin = wave_min_u32(emin);
+    emax = wave_max_u32(emax);
+    // every window sum of the chunk lies below this: each step folded its own bound (fast: tracked sum + margin, which
+    // covers drift, speculation and rounding; exact: sum + total variation of the step)
+    const uint32_t vtop = wave_max_u32(__float_as_uint(fmaxf(__uint_as_float(wave_max_u32(vmax)), ssf * (1.0f + eps + RND_SUM)) * 1.0009765625f));
+    untouched = (uint32_t)wave_sum_f32((float)untouched);
+    flags = wave_max_u32(flags);
+    if (lane == 0) {
+        ChunkInfo ci;
+        ci.ss_out = ss_out;   // informational
+        ci.low_key = chunk_kl;
+        ci.last_nonlow = chunk_nl;
+        ci.emin = emin;
+        ci.emax = emax;
+        ci.flags = flags;
+        ci.n_untouched = untouched;
+        A.info[vb_new][c] = ci;
+        A.gmin[c] = (uint8_t)emin;
+        A.gmax[c] = (uint8_t)emax;
+        A.gflags[c] = (uint8_t)(flags | (untouched ? 2u : 0u));
+        A.gvtop[c] = vtop;
+        RunMeta mt;
+        mt.min_ss = min_ss;
+        mt.eps = eps;
+        mt.nl_in = nl_in;
+        mt.kl_in = kl_in;
+        mt.all_robust = all_robust;
+        mt.pad = 0;
+        A.meta[c] = mt;
+    }
+}
+
+// GRING: the ring lives in global memory (one row of A.gring per chunk) instead of LDS -- for windows whose LDS ring would
+// leave a SIMD with one or two waves; its old values are then asked for one step ahead, like the input.
+template <int KIND, int NR, bool GRING>
+__global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
+    constexpr uint32_t STEPN = 64u * NR;   // samples per step: NR rows of 64
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
+    const int wpb = blockDim.x >> 6;
+    const uint32_t slotid = blockIdx.x * wpb + wave;
+    uint32_t c;
+    if (A.list) {
+        if (slotid >= A.nlist) return;
+        c = rfl(A.list[slotid]);
+    } else {
+        if (slotid >= (uint32_t)A.nchunks) return;
+        c = slotid;
+    }
+    // Envelopes are >= 0, so the ring keeps "not yet accepted into during this chunk" in the SIGN bit of a slot
+    // (-|v|: untouched); the first accepted sample stores +x.  (A raw-envelope input may be negative: that
+    // kind keeps a byte map after the ring.)
+    constexpr bool SIGN_T = (KIND != IN_ENV_F32);
+    const size_t lds_wave = SIGN_T ? (size_t)A.Lpad * 4 : (size_t)A.Lpad * 5;
+    float *ring = GRING ? (float *)((unsigned char *)A.gring + (size_t)c * lds_wave) : (float *)(smem + (size_t)wave * lds_wave);
+    unsigned char *tch = (unsigned char *)(ring + A.Lpad);
+    auto mark = [&](uint32_t sl) { if constexpr (!SIGN_T) tch[sl] = 1; };
+    const int L = A.L;
+    const int mx = A.mx;
+    const uint32_t m_chunk = c * (uint32_t)A.C;   // this kernel runs with A.off == 0
+    const uint32_t n1 = min(A.n, m_chunk + (uint32_t)A.C);
+    const uint32_t m_start = max(m_chunk, A.skip);
+    const Carry cr = *A.carry;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+    uint32_t emin = 255u, emax = 0u;
+    int w_nl, w_kl;  // last non-LOW index / key of the last LOW sample, before the current row
+    double ss0;
+    float eps = 0.f;  // margin of this evaluation
+
+    // ---------------- incoming state ----------------
+    chunk_incoming<KIND>(A, c, lane, ring, cr, m_chunk, ss0, w_nl, w_kl, eps);
+    ss0 = rfl(ss0);
+    w_nl = rfl(w_nl);
+    w_kl = rfl(w_kl);
+    const int nl_in = w_nl, kl_in = w_kl;
+    const uint32_t vtop0 = chunk_save_in<SIGN_T>(A, c, lane, ring, tch, emin, emax);
 
     // ---------------- the chunk, NR rows of 64 samples per step ----------------
     uint32_t flags = 0;
@@ -542,7 +634,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     // so it tracks the sum in f32 (ssf) and pays for the accumulated rounding with RND * ss of extra margin
     // (each step adds < 2^-22 relative; ssf is re-derived from the ring at least every 256 steps).  The exact
     // fp64 sum is re-derived from the ring -- S(ring) + delta -- whenever the exact path needs it.
-    const float RND = 2.44140625e-04f;   // 2^-12
+    const float RND = RND_SUM;
     float ssf = (float)ss0;
     bool ss0_valid = true;
     int steps_since_sync = 0;
@@ -843,63 +935,8 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         slot_step += STEPN;
         slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
     }
-    // fold the raw-bit extremes of the fast path into the exponent guard
-    if (vmax != 0u) {
-        emax = max(emax, (vmax >> 31) ? 255u : max((vmax >> 23) & 0xFFu, 1u));
-        if (vmin != 0xFFFFFFFFu) emin = min(emin, max((vmin >> 23) & 0xFFu, 1u));
-    }
-
-    // ---------------- publish the summary ----------------
-    const int vb_old = A.ver[c];
-    const int vb_new = (A.mode == 1) ? (1 - vb_old) : vb_old;  // pass 0 fills buffer ver[c] directly
-    float *ro = A.ring_out[vb_new] + (size_t)c * L;
-    uint32_t *to = A.touched[vb_new] + (size_t)c * A.twords;
-    uint32_t untouched = 0;
-    for (int sbase = 0; sbase < A.twords * 32; sbase += 64) {
-        const int s = sbase + lane;
-        const float rv = (s < L) ? ring[s] : 0.f;
-        const bool t = (s < L) && (SIGN_T ? !(__float_as_uint(rv) >> 31) : (tch[s] != 0));
-        const unsigned long long bal = __ballot(t);
-        if (s < L) {
-            ro[s] = SIGN_T ? fabsf(rv) : rv;
-            if (!t) untouched++;
-        }
-        const int w = sbase >> 5;
-        if (lane == 0) {
-            to[w] = (uint32_t)bal;
-            if (w + 1 < A.twords) to[w + 1] = (uint32_t)(bal >> 32);
-        }
-    }
-    emin = wave_min_u32(emin);
-    emax = wave_max_u32(emax);
-    // every window sum of the chunk lies below this: each step folded its own bound (fast: tracked sum + margin, which
-    // covers drift, speculation and rounding; exact: sum + total variation of the step)
-    const uint32_t vtop = wave_max_u32(__float_as_uint(fmaxf(__uint_as_float(wave_max_u32(vmax)), ssf * (1.0f + eps + RND)) * 1.0009765625f));
-    untouched = (uint32_t)wave_sum_f32((float)untouched);
-    flags = wave_max_u32(flags);
-    if (lane == 0) {
-        ChunkInfo ci;
-        ci.ss_out = ss0_valid ? ss0 : (double)ssf;   // informational
-        ci.low_key = chunk_kl;
-        ci.last_nonlow = chunk_nl;
-        ci.emin = emin;
-        ci.emax = emax;
-        ci.flags = flags;
-        ci.n_untouched = untouched;
-        A.info[vb_new][c] = ci;
-        A.gmin[c] = (uint8_t)emin;
-        A.gmax[c] = (uint8_t)emax;
-        A.gflags[c] = (uint8_t)(flags | (untouched ? 2u : 0u));
-        A.gvtop[c] = vtop;
-        RunMeta mt;
-        mt.min_ss = min_ss;
-        mt.eps = eps;
-        mt.nl_in = nl_in;
-        mt.kl_in = kl_in;
-        mt.all_robust = all_robust;
-        mt.pad = 0;
-        A.meta[c] = mt;
-    }
+    chunk_publish<SIGN_T>(A, c, lane, ring, tch, emin, emax, vmin, vmax, ssf, eps, flags, chunk_kl, chunk_nl,
+                          ss0_valid ? ss0 : (double)ssf, min_ss, nl_in, kl_in, all_robust);
 }
 
 // ---------------------------------------------------------------------------
@@ -1010,6 +1047,10 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     const uint32_t slotid = bid * (blockDim.x >> 6) + wave;
     if (slotid >= A.nlist) return;
     const uint32_t c = A.list ? A.list[slotid] : slotid + 1;
+    if (c == 0) {   // (chunk 0 re-run from the carried state: nothing it could disagree with)
+        if (lane == 0) cert[0] = 1;
+        return;
+    }
     const int L = A.L;
     const float *rin = A.ring_in + (size_t)c * L;
     const RunMeta mt = A.meta[c];
