@@ -123,8 +123,8 @@ struct nfc_ctx {
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
-    int lean = 1, lean_k = 2;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
-    float lean_gfac = 1.5f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
+    int lean = 1, lean_k = 3;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
+    float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
     int gring_ok = 0, gring_force = 0, wave_slots_g = 0;   // long windows qualify (NFC_RING=lds|global overrides the choice)
     DevBuf d_gring;
@@ -309,9 +309,9 @@ void launch_lean(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hi
         else hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, A);
     };
     switch (c->lean_k) {
-    case 2: go(k_threshold_lean<KIND, 4, 2>); break;
-    case 3: go(k_threshold_lean<KIND, 4, 3>); break;
-    default: go(k_threshold_lean<KIND, 4, 4>); break;
+    case 2: go(k_threshold_lean<KIND, 2>); break;
+    case 3: go(k_threshold_lean<KIND, 3>); break;
+    default: go(k_threshold_lean<KIND, 4>); break;
     }
 }
 void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, bool lean = false) {
@@ -321,7 +321,6 @@ void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, bool le
     if (lean) {
         switch (c->P.input_kind) {
         case NFC_IN_IQ_F32: launch_lean<IN_IQ_F32>(c, A, nwork, e0, e1); break;
-        case NFC_IN_ENV_F32: launch_lean<IN_ENV_F32>(c, A, nwork, e0, e1); break;
         case NFC_IN_REAL_F32_SQ: launch_lean<IN_REAL_F32_SQ>(c, A, nwork, e0, e1); break;
         default: launch_lean<IN_I16_SQ>(c, A, nwork, e0, e1); break;
         }
@@ -412,7 +411,8 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     c->gring = c->gring_ok && (c->gring_force || (uint64_t)n >= (uint64_t)c->wave_slots_g * 8u * (uint64_t)c->L);
     if (!c->P.chunk_samples) {
         const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : c->wave_slots);
-        const int stp = 64 * c->rows_per_step;
+        // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps)
+        const int stp = 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
         uint64_t want = ((uint64_t)n + slots - 1) / slots;
         want = (want + stp - 1) / stp * stp;
         c->C = (int)std::max<uint64_t>(want, (uint64_t)c->C_min);
@@ -524,12 +524,13 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
         A.nlist = 0;
         A.mode = 0;
         // the lean kernel wherever it applies (LDS ring, more than one chunk: chunk 0's verdict travels with the certification)
-        const bool lean = c->lean && !c->gring && nch > 1;
+        const bool lean = c->lean && !c->gring && nch > 1 && c->P.input_kind != NFC_IN_ENV_F32;   // (raw envelopes may be negative: no sign bit to spare)
         A.cert = d_cert;
         A.sum = (CertSummary *)(dT(c) + TOT_CERT);
         A.ksteps = c->lean_k;
         A.gfac = c->lean_gfac;
         A.gfloor = c->lean_gmin;
+        A.blk = 1 << c->nfold;
         launch_threshold_kind(c, A, nch, lean);
         c->stats.threshold_passes++;
         passes++;
@@ -1302,18 +1303,15 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // decoder LUTs
     DecoderTables t = build_tables(p->samp_rate, c->mx);

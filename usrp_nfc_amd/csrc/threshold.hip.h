@@ -128,7 +128,8 @@ struct ThrArgs {
     uint8_t *cert;         // per-chunk verdict bytes: chunk 0's is written by the threshold kernel itself
     CertSummary *sum;      // n_fail takes chunk 0's failure
     int32_t ksteps;        // steps per superstep
-    float gfac, gfloor;    // next drift allowance = max(gfac * B, gfloor * ss)
+    float gfac, gfloor;    // drift allowance = max(gfac * (largest B needed so far), gfloor * ss)
+    int32_t blk;           // a LOW run longer than max_len covers an aligned block of blk samples (a power of two)
 };
 
 // ---------------------------------------------------------------------------
@@ -199,6 +200,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
+// One dword of a wave mask into lane LANE of pk.  An asm statement because there is no builtin for it in this toolchain -- and
+// therefore with its own wait states: on gfx950 a scalar register written by a vector instruction (the v_cmp behind a ballot)
+// must not be read by a vector instruction within the next two issue slots, and inside an asm statement nobody pads that
+// (measured: the low half of a fresh mask arrived as the previous row's).
+#define PLANE_PUT(pk, dword_of_mask, LANE) asm volatile("s_nop 2\n\tv_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)(dword_of_mask)), "n"(LANE))
 __device__ __forceinline__ int last_set(unsigned long long m) { return 63 - __clzll((long long)m); }  // m != 0
 
 // Envelope of one sample (gnuradio complex_to_mag_squared; compiled with
@@ -918,14 +924,15 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
             ssf = (float)ss0;
         }
         {   // the step's NR words per plane: the masks are scalar pairs, v_writelane puts their halves into lanes 0 .. 2 NR - 1
-            // (neg) and 2 NR .. 4 NR - 1 (pos) of ONE register, and those lanes store a dword each
+            // (neg) and 2 NR .. 4 NR - 1 (pos) of ONE register, and those lanes store a dword each (the builtin, not an asm
+            // statement: a mask fresh from a v_cmp needs wait states before v_writelane may read it, and only the compiler pads them)
             int pk = 0;
 #pragma unroll
             for (int k = 0; k < NR; k++) {
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)lowm[k]), "n"(2 * k));
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)(lowm[k] >> 32)), "n"(2 * k + 1));
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)posm[k]), "n"(2 * NR + 2 * k));
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)(posm[k] >> 32)), "n"(2 * NR + 2 * k + 1));
+                PLANE_PUT(pk, lowm[k], 2 * k);
+                PLANE_PUT(pk, (lowm[k] >> 32), 2 * k + 1);
+                PLANE_PUT(pk, posm[k], 2 * NR + 2 * k);
+                PLANE_PUT(pk, (posm[k] >> 32), 2 * NR + 2 * k + 1);
             }
             const int h = lane & (2 * NR - 1);                      // dword within the plane's NR words
             const uint32_t w = (base >> 6) + (uint32_t)(h >> 1);    // its word

@@ -1,26 +1,35 @@
 // threshold_lean.hip.h -- pass 0 of the threshold stage (transition_sink.py:55-82) as a lean, purely optimistic kernel.
 //
-// Same decomposition as k_threshold (threshold.hip.h): one wavefront per time chunk, NR rows of 64 samples per step,
-// the ring of the last L accepted samples in LDS with "untouched" in the sign bit.  What differs is WHEN the bound of
-// the window sum's drift is established.  k_threshold reduces B = sum |x - prev| over a step BEFORE it classifies the
-// step (two wave reductions and a dozen wave-uniform float operations on every step's critical path).  Here a
-// SUPERSTEP of K steps is classified against thresholds fixed at its start:
+// Same decomposition as k_threshold (threshold.hip.h): one wavefront per time chunk, 4 rows of 64 samples per step (lane l
+// holds samples l, 64+l, 128+l, 192+l), the ring of the last L accepted samples in LDS with "untouched" in the sign bit.
+// Two things differ.
 //
-//     M = G + (eps + RND) * ss        G: drift allowance (guessed from the last superstep's B),
-//                                     eps: certification margin of the speculated incoming ring, RND: f32 sum tracking
+// (1) WHEN the bound of the window sum's drift is established.  k_threshold reduces B = sum |x - prev| over a step BEFORE it
+// classifies the step.  Here a SUPERSTEP of PF steps is classified against thresholds fixed at its start,
+//
+//     M = G + (eps + RND) * ss        G: drift allowance (a guess), eps: certification margin of the speculated incoming
+//                                     ring, RND: rounding of the f32 sum tracking
 //     LOW   <=  x < (ss - M) * lo / L      not LOW  <=  x > (ss + M) * lo / L
 //     HIGH  <=  x > (ss + M) * hi / L      not HIGH <=  x < (ss - M) * hi / L
 //
-// while every lane only ACCUMULATES |x - prev| and (x - prev) of the samples it accepts.  After the K steps one pair of
-// wave reductions gives B and D.  If B <= G the classifications are the reference's: by induction over the samples of the
-// superstep -- while the drift so far is <= G every classification made is exact, so the accepted set is exact, so the
-// drift after the next sample is a partial sum of accepted (x - prev), in magnitude <= B <= G.  Then ss += D.
+// while every lane only ACCUMULATES |x - prev| and (x - prev) of the samples it accepts; one pair of wave reductions per
+// superstep gives B and D.  If B <= G the classifications are the reference's: by induction over the samples of the
+// superstep -- while the drift so far is <= G every classification made is exact, so the accepted set is exact, so the drift
+// after the next sample is a partial sum of accepted (x - prev), in magnitude <= B <= G.  Then ss += D.
 //
-// Nothing is ever repaired in place: a sample inside a band, a LOW run that may reach max_len, B > G, parameters the
-// banded test cannot serve -- the wave GIVES UP: it flags its chunk (RunMeta.all_robust = 0; chunk 0: cert[0] = 0 and the
-// failure count), and the host re-runs that chunk from the exact state with k_threshold (mode 1), exactly as it does for
-// a chunk whose speculation cannot be certified.  So this kernel has no fp64, no exact path and no retry structure in its
-// loop; the result that stands is always one whose every step was proven.
+// (2) WHERE the work is done.  Measured on MI355X (tools/ubench/issue_rate.hip, 5 waves per SIMD): a scalar instruction costs
+// a SIMD 4.2 cycles, a v_cmp into a scalar pair 4.5, a plain vector instruction 2.8 -- a formulation on wave masks (ballots
+// combined by s_and / s_or, exec juggling around every conditional store) is the expensive one.  So the common steps stay in
+// the lanes: two pre-tests (min / max of the lane's four samples against the bands) pick one of three straight-line forms --
+// nothing classifies / only LOW samples / only HIGH samples with no LOW sample in reach -- whose conditional work is v_cndmask
+// on the ONE compare the planes need anyway; "a sample inside a band" and "a LOW run that may reach max_len" are tracked as
+// per-lane minima and looked at once per superstep.  Everything else (LOW and HIGH in one step, the stream's first stable
+// sample, a batch's ragged end, a chunk that starts inside a LOW run) takes the general step on wave masks.
+//
+// Nothing is ever repaired in place: when a check fails the wave GIVES UP -- it flags its chunk (RunMeta.all_robust = 0;
+// chunk 0: cert[0] = 0 and the failure count) and the host re-runs that chunk from the exact state with k_threshold (mode 1),
+// exactly as it does for a chunk whose speculation cannot be certified.  The result that stands is always one whose every
+// step was proven.
 #pragma once
 #include "threshold.hip.h"
 
@@ -28,54 +37,111 @@
 
 namespace nfc {
 
-// The raw samples of the steps ahead sit in registers whose loads the compiler must neither wait for nor move: they are
-// issued by asm statements (a compiler-issued load whose result lives across the loop's back edge is copied there, behind a
-// wait for EVERY load in flight) and counted by hand -- `lean_wait<N>` names every register of the step it releases, so no
-// read of them can be scheduled above it (cdna_hip_programming.md 5.7, form (ii)).
-typedef float lean_v2f __attribute__((ext_vector_type(2)));
-template <int KIND> struct LeanRaw { using T = float; static constexpr int BYTES = 4; };
-template <> struct LeanRaw<IN_IQ_F32> { using T = lean_v2f; static constexpr int BYTES = 8; };
-template <> struct LeanRaw<IN_I16_SQ> { using T = int; static constexpr int BYTES = 2; };
-template <int KIND, int OFF>
-__device__ __forceinline__ void lean_load(typename LeanRaw<KIND>::T &q, const void *p) {
-    if constexpr (KIND == IN_IQ_F32) asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "+v"(q) : "v"(p), "n"(OFF) : "memory");
-    else if constexpr (KIND == IN_I16_SQ) asm volatile("global_load_sshort %0, %1, off offset:%2" : "+v"(q) : "v"(p), "n"(OFF) : "memory");
-    else asm volatile("global_load_dword %0, %1, off offset:%2" : "+v"(q) : "v"(p), "n"(OFF) : "memory");
-}
-template <int KIND>
-__device__ __forceinline__ float lean_env(typename LeanRaw<KIND>::T v, float i16_scale) {
+// The raw samples of the steps ahead must sit in registers whose loads the compiler neither waits for nor moves.  A
+// compiler-issued load whose result lives across the loop's back edge is copied there, behind a wait for EVERY load in flight;
+// an asm load into a compiler-allocated register ("+v") fares no better -- the allocator copies that register between the load
+// and its hand-counted wait whenever the control flow gets interesting, i.e. reads it while it is still being loaded.  So the
+// samples land in ACCUMULATOR registers named literally (a0 ..: gfx950 loads straight into them; the compiler itself never
+// touches them unless it spills -- tools/audit_lean_isa.py checks that it does not) and reach the compiler's registers only
+// through the statement that first waits for them: lean_take<K> = s_waitcnt vmcnt(N) + v_accvgpr_read.
+// Step k of a superstep owns a[8 k .. 8 k + 7] (IQ: four pairs; the one-dword kinds use the first four).
+#define LEAN_LOAD4(OP, R0, R1, R2, R3, STRIDE, ...)                                                                                         \
+    asm volatile(OP " " R0 ", %0, off\n\t" OP " " R1 ", %0, off offset:%1\n\t" OP " " R2 ", %0, off offset:%2\n\t" OP " " R3 ", %0, off offset:%3" \
+                 :                                                                                                                          \
+                 : "v"(p), "n"(STRIDE), "n"(2 * STRIDE), "n"(3 * STRIDE)                                                                    \
+                 : "memory", __VA_ARGS__)
+#define LEAN_CLOB0 "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7"
+#define LEAN_CLOB1 "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"
+#define LEAN_CLOB2 "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23"
+#define LEAN_CLOB3 "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"
+template <int KIND, int K>
+__device__ __forceinline__ void lean_load_step(const void *p) {   // the 256 samples at p (lane's own address) into step K's registers
+    static_assert(K >= 0 && K < 4, "four steps of registers");
     if constexpr (KIND == IN_IQ_F32) {
-        const float a = v.x * v.x, b = v.y * v.y;
-        return a + b;
-    } else if constexpr (KIND == IN_ENV_F32) {
-        return v;
-    } else if constexpr (KIND == IN_REAL_F32_SQ) {
-        return v * v;
+        if constexpr (K == 0) LEAN_LOAD4("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", 512, LEAN_CLOB0);
+        if constexpr (K == 1) LEAN_LOAD4("global_load_dwordx2", "a[8:9]", "a[10:11]", "a[12:13]", "a[14:15]", 512, LEAN_CLOB1);
+        if constexpr (K == 2) LEAN_LOAD4("global_load_dwordx2", "a[16:17]", "a[18:19]", "a[20:21]", "a[22:23]", 512, LEAN_CLOB2);
+        if constexpr (K == 3) LEAN_LOAD4("global_load_dwordx2", "a[24:25]", "a[26:27]", "a[28:29]", "a[30:31]", 512, LEAN_CLOB3);
+    } else if constexpr (KIND == IN_I16_SQ) {
+        if constexpr (K == 0) LEAN_LOAD4("global_load_sshort", "a0", "a1", "a2", "a3", 128, LEAN_CLOB0);
+        if constexpr (K == 1) LEAN_LOAD4("global_load_sshort", "a8", "a9", "a10", "a11", 128, LEAN_CLOB1);
+        if constexpr (K == 2) LEAN_LOAD4("global_load_sshort", "a16", "a17", "a18", "a19", 128, LEAN_CLOB2);
+        if constexpr (K == 3) LEAN_LOAD4("global_load_sshort", "a24", "a25", "a26", "a27", 128, LEAN_CLOB3);
     } else {
-        const float s = (float)v * i16_scale;
-        return s * s;
+        if constexpr (K == 0) LEAN_LOAD4("global_load_dword", "a0", "a1", "a2", "a3", 256, LEAN_CLOB0);
+        if constexpr (K == 1) LEAN_LOAD4("global_load_dword", "a8", "a9", "a10", "a11", 256, LEAN_CLOB1);
+        if constexpr (K == 2) LEAN_LOAD4("global_load_dword", "a16", "a17", "a18", "a19", 256, LEAN_CLOB2);
+        if constexpr (K == 3) LEAN_LOAD4("global_load_dword", "a24", "a25", "a26", "a27", 256, LEAN_CLOB3);
     }
 }
-template <int N, class T>
-__device__ __forceinline__ void lean_wait(T (&q)[4]) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "n"(N) : "memory");
+#define LEAN_TAKE8(R0, R1, R2, R3, R4, R5, R6, R7)                                                                                          \
+    asm volatile("s_waitcnt vmcnt(%8)\n\tv_accvgpr_read_b32 %0, " R0 "\n\tv_accvgpr_read_b32 %1, " R1 "\n\tv_accvgpr_read_b32 %2, " R2             \
+                 "\n\tv_accvgpr_read_b32 %3, " R3 "\n\tv_accvgpr_read_b32 %4, " R4 "\n\tv_accvgpr_read_b32 %5, " R5 "\n\tv_accvgpr_read_b32 %6, " R6 \
+                 "\n\tv_accvgpr_read_b32 %7, " R7                                                                                            \
+                 : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])                            \
+                 : "n"(N)                                                                                                                   \
+                 : "memory")
+#define LEAN_TAKE4(R0, R1, R2, R3)                                                                                                          \
+    asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, " R0 "\n\tv_accvgpr_read_b32 %1, " R1 "\n\tv_accvgpr_read_b32 %2, " R2             \
+                 "\n\tv_accvgpr_read_b32 %3, " R3                                                                                            \
+                 : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3])                                                                            \
+                 : "n"(N)                                                                                                                   \
+                 : "memory")
+// Waits until at most N vector-memory operations are in flight, then hands step K's samples over as envelopes.
+template <int KIND, int K, int N>
+__device__ __forceinline__ void lean_take(float (&x)[4], float i16_scale) {
+    if constexpr (KIND == IN_IQ_F32) {
+        float w[8];
+        if constexpr (K == 0) LEAN_TAKE8("a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7");
+        if constexpr (K == 1) LEAN_TAKE8("a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+        if constexpr (K == 2) LEAN_TAKE8("a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
+        if constexpr (K == 3) LEAN_TAKE8("a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float a = w[2 * j] * w[2 * j], b = w[2 * j + 1] * w[2 * j + 1];   // gnuradio complex_to_mag_squared: two products, one sum
+            x[j] = a + b;
+        }
+    } else {
+        float w[4];
+        if constexpr (K == 0) LEAN_TAKE4("a0", "a1", "a2", "a3");
+        if constexpr (K == 1) LEAN_TAKE4("a8", "a9", "a10", "a11");
+        if constexpr (K == 2) LEAN_TAKE4("a16", "a17", "a18", "a19");
+        if constexpr (K == 3) LEAN_TAKE4("a24", "a25", "a26", "a27");
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if constexpr (KIND == IN_I16_SQ) {
+                const float sv = (float)__float_as_int(w[j]) * i16_scale;   // (global_load_sshort sign-extends into the register)
+                x[j] = sv * sv;
+            } else {
+                x[j] = w[j] * w[j];   // IN_REAL_F32_SQ
+            }
+        }
+    }
+}
+template <int KIND> struct LeanRaw { static constexpr int BYTES = (KIND == IN_IQ_F32) ? 8 : (KIND == IN_I16_SQ) ? 2 : 4; };
+typedef __attribute__((address_space(3))) float lean_lds_f;
+__device__ __forceinline__ float lean_dpp_shl8(float v) {   // lane l <- lane l + 8 of its row of 16 (other lanes: themselves)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x108, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lean_dpp_shl15(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x10F, 0xF, 0xF, false));
 }
 
 // PF: steps per superstep = how many steps ahead the raw samples are asked for (a step's registers are refilled, for the
-// step PF later, as soon as its envelopes are taken: PF * NR * 512 bytes in flight per wave).
-template <int KIND, int NR, int PF>
+// step PF later, as soon as its envelopes are taken: PF * 2 KB in flight per wave for IQ input).
+template <int KIND, int PF>
 __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
+    static_assert(KIND != IN_ENV_F32, "raw envelopes may be negative: no sign bit to spare (they take k_threshold)");
+    static_assert(PF >= 2 && PF <= 4, "planes of a superstep leave in one store of 16 lanes per step");
+    constexpr int NR = 4;
     constexpr uint32_t STEPN = 64u * NR;
-    constexpr bool SIGN_T = (KIND != IN_ENV_F32);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
     const int wpb = blockDim.x >> 6;
     const uint32_t c = blockIdx.x * wpb + wave;
     if (c >= (uint32_t)A.nchunks) return;
-    const size_t lds_wave = SIGN_T ? (size_t)A.Lpad * 4 : (size_t)A.Lpad * 5;
-    float *ring = (float *)(smem + (size_t)wave * lds_wave);
-    unsigned char *tch = (unsigned char *)(ring + A.Lpad);
-    auto mark = [&](uint32_t sl) { if constexpr (!SIGN_T) tch[sl] = 1; };
+    float *ring = (float *)(smem + (size_t)wave * (size_t)A.Lpad * 4);
+    lean_lds_f *const rl = (lean_lds_f *)ring;
     const int L = A.L;
     const int mx = A.mx;
     const uint32_t m_chunk = c * (uint32_t)A.C;
@@ -94,7 +160,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     w_nl = rfl(w_nl);
     w_kl = rfl(w_kl);
     const int nl_in = w_nl, kl_in = w_kl;
-    const uint32_t vtop0 = chunk_save_in<SIGN_T>(A, c, lane, ring, tch, emin, emax);
+    const uint32_t vtop0 = chunk_save_in<true>(A, c, lane, ring, nullptr, emin, emax);
 
     bool good_run = A.fast_ok != 0;   // false: the wave gave up
     uint32_t why = good_run ? 0u : 1u;   // (debugging aid: 1 parameters / sums out of range, 2 a sample inside a band, 3 LOW run, 4 allowance, 5 first stable sample)
@@ -105,37 +171,14 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     const float etaD = 1.0f - 9.5367431640625e-07f;  // 1 - 2^-20
     const float slD = 1.0f - 3.814697265625e-06f, slU = 1.0f + 3.814697265625e-06f;
     const float loLf = (float)A.lo_L, hiLf = (float)A.hi_L;   // f32 thresholds carry 2^-18 of slack (slD / slU)
-    static_assert(NR == 4, "lean_wait names four registers");
-    using Raw = typename LeanRaw<KIND>::T;
     constexpr int RB = LeanRaw<KIND>::BYTES;
-    Raw r[PF][NR];
-#pragma unroll
-    for (int k = 0; k < PF; k++)
-#pragma unroll
-        for (int j = 0; j < NR; j++) r[k][j] = Raw(0);
     const char *const in_lane = (const char *)A.in + (size_t)lane * RB;
-    // a whole step's samples into q (asm loads: counted by hand, see above)
-    auto fetch_whole = [&](uint32_t b, Raw (&q)[NR]) {
-        const char *p = in_lane + (size_t)b * RB;
-        lean_load<KIND, 0 * 64 * RB>(q[0], p);
-        lean_load<KIND, 1 * 64 * RB>(q[1], p);
-        lean_load<KIND, 2 * 64 * RB>(q[2], p);
-        lean_load<KIND, 3 * 64 * RB>(q[3], p);
-    };
-    // any step, synchronously (compiler loads; no asm load may be in flight): lanes past the batch's end read nothing
-    auto fetch = [&](uint32_t b, Raw (&q)[NR]) {
+    // any step, synchronously (compiler loads): lanes past the batch's end read nothing
+    auto fetch_env = [&](uint32_t b, float (&x)[NR]) {
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             const uint32_t m = b + 64u * j + lane;
-            if constexpr (KIND == IN_IQ_F32) {
-                const float2 v = (m < A.n) ? ((const float2 *)A.in)[m] : make_float2(0.f, 0.f);
-                q[j].x = v.x;
-                q[j].y = v.y;
-            } else if constexpr (KIND == IN_I16_SQ) {
-                q[j] = (m < A.n) ? (int)((const int16_t *)A.in)[m] : 0;
-            } else {
-                q[j] = (m < A.n) ? ((const float *)A.in)[m] : 0.f;
-            }
+            x[j] = (m < A.n) ? envelope_at<KIND>(A.in, (size_t)m, A.i16_scale) : 0.f;
         }
     };
     float ssf = (float)ss0;
@@ -151,15 +194,27 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
         slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
     }
     float G = ssf * 0.00390625f;   // (masked first step: 2^-8 of the sum; whole steps: a bound taken from the samples, below)
+    float Bneed = 0.f;             // the largest B a superstep of whole steps has needed (or is expected to need)
     float b_acc = 0.f, dl_acc = 0.f;
     float tlo_dn = 0.f, tlo_up = 0.f, thi_dn = 0.f, thi_up = 0.f;
+    // deferred per-lane checks of the straight-line step forms (looked at when the superstep closes)
+    uint32_t amb_lo = 0xFFFFFFFFu, amb_hi = 0xFFFFFFFFu;   // min of (bits(x) - bits(band bottom)): inside the band iff <= its width
+    float lrun = 3.0e38f;                                  // min over rows of max(x[l], x[l + 8], x[l + 15]) at the lanes that start a 16-block
+    // LOW bookkeeping of the straight-line forms, made explicit (w_nl, w_kl) only when the general step or the summary needs it
+    unsigned long long lzm[NR] = {0, 0, 0, 0};   // LOW masks of the latest step that had LOW samples ...
+    uint32_t lz_base = 0;                        // ... and its base
+    bool lz_set = false, hot_since = false;      // such a step / any straight-line step since w_nl, w_kl were last explicit
+    const int ssl_min = (mx + 1 + (int)STEPN - 1) / (int)STEPN;   // steps without LOW samples after which no LOW sample is in reach of a HIGH one
+    int steps_since_low = ((w_kl & 1) && ((int)m_chunk - (w_kl >> 1)) <= mx + 1) ? 0 : ssl_min;
+    bool force_general = ((int)m_chunk - 1 - w_nl) > 0;   // the chunk starts inside a LOW run: its first step checks the carried length
+    int pk = 0;   // the superstep's plane words: lanes 16 k .. 16 k + 7 the neg plane of step k (dwords), + 8 .. + 15 the pos plane
 
     // thresholds of a superstep from the tracked sum and the allowance; false: the banded test cannot serve
     auto open_superstep = [&]() -> bool {
         if (steps_since_sync >= 256) {   // bound the rounding the f32 sum accumulates: re-derive it from the ring
             double part = 0;
 #pragma unroll 8
-            for (int s2 = lane; s2 < L; s2 += 64) part += (double)(SIGN_T ? fabsf(ring[s2]) : ring[s2]);
+            for (int s2 = lane; s2 < L; s2 += 64) part += (double)fabsf(ring[s2]);
             ssf = (float)rfl(wave_sum_f64(part) + cr.delta);
             steps_since_sync = 0;
         }
@@ -172,61 +227,89 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
         if (!(ssf > 1e-30f && ssf < 1e30f && M < 0.25f * ssf && tlo_dn > 1e-30f && thi_up < 1e30f)) { why = 1u; return false; }
         min_ss = fminf(min_ss, ssf * (etaD - RND_SUM));
         vmax = max(vmax, __float_as_uint(up));   // every window sum of the superstep lies below ssf + M
+        vmin = min(vmin, __float_as_uint(tlo_dn));   // what the straight-line forms accept lies inside [tlo_dn, thi_up]
         return true;
     };
-    // was the allowance enough for what the lanes accumulated?  then the sum moves on and the next allowance is set
-    // (the next allowance is what this superstep needed PER ACCEPTED SAMPLE, for a superstep of accepted samples only:
-    // inside a frame a third or a half of the samples are rejected, and the first idle superstep after it is not)
-    uint32_t nrej = 0;   // rejected samples of the superstep
-    auto close_superstep = [&](int kdone, int knext) -> bool {
+    // was the allowance enough for what the lanes accumulated, did no sample sit inside a band, can no LOW run have reached
+    // max_len?  then the sum moves on and the next allowance is set
+    auto close_superstep = [&](bool whole) -> bool {
         const float B = wave_sum_f32(b_acc) * 1.001f;
         const float D = wave_sum_f32(dl_acc);
         b_acc = 0.f;
         dl_acc = 0.f;
         if (!(B <= G)) { why = 4u; return false; }
+        const uint32_t wlo = __float_as_uint(tlo_up) - __float_as_uint(tlo_dn), whi = __float_as_uint(thi_up) - __float_as_uint(thi_dn);
+        const unsigned long long inband = __ballot(amb_lo <= wlo || amb_hi <= whi);
+        const unsigned long long longlow = __ballot(lrun <= tlo_up) & 0x0001000100010001ull;
+        amb_lo = 0xFFFFFFFFu;
+        amb_hi = 0xFFFFFFFFu;
+        lrun = 3.0e38f;
+        if (inband) { why = 2u; return false; }
+        if (longlow) { why = 3u; return false; }
         ssf = rfl(ssf + D);
-        const uint32_t nacc = (uint32_t)kdone * STEPN - nrej;
-        nrej = 0;
-        if (knext > 0 && nacc >= STEPN / 2) {   // (knext 0: a masked step says nothing about the noise level)
-            const float per = B / (float)nacc;
-            G = rfl(fminf(fmaxf(A.gfac * per * (float)((uint32_t)knext * STEPN), ssf * A.gfloor), ssf * 0.125f));
+        if (whole) {
+            Bneed = fmaxf(Bneed, B);
+            G = rfl(fminf(fmaxf(A.gfac * Bneed, ssf * A.gfloor), ssf * 0.125f));
         }
         return true;
     };
-    // one step of NR rows.  MASKED: lanes outside [m_start, n1) are not samples (the stream's first stable sample, the
-    // batch's ragged end): at most two steps of a chunk, kept out of the hot loop's register allocation.
-    auto step = [&](auto masked_tag, Raw (&rq)[NR]) -> bool {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        float x[NR], prev[NR];
-        uint32_t slot[NR];
-        if constexpr (!MASKED) lean_wait<(PF - 1) * NR>(rq);   // this step's samples have landed (the loads of the PF - 1 steps after it may be in flight)
+    // w_nl / w_kl (last non-LOW index, key of the last LOW sample) as of the step that starts at `base`, from what the
+    // straight-line steps left behind
+    auto materialize = [&]() -> bool {
+        if (lz_set) {
+            int ll = LL_NONE;
 #pragma unroll
-        for (int j = 0; j < NR; j++) x[j] = lean_env<KIND>(rq[j], A.i16_scale);
-        if constexpr (!MASKED) {
-            // these registers now take the step PF later.  Unconditionally -- a branch around the loads would cost the loop its
-            // counted waits (the compiler then drains every load in flight at each use): past the chunk's last whole step the
-            // address is clamped to it and the values are never used
-            // the envelopes are taken BEFORE the registers are handed to the loads (an envelope computed later would make the
-            // compiler keep a copy of the raw sample -- taken before the wait above, i.e. of a register still being loaded)
-            asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-            fetch_whole(min(base + (uint32_t)PF * STEPN, last_whole), rq);
+            for (int j = 0; j < NR; j++) ll = lzm[j] ? (int)(lz_base + 64u * j) + last_set(lzm[j]) : ll;
+            w_kl = 2 * ll + 1;   // (a LOW sample of a straight-line step never ends on a time-out: its key is good)
+            chunk_kl = w_kl;
+            if (steps_since_low == 0) {   // that step was the latest one
+                int nl = LL_NONE;
+#pragma unroll
+                for (int j = 0; j < NR; j++) nl = (~lzm[j]) ? (int)(lz_base + 64u * j) + last_set(~lzm[j]) : nl;
+                if (nl == LL_NONE) { why = 3u; return false; }   // (256 LOW samples: the block test will have seen it)
+                w_nl = nl;
+                chunk_nl = nl;
+            }
         }
-        const bool nowrap = slot_step + STEPN <= (uint32_t)L;
-        if (nowrap) {
-            const float *rp = ring + slot_step + lane;
+        if (hot_since && (steps_since_low > 0 || !lz_set)) {   // the latest step had no LOW sample
+            w_nl = (int)base - 1;
+            chunk_nl = w_nl;
+        }
+        lz_set = false;
+        hot_since = false;
+        return true;
+    };
+    // plane words of a single step stored at once (masked steps, outside the superstep's collective store)
+    auto store_planes_now = [&](const unsigned long long (&lowm)[NR], const unsigned long long (&posm)[NR]) {
+        int q = 0;
 #pragma unroll
-            for (int j = 0; j < NR; j++) {
-                slot[j] = slot_step + 64u * j + lane;
-                prev[j] = SIGN_T ? fabsf(rp[64 * j]) : rp[64 * j];
-            }
-        } else {
+        for (int k = 0; k < NR; k++) {
+            PLANE_PUT(q, lowm[k], 2 * k);
+            PLANE_PUT(q, (lowm[k] >> 32), 2 * k + 1);
+            PLANE_PUT(q, posm[k], 2 * NR + 2 * k);
+            PLANE_PUT(q, (posm[k] >> 32), 2 * NR + 2 * k + 1);
+        }
+        const int h = lane & (2 * NR - 1);
+        const uint32_t w = (base >> 6) + (uint32_t)(h >> 1);
+        uint32_t *dst = (uint32_t *)(lane < 2 * NR ? neg_p : pos_p) + 2 * (size_t)(base >> 6) + h;
+        if (lane < 4 * NR && (size_t)w * 64 < A.n) *dst = (uint32_t)q;
+    };
+
+    // ---------------- the general step, on wave masks ----------------
+    // KS >= 0: step KS of a superstep of whole steps (plane words into pk); KS < 0: a masked step on its own -- lanes outside
+    // [m_start, n1) are not samples (the stream's first stable sample, the batch's ragged end).  x: the step's envelopes.
+    auto general_step = [&](auto ks_tag, float (&x)[NR]) -> bool {
+        constexpr int KS = decltype(ks_tag)::value;
+        constexpr bool MASKED = KS < 0;
+        if (!materialize()) return false;
+        float prev[NR];
+        uint32_t slot[NR];
 #pragma unroll
-            for (int j = 0; j < NR; j++) {
-                uint32_t s = slot_step + 64u * j + lane;
-                s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
-                slot[j] = s;
-                prev[j] = SIGN_T ? fabsf(ring[s]) : ring[s];
-            }
+        for (int j = 0; j < NR; j++) {
+            uint32_t s = slot_step + 64u * j + lane;
+            s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
+            slot[j] = s;
+            prev[j] = fabsf(ring[s]);
         }
         unsigned long long unt[NR], am[NR];
         if constexpr (MASKED) {
@@ -236,9 +319,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
             for (int j = 0; j < NR; j++) {
                 const uint32_t m = base + 64u * j + lane;
                 const bool inact = (m < m_start) || (m >= n1);
-                bool untouched;
-                if constexpr (SIGN_T) untouched = (__float_as_uint(ring[slot[j]]) >> 31) != 0u;
-                else untouched = tch[slot[j]] == 0;
+                const bool untouched = (__float_as_uint(ring[slot[j]]) >> 31) != 0u;
                 unt[j] = __ballot(inact && untouched);
                 am[j] = __ballot(!inact);
                 if (inact) x[j] = prev[j];
@@ -284,85 +365,40 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
             if (hit || ((carry_run > 0) && (carry_run + lead > mx))) { ok = false; why = 3u; }
             if (MASKED && base < m_start) { ok = false; why = 5u; }   // (a LOW run across the first stable sample: leave it to the exact kernel)
         }
-        if (__builtin_expect(!ok, 0)) return false;
-        const bool key_live = (w_kl & 1) && ((int)base - (w_kl >> 1)) <= mx + 1;
-        if (anyhi == 0) {
+        if (!ok) return false;
+        int before = (w_kl & 1) ? (w_kl >> 1) : LL_NONE;  // last LOW before the row (every key here is good)
 #pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const float t = x[j] - prev[j];
-                if (!(x[j] < tlo_dn)) {
-                    b_acc += fabsf(t);
-                    dl_acc += t;
-                    ring[slot[j]] = x[j];
-                    mark(slot[j]);
-                }
+        for (int j = 0; j < NR; j++) {
+            // HIGH is ignored within max_len + 1 samples after a LOW sample
+            const int rb = (int)(base + 64u * j);
+            const unsigned long long below = lowm[j] & lane_lt;
+            const int lastlow = below ? rb + last_set(below) : before;
+            const bool ps = (x[j] > thi_up) && ((rb + lane - lastlow) > mx + 1);
+            const bool a = !(x[j] < tlo_dn) && !ps;
+            const float t = x[j] - prev[j];
+            if (a) {
+                b_acc += fabsf(t);
+                dl_acc += t;
+                ring[slot[j]] = x[j];
             }
-            vmin = min(vmin, __float_as_uint(tlo_dn));
-        } else if (anylow == 0 && !key_live) {
-            // HIGH samples with no LOW sample within reach: all of them are rejected (transition_sink.py:71-74)
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const float t = x[j] - prev[j];
-                if (!(x[j] > thi_up)) {
-                    b_acc += fabsf(t);
-                    dl_acc += t;
-                    ring[slot[j]] = x[j];
-                    mark(slot[j]);
-                }
-            }
-            vmin = min(vmin, __float_as_uint(tlo_dn));
-        } else {
-            int before = (w_kl & 1) ? (w_kl >> 1) : LL_NONE;  // last LOW before the row (every key here is good)
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                // HIGH is ignored within max_len + 1 samples after a LOW sample
-                const int rb = (int)(base + 64u * j);
-                const unsigned long long below = lowm[j] & lane_lt;
-                const int lastlow = below ? rb + last_set(below) : before;
-                const bool ps = (x[j] > thi_up) && ((rb + lane - lastlow) > mx + 1);
-                const bool a = !(x[j] < tlo_dn) && !ps;
-                const float t = x[j] - prev[j];
-                if (a) {
-                    b_acc += fabsf(t);
-                    dl_acc += t;
-                    ring[slot[j]] = x[j];
-                    mark(slot[j]);
-                }
-                const uint32_t xb = __float_as_uint(x[j]);
-                vmin = min(vmin, (a && xb != 0u) ? xb : 0xFFFFFFFFu);
-                vmax = max(vmax, a ? xb : 0u);
-                posm[j] = __ballot(ps);
-                if constexpr (MASKED) posm[j] &= am[j];
-                before = lowm[j] ? rb + last_set(lowm[j]) : before;
-            }
+            const uint32_t xb = __float_as_uint(x[j]);
+            vmin = min(vmin, (a && xb != 0u) ? xb : 0xFFFFFFFFu);
+            vmax = max(vmax, a ? xb : 0u);
+            posm[j] = __ballot(ps);
+            if constexpr (MASKED) posm[j] &= am[j];
+            before = lowm[j] ? rb + last_set(lowm[j]) : before;
         }
-        int step_nl = (int)(base + STEPN) - 1, step_ll = LL_NONE;   // nothing LOW: the last sample is the last non-LOW
-        if constexpr (MASKED) {
-            step_nl = LL_NONE;
+        int step_nl = LL_NONE, step_ll = LL_NONE;
 #pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const int rb = (int)(base + 64u * j);
-                const unsigned long long nonlow = ~lowm[j] & am[j];
-                step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
-                step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
-                if ((unt[j] >> lane) & 1ull) {
-                    if constexpr (SIGN_T) ring[slot[j]] = __uint_as_float(__float_as_uint(x[j]) | 0x80000000u);
-                    else tch[slot[j]] = 0;
-                }
+        for (int j = 0; j < NR; j++) {
+            const int rb = (int)(base + 64u * j);
+            unsigned long long nonlow = ~lowm[j];
+            if constexpr (MASKED) {
+                nonlow &= am[j];
+                if ((unt[j] >> lane) & 1ull) ring[slot[j]] = __uint_as_float(__float_as_uint(x[j]) | 0x80000000u);
             }
-        } else if (anylow) {
-            step_nl = LL_NONE;
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const int rb = (int)(base + 64u * j);
-                const unsigned long long nonlow = ~lowm[j];
-                step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
-                step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
-            }
-        }
-        if (anylow | anyhi) {
-#pragma unroll
-            for (int j = 0; j < NR; j++) nrej += (uint32_t)__popcll(lowm[j]) + (uint32_t)__popcll(posm[j]);
+            step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
+            step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
         }
         if (step_ll != LL_NONE) {
             w_kl = 2 * step_ll + 1;
@@ -372,100 +408,218 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
             w_nl = step_nl;
             chunk_nl = step_nl;
         }
-        {   // the step's NR words per plane (see k_threshold): only non-zero masks cost their v_writelane
-            int pk = 0;
-            if (anylow) {
+        steps_since_low = anylow ? 0 : steps_since_low + 1;
+        if constexpr (MASKED) {
+            store_planes_now(lowm, posm);
+        } else {
 #pragma unroll
-                for (int k = 0; k < NR; k++) {
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)lowm[k]), "n"(2 * k));
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)(lowm[k] >> 32)), "n"(2 * k + 1));
+            for (int k = 0; k < NR; k++) {
+                PLANE_PUT(pk, lowm[k], 16 * KS + 2 * k);
+                PLANE_PUT(pk, (lowm[k] >> 32), 16 * KS + 2 * k + 1);
+                PLANE_PUT(pk, posm[k], 16 * KS + 8 + 2 * k);
+                PLANE_PUT(pk, (posm[k] >> 32), 16 * KS + 8 + 2 * k + 1);
+            }
+        }
+        return true;
+    };
+
+    // ---------------- step KS of a superstep of whole steps ----------------
+    auto step = [&](auto ks_tag) -> bool {
+        constexpr int KS = decltype(ks_tag)::value;
+        float x[NR];
+        // this step's samples have landed (the loads of the PF - 1 steps after it may be in flight) ...
+        lean_take<KIND, KS, (PF - 1) * NR>(x, A.i16_scale);
+        // ... and its registers take the step PF later.  Unconditionally -- a branch around the loads would not be worth its
+        // scalar instructions: past the chunk's last whole step the address is clamped to it and the values are never used.
+        lean_load_step<KIND, KS>(in_lane + (size_t)min(base + (uint32_t)PF * STEPN, last_whole) * RB);
+
+        // can anything be LOW / HIGH (or inside those bands) at all?
+        const float xmin = fminf(fminf(x[0], x[1]), fminf(x[2], x[3])), xmax = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+        const bool lowp = __ballot(!(xmin > tlo_up)) != 0ull;
+        const bool highp = __ballot(!(xmax < thi_dn)) != 0ull;
+        bool ok = true;
+        if (__builtin_expect((lowp && highp) || force_general || (highp && steps_since_low < ssl_min), 0)) {
+            force_general = false;
+            ok = general_step(ks_tag, x);
+        } else {
+            // straight-line forms: ring addresses (a step wraps the ring once in L / 256 steps)
+            lean_lds_f *pa[NR];
+            {
+                const uint32_t s0 = slot_step + (uint32_t)lane;
+                if (slot_step + STEPN <= (uint32_t)L) {
+#pragma unroll
+                    for (int j = 0; j < NR; j++) pa[j] = rl + s0 + 64u * j;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
+                        const uint32_t s = s0 + 64u * j;
+                        pa[j] = rl + min(s, s - (uint32_t)L);
+                    }
                 }
             }
-            if (anyhi) {
+            float praw[NR];
 #pragma unroll
-                for (int k = 0; k < NR; k++) {
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)posm[k]), "n"(2 * NR + 2 * k));
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)(posm[k] >> 32)), "n"(2 * NR + 2 * k + 1));
+            for (int j = 0; j < NR; j++) praw[j] = *pa[j];
+            if (!lowp && !highp) {
+                // nothing classifies: every sample is accepted
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const float t = x[j] - fabsf(praw[j]);
+                    b_acc += fabsf(t);
+                    dl_acc += t;
+                    *pa[j] = x[j];
                 }
+                steps_since_low++;
+            } else if (lowp) {
+                // LOW samples only: rejected ones keep their slot (value and sign bit)
+                unsigned long long lw[NR];
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const bool lo = x[j] < tlo_dn;
+                    lw[j] = __ballot(lo);
+                    const float t = x[j] - fabsf(praw[j]);
+                    const float ts = lo ? 0.f : t;
+                    b_acc += fabsf(ts);
+                    dl_acc += ts;
+                    *pa[j] = lo ? praw[j] : x[j];
+                }
+                // a sample inside the LOW band?  (looked at when the superstep closes)
+                amb_lo = min(min(amb_lo, __float_as_uint(x[0]) - __float_as_uint(tlo_dn)),
+                             min(__float_as_uint(x[1]) - __float_as_uint(tlo_dn), __float_as_uint(x[2]) - __float_as_uint(tlo_dn)));
+                amb_lo = min(amb_lo, __float_as_uint(x[3]) - __float_as_uint(tlo_dn));
+                // a LOW run longer than max_len covers an aligned block of b samples (b = A.blk)
+                if (A.blk == 16) {
+                    // ... whose first, middle and last sample are then LOW: per 16-lane row of the wave, in the lanes
+#pragma unroll
+                    for (int j = 0; j < NR; j++) lrun = fminf(lrun, fmaxf(fmaxf(x[j], lean_dpp_shl8(x[j])), lean_dpp_shl15(x[j])));
+                } else if (A.blk == 64) {
+                    if ((lw[0] == ~0ull) || (lw[1] == ~0ull) || (lw[2] == ~0ull) || (lw[3] == ~0ull)) { ok = false; why = 3u; }
+                } else {
+                    unsigned long long hit = 0;
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
+                        unsigned long long t = lw[j];
+#pragma unroll
+                        for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
+                        hit |= t & A.selmask;
+                    }
+                    if (hit) { ok = false; why = 3u; }
+                }
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    lzm[j] = lw[j];
+                    PLANE_PUT(pk, lw[j], 16 * KS + 2 * j);
+                    PLANE_PUT(pk, (lw[j] >> 32), 16 * KS + 2 * j + 1);
+                }
+                lz_base = base;
+                lz_set = true;
+                steps_since_low = 0;
+            } else {
+                // HIGH samples only, no LOW sample in reach: all of them are rejected (transition_sink.py:71-74)
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const bool hi = x[j] > thi_up;
+                    const unsigned long long hw = __ballot(hi);
+                    const float t = x[j] - fabsf(praw[j]);
+                    const float ts = hi ? 0.f : t;
+                    b_acc += fabsf(ts);
+                    dl_acc += ts;
+                    *pa[j] = hi ? praw[j] : x[j];
+                    PLANE_PUT(pk, hw, 16 * KS + 8 + 2 * j);
+                    PLANE_PUT(pk, (hw >> 32), 16 * KS + 8 + 2 * j + 1);
+                }
+                amb_hi = min(min(amb_hi, __float_as_uint(x[0]) - __float_as_uint(thi_dn)),
+                             min(__float_as_uint(x[1]) - __float_as_uint(thi_dn), __float_as_uint(x[2]) - __float_as_uint(thi_dn)));
+                amb_hi = min(amb_hi, __float_as_uint(x[3]) - __float_as_uint(thi_dn));
+                steps_since_low++;
             }
-            const int h = lane & (2 * NR - 1);
-            const uint32_t w = (base >> 6) + (uint32_t)(h >> 1);
-            uint32_t *dst = (uint32_t *)(lane < 2 * NR ? neg_p : pos_p) + 2 * (size_t)(base >> 6) + h;
-            if (lane < 4 * NR && (size_t)w * 64 < A.n) *dst = (uint32_t)pk;
+            hot_since = true;
         }
         slot_step += STEPN;
         slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
         steps_since_sync++;
         base += STEPN;
-        return true;
+        return ok;
     };
-    using MaskedT = std::integral_constant<bool, true>;
-    using WholeT = std::integral_constant<bool, false>;
-
-    // (1) the step that holds the stream's first stable sample (chunk 0 of its first batches), a superstep of its own
-    if (good_run && base < n1 && base < m_start) {
-        fetch(base, r[0]);
-        good_run = open_superstep() && step(MaskedT{}, r[0]) && close_superstep(1, 0);
-    }
-    // (2) whole steps, PF to a superstep; step k of a superstep lives in r[k]
-    if (good_run && base + STEPN <= n1) {
-        last_whole = base + (n1 - base - STEPN) / STEPN * STEPN;
-#pragma unroll
-        for (int k = 0; k < PF; k++) fetch_whole(min(base + (uint32_t)k * STEPN, last_whole), r[k]);
-#pragma unroll
-        for (int k = 0; k < PF; k++) lean_wait<0>(r[k]);   // (the first allowance reads them all)
-        {   // first allowance: sum |x - prev| over the samples of the first superstep that look acceptable (a guess like any
-            // other allowance: the superstep's own B decides)
-            const float wlo = ssf * loLf * 0.5f, whi = ssf * hiLf * 1.02f;
-            float b0 = 0.f;
-            uint32_t sl = slot_step;
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                if (base + (uint32_t)(k + 1) * STEPN <= n1) {
-#pragma unroll
-                    for (int j = 0; j < NR; j++) {
-                        const float xv = lean_env<KIND>(r[k][j], A.i16_scale);
-                        uint32_t q = sl + 64u * j + lane;
-                        q = (q >= (uint32_t)L) ? q - (uint32_t)L : q;
-                        const float pv = SIGN_T ? fabsf(ring[q]) : ring[q];
-                        b0 += (xv > wlo && xv < whi) ? fabsf(xv - pv) : 0.f;
-                    }
-                    sl += STEPN;
-                    sl = (sl >= (uint32_t)L) ? sl - (uint32_t)L : sl;
-                }
-            }
-            G = rfl(fminf(fmaxf(A.gfac * wave_sum_f32(b0), ssf * A.gfloor), ssf * 0.125f));
-        }
-    }
-    while (good_run && base + (uint32_t)PF * STEPN <= n1) {
-        if (!open_superstep()) { good_run = false; break; }
-        bool okk = true;
-#pragma unroll
-        for (int k = 0; k < PF; k++) okk = okk && step(WholeT{}, r[k]);
-        if (!okk || !close_superstep(PF, PF)) { good_run = false; break; }
-    }
-#pragma unroll
-    for (int k = 0; k < PF; k++) lean_wait<0>(r[k]);   // nothing of the loop's may still be landing in registers the code below reuses
-    // (2b) fewer than PF whole steps left (chunk lengths are cut to multiples of PF steps: only a batch's last chunk has
-    // them): one at a time, each loading its own samples
-    while (good_run && base + STEPN <= n1) {
-        fetch(base, r[0]);
-        G = rfl(fminf(fmaxf(G, ssf * A.gfloor), ssf * 0.125f));
-        if (!(open_superstep() && step(MaskedT{}, r[0]) && close_superstep(1, 0))) { good_run = false; break; }
-    }
-    // (3) the batch's ragged end
-    if (good_run && base < n1) {
-        fetch(base, r[0]);
+    // a masked step as a superstep of its own: synchronous loads, general form, plane words stored at once
+    auto masked_superstep = [&]() -> bool {
+        float x[NR];
+        fetch_env(base, x);
         G = rfl(fminf(fmaxf(G, ssf * 0.00390625f), ssf * 0.125f));
-        good_run = open_superstep() && step(MaskedT{}, r[0]) && close_superstep(1, 0);
+        if (!open_superstep()) return false;
+        if (!general_step(std::integral_constant<int, -1>{}, x)) return false;
+        slot_step += STEPN;
+        slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
+        steps_since_sync++;
+        base += STEPN;
+        return close_superstep(false);
+    };
+
+    // (1) the step that holds the stream's first stable sample (chunk 0 of its first batches)
+    if (good_run && base < n1 && base < m_start) good_run = masked_superstep();
+    // (2) whole steps, PF to a superstep; step k of a superstep lives in the accumulator registers a[8 k ..]
+    if (good_run && base + (uint32_t)PF * STEPN <= n1) {
+        last_whole = base + (n1 - base - STEPN) / STEPN * STEPN;
+        lean_load_step<KIND, 0>(in_lane + (size_t)base * RB);
+        lean_load_step<KIND, 1>(in_lane + (size_t)(base + STEPN) * RB);
+        if constexpr (PF > 2) lean_load_step<KIND, 2>(in_lane + (size_t)(base + 2 * STEPN) * RB);
+        if constexpr (PF > 3) lean_load_step<KIND, 3>(in_lane + (size_t)(base + 3 * STEPN) * RB);
+        // first allowance: sum |x - prev| over the samples of the first superstep that look acceptable, per such sample, for a
+        // superstep of acceptable samples only (a guess like any other allowance: the superstep's own B decides)
+        {
+            const float wlo = ssf * loLf * 0.5f, whi = ssf * hiLf * 1.02f;
+            float b0 = 0.f, n0 = 0.f;
+            uint32_t sl = slot_step;
+            auto look = [&](auto kt) {
+                float xv[NR];
+                lean_take<KIND, decltype(kt)::value, 0>(xv, A.i16_scale);   // (reading leaves the registers as they are: the loop takes them again)
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    uint32_t q = sl + 64u * j + lane;
+                    q = (q >= (uint32_t)L) ? q - (uint32_t)L : q;
+                    const bool in = xv[j] > wlo && xv[j] < whi;
+                    b0 += in ? fabsf(xv[j] - fabsf(ring[q])) : 0.f;
+                    n0 += in ? 1.f : 0.f;
+                }
+                sl += STEPN;
+                sl = (sl >= (uint32_t)L) ? sl - (uint32_t)L : sl;
+            };
+            look(std::integral_constant<int, 0>{});
+            look(std::integral_constant<int, 1>{});
+            if constexpr (PF > 2) look(std::integral_constant<int, 2>{});
+            if constexpr (PF > 3) look(std::integral_constant<int, 3>{});
+            b0 = wave_sum_f32(b0);
+            n0 = wave_sum_f32(n0);
+            Bneed = (n0 >= 64.f) ? b0 / n0 * (float)(PF * STEPN) : ssf * 0.001953125f * (float)PF;
+            G = rfl(fminf(fmaxf(A.gfac * Bneed, ssf * A.gfloor), ssf * 0.125f));
+        }
+        // this lane's dword of the superstep's plane store: lane 16 k + i -> step k, i < 8 the neg plane (dword i), else pos
+        uint32_t *pl_ptr = (uint32_t *)((lane & 8) ? pos_p : neg_p) + 2 * (size_t)(base >> 6) + 8 * (size_t)(lane >> 4) + (lane & 7);
+        while (good_run && base + (uint32_t)PF * STEPN <= n1) {
+            if (!open_superstep()) { good_run = false; break; }
+            pk = 0;
+            bool okk = step(std::integral_constant<int, 0>{});
+            okk = okk && step(std::integral_constant<int, 1>{});
+            if constexpr (PF > 2) okk = okk && step(std::integral_constant<int, 2>{});
+            if constexpr (PF > 3) okk = okk && step(std::integral_constant<int, 3>{});
+            if (!okk || !close_superstep(true)) { good_run = false; break; }
+            if (lane < 16 * PF) *pl_ptr = (uint32_t)pk;
+            pl_ptr += 8 * PF;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the loop's is left in flight)
     }
+    // (3) fewer than PF whole steps left (chunk lengths are cut to multiples of PF steps: only a batch's last chunk has
+    // them), and the batch's ragged end: one at a time, each loading its own samples
+    while (good_run && base < n1) good_run = masked_superstep();
+    if (good_run) good_run = materialize();
+
     const uint32_t all_robust = good_run ? 1u : 0u;
     if (c == 0 && lane == 0) {   // chunk 0 has no certification of its own: its verdict travels here
         A.cert[0] = good_run ? 1 : 0;
         if (!good_run) atomicAdd(&A.sum->n_fail, 1u);
     }
-    chunk_publish<SIGN_T>(A, c, lane, ring, tch, emin, emax, vmin, vmax, ssf, eps, good_run ? 0u : (4u | (why << 4)), chunk_kl, chunk_nl, (double)ssf,
-                          min_ss, nl_in, kl_in, all_robust);
+    chunk_publish<true>(A, c, lane, ring, nullptr, emin, emax, vmin, vmax, ssf, eps, good_run ? 0u : (4u | (why << 4)), chunk_kl, chunk_nl,
+                        (double)ssf, min_ss, nl_in, kl_in, all_robust);
 }
 
 }  // namespace nfc
