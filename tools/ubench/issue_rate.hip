@@ -9,8 +9,9 @@
 #define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(float *out, int iters) {
+__global__ __launch_bounds__(256) void k(float *out, int iters, unsigned long long *clk) {
     extern __shared__ char smem[];
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     float a0 = threadIdx.x, a1 = 1.f, a2 = 2.f, a3 = 3.f;
     unsigned long long m0 = 1, m1 = 2, m2 = 3, m3 = 4;
     int s0 = 1, s1 = 2, s2 = 3, s3 = 4;
@@ -41,12 +42,18 @@ __global__ __launch_bounds__(256) void k(float *out, int iters) {
         }
     }
     if (a0 + a1 + a2 + a3 + (float)(s0 + s1 + s2 + s3) + (float)(m0 + m1 + m2 + m3) == 12345.f) out[0] = a0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = clock64() - c0;
+        clk[1] = wall_clock64() - w0;
+    }
 }
 
 template <int MODE>
 void run(const char *name, int per_iter, int waves_per_simd) {
     float *d;
     hipMalloc(&d, 4);
+    unsigned long long *dc, hc[2];
+    hipMalloc(&dc, 16);
     const int iters = 2000;
     const size_t lds = 160 * 1024 / waves_per_simd - 512;   // one 256-thread block = 1 wave per SIMD; LDS limits blocks per CU
     hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -54,17 +61,19 @@ void run(const char *name, int per_iter, int waves_per_simd) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int blocks = 256 * waves_per_simd;
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), lds, 0, d, iters);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), lds, 0, d, iters, dc);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), lds, 0, d, iters);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), lds, 0, d, iters, dc);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    const double cyc = ms * 1e-3 * 2.4e9;
+    hipMemcpy(hc, dc, 16, hipMemcpyDeviceToHost);
+    const double ghz = (double)hc[0] / ((double)hc[1] * 10.0);   // wall_clock64 ticks at 100 MHz
+    const double cyc = ms * 1e-3 * ghz * 1e9;
     const double inst_per_simd = (double)iters * per_iter * waves_per_simd;
-    printf("%-44s waves/SIMD %d: %.3f ms, %.2f cycles per instruction per SIMD (at 2.4 GHz)\n", name, waves_per_simd, ms, cyc / inst_per_simd);
+    printf("%-44s waves/SIMD %d: %.3f ms, %.2f cycles per instruction per SIMD (shader clock %.2f GHz by s_memtime / s_memrealtime)\n", name, waves_per_simd, ms, cyc / inst_per_simd, ghz);
 }
 
 int main() {

@@ -123,7 +123,7 @@ struct nfc_ctx {
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
-    int lean = 1, lean_k = 3;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
+    int lean = 1, lean_k = 3, lean_rounds = 1;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
     int gring_ok = 0, gring_force = 0, wave_slots_g = 0;   // long windows qualify (NFC_RING=lds|global overrides the choice)
@@ -527,11 +527,45 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
         const bool lean = c->lean && !c->gring && nch > 1 && c->P.input_kind != NFC_IN_ENV_F32;   // (raw envelopes may be negative: no sign bit to spare)
         A.cert = d_cert;
         A.sum = (CertSummary *)(dT(c) + TOT_CERT);
-        A.ksteps = c->lean_k;
+        A.ksteps = c->lean_rounds;
         A.gfac = c->lean_gfac;
         A.gfloor = c->lean_gmin;
         A.blk = 1 << c->nfold;
+        const bool dbg_clk = lean && getenv("NFC_DEBUG_CLK") != nullptr;
+        if (dbg_clk) {
+            HIPCHK(c, c->d_certinfo.ensure((size_t)nch * 32));
+            A.dbg_clk = c->d_certinfo.as<unsigned long long>();
+        }
         launch_threshold_kind(c, A, nch, lean);
+        if (dbg_clk) {
+            std::vector<unsigned long long> h((size_t)nch * 4);
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            HIPCHK(c, hipMemcpy(h.data(), c->d_certinfo.p, (size_t)nch * 32, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            double pro = 0, loop = 0, epi = 0, maxtot = 0, maxstart = 0;
+            for (uint32_t k = 0; k < nch; k++) {
+                t0 = std::min(t0, h[4 * k]);
+                t1 = std::max(t1, h[4 * k + 3]);
+            }
+            for (uint32_t k = 0; k < nch; k++) {
+                pro += (double)(h[4 * k + 1] - h[4 * k]);
+                loop += (double)(h[4 * k + 2] - h[4 * k + 1]);
+                epi += (double)(h[4 * k + 3] - h[4 * k + 2]);
+                maxtot = std::max(maxtot, (double)(h[4 * k + 3] - h[4 * k]));
+                maxstart = std::max(maxstart, (double)(h[4 * k] - t0));
+            }
+            fprintf(stderr, "[nfc] lean kernel, %u chunks, s_memtime ticks: first start .. last end %llu; per wave: incoming state %.0f, loop %.0f, "
+                    "summary %.0f, longest wave %.0f, latest start %.0f\n", nch, t1 - t0, pro / nch, loop / nch, epi / nch, maxtot, maxstart);
+            if (const char *path = getenv("NFC_DEBUG_CLK")) {
+                if (path[0] == '/' || path[0] == '.' || path[0] == 'g') {   // a file name: the raw stamps, for tools/clk_hist.py
+                    if (FILE *f = fopen(path, "wb")) {
+                        fwrite(h.data(), 8, h.size(), f);
+                        fclose(f);
+                    }
+                }
+            }
+            A.dbg_clk = nullptr;
+        }
         c->stats.threshold_passes++;
         passes++;
 
@@ -1221,6 +1255,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     c->use_small = getenv("NFC_NO_SMALL") ? 0 : 1;
     if (const char *e = getenv("NFC_LEAN")) c->lean = atoi(e) != 0;
     if (const char *e = getenv("NFC_LEAN_K")) c->lean_k = std::min(4, std::max(2, atoi(e)));   // (one step ahead does not survive the compiler: tools/audit_lean_isa.py)
+    if (const char *e = getenv("NFC_LEAN_ROUNDS")) c->lean_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("NFC_LEAN_GFAC")) c->lean_gfac = (float)atof(e);
     if (const char *e = getenv("NFC_LEAN_GMIN")) c->lean_gmin = (float)atof(e);
     if (const char *e = getenv("NFC_OWN_PREFIX_MAX")) c->own_prefix_max = (uint32_t)strtoul(e, nullptr, 10);

@@ -130,6 +130,7 @@ struct ThrArgs {
     int32_t ksteps;        // steps per superstep
     float gfac, gfloor;    // drift allowance = max(gfac * (largest B needed so far), gfloor * ss)
     int32_t blk;           // a LOW run longer than max_len covers an aligned block of blk samples (a power of two)
+    unsigned long long *dbg_clk;   // debugging aid (NFC_DEBUG_CLK): per chunk four s_memtime stamps -- start, incoming state ready, loop done, end
 };
 
 // ---------------------------------------------------------------------------
@@ -205,6 +206,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // must not be read by a vector instruction within the next two issue slots, and inside an asm statement nobody pads that
 // (measured: the low half of a fresh mask arrived as the previous row's).
 #define PLANE_PUT(pk, dword_of_mask, LANE) asm volatile("s_nop 2\n\tv_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)(dword_of_mask)), "n"(LANE))
+// the eight dwords of four masks into lanes LANE0 .. LANE0 + 7 of pk, behind one pad
+#define PLANE_PUT8(pk, m, LANE0)                                                                                                             \
+    asm volatile("s_nop 2\n\tv_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %9+1\n\tv_writelane_b32 %0, %3, %9+2\n\tv_writelane_b32 %0, %4, %9+3" \
+                 "\n\tv_writelane_b32 %0, %5, %9+4\n\tv_writelane_b32 %0, %6, %9+5\n\tv_writelane_b32 %0, %7, %9+6\n\tv_writelane_b32 %0, %8, %9+7"       \
+                 : "+v"(pk)                                                                                                                  \
+                 : "s"((uint32_t)(m)[0]), "s"((uint32_t)((m)[0] >> 32)), "s"((uint32_t)(m)[1]), "s"((uint32_t)((m)[1] >> 32)),               \
+                   "s"((uint32_t)(m)[2]), "s"((uint32_t)((m)[2] >> 32)), "s"((uint32_t)(m)[3]), "s"((uint32_t)((m)[3] >> 32)), "n"(LANE0))
 __device__ __forceinline__ int last_set(unsigned long long m) { return 63 - __clzll((long long)m); }  // m != 0
 
 // Envelope of one sample (gnuradio complex_to_mag_squared; compiled with

@@ -149,19 +149,29 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     const uint32_t m_start = max(m_chunk, A.skip);
     const Carry cr = *A.carry;
     uint64_t *const neg_p = A.neg, *const pos_p = A.pos;   // (by value: a per-lane choice between two kernel-argument FIELDS would be a vector load)
+    const int blk = A.blk;                  // (kernel arguments the loop reads go to registers once: a scalar load in the loop stalls its wave)
+    const float i16s = A.i16_scale;
+    const float gfac = A.gfac, gfloor = A.gfloor;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
 
+    unsigned long long clk0 = 0, clk1 = 0, clk2 = 0;
+    if (A.dbg_clk) clk0 = clock64();
     uint32_t emin = 255u, emax = 0u;
     int w_nl, w_kl;
-    double ss0;
+    float ssf;
     float eps = 0.f;
+    // (measured: a form of this prologue that keeps the whole window in registers -- one pass instead of seven over LDS, at
+    // 100 instead of 96 registers -- was 4 % SLOWER on the kernel: all waves run it at once, behind the same burst of loads)
+    double ss0;
     chunk_incoming<KIND>(A, c, lane, ring, cr, m_chunk, ss0, w_nl, w_kl, eps);
-    ss0 = rfl(ss0);
+    ssf = (float)ss0;
+    const uint32_t vtop0 = chunk_save_in<true>(A, c, lane, ring, nullptr, emin, emax);
+    ssf = rfl(ssf);
     w_nl = rfl(w_nl);
     w_kl = rfl(w_kl);
     const int nl_in = w_nl, kl_in = w_kl;
-    const uint32_t vtop0 = chunk_save_in<true>(A, c, lane, ring, nullptr, emin, emax);
 
+    if (A.dbg_clk) clk1 = clock64();
     bool good_run = A.fast_ok != 0;   // false: the wave gave up
     uint32_t why = good_run ? 0u : 1u;   // (debugging aid: 1 parameters / sums out of range, 2 a sample inside a band, 3 LOW run, 4 allowance, 5 first stable sample)
     float min_ss = 3.0e38f;
@@ -181,7 +191,6 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
             x[j] = (m < A.n) ? envelope_at<KIND>(A.in, (size_t)m, A.i16_scale) : 0.f;
         }
     };
-    float ssf = (float)ss0;
     int steps_since_sync = 0;
     uint32_t last_whole = 0;   // base of the chunk's last whole step
     // steps wholly inside the fill stretch (chunk 0 of a stream's first batches) classify nothing
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
         ssf = rfl(ssf + D);
         if (whole) {
             Bneed = fmaxf(Bneed, B);
-            G = rfl(fminf(fmaxf(A.gfac * Bneed, ssf * A.gfloor), ssf * 0.125f));
+            G = rfl(fminf(fmaxf(gfac * Bneed, ssf * gfloor), ssf * 0.125f));
         }
         return true;
     };
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
         constexpr int KS = decltype(ks_tag)::value;
         float x[NR];
         // this step's samples have landed (the loads of the PF - 1 steps after it may be in flight) ...
-        lean_take<KIND, KS, (PF - 1) * NR>(x, A.i16_scale);
+        lean_take<KIND, KS, (PF - 1) * NR>(x, i16s);
         // ... and its registers take the step PF later.  Unconditionally -- a branch around the loads would not be worth its
         // scalar instructions: past the chunk's last whole step the address is clamped to it and the values are never used.
         lean_load_step<KIND, KS>(in_lane + (size_t)min(base + (uint32_t)PF * STEPN, last_whole) * RB);
@@ -477,22 +486,22 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
                 for (int j = 0; j < NR; j++) {
                     const bool lo = x[j] < tlo_dn;
                     lw[j] = __ballot(lo);
-                    const float t = x[j] - fabsf(praw[j]);
-                    const float ts = lo ? 0.f : t;
+                    const float val = lo ? praw[j] : x[j];
+                    const float ts = fabsf(val) - fabsf(praw[j]);   // 0 for a rejected sample
                     b_acc += fabsf(ts);
                     dl_acc += ts;
-                    *pa[j] = lo ? praw[j] : x[j];
+                    *pa[j] = val;
                 }
                 // a sample inside the LOW band?  (looked at when the superstep closes)
                 amb_lo = min(min(amb_lo, __float_as_uint(x[0]) - __float_as_uint(tlo_dn)),
                              min(__float_as_uint(x[1]) - __float_as_uint(tlo_dn), __float_as_uint(x[2]) - __float_as_uint(tlo_dn)));
                 amb_lo = min(amb_lo, __float_as_uint(x[3]) - __float_as_uint(tlo_dn));
-                // a LOW run longer than max_len covers an aligned block of b samples (b = A.blk)
-                if (A.blk == 16) {
-                    // ... whose first, middle and last sample are then LOW: per 16-lane row of the wave, in the lanes
+                // a LOW run longer than max_len covers an aligned block of b samples (b = blk)
+                if (blk == 16) {
+                    // ... whose first and ninth sample are then LOW: per 16-lane row of the wave, in the lanes
 #pragma unroll
-                    for (int j = 0; j < NR; j++) lrun = fminf(lrun, fmaxf(fmaxf(x[j], lean_dpp_shl8(x[j])), lean_dpp_shl15(x[j])));
-                } else if (A.blk == 64) {
+                    for (int j = 0; j < NR; j++) lrun = fminf(lrun, fmaxf(x[j], lean_dpp_shl8(x[j])));
+                } else if (blk == 64) {
                     if ((lw[0] == ~0ull) || (lw[1] == ~0ull) || (lw[2] == ~0ull) || (lw[3] == ~0ull)) { ok = false; why = 3u; }
                 } else {
                     unsigned long long hit = 0;
@@ -506,28 +515,25 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
                     if (hit) { ok = false; why = 3u; }
                 }
 #pragma unroll
-                for (int j = 0; j < NR; j++) {
-                    lzm[j] = lw[j];
-                    PLANE_PUT(pk, lw[j], 16 * KS + 2 * j);
-                    PLANE_PUT(pk, (lw[j] >> 32), 16 * KS + 2 * j + 1);
-                }
+                for (int j = 0; j < NR; j++) lzm[j] = lw[j];
+                PLANE_PUT8(pk, lw, 16 * KS);
                 lz_base = base;
                 lz_set = true;
                 steps_since_low = 0;
             } else {
                 // HIGH samples only, no LOW sample in reach: all of them are rejected (transition_sink.py:71-74)
+                unsigned long long hw[NR];
 #pragma unroll
                 for (int j = 0; j < NR; j++) {
                     const bool hi = x[j] > thi_up;
-                    const unsigned long long hw = __ballot(hi);
-                    const float t = x[j] - fabsf(praw[j]);
-                    const float ts = hi ? 0.f : t;
+                    hw[j] = __ballot(hi);
+                    const float val = hi ? praw[j] : x[j];
+                    const float ts = fabsf(val) - fabsf(praw[j]);
                     b_acc += fabsf(ts);
                     dl_acc += ts;
-                    *pa[j] = hi ? praw[j] : x[j];
-                    PLANE_PUT(pk, hw, 16 * KS + 8 + 2 * j);
-                    PLANE_PUT(pk, (hw >> 32), 16 * KS + 8 + 2 * j + 1);
+                    *pa[j] = val;
                 }
+                PLANE_PUT8(pk, hw, 16 * KS + 8);
                 amb_hi = min(min(amb_hi, __float_as_uint(x[0]) - __float_as_uint(thi_dn)),
                              min(__float_as_uint(x[1]) - __float_as_uint(thi_dn), __float_as_uint(x[2]) - __float_as_uint(thi_dn)));
                 amb_hi = min(amb_hi, __float_as_uint(x[3]) - __float_as_uint(thi_dn));
@@ -590,21 +596,29 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
             if constexpr (PF > 3) look(std::integral_constant<int, 3>{});
             b0 = wave_sum_f32(b0);
             n0 = wave_sum_f32(n0);
-            Bneed = (n0 >= 64.f) ? b0 / n0 * (float)(PF * STEPN) : ssf * 0.001953125f * (float)PF;
-            G = rfl(fminf(fmaxf(A.gfac * Bneed, ssf * A.gfloor), ssf * 0.125f));
+            Bneed = ((n0 >= 64.f) ? b0 / n0 * (float)(PF * STEPN) : ssf * 0.001953125f * (float)PF) * (float)max(1, A.ksteps);
+            G = rfl(fminf(fmaxf(gfac * Bneed, ssf * gfloor), ssf * 0.125f));
         }
         // this lane's dword of the superstep's plane store: lane 16 k + i -> step k, i < 8 the neg plane (dword i), else pos
         uint32_t *pl_ptr = (uint32_t *)((lane & 8) ? pos_p : neg_p) + 2 * (size_t)(base >> 6) + 8 * (size_t)(lane >> 4) + (lane & 7);
+        // a superstep is `rounds` trips through the PF unrolled steps (thresholds, reductions and checks once per superstep;
+        // the plane words leave once per trip)
+        const int rounds = max(1, A.ksteps);
         while (good_run && base + (uint32_t)PF * STEPN <= n1) {
             if (!open_superstep()) { good_run = false; break; }
-            pk = 0;
-            bool okk = step(std::integral_constant<int, 0>{});
-            okk = okk && step(std::integral_constant<int, 1>{});
-            if constexpr (PF > 2) okk = okk && step(std::integral_constant<int, 2>{});
-            if constexpr (PF > 3) okk = okk && step(std::integral_constant<int, 3>{});
+            bool okk = true;
+            for (int rd = 0; rd < rounds && okk && base + (uint32_t)PF * STEPN <= n1; rd++) {
+                pk = 0;
+                okk = step(std::integral_constant<int, 0>{});
+                okk = okk && step(std::integral_constant<int, 1>{});
+                if constexpr (PF > 2) okk = okk && step(std::integral_constant<int, 2>{});
+                if constexpr (PF > 3) okk = okk && step(std::integral_constant<int, 3>{});
+                if (okk) {
+                    if (lane < 16 * PF) *pl_ptr = (uint32_t)pk;
+                    pl_ptr += 8 * PF;
+                }
+            }
             if (!okk || !close_superstep(true)) { good_run = false; break; }
-            if (lane < 16 * PF) *pl_ptr = (uint32_t)pk;
-            pl_ptr += 8 * PF;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the loop's is left in flight)
     }
@@ -613,6 +627,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     while (good_run && base < n1) good_run = masked_superstep();
     if (good_run) good_run = materialize();
 
+    if (A.dbg_clk) clk2 = clock64();
     const uint32_t all_robust = good_run ? 1u : 0u;
     if (c == 0 && lane == 0) {   // chunk 0 has no certification of its own: its verdict travels here
         A.cert[0] = good_run ? 1 : 0;
@@ -620,6 +635,12 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     }
     chunk_publish<true>(A, c, lane, ring, nullptr, emin, emax, vmin, vmax, ssf, eps, good_run ? 0u : (4u | (why << 4)), chunk_kl, chunk_nl,
                         (double)ssf, min_ss, nl_in, kl_in, all_robust);
+    if (A.dbg_clk && lane == 0) {
+        A.dbg_clk[4 * (size_t)c + 0] = clk0;
+        A.dbg_clk[4 * (size_t)c + 1] = clk1;
+        A.dbg_clk[4 * (size_t)c + 2] = clk2;
+        A.dbg_clk[4 * (size_t)c + 3] = clock64();
+    }
 }
 
 }  // namespace nfc
