@@ -1,49 +1,81 @@
 #!/usr/bin/env python3
 """bench.py -- IQ Msamples/s -> decoded bits on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--samples S] [--workload miller|manchester|all]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--samples S] [--workload miller|manchester|all|classic1k]
 
-One "step" = one pass of the whole hot path (envelope -> threshold -> edges -> Miller/Manchester ->
-framing) over the rank's batch of synthetic IQ, input already resident in HBM.  At N=1 the workload is
-BASELINE.json configs[1]: Miller-only decode of 1e8 synthetic IQ samples @ 2 Msps.  For N>1 (launched by
-torch.distributed.run, one rank per GPU) every rank holds one contiguous time chunk of a single N*1e8-sample
-capture plus an overlap prefix; it decodes its chunk from a speculated boundary state, the true boundary
-states travel over RCCL (all_gather), and a rank whose speculation was wrong re-decodes (weak scaling).
+One "step" = one pass of the whole hot path (envelope -> threshold -> edges -> Miller/Manchester -> framing) over the
+rank's batch of synthetic IQ, input already resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: Miller-only
+decode of 1e8 synthetic IQ samples @ 2 Msps.
+
+N > 1: one process per GPU.  Launched by ``python -m torch.distributed.run ... bench.py --gpus N`` the ranks read RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; launched as plain ``python bench.py --gpus N`` this process spawns
+the N ranks itself (before anything touches HIP) and relays rank 0's line.  Every rank holds one contiguous time chunk of a
+single N x S-sample capture plus an overlap prefix; it decodes its chunk from a speculated boundary state, the boundary
+states travel in ONE ncclAllGather per round (RCCL over xGMI through ctypes: usrp_nfc_amd/comm.py -- no PyTorch anywhere in
+the path), and a rank whose speculation was wrong re-decodes (weak scaling; usrp_nfc_amd/sharding.py).
+NFC_BENCH_BACKEND=host carries the states over TCP instead (ranks that share one GPU: plumbing tests).
+
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from usrp_nfc_amd import api, synth  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-OVERLAP = 8192          # samples of the predecessor's chunk each rank > 0 also holds: the 2000-sample window plus twice the longest
-                        # ISO 14443A frame at 2 Msps (163 bits ~ 3.1 k samples); a wrong guess costs a re-decode, never exactness
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)   # 0.45 ms each: the device reaches its steady clocks within the first few dozen
+    ap.add_argument('--steps', type=int, default=100)   # 0.4 ms each: the device reaches its steady clocks within the first few dozen
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--samples', type=float, default=1e8, help='samples per GPU')
+    ap.add_argument('--samples', type=float, default=0, help='samples per GPU (default: 1e8; 1e9 for classic1k)')
     ap.add_argument('--workload', default='miller', choices=['miller', 'manchester', 'all', 'classic1k'],
                     help="BASELINE.json configs[1] / [2] / both decoders at 2 Msps, or configs[3] / [4]: the MIFARE Classic 1K "
-                         "transaction of outputs/1k_with_enc.out at 10 Msps (pass --samples 1e9)")
+                         "transaction of outputs/1k_with_enc.out at 10 Msps, 1e9 samples per GPU (a 1e8-sample capture tiled)")
     ap.add_argument('--chunk', type=int, default=0, help='time-chunk samples of the threshold kernel (0: library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the end-to-end figure and the other configurations')
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: spawn the ranks (nothing HIP-related is imported before this point)
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(a):
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write('bench: ranks failed: %s\n' % bad)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
 def decoder_flags(workload):
     return dict(reader=workload in ('miller', 'all', 'classic1k'), tag=workload in ('manchester', 'all', 'classic1k'))
 
@@ -57,26 +89,44 @@ def stream_params(workload):
     return dict(samp_rate=2e6, hi_val=1.1)
 
 
-def shard_overlap(workload):
-    return OVERLAP * 5 if workload == 'classic1k' else OVERLAP   # the same time span at 10 Msps
+WORKLOAD_NAMES = {'miller': 'configs[1]: Miller-only decode, synthetic IQ @2 Msps',
+                  'manchester': 'configs[2]: Manchester-only decode, synthetic IQ @2 Msps',
+                  'all': 'both decoders (-t all), Ultralight transaction, synthetic IQ @2 Msps',
+                  'classic1k': 'configs[3]/[4]: -t all @10 Msps, MIFARE Classic 1K transaction tiled (av_window 10000, max_len 250)'}
+TILE = 100_000_000   # classic1k: samples of the synthetic capture that is tiled to the configuration's length
+
+
+def default_samples(workload):
+    return 1_000_000_000 if workload == 'classic1k' else 100_000_000
+
+
+def capture_overlap(workload):
+    from usrp_nfc_amd import sharding
+    sp = stream_params(workload)
+    return sharding.shard_overlap(sp['samp_rate'], sp.get('av_window', 2000))
 
 
 def make_capture_slice(workload, n_per_rank, rank, world):
-    """Rank's time chunk of ONE capture of world*n_per_rank samples (plus OVERLAP samples before it).
+    """Rank's time chunk of ONE capture of world*n_per_rank samples (plus the overlap samples before it).
 
-    The modulation profile is a pure function of the global sample index (a frame sequence tiled after a
-    3000-sample idle lead-in); the noise comes from a per-rank PCG64 stream, the overlap region from the
-    predecessor's stream, so neighbouring ranks agree on the samples they share."""
+    The modulation profile is a pure function of the global sample index (a frame sequence tiled after an idle lead-in
+    that covers the averaging window); the noise comes from a per-rank PCG64 stream, the overlap region from the
+    predecessor's stream, so neighbouring ranks agree on the samples they share.  classic1k: every rank's chunk is a
+    TILE-sample capture repeated (BASELINE.json: "recordings/classic1k.wav tiled"); the returned array is ONE tile."""
+    import numpy as np
+    from usrp_nfc_amd import synth
     if workload == 'classic1k':
         frames, _ = synth.frames_from_trace(os.path.join(ROOT, 'tests', 'golden', '1k_with_enc.out'))
         period = synth.modulation_profile(frames, rate_msps=10.0, lead_in=0, tail=0)
         lead = 15000   # covers the 10000-sample window
+        n_gen = min(n_per_rank, TILE)
     else:
         picks = {'miller': (0, 2, 4, 10), 'manchester': (1, 3, 5, 11), 'all': tuple(range(19))}[workload]
         frames = [(d, synth.frame_bits(data, sb)) for d, _, data, sb in (synth.ULTRALIGHT_TXN[i] for i in picks)]
         period = synth.modulation_profile(frames, rate_msps=2.0, lead_in=0, tail=0)
         lead = 3000
-    overlap = shard_overlap(workload)
+        n_gen = n_per_rank
+    overlap = capture_overlap(workload)
 
     def profile(g_lo, g_hi):
         g = np.arange(g_lo, g_hi, dtype=np.int64)
@@ -86,16 +136,22 @@ def make_capture_slice(workload, n_per_rank, rank, world):
         return m
 
     def noisy(g_lo, g_hi, owner):
-        # owner's stream covers [owner*n, (owner+1)*n); take the sub-range
+        # owner's stream covers [owner*n_gen, (owner+1)*n_gen); take the sub-range
         rng = np.random.Generator(np.random.PCG64([synth.SEED, owner]))
-        base = owner * n_per_rank
-        iq = rng.standard_normal(2 * n_per_rank, dtype=np.float32)[2 * (g_lo - base):2 * (g_hi - base)]
+        base = owner * n_gen
+        iq = rng.standard_normal(2 * n_gen, dtype=np.float32)[2 * (g_lo - base):2 * (g_hi - base)]
         iq *= np.float32(0.002)
         m = profile(g_lo, g_hi)
         iq[0::2] += (np.float32(0.5 * np.cos(0.3)) * m).astype(np.float32)
         iq[1::2] += (np.float32(0.5 * np.sin(0.3)) * m).astype(np.float32)
         return iq
 
+    if workload == 'classic1k' and n_per_rank > TILE:
+        # a rank's chunk = its tile repeated: the capture every rank decodes is rank 0's tile, so that the tile seams of
+        # all ranks look alike and the overlap a rank holds is the END of that same tile
+        own = noisy(0, n_gen, 0)
+        ov = own[2 * (n_gen - overlap):].copy() if rank else np.zeros(0, np.float32)
+        return ov, own
     lo = rank * n_per_rank
     own = noisy(lo, lo + n_per_rank, rank)
     if rank == 0:
@@ -104,76 +160,59 @@ def make_capture_slice(workload, n_per_rank, rank, world):
     return ov, own
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    n = int(a.samples)
-    dist = None
-    backend = os.environ.get('NFC_BENCH_BACKEND', 'nccl')   # 'gloo': plumbing test of the N>1 path on one GPU
-    force_x = bool(os.environ.get('NFC_BENCH_FORCE_EXCHANGE')) and 'MASTER_ADDR' in os.environ   # 1-rank smoke of the RCCL path
-    if world > 1 or force_x:
-        import torch
-        import torch.distributed as dist
-        ndev = max(1, torch.cuda.device_count())
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+class Resident(object):
+    """A rank's input in HBM: the host capture uploaded once -- a tile repeated `reps` times for classic1k."""
+
+    def __init__(self, api, own, n, dev):
+        import numpy as np
+        self.n = n
+        tile = len(own) // 2
+        self.reps = (n + tile - 1) // tile
+        if self.reps == 1:
+            self.buf = api.DeviceBuffer(own, dev)
         else:
-            dist.init_process_group('gloo')
+            self.buf = api.DeviceBuffer(np.zeros(0, np.float32), dev, nbytes=8 * tile * self.reps)
+            L = self.buf.L
+            for k in range(self.reps):
+                assert L.nfc_device_upload(dev, self.buf.ptr.value + 8 * tile * k, own.ctypes.data, own.nbytes) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one configuration on this rank
+# ---------------------------------------------------------------------------------------------------------------------
+def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend, want_parity, chunk=0):
+    import numpy as np
+    from usrp_nfc_amd import api, sharding, synth
+    ndev = max(1, api.device_count())
     dev = (local % ndev) if world > 1 else 0
-
-    ov, own = make_capture_slice(a.workload, n, rank, world)
-    flags = decoder_flags(a.workload)
-    d_own = api.DeviceBuffer(own, dev)
+    ov, own = make_capture_slice(workload, n, rank, world)
+    flags = decoder_flags(workload)
+    res = Resident(api, own, n, dev)
     d_ov = api.DeviceBuffer(ov, dev) if len(ov) else None
-    ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, device=dev, chunk_samples=a.chunk, **stream_params(a.workload), **flags)
-
-    def barrier():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            if backend == 'nccl':
-                torch.cuda.synchronize()
-
-    from usrp_nfc_amd import sharding
-    if dist is not None:
-        import torch
-        comm = sharding.TorchDistComm(dist, torch.device('cuda', local) if backend == 'nccl' else torch.device('cpu'))   # nccl == RCCL over xGMI
-        if backend == 'nccl':
-            # a stream of its own as torch's current one: the decode context joins it (nfc_set_stream), so the exported
-            # boundary states are ordered before the all-gather on the device, without a host wait
-            torch.cuda.set_stream(torch.cuda.Stream(device=local))
-    else:
-        comm = sharding.LocalComm()
+    ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, device=dev, chunk_samples=chunk, **stream_params(workload), **flags)
     level = sharding.carrier_level(synth.envelope_f32(ov[:2 * 4096])) if len(ov) else 0.0
     g_lo = rank * n
-    redo_count = 0
-
-    force_exchange = bool(os.environ.get('NFC_BENCH_FORCE_EXCHANGE'))
     n_ov = len(ov) // 2
-
-    def push_overlap():
-        ctx.push_device(d_ov, n_ov)
-
-    def push_own():
-        ctx.push_device(d_own, n)
+    redo = [0]
+    force_exchange = bool(os.environ.get('NFC_BENCH_FORCE_EXCHANGE'))   # 1-rank smoke of the collective path
 
     def one_step():
-        nonlocal redo_count
-        redo_count += sharding.decode_shard(ctx, comm, push_overlap, push_own, g_lo - n_ov, level, force_exchange=force_exchange)
+        redo[0] += sharding.decode_shard(ctx, comm, lambda: ctx.push_device(d_ov, n_ov), lambda: ctx.push_device(res.buf, n),
+                                         g_lo - n_ov, level, force_exchange=force_exchange)
 
-    for _ in range(a.warmup):
+    def barrier():
+        if hasattr(comm, 'barrier'):
+            comm.barrier()
+        ctx.sync()
+
+    for _ in range(warmup):
         one_step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = []
-    n_pass = []
-    for k in range(a.steps):
+    kernel_ms, n_pass = [], []
+    for k in range(steps):
         # every 8th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
-        # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are); the host reads the statistics
-        # of those steps only (the device idles while the host is between two pushes)
+        # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are)
         timed = k % 8 == 0
         if timed or k % 8 == 1:
             ctx.set_timing(1 if timed else 0)
@@ -184,102 +223,101 @@ def main():
             n_pass.append(st.threshold_passes)
     barrier()
     dt = time.perf_counter() - t0
+    if hasattr(comm, 'max_over_ranks'):
+        dt = comm.max_over_ranks(dt)
     ctx.set_timing(2)   # one more, untimed, step for the per-stage split reported beside the headline
     one_step()
     st = ctx.stats()
-    if dist is not None:
-        import torch
-        tmax = torch.tensor([dt], device='cuda' if backend == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
     cnt = ctx.counts()
-    st = ctx.stats()
     n_edges = int(cnt.n_edges)
     out = None
     if rank == 0:
-        ms_step = dt / a.steps * 1e3
         k_avg = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
-        alg_bytes = 8.0 * n + 16.0 * n_edges                       # 8 B/sample + 16 B/edge
-        achieved = alg_bytes / (k_avg * 1e-3) / 1e9
+        thr_bytes = 8.0 * n                              # 8 B per sample read by the envelope + threshold kernel ...
+        edge_bytes = 16.0 * n_edges                      # ... 16 B per emitted edge, written by the edge stage
+        achieved = thr_bytes / (k_avg * 1e-3) / 1e9
+        traffic, tsrc = hbm_traffic(workload, n)
         out = {
-            'metric': 'IQ Msamples/s -> decoded bits (2 Msps stream)',
-            'value': world * n * a.steps / dt / 1e6,
-            'unit': 'Msamples/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 envelope / f64 window sums / u8 symbols', 'data': 'synthetic',
-            'config': {'workload': {'miller': 'configs[1]: Miller-only decode, synthetic IQ @2 Msps',
-                                    'manchester': 'configs[2]: Manchester-only decode, synthetic IQ @2 Msps',
-                                    'all': 'both decoders (-t all), Ultralight transaction, synthetic IQ @2 Msps',
-                                    'classic1k': 'configs[3]/[4]: -t all @10 Msps, MIFARE Classic 1K transaction tiled '
-                                                 '(av_window 10000, max_len 250)'}[a.workload],
-                       'samples_per_gpu': n, 'time_chunk_samples': int(st.chunk_samples), 'time_chunks': int(st.n_chunks), 'parallelism': 'time-chunk x%d' % world,
-                       'edges_per_gpu': n_edges, 'symbols_reader': int(cnt.n_symbols[1]),
-                       'symbols_tag': int(cnt.n_symbols[0]), 'packets': int(cnt.n_packets[0] + cnt.n_packets[1]),
-                       'boundary_redos': redo_count},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_threshold (fused envelope + gated-mean threshold)',
+            'ms_per_step': dt / steps * 1e3,
+            'value': world * n * steps / dt / 1e6,
+            'config': {'workload': WORKLOAD_NAMES[workload], 'samples_per_gpu': n, 'time_chunk_samples': int(st.chunk_samples),
+                       'time_chunks': int(st.n_chunks), 'parallelism': 'time-chunk x%d' % world, 'edges_per_gpu': n_edges,
+                       'symbols_reader': int(cnt.n_symbols[1]), 'symbols_tag': int(cnt.n_symbols[0]),
+                       'packets': int(cnt.n_packets[0] + cnt.n_packets[1]), 'boundary_redos': redo[0],
+                       'shard_overlap_samples': capture_overlap(workload) if world > 1 else 0, 'exchange': backend if world > 1 else 'none'},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_lean / k_threshold (fused envelope + gated-mean threshold)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': hbm_traffic(a, n), 'avg_launch_ms': k_avg, 'launches_timed': len(kernel_ms),
+                         'traffic': traffic, 'traffic_source': tsrc, 'avg_launch_ms': k_avg, 'launches_timed': len(kernel_ms),
                          'launches_per_step': float(np.mean(n_pass)) if n_pass else None,
-                         'algorithmic_bytes_per_launch': alg_bytes},
+                         'algorithmic_bytes_per_launch': thr_bytes,
+                         'note': '8 B/sample only: the 16 B/edge of SURVEY 8(d) are written by the edge stage, listed under edge_stage'},
+            'edge_stage': {'algorithmic_bytes': edge_bytes, 'stage_ms': st.ms_edges,
+                           'achieved_GBs': (edge_bytes / (st.ms_edges * 1e-3) / 1e9) if st.ms_edges > 0 else None,
+                           'note': 'all kernels of the edge stage of the extra, marker-timed step (scan, count, write)'},
+            'whole_path': {'algorithmic_bytes': thr_bytes + edge_bytes,
+                           'achieved_GBs': (thr_bytes + edge_bytes) / (dt / steps) / 1e9, 'frac': (thr_bytes + edge_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS},
             'stage_ms_extra_step': {'total_device': st.ms_total, 'threshold': st.ms_threshold, 'edges': st.ms_edges,
-                                   'decode': st.ms_decode, 'used_sequential': int(st.used_sequential)},
+                                    'decode': st.ms_decode, 'used_sequential': int(st.used_sequential)},
         }
-        if not a.no_parity:
-            out['parity'] = parity_check(a, own, flags, n)
-            # the context the timed loop ran in must have produced the same decode (rank 0's shard starts the stream, so
-            # its outputs are those of the fresh decode the oracle was compared with): not only the side context is checked
-            out['parity']['timed_loop_counts_equal'] = bool(
-                n_edges == out['parity']['n_edges'] and int(cnt.n_packets[0] + cnt.n_packets[1]) == out['parity']['n_packets'])
-            if not out['parity']['timed_loop_counts_equal']:
+        if want_parity:
+            out['parity'] = parity_check(workload, own, flags, n)
+            # the context the timed loop ran in must have produced the same decode (rank 0's shard starts the stream)
+            same = bool(n_edges == out['parity']['n_edges'] and int(cnt.n_packets[0] + cnt.n_packets[1]) == out['parity']['n_packets'])
+            out['parity']['timed_loop_counts_equal'] = same
+            if not same:
                 raise SystemExit('bench: the timed loop decoded %d edges / %d packets, the oracle %d / %d' % (
                     n_edges, int(cnt.n_packets[0] + cnt.n_packets[1]), out['parity']['n_edges'], out['parity']['n_packets']))
-        if not a.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
-            out['cpu_baseline'] = cpu_baseline(own, flags, stream_params(a.workload))
-        print(json.dumps(out))
-        sys.stdout.flush()
-    if dist is not None:
-        ctx.set_stream(None)   # back on its own stream before torch's streams go away
-        dist.barrier()
-        dist.destroy_process_group()
+    ctx.set_stream(None)   # back on its own stream before the communicator's goes away
+    ctx.close()
+    return out, own, flags
 
 
-def hbm_traffic(a, n):
-    """HBM bytes per k_threshold launch from the rocprofv3 PMC passes recorded under profiles/ (separate
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md).  None unless the recorded run matches this workload."""
+def hbm_traffic(workload, n):
+    """HBM bytes per threshold launch from the rocprofv3 PMC passes recorded under profiles/ (separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md): a record of an
+    earlier run, not a measurement of this one -- `traffic_source` says so.  None unless the record matches the workload."""
     try:
         rec = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
-        if rec.get('workload') == a.workload and int(rec.get('samples', 0)) == n:
-            return rec['bytes_per_launch']
+        if rec.get('workload') == workload and int(rec.get('samples', 0)) == n:
+            return rec['bytes_per_launch'], 'profiles/hbm_traffic.json (%s)' % rec.get('kernel', 'k_threshold')
     except Exception:
         pass
-    return None
+    return None, None
 
 
-def parity_check(a, own, flags, n):
-    """Rank 0's chunk decoded from a fresh stream, GPU vs the pinned C oracle, full size."""
+def parity_check(workload, own, flags, n):
+    """Rank 0's chunk decoded from a fresh stream, GPU vs the pinned C oracle, full size (a tiled capture: tile by tile)."""
+    import numpy as np
     from oracle import c_oracle as co
-    ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **stream_params(a.workload), **flags)
-    ctx.push(own)
-    o = co.COracle(**stream_params(a.workload), **flags)
-    o.push_iq(own)
-    ge, oe = ctx.edges(), o.edges()
-    ok_edges = len(ge) == len(oe) and np.array_equal(ge['idx'].astype(np.int64), oe['idx']) and \
-        np.array_equal(ge['d'], oe['d']) and np.array_equal(ge['v'], oe['v']) and np.array_equal(ge['t'], oe['t'])
-    ok_sym = all(np.array_equal(ctx.symbols(t), o.symbols(t)) for t in (0, 1))
-    gp = ctx.packets()
-    ok_pk = gp == o.packets()
+    from usrp_nfc_amd import api
+    tile = len(own) // 2
+    reps = (n + tile - 1) // tile
+    ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **stream_params(workload), **flags)
+    o = co.COracle(**stream_params(workload), **flags)
+    ok_edges = ok_sym = ok_pk = True
+    n_edges = n_packets = 0
+    for _ in range(reps):   # the stream carries over from tile to tile on both sides; outputs are compared per tile
+        ctx.push(own)
+        o.clear_outputs()
+        o.push_iq(own)
+        ge, oe = ctx.edges(), o.edges()
+        ok_edges &= bool(len(ge) == len(oe) and np.array_equal(ge['idx'].astype(np.int64), oe['idx']) and np.array_equal(ge['d'], oe['d'])
+                         and np.array_equal(ge['v'], oe['v']) and np.array_equal(ge['t'], oe['t']))
+        ok_sym &= all(np.array_equal(ctx.symbols(t), o.symbols(t)) for t in (0, 1))
+        gp = ctx.packets()
+        ok_pk &= gp == o.packets()
+        n_edges += len(oe)
+        n_packets += len(gp)
     ctx.close()
-    return {'vs': 'oracle/nfc_oracle.c on the same %d samples' % n, 'edges_equal': bool(ok_edges),
-            'symbols_equal': bool(ok_sym), 'packets_equal': bool(ok_pk), 'n_edges': int(len(oe)), 'n_packets': len(gp)}
+    return {'vs': 'oracle/nfc_oracle.c on the same %d samples' % n, 'edges_equal': bool(ok_edges), 'symbols_equal': bool(ok_sym),
+            'packets_equal': bool(ok_pk), 'n_edges': int(n_edges), 'n_packets': int(n_packets), 'tiles': reps}
 
 
 def cpu_baseline(own, flags, params):
     """The reference's CPU path timed on this host: the pinned C port of the per-sample loop (1 core),
     and -- for the reference's own language -- the line-for-line Python restatement on a prefix."""
     from oracle import c_oracle as co, py_oracle as po
+    from usrp_nfc_amd import synth
     o = co.COracle(**params, **flags)
     n = len(own) // 2
     t0 = time.perf_counter()
@@ -297,6 +335,116 @@ def cpu_baseline(own, flags, params):
             'python_sample': 'oracle/py_oracle.py on the first %d samples in 8192-sample work() calls '
                              '(GNU Radio is not installed: envelope by numpy)' % npy,
             'host_cpus': os.cpu_count()}
+
+
+def end_to_end(workload, own, flags):
+    """Host IQ in, decoded commands out (SURVEY.md 8(d) "separately end-to-end"): pinned host samples -> H2D in pieces (a second
+    thread uploads piece k + 1 while piece k decodes) -> GPU path -> edges, packet tables and packet bits D2H -> packets to
+    bytes / commands on the host (fsm.process_packets, C).  Which link bounds it: PCIe (8 B per sample in, 16 B per edge out)."""
+    import ctypes as C
+    import numpy as np
+    from usrp_nfc_amd import api, fsm, _lib
+    L = _lib.load()
+    n = len(own) // 2
+    piece = 1 << 23
+    pin = C.c_void_p()
+    assert L.nfc_host_alloc_pinned(own.nbytes, C.byref(pin)) == 0
+    C.memmove(pin, own.ctypes.data, own.nbytes)
+    bufs = [api.DeviceBuffer(np.zeros(0, np.float32), 0, nbytes=8 * piece) for _ in range(2)]
+    ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **stream_params(workload), **flags)
+    machine = fsm.fsm(callback=lambda cmd, st: None)
+    pieces = [(o, min(piece, n - o)) for o in range(0, n, piece)]
+
+    def upload(k):
+        o, m = pieces[k]
+        assert L.nfc_device_upload(0, bufs[k & 1].ptr, pin.value + 8 * o, 8 * m) == 0
+
+    n_edges = n_frames = 0
+    t0 = time.perf_counter()
+    upload(0)
+    for k, (o, m) in enumerate(pieces):
+        th = None
+        if k + 1 < len(pieces):
+            th = threading.Thread(target=upload, args=(k + 1,))
+            th.start()
+        ctx.push_device(bufs[k & 1], m)
+        n_edges += len(ctx.edges())
+        tabs = [ctx.packet_table(t) for t in (0, 1)]
+        bits = [ctx.packet_bits(t) for t in (0, 1)]
+        table = np.concatenate(tabs)
+        table = table[np.argsort(table['idx'], kind='stable')]
+        table = table[table['n_bits'] > 0]
+        if len(table):
+            frames, _ = machine.process_packets(table, bits[0], bits[1], dispatch=False)
+            n_frames += len(frames)
+        if th:
+            th.join()
+    dt = time.perf_counter() - t0
+    ctx.close()
+    L.nfc_host_free_pinned(pin)
+    return {'value': n / dt / 1e6, 'unit': 'Msamples/s', 'ms_total': dt * 1e3, 'samples': n, 'edges_to_host': n_edges,
+            'commands': n_frames, 'piece_samples': piece,
+            'what': 'pinned host IQ -> H2D (overlapped, second thread) -> GPU path -> edges + packets D2H -> fsm (C) on the host',
+            'bound': 'PCIe: %.0f MB in + %.0f MB out per pass = %.1f GB/s over the link' % (8 * n / 1e6, 16 * n_edges / 1e6,
+                                                                                           (8 * n + 16 * n_edges) / dt / 1e9)}
+
+
+def rank_main(a):
+    import numpy as np
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.gpus != world and not (a.gpus == 1 and world == 1):
+        raise SystemExit('bench: --gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    from usrp_nfc_amd import api, comm as cm, sharding
+    backend = os.environ.get('NFC_BENCH_BACKEND', 'rccl')
+    backend = 'host' if backend in ('host', 'gloo', 'tcp') else 'rccl'
+    force_x = bool(os.environ.get('NFC_BENCH_FORCE_EXCHANGE'))
+    ndev = max(1, api.device_count())
+    if world > 1 or force_x:
+        if backend == 'rccl':
+            if world > ndev:
+                raise SystemExit('bench: %d ranks but %d GPU(s): RCCL wants one rank per GPU (NFC_BENCH_BACKEND=host shares a GPU)' % (world, ndev))
+            comm = cm.RcclComm(local % ndev)
+        else:
+            comm = cm.HostComm()
+    else:
+        comm = sharding.LocalComm()
+    assert comm.world == world
+    n = int(a.samples) if a.samples else default_samples(a.workload)
+    out, own, flags = run_config(a, a.workload, n, a.steps, a.warmup, rank, world, local, comm, backend, not a.no_parity, a.chunk)
+    if rank == 0:
+        line = {'metric': 'IQ Msamples/s -> decoded bits (2 Msps stream)' if a.workload != 'classic1k' else 'IQ Msamples/s -> decoded bits (10 Msps stream)',
+                'value': out['value'], 'unit': 'Msamples/s', 'n_gpus': comm.world, 'steps': a.steps, 'warmup': a.warmup,
+                'ms_per_step': out['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': 'f32 envelope / f64 window sums / u8 symbols', 'data': 'synthetic'}
+        line.update({k: v for k, v in out.items() if k not in ('value', 'ms_per_step')})
+        if not a.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
+            line['cpu_baseline'] = cpu_baseline(own, flags, stream_params(a.workload))
+        if world == 1 and not a.no_extras and a.workload == 'miller' and n == 100_000_000:
+            # the figures SURVEY.md 8(d) asks for beside the headline, measured in this same invocation
+            line['end_to_end'] = end_to_end(a.workload, own, flags)
+            del own
+            others = []
+            for wl, nn, st in (('manchester', 100_000_000, 20), ('classic1k', 1_000_000_000, 10)):
+                o2, _, _ = run_config(a, wl, nn, st, 3, 0, 1, 0, sharding.LocalComm(), 'none', not a.no_parity)
+                others.append({'workload': WORKLOAD_NAMES[wl], 'samples': nn, 'steps': st, 'ms_per_step': o2['ms_per_step'], 'value': o2['value'],
+                               'unit': 'Msamples/s', 'roofline': o2['roofline'], 'time_chunks': o2['config']['time_chunks'],
+                               'parity': o2.get('parity')})
+            line['other_configs'] = others
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if hasattr(comm, 'barrier'):
+        comm.barrier()
+    if hasattr(comm, 'close'):
+        comm.close()
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(a))   # (this process never touches HIP)
+    rank_main(a)
 
 
 if __name__ == '__main__':

@@ -266,6 +266,15 @@ int nfc_device_alloc(int device, size_t bytes, void **out);
 int nfc_device_free(int device, void *p);
 int nfc_device_upload(int device, void *dst, const void *src_host, size_t bytes);
 int nfc_device_download(int device, void *dst_host, const void *src, size_t bytes);
+/* The same for a caller that enqueues other libraries' work (an RCCL collective) next to a context's: a stream to share with
+ * nfc_set_stream, a wait for it, a device-to-host copy on it, pinned host memory to copy into, a fill. */
+int nfc_stream_create(int device, void **stream_out);
+int nfc_stream_destroy(int device, void *stream);
+int nfc_stream_sync(int device, void *stream);
+int nfc_device_download_async(int device, void *dst_host, const void *src, size_t bytes, void *stream);
+int nfc_device_fill(int device, void *dst, int byte_value, size_t bytes);
+int nfc_host_alloc_pinned(size_t bytes, void **out);
+int nfc_host_free_pinned(void *p);
 
 /* Host-only helpers (no GPU needed): the duration LUTs the decode kernels use,
  * driven sequentially.  Used by the CPU test-suite to pin the tables to the

@@ -1,5 +1,5 @@
-"""Time sharding across ranks (usrp_nfc_amd/sharding.py): world_size-2 gloo run on CPU with an
-oracle-backed engine (the protocol is host logic), and the same boundary hand-off on one GPU."""
+"""Time sharding across ranks (usrp_nfc_amd/sharding.py): world_size-2 runs on CPU with an oracle-backed engine (the protocol
+is host logic) over gloo and over the package's own TCP carrier, and the same boundary hand-off on one GPU."""
 import os
 import pickle
 import socket
@@ -91,14 +91,14 @@ def _worker(rank, world, port, wrong_level, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        import torch
         x, _ = capture(world)
         lo = rank * N_PER
         own = x[lo:lo + N_PER]
         nov = 64 if wrong_level else OVERLAP          # sabotage: an overlap far too short to converge
         ov = x[lo - nov:lo] if rank else x[:0]
         eng = OracleEngine()
-        comm = sharding.TorchDistComm(dist, torch.device('cpu'))
+        from tests.dist_util import GlooComm
+        comm = GlooComm(dist)
         level = sharding.carrier_level(ov[:4096]) if rank else 0.0
         redos = sharding.decode_shard(eng, comm, lambda: eng.push(ov), lambda: eng.push(own), lo - len(ov), level)
         res = [None] * world
@@ -141,6 +141,62 @@ def test_two_ranks_gloo(wrong_level):
         assert res[1][0] == 1      # the speculation was sabotaged: exactly one re-decode, result still exact
     else:
         assert res[1][0] == 0      # the overlap speculation hit the true boundary state
+
+
+def _worker_tcp(rank, world, port, wrong_level, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RANK'], os.environ['WORLD_SIZE'] = str(rank), str(world)
+    from usrp_nfc_amd import comm as cm
+    comm = cm.HostComm(tag='t%d' % port)
+    try:
+        x, _ = capture(world)
+        lo = rank * N_PER
+        own = x[lo:lo + N_PER]
+        nov = 64 if wrong_level else OVERLAP
+        ov = x[lo - nov:lo] if rank else x[:0]
+        eng = OracleEngine()
+        level = sharding.carrier_level(ov[:4096]) if rank else 0.0
+        redos = sharding.decode_shard(eng, comm, lambda: eng.push(ov), lambda: eng.push(own), lo - len(ov), level)
+        assert comm.max_over_ranks(float(rank)) == float(world - 1)
+        res = comm.gather_objects((redos, eng.out, eng.sink.packets))
+        if rank == 0:
+            q.put(res)
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize('wrong_level', [False, True])
+def test_three_ranks_tcp(wrong_level):
+    # the package's own torch-free carrier (usrp_nfc_amd/comm.py: HostComm), three ranks: the middle rank's sabotage shows
+    # that a re-decode of rank 1 leaves rank 2's comparison to be evaluated against the corrected end state
+    import multiprocessing as mp
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tcp, args=(r, world, port, wrong_level, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, _ = capture(world)
+    ref = po.run_path(x, hi_val=1.1)
+    assert [t for _, tr, _ in res for t in tr] == ref['transitions']
+    assert [p for _, _, pk in res for p in pk] == ref['packets']
+    assert res[0][0] == 0
+    if wrong_level:
+        assert res[1][0] == 1 and res[2][0] >= 1
+    else:
+        assert res[1][0] == 0 and res[2][0] == 0
+
+
+def test_shard_overlap_rule():
+    assert sharding.shard_overlap(2e6, 2000) == 8448        # 2000 + 2 * 3097, to the next multiple of 256
+    assert sharding.shard_overlap(10e6, 10000) == 41216
+    assert sharding.shard_overlap(2e6, 2000) % 256 == 0
 
 
 @pytest.mark.gpu
@@ -208,50 +264,84 @@ def test_export_state_matches_state_blob():
     ctx.close()
 
 
-_CALLERS_STREAM = r"""
-import sys
-import numpy as np
-import torch
-torch.cuda.init()            # torch's HIP runtime first: it cannot start after another one has claimed the device
-sys.path.insert(0, %r)
-from oracle import c_oracle as co
-from tests.test_sharding import capture
-from usrp_nfc_amd import api, sharding
-_, iq = capture(1)
-o = co.COracle(hi_val=1.1)
-o.push_iq(iq)
-side = torch.cuda.Stream(device=0)
-ctx = api.NfcContext(hi_val=1.1)
-cap = sharding.slot_bytes(ctx.av_window)
-slot = torch.zeros(cap, dtype=torch.uint8, device='cuda:0')
-torch.cuda.synchronize()
-with torch.cuda.stream(side):
-    ctx.set_stream(side.cuda_stream)
-    ctx.push(iq)
-    tr, pk = ctx.transitions(), ctx.packets()
-    n = ctx.export_state(slot.data_ptr(), cap)     # asynchronous, on `side`
-    got = slot.clone()                             # ordered behind it by the stream alone
-side.synchronize()
-assert tr == o.transitions() and pk == o.packets()
-blob = ctx.state_blob()
-got = got.cpu().numpy()
-assert n == blob.size and np.array_equal(got[16:16 + n], blob)
-ctx.set_stream(None)   # back on its own stream
-ctx.reset()
-ctx.push(iq)
-assert ctx.transitions() == o.transitions()
-ctx.close()
-print('caller-stream ok')
-"""
-
-
 @pytest.mark.gpu
 def test_context_on_the_callers_stream():
     # nfc_set_stream: the context enqueues on the caller's HIP stream, so a consumer the caller puts on that stream next
-    # (here a torch copy of the exported boundary state; in bench.py the RCCL all-gather) needs no host wait in between.
-    # In a process of its own: torch brings its own HIP runtime, which has to be the first to open the device.
+    # (here a device-to-host copy of the exported boundary state; in bench.py the RCCL all-gather) needs no host wait in between
+    import ctypes as C
+    from oracle import c_oracle as co
+    from usrp_nfc_amd import api, _lib
+    L = _lib.load()
+    _, iq = capture(1)
+    o = co.COracle(hi_val=1.1)
+    o.push_iq(iq)
+    side = C.c_void_p()
+    assert L.nfc_stream_create(0, C.byref(side)) == 0
+    ctx = api.NfcContext(hi_val=1.1)
+    cap = sharding.slot_bytes(ctx.av_window)
+    slot = api.DeviceBuffer(np.zeros(cap, np.uint8), 0)
+    pinned = C.c_void_p()
+    assert L.nfc_host_alloc_pinned(cap, C.byref(pinned)) == 0
+    ctx.set_stream(side.value)
+    ctx.push(iq)
+    tr, pk = ctx.transitions(), ctx.packets()
+    n = ctx.export_state(slot.ptr.value, cap)                                   # asynchronous, on `side`
+    assert L.nfc_device_download_async(0, pinned, slot.ptr, cap, side) == 0      # ordered behind it by the stream alone
+    assert L.nfc_stream_sync(0, side) == 0
+    got = np.frombuffer((C.c_uint8 * cap).from_address(pinned.value), np.uint8).copy()
+    assert tr == o.transitions() and pk == o.packets()
+    blob = ctx.state_blob()
+    assert n == blob.size and np.array_equal(got[16:16 + n], blob)
+    ctx.set_stream(None)   # back on its own stream
+    ctx.reset()
+    ctx.push(iq)
+    assert ctx.transitions() == o.transitions()
+    ctx.close()
+    L.nfc_host_free_pinned(pinned)
+    L.nfc_stream_destroy(0, side)
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_one_rank():
+    # the ctypes binding of librccl (usrp_nfc_amd/comm.py): communicator of one rank, the all-gather of the boundary frames out
+    # of the device buffer nfc_export_state fills, the scalar all-reduce behind barrier / max_over_ranks
+    from oracle import c_oracle as co
+    from usrp_nfc_amd import api, comm as cm
+    os.environ.setdefault('MASTER_PORT', str(_free_port()))
+    comm = cm.RcclComm(0, rank=0, world=1, tag='t1')
+    try:
+        _, iq = capture(1)
+        ctx = api.NfcContext(hi_val=1.1)
+        n = len(iq) // 2
+        buf = api.DeviceBuffer(iq, 0)
+        redos = sharding.decode_shard(ctx, comm, lambda: None, lambda: ctx.push_device(buf, n), 0, 0.0, force_exchange=True)
+        assert redos == 0
+        o = co.COracle(hi_val=1.1)
+        o.push_iq(iq)
+        assert ctx.transitions() == o.transitions() and ctx.packets() == o.packets()
+        pairs = comm.exchange()
+        assert len(pairs) == 1 and pairs[0][0].size == 0 and np.array_equal(pairs[0][1], ctx.state_blob())
+        assert comm.max_over_ranks(3.25) == 3.25
+        comm.barrier()
+        ctx.set_stream(None)
+        ctx.close()
+    finally:
+        comm.close()
+
+
+@pytest.mark.gpu
+def test_bench_spawns_two_ranks_on_one_gpu():
+    # `python bench.py --gpus 2` without a launcher: the parent spawns the ranks itself; on a one-GPU box they share the device
+    # and carry the boundary states over TCP (NFC_BENCH_BACKEND=host)
+    import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', _CALLERS_STREAM % root], capture_output=True, text=True, timeout=300, cwd=root)
-    assert r.returncode == 0 and 'caller-stream ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    env = dict(os.environ, NFC_BENCH_BACKEND='host')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--samples', '2e6', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-extras'], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['config']['exchange'] == 'host' and line['config']['boundary_redos'] == 0
+    assert line['parity']['edges_equal'] and line['parity']['packets_equal']

@@ -62,7 +62,8 @@ PACKET_DTYPE = np.dtype([('idx', '<u8'), ('bit_off', '<u8'), ('n_bits', '<u4'), 
 SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', 'nfc_last_error', 'nfc_push',
            'nfc_push_device', 'nfc_sync', 'nfc_set_stream', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_symbols', 'nfc_read_packets',
            'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_prime', 'nfc_export_state', 'nfc_get_stats', 'nfc_set_timing',
-           'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_host_decode_lut',
+           'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_stream_create', 'nfc_stream_destroy',
+           'nfc_stream_sync', 'nfc_device_download_async', 'nfc_device_fill', 'nfc_host_alloc_pinned', 'nfc_host_free_pinned', 'nfc_host_decode_lut',
            'nfc_fsm_create', 'nfc_fsm_destroy', 'nfc_fsm_reset', 'nfc_fsm_process', 'nfc_fsm_process_packets', 'nfc_fsm_set_keys',
            'nfc_command_count', 'nfc_command_get', 'nfc_crc_a', 'nfc_tx_encode', 'nfc_tx_sample_count', 'nfc_tx_render_device']
 
@@ -110,6 +111,13 @@ def load():
     L.nfc_device_free.argtypes = [C.c_int, vp]
     L.nfc_device_upload.argtypes = [C.c_int, vp, vp, sz]
     L.nfc_device_download.argtypes = [C.c_int, vp, vp, sz]
+    L.nfc_stream_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.nfc_stream_destroy.argtypes = [C.c_int, vp]
+    L.nfc_stream_sync.argtypes = [C.c_int, vp]
+    L.nfc_device_download_async.argtypes = [C.c_int, vp, vp, sz, vp]
+    L.nfc_device_fill.argtypes = [C.c_int, vp, C.c_int, sz]
+    L.nfc_host_alloc_pinned.argtypes = [sz, C.POINTER(vp)]
+    L.nfc_host_free_pinned.argtypes = [vp]
     L.nfc_host_decode_lut.argtypes = [C.POINTER(Params), C.c_int, vp, vp, sz, vp, sz, psz]
     L.nfc_fsm_create.argtypes = [C.POINTER(vp)]
     L.nfc_fsm_destroy.argtypes = [vp]

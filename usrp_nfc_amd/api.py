@@ -245,6 +245,11 @@ class DeviceBuffer(object):
     __del__ = free
 
 
+def device_count():
+    """HIP devices this process sees (nfc_device_count; 0 without a GPU)."""
+    return int(_lib.load().nfc_device_count())
+
+
 def host_decode_lut(ptype, cur, d, samp_rate=2e6, max_len=50):
     """Drive the decode kernels' duration LUTs sequentially on the host (no GPU)."""
     L = _lib.load()

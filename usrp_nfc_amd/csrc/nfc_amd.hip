@@ -1903,6 +1903,44 @@ int nfc_device_download(int device, void *dst, const void *src, size_t bytes) {
     return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? NFC_OK : NFC_ERR_DEVICE;
 }
 
+int nfc_stream_create(int device, void **stream_out) {
+    if (!stream_out) return NFC_ERR_ARG;
+    *stream_out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, NFC_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(nullptr, NFC_ERR_DEVICE, "hipStreamCreate failed");
+    *stream_out = (void *)st;
+    return NFC_OK;
+}
+
+int nfc_stream_destroy(int device, void *stream) {
+    if (hipSetDevice(device) != hipSuccess) return NFC_ERR_DEVICE;
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? NFC_OK : NFC_ERR_DEVICE;
+}
+
+int nfc_stream_sync(int device, void *stream) {
+    if (hipSetDevice(device) != hipSuccess) return NFC_ERR_DEVICE;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? NFC_OK : NFC_ERR_DEVICE;
+}
+
+int nfc_device_download_async(int device, void *dst, const void *src, size_t bytes, void *stream) {
+    if (hipSetDevice(device) != hipSuccess) return NFC_ERR_DEVICE;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? NFC_OK : NFC_ERR_DEVICE;
+}
+
+int nfc_device_fill(int device, void *dst, int byte_value, size_t bytes) {
+    if (hipSetDevice(device) != hipSuccess) return NFC_ERR_DEVICE;
+    return hipMemset(dst, byte_value, bytes) == hipSuccess ? NFC_OK : NFC_ERR_DEVICE;
+}
+
+int nfc_host_alloc_pinned(size_t bytes, void **out) {
+    if (!out) return NFC_ERR_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? NFC_OK : NFC_ERR_NOMEM;
+}
+
+int nfc_host_free_pinned(void *p) { return hipHostFree(p) == hipSuccess ? NFC_OK : NFC_ERR_DEVICE; }
+
 int nfc_host_decode_lut(const nfc_params *p, int type, const int8_t *cur, const int32_t *d, size_t n, uint8_t *sym_out,
                         size_t cap, size_t *n_out) {
     if (!p || !cur || !d || !n_out || type < 0 || type > 1) return NFC_ERR_ARG;

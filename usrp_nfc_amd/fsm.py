@@ -92,9 +92,10 @@ class fsm(object):
         f = frame[0]
         return self._dispatch(f, data[:int(f['n_bytes'])].tolist(), enc[:int(f['n_enc'])])
 
-    def process_packets(self, table, bits0, bits1):
+    def process_packets(self, table, bits0, bits1, dispatch=True):
         """A batch: `table` rows of nfc_packet (both types, in stream order) over the per-type bit arrays.
-        Returns (frames, bytes) as numpy arrays; the callback sees every command in order."""
+        Returns (frames, bytes) as numpy arrays; the callback sees every command in order (dispatch=False: only the
+        arrays -- a caller that consumes the frame table itself)."""
         t = np.ascontiguousarray(table)
         b0 = np.ascontiguousarray(bits0, np.uint8)
         b1 = np.ascontiguousarray(bits1, np.uint8)
@@ -107,7 +108,7 @@ class fsm(object):
                                             C.byref(used), enc.ctypes.data)
         if rc != 0:
             raise ValueError('nfc_fsm_process_packets status %d' % rc)
-        for f in frames:
+        for f in (frames if dispatch else ()):
             o = int(f['byte_off'])
             self._dispatch(f, data[o:o + int(f['n_bytes'])].tolist(), enc[o:o + int(f['n_enc'])])
         return frames, data[:used.value]

@@ -11,8 +11,9 @@ states, bits of a packet that straddles the boundary).  Protocol:
    chunk boundary the state is -- almost always -- exactly the true one;
 2. decode the own chunk from that state;
 3. exchange: ONE all-gather per round of every rank's (speculated START state, true END state) pair
-   (about 8.2 KB each: header + ring + pending packet bits; RCCL over xGMI on a GPU node, gloo in the
-   CPU tests), so that every rank can evaluate every comparison itself -- no second collective;
+   (about 8.2 KB each: header + ring + pending packet bits; comm.RcclComm: ncclAllGather over xGMI on a GPU
+   node; comm.HostComm: TCP through rank 0 for ranks that share a GPU and for the CPU tests), so that every
+   rank can evaluate every comparison itself -- no second collective;
 4. verify: rank r's speculated start state must equal rank r-1's true end state, bit for bit.
    By induction from rank 0 (whose start is the stream start) all chunks are exact when every
    comparison holds.  Otherwise the first mismatching rank re-decodes its chunk from the true state and
@@ -50,73 +51,14 @@ class LocalComm(object):
     device_slots = False
 
 
-class TorchDistComm(object):
-    """The boundary exchange over torch.distributed (backend nccl == RCCL over xGMI on a GPU node, gloo in the
-    CPU tests): ONE all_gather per round of a two-slot frame (speculated start state | true end state), through
-    buffers allocated once.  On a GPU the engine writes its states straight into the send buffer in device
-    memory (nfc_export_state), so a state travels GPU -> GPU and reaches the host once, gathered."""
-
-    def __init__(self, dist, device):
-        import torch
-        self.dist = dist
-        self.device = device
-        self.world = dist.get_world_size()
-        self.rank = dist.get_rank()
-        self.device_slots = device.type != 'cpu'
-        self._torch = torch
-        self.half = 0
-
-    def bind(self, av_window, state_bytes=None):
-        half = slot_bytes(av_window) if state_bytes is None else (PREFIX + int(state_bytes) + 15) // 16 * 16
-        if half == self.half:
-            return
-        torch = self._torch
-        self.half = half
-        self._send = torch.zeros(2 * half, dtype=torch.uint8, device=self.device)
-        self._recv = torch.zeros(self.world * 2 * half, dtype=torch.uint8, device=self.device)
-        self._recv_parts = list(self._recv.chunk(self.world))
-        self._recv_host = torch.zeros(self.world * 2 * half, dtype=torch.uint8)
-        if self.device_slots:
-            self._recv_host = self._recv_host.pin_memory()
-
-    def slot_ptr(self, slot):
-        return self._send.data_ptr() + slot * self.half
-
-    def stream_handle(self):
-        """The HIP stream the collective is enqueued on (hipStream_t as an integer), or None on the CPU."""
-        return int(self._torch.cuda.current_stream(self.device).cuda_stream) if self.device_slots else None
-
-    def put(self, slot, blob):
-        """Host path (CPU engines, gloo): frame a state into a slot of the send buffer."""
-        blob = np.ascontiguousarray(blob, np.uint8)
-        frame = np.zeros(self.half, np.uint8)
-        frame[:4] = np.array([blob.size], '<u4').view(np.uint8)
-        if PREFIX + blob.size <= self.half:
-            frame[PREFIX:PREFIX + blob.size] = blob
-        self._send[slot * self.half:(slot + 1) * self.half] = self._torch.from_numpy(frame).to(self.device)
-
-    def exchange(self):
-        """All ranks' (speculated start state, true end state) as byte vectors, in rank order."""
-        if self.device_slots:
-            self.dist.all_gather_into_tensor(self._recv, self._send)   # RCCL's native form: one flat buffer
-        else:
-            self.dist.all_gather(self._recv_parts, self._send)
-        if self.device_slots:
-            self._recv_host.copy_(self._recv, non_blocking=True)   # one pinned copy of the gathered frames
-            self._torch.cuda.current_stream().synchronize()
-            got = self._recv_host.numpy().reshape(self.world, 2, self.half)
-        else:
-            got = self._recv.numpy().reshape(self.world, 2, self.half)
-        pairs = []
-        for r in range(self.world):
-            pair = []
-            for slot in range(2):
-                ln = int(got[r, slot, :4].view('<u4')[0])
-                if PREFIX + ln > self.half:   # every rank sees this and fails alike (no rank is left waiting)
-                    raise RuntimeError('rank %d: boundary state of %d bytes exceeds the %d-byte exchange slot' % (r, ln, self.half))
-                pair.append(got[r, slot, PREFIX:PREFIX + ln].copy())
-            pairs.append(tuple(pair))
-        return pairs
+def shard_overlap(samp_rate, av_window, longest_frame_bits=164):
+    """Samples of its predecessor's chunk a rank > 0 also decodes (its speculation warm-up): the averaging window plus twice
+    the longest frame of the capture at the stream's rate -- by default an 18-byte answer with parity, start and end bit,
+    164 bit periods of 128 / fc = 9.44 us -- so that the warm-up normally starts in idle and always
+    sees a frame gap.  A wrong guess costs a re-decode, never exactness.  Rounded up to a multiple of 256."""
+    frame = int(np.ceil(longest_frame_bits * 128.0 / 13.56e6 * samp_rate))
+    n = int(av_window) + 2 * frame
+    return (n + 255) // 256 * 256
 
 
 def decode_shard(engine, comm, push_overlap, push_own, start_index, level, force_exchange=False):
