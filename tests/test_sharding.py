@@ -194,8 +194,8 @@ def test_three_ranks_tcp(wrong_level):
 
 
 def test_shard_overlap_rule():
-    assert sharding.shard_overlap(2e6, 2000) == 8448        # 2000 + 2 * 3097, to the next multiple of 256
-    assert sharding.shard_overlap(10e6, 10000) == 41216
+    assert sharding.shard_overlap(2e6, 2000) == 38400       # 16 * 2000 + 2 * 3097, to the next multiple of 256
+    assert sharding.shard_overlap(10e6, 10000) == 190976
     assert sharding.shard_overlap(2e6, 2000) % 256 == 0
 
 
@@ -345,3 +345,93 @@ def test_bench_spawns_two_ranks_on_one_gpu():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['config']['exchange'] == 'host' and line['config']['boundary_redos'] == 0
     assert line['parity']['edges_equal'] and line['parity']['packets_equal']
+
+
+class ThreadComm(object):
+    """Test infrastructure: the ranks of one job as threads of this process (one NfcContext each, all on GPU 0), the boundary
+    frames gathered through shared memory behind a barrier -- the host-staged path of decode_shard with real contexts."""
+    device_slots = False
+
+    class Shared(object):
+        def __init__(self, world):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.frames = [None] * world
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.world = shared, rank, shared.world
+        self.half = 0
+
+    def bind(self, av_window, state_bytes=None):
+        self.half = sharding.slot_bytes(av_window)
+        self._slots = [np.zeros(0, np.uint8), np.zeros(0, np.uint8)]
+
+    def stream_handle(self):
+        return None
+
+    def put(self, slot, blob):
+        self._slots[slot] = np.array(blob, np.uint8, copy=True)
+
+    def exchange(self):
+        self.sh.frames[self.rank] = (self._slots[0].copy(), self._slots[1].copy())
+        self.sh.barrier.wait()
+        pairs = list(self.sh.frames)
+        self.sh.barrier.wait()
+        return pairs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sabotage', [None, 2])
+def test_classic1k_10msps_four_shards_on_gpu(sabotage):
+    # BASELINE.json configs[4] in miniature: the MIFARE Classic 1K transaction at 10 Msps (av_window 10000, max_len 250) cut into
+    # four time shards with the derived overlap, every shard decoded by a real NfcContext from its speculated boundary state, the
+    # states exchanged and verified (decode_shard); concatenated outputs against the C oracle over the whole capture.  With a
+    # sabotaged (far too short) overlap on one rank its speculation must be caught and that shard re-decoded from the true state.
+    import threading
+    from oracle import c_oracle as co
+    from usrp_nfc_amd import api
+    world, n_per = 4, 700_000
+    params = dict(samp_rate=10e6, hi_val=1.1, av_window=10000, max_len=250)
+    gold = os.path.join(os.path.dirname(__file__), 'golden', '1k_with_enc.out')
+    frames, _ = synth.frames_from_trace(gold)
+    m = synth.tiled_profile(synth.modulation_profile(frames, rate_msps=10.0, lead_in=0, tail=0), world * n_per)
+    m[:15000] = 1.0   # idle lead-in that covers the window
+    iq = synth.iq_from_profile(m, seed=11)
+    overlap = sharding.shard_overlap(10e6, 10000)
+    assert overlap == 190976
+    o = co.COracle(**params)
+    o.push_iq(iq)
+    shared = ThreadComm.Shared(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            lo = rank * n_per
+            nov = (512 if sabotage == rank else overlap) if rank else 0
+            own = iq[2 * lo:2 * (lo + n_per)]
+            ov = iq[2 * (lo - nov):2 * lo]
+            ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **params)
+            comm = ThreadComm(shared, rank)
+            level = sharding.carrier_level(synth.envelope_f32(ov[:2 * 4096])) if rank else 0.0
+            redos = sharding.decode_shard(ctx, comm, lambda: ctx.push(ov), lambda: ctx.push(own), lo - nov, level)
+            results[rank] = (redos, ctx.transitions(), ctx.packets(), ctx.stats().used_sequential)
+            ctx.close()
+        except Exception as e:   # noqa: BLE001 -- a failing rank must not leave the others waiting at the barrier
+            errors.append((rank, repr(e)))
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert [t for _, tr, _, _ in results for t in tr] == o.transitions()
+    assert [p for _, _, pk, _ in results for p in pk] == o.packets()
+    assert len(o.packets()) > 100
+    redos = [r[0] for r in results]
+    if sabotage is None:
+        assert redos == [0, 0, 0, 0]
+    else:
+        assert redos[sabotage] == 1 and redos[0] == 0

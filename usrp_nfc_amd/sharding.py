@@ -51,13 +51,20 @@ class LocalComm(object):
     device_slots = False
 
 
-def shard_overlap(samp_rate, av_window, longest_frame_bits=164):
-    """Samples of its predecessor's chunk a rank > 0 also decodes (its speculation warm-up): the averaging window plus twice
-    the longest frame of the capture at the stream's rate -- by default an 18-byte answer with parity, start and end bit,
-    164 bit periods of 128 / fc = 9.44 us -- so that the warm-up normally starts in idle and always
-    sees a frame gap.  A wrong guess costs a re-decode, never exactness.  Rounded up to a multiple of 256."""
+def shard_overlap(samp_rate, av_window, longest_frame_bits=164, windows=16):
+    """Samples of its predecessor's chunk a rank > 0 also decodes (its speculation warm-up).
+
+    Two things have to converge before the boundary.  The state machines (edge timing, decoders, framing) re-synchronise
+    at a frame gap: twice the longest frame of the capture at the stream's rate -- by default an 18-byte answer with parity,
+    start and end bit, 164 bit periods of 128 / fc = 9.44 us -- always contains one.  The ring of
+    accepted samples starts from a level estimate in every slot, and a slot only takes its true value when a sample that
+    lands on it is ACCEPTED; inside frames a third to a half of the samples are rejected (pauses, loaded half bits), so a
+    slot needs several passes of the window before the chance that it was rejected every time is negligible: `windows`
+    averaging windows (16: measured -- the 10 Msps MIFARE Classic capture, frames back to back with 150 us gaps, still had
+    stale slots after 4 windows on every boundary).  A wrong guess costs a re-decode, never exactness; the warm-up itself
+    costs windows * av_window samples per rank (0.02 % of a 1e9-sample shard).  Rounded up to a multiple of 256."""
     frame = int(np.ceil(longest_frame_bits * 128.0 / 13.56e6 * samp_rate))
-    n = int(av_window) + 2 * frame
+    n = int(windows) * int(av_window) + 2 * frame
     return (n + 255) // 256 * 256
 
 
