@@ -45,7 +45,7 @@ typedef enum {
     NFC_IN_IQ_F32 = 0,      /* interleaved float32 I,Q; x = fl(fl(I*I)+fl(Q*Q))  (uhd branch, usrp_src.py:31) */
     NFC_IN_ENV_F32 = 1,     /* float32 envelope already computed; x = sample                                    */
     NFC_IN_REAL_F32_SQ = 2, /* float32 real sample, Q = 0; x = fl(s*s)              (wav branch, decoder.py:25-28) */
-    NFC_IN_I16_SQ = 3       /* int16 PCM; s = fl((float)pcm * i16_scale); x = fl(s*s)  (wavfile_source + wav branch) */
+    NFC_IN_I16_SQ = 3       /* int16 PCM; s = fl(pcm / 32767) (or fl(pcm * i16_scale)); x = fl(s*s)  (wavfile_source + wav branch) */
 } nfc_input_kind;
 
 /* nfc_params.flags */
@@ -63,7 +63,11 @@ typedef struct {
     int32_t enable_tag;    /* Manchester decoder present      (background.py:21) */
     int32_t input_kind;    /* nfc_input_kind */
     int32_t device;        /* HIP device ordinal */
-    float i16_scale;       /* NFC_IN_I16_SQ only; 0 -> 1/32768 */
+    float i16_scale;       /* NFC_IN_I16_SQ only.  0: GNU Radio's wavfile_source normalisation, s = fl((float)pcm / 32767.0f) -- what
+                            * decoder.py:25 feeds the path (gr-blocks wavfile_source_impl.cc divides 16-bit samples by 0x7FFF; GNU Radio
+                            * is third party and absent from the reference tree, so this boundary is UNPINNED: SURVEY.md 8c).  > 0: s =
+                            * fl((float)pcm * i16_scale) for a source normalised differently (1/32768 is a power of two; 1/32767 is not:
+                            * fl(s*s) then rounds differently near the thresholds) */
     uint32_t flags;
     int32_t chunk_samples; /* samples per time chunk of the threshold kernel; 0 -> default */
     int32_t reserved;
@@ -281,6 +285,15 @@ int nfc_host_free_pinned(void *p);
  * reference decoders' golden vectors.  type: 0 Manchester, 1 Miller. */
 int nfc_host_decode_lut(const nfc_params *params, int type, const int8_t *cur, const int32_t *d, size_t n,
                         uint8_t *sym_out, size_t cap, size_t *n_out);
+
+/* The decoders themselves on the host, one transition at a time with any duration in microseconds (the walk the LUTs are
+ * built from: csrc/decoder_tables.h), decoder state carried across calls in *state (0 before the first call; type 0
+ * Manchester: manchester.py:30-61, type 1 Modified Miller: miller.py:153-197).  Behind usrp_nfc_amd.miller.miller_decoder /
+ * manchester.manchester_decoder, the reference-named classes that keep `process_transition(list)`. */
+int nfc_host_decode_steps(int type, const int8_t *cur, const double *dur_us, size_t n, int32_t *state, uint8_t *sym_out,
+                          size_t cap, size_t *n_out);
+/* the int16 -> float conversion of the NFC_IN_I16_SQ kernels, on the host (i16_scale as in nfc_params) */
+float nfc_host_i16_to_float(int16_t pcm, float i16_scale);
 
 #ifdef __cplusplus
 }

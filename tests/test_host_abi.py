@@ -77,3 +77,18 @@ def test_no_gpu_means_loud_failure_for_the_tx_renderer():
     assert tx.sample_count(runs, 2e6) == 24
     with pytest.raises(RuntimeError):
         tx.render_device(runs, 2e6, 32, 24)   # (any pointer: the call must fail before touching it)
+
+
+def test_wavfile_source_normalisation_is_the_ieee_quotient():
+    # NFC_IN_I16_SQ, i16_scale 0: s = fl(pcm / 32767) as GNU Radio's wavfile_source computes it.  The kernels get there
+    # without a division (threshold.hip.h: i16_to_float); the identity is checked here for all 65536 inputs on the host
+    import ctypes as C
+    from usrp_nfc_amd import _lib
+    L = _lib.load()
+    v = np.arange(-32768, 32768, dtype=np.int64)
+    want = (v.astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+    got = np.array([L.nfc_host_i16_to_float(int(k), 0.0) for k in v], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    sc = np.float32(1.0 / 32768.0)
+    got2 = np.array([L.nfc_host_i16_to_float(int(k), float(sc)) for k in v[::257]], np.float32)
+    assert np.array_equal(got2, (v[::257].astype(np.float32) * sc).astype(np.float32))

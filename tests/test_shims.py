@@ -85,10 +85,51 @@ def test_decoder_reads_16bit_wav(tmp_path):
     decoder(src=path, reader=True, tag=True, samp_rate=2e6, fsm=f).run()
     from oracle import c_oracle as co
     o = co.COracle(samp_rate=2e6, hi_val=1.09)
-    sc = np.float32(1.0 / 32768.0)
-    o.push_real_sq((pcm.astype(np.float32) * sc).astype(np.float32))
+    o.push_real_sq((pcm.astype(np.float32) / np.float32(32767.0)).astype(np.float32))   # wavfile_source: sample / 0x7FFF (IEEE division)
     assert f.got == o.packets()
     assert len(f.got) >= 17
+    # a source normalised by a plain factor instead; and the non-default constructor arguments reach the one context
+    f2 = _Fsm()
+    decoder(src=pcm, reader=True, tag=True, samp_rate=2e6, fsm=f2, wav_scale=1.0 / 32768.0, av_window=1000, max_len=40).run()
+    o2 = co.COracle(samp_rate=2e6, hi_val=1.09, av_window=1000, max_len=40)
+    o2.push_real_sq((pcm.astype(np.float32) * np.float32(1.0 / 32768.0)).astype(np.float32))
+    assert f2.got == o2.packets() and len(f2.got) >= 10
+
+
+@pytest.mark.gpu
+def test_live_flush_cadence():
+    # work() in 8192-sample scheduler calls: with flush_ms=0 and batch=1 the callback comes once per call (the reference's
+    # cadence, transition_sink.py:101); with a time limit the hand-over happens without waiting for `batch` samples
+    import time
+    from usrp_nfc_amd import synth
+    from usrp_nfc_amd.background import background
+    from usrp_nfc_amd.transition_sink import transition_sink
+    from oracle import c_oracle as co
+    x = synth.envelope_f32(synth.workload('all', 200_000))
+    o = co.COracle(samp_rate=2e6, hi_val=1.1)
+    o.push_env(x)
+    for kw, expect_calls in ((dict(batch=1, flush_ms=0), 25), (dict(flush_ms=1.0), None), (dict(flush_calls=5, flush_ms=0), 5)):
+        calls = []
+        got = []
+        f = _Fsm()
+        back = background(True, True, fsm=f, keep=0)
+        back.transitions = got
+        ts = transition_sink(2e6, back.append, hi_val=1.1, **kw)
+        orig = ts._callback
+        ts._callback = lambda lst, _o=orig: (calls.append(1), _o(lst))[1]   # count the callbacks on their way to background.append
+        for i in range(0, len(x), 8192):
+            ts.work([x[i:i + 8192]], None)
+            if 'flush_ms' in kw and kw['flush_ms']:
+                time.sleep(0.0005)
+        before_stop = len(calls)
+        ts.stop()
+        assert got == o.transitions() and f.got == o.packets()
+        assert len(back.packets) == 0          # keep=0: nothing retained
+        if expect_calls is not None:
+            assert len(calls) == expect_calls, (kw, len(calls))
+        else:
+            assert before_stop >= 3            # handed over on the clock, long before 4 Mi samples were buffered
+        ts.close()
 
 
 @pytest.mark.gpu

@@ -23,11 +23,16 @@ class _Recorder(object):
 
 
 class background(object):
-    def __init__(self, reader=False, tag=False, emulator=None, fsm=None):
+    def __init__(self, reader=False, tag=False, emulator=None, fsm=None, keep=None):
+        """keep: how many packets / symbols of the stream stay in ``self.packets`` / ``self.symbols`` -- None: everything (offline
+        decodes, tests), 0: nothing (the reference keeps nothing: a long live capture must not grow without bound), N: the last N."""
+        import collections
         self.reader = bool(reader)   # Modified-Miller decoder present (background.py:20)
         self.tag = bool(tag)         # Manchester decoder present      (background.py:21)
-        self.packets = []            # (packet_type, [bits]) in stream order
-        self.symbols = {PacketType.TAG_TO_READER: [], PacketType.READER_TO_TAG: []}
+        self._keep = keep
+        mk = (lambda: []) if keep is None else (lambda: collections.deque(maxlen=int(keep)))
+        self.packets = mk()          # (packet_type, [bits]) in stream order
+        self.symbols = {PacketType.TAG_TO_READER: mk(), PacketType.READER_TO_TAG: mk()}
         self.transitions = None      # set to a list to also keep the raw transitions
         if fsm is None:
             try:                      # packets.py:88-92
@@ -53,8 +58,9 @@ class background(object):
 
     # -- GPU delivery (called by transition_sink after each batch) ---------------------
     def _deliver(self, ctx):
-        for t in (PacketType.TAG_TO_READER, PacketType.READER_TO_TAG):
-            self.symbols[t].extend(ctx.symbols(t).tolist())
+        if self._keep != 0:
+            for t in (PacketType.TAG_TO_READER, PacketType.READER_TO_TAG):
+                self.symbols[t].extend(ctx.symbols(t).tolist())
         for ptype, bits in ctx.packets():
             self.packets.append((ptype, bits))
             self._fsm.process_bits(bits, ptype)

@@ -1296,7 +1296,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         for (int k = 0; k < 64; k += b) c->selmask |= 1ull << k;
     }
     c->eps = 0.01f;  // certification margin of the speculative pass, relative to the window sum
-    c->i16_scale = p->i16_scale != 0.f ? p->i16_scale : 1.0f / 32768.0f;
+    c->i16_scale = p->i16_scale > 0.f ? p->i16_scale : -1.0f;   // (0: GNU Radio's wavfile_source normalisation, sample / 32767; threshold.hip.h: i16_to_float)
     static const size_t bps[4] = {8, 4, 4, 2};
     c->in_bytes_per_sample = bps[p->input_kind];
     memset(&c->h_carry, 0, sizeof c->h_carry);
@@ -1940,6 +1940,28 @@ int nfc_host_alloc_pinned(size_t bytes, void **out) {
 }
 
 int nfc_host_free_pinned(void *p) { return hipHostFree(p) == hipSuccess ? NFC_OK : NFC_ERR_DEVICE; }
+
+float nfc_host_i16_to_float(int16_t pcm, float i16_scale) { return i16_to_float((int)pcm, i16_scale > 0.f ? i16_scale : -1.0f); }
+
+int nfc_host_decode_steps(int type, const int8_t *cur, const double *dur_us, size_t n, int32_t *state, uint8_t *sym_out, size_t cap,
+                          size_t *n_out) {
+    if (!cur || !dur_us || !state || !n_out || type < 0 || type > 1) return NFC_ERR_ARG;
+    // the packed states of decoder_tables.h; a fresh decoder: Miller stage BEGINNING, not started, prev 0 (miller.py:22,29) /
+    // Manchester prev_set False, prev 0 (manchester.py:22-25).  The caller's 0 stands for "fresh" in both.
+    int st = *state ? (*state - 1) : (type ? 0 : ((0 + 1) << 1));
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        const Step r = type ? miller_step(st, cur[i], dur_us[i]) : manch_step(st, cur[i], dur_us[i]);
+        st = r.next;
+        for (int j = 0; j < r.nout; j++) {
+            if (k < cap && sym_out) sym_out[k] = (uint8_t)r.out[j];
+            k++;
+        }
+    }
+    *state = st + 1;
+    *n_out = k;
+    return (k <= cap) ? NFC_OK : NFC_ERR_ARG;
+}
 
 int nfc_host_decode_lut(const nfc_params *p, int type, const int8_t *cur, const int32_t *d, size_t n, uint8_t *sym_out,
                         size_t cap, size_t *n_out) {

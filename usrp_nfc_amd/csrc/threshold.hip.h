@@ -215,6 +215,18 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
                    "s"((uint32_t)(m)[2]), "s"((uint32_t)((m)[2] >> 32)), "s"((uint32_t)(m)[3]), "s"((uint32_t)((m)[3] >> 32)), "n"(LANE0))
 __device__ __forceinline__ int last_set(unsigned long long m) { return 63 - __clzll((long long)m); }  // m != 0
 
+// int16 PCM -> float as GNU Radio's wavfile_source does it (gr-blocks wavfile_source_impl.cc: 16-bit samples are DIVIDED by
+// 0x7FFF): i16_scale < 0 asks for exactly that -- fl(v / 32767), obtained without a division as fma(v', 2^-15 + 2^-30, v') with
+// v' = v * 2^-15 (exact): equal to the IEEE quotient for every one of the 65536 inputs (tests/test_host_abi.py checks the
+// identity exhaustively).  i16_scale > 0: the plain product fl(v * i16_scale).
+__host__ __device__ __forceinline__ float i16_to_float(int v, float i16_scale) {
+    if (i16_scale < 0.f) {
+        const float vp = (float)v * 3.0517578125e-05f;
+        return fmaf(vp, 3.0517578125e-05f + 9.31322574615478515625e-10f, vp);
+    }
+    return (float)v * i16_scale;
+}
+
 // Envelope of one sample (gnuradio complex_to_mag_squared; compiled with
 // -ffp-contract=off so the products and the sum round separately).
 template <int KIND>
@@ -229,7 +241,7 @@ __device__ __forceinline__ float envelope_at(const void *in, size_t m, float i16
         const float s = ((const float *)in)[m];
         return s * s;
     } else {
-        const float s = (float)((const int16_t *)in)[m] * i16_scale;
+        const float s = i16_to_float((int)((const int16_t *)in)[m], i16_scale);
         return s * s;
     }
 }
@@ -253,7 +265,7 @@ __device__ __forceinline__ float env_of(typename RawOf<KIND>::T v, float i16_sca
     } else if constexpr (KIND == IN_REAL_F32_SQ) {
         return v * v;
     } else {
-        const float s = (float)v * i16_scale;
+        const float s = i16_to_float((int)v, i16_scale);
         return s * s;
     }
 }

@@ -110,7 +110,7 @@ __device__ __forceinline__ void lean_take(float (&x)[4], float i16_scale) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if constexpr (KIND == IN_I16_SQ) {
-                const float sv = (float)__float_as_int(w[j]) * i16_scale;   // (global_load_sshort sign-extends into the register)
+                const float sv = i16_to_float(__float_as_int(w[j]), i16_scale);   // (global_load_sshort sign-extends into the register)
                 x[j] = sv * sv;
             } else {
                 x[j] = w[j] * w[j];   // IN_REAL_F32_SQ

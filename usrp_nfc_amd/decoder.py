@@ -74,32 +74,26 @@ else:
 
     class decoder(object):
         def __init__(self, src="uhd", dst=None, repeat=False, reader=True, tag=True, samp_rate=2e6, emulator=None,
-                     wav_scale=1.0 / 32768.0, fsm=None, batch=1 << 22, device=0):
+                     wav_scale=0.0, fsm=None, batch=1 << 22, device=0, lo_val=0.1, av_window=2000, max_len=50, keep=None):
+            """wav_scale: int16 PCM -> float.  0 (default): GNU Radio's wavfile_source normalisation, sample / 32767 (what the
+            reference's WAV branch feeds the path, decoder.py:25; third party, unpinned: nfc_amd.h); > 0: sample * wav_scale.
+            lo_val / av_window / max_len: transition_sink's keyword arguments (transition_sink.py:12), e.g. scaled with the rate."""
             if isinstance(src, str) and src == "uhd":
                 raise RuntimeError('the UHD source needs GNU Radio + UHD; pass a recording or an array')
             data, kind, scale = _load_source(src, wav_scale)
             self._data = data
             self._per = 2 if kind == api.NFC_IN_IQ_F32 else 1
             hi_val = 1.1 if kind == api.NFC_IN_IQ_F32 else 1.09   # decoder.py:23 / :29
-            self._back = background(reader, tag, emulator, fsm=fsm)
-            self._trans = transition_sink(samp_rate, self._back.append, hi_val=hi_val, batch=batch, device=device,
-                                          input_kind=kind)
-            if kind == api.NFC_IN_I16_SQ and scale:
-                # the context was created with the default scale; recreate with the requested one
-                self._trans._ctx.close()
-                self._trans._ctx = api.NfcContext(samp_rate=samp_rate, hi_val=hi_val, reader=reader, tag=tag,
-                                                  input_kind=kind, device=device, i16_scale=scale)
+            self._back = background(reader, tag, emulator, fsm=fsm, keep=keep)
+            self._trans = transition_sink(samp_rate, self._back.append, lo_val=lo_val, hi_val=hi_val, av_window=av_window, max_len=max_len,
+                                          batch=batch, device=device, input_kind=kind, i16_scale=scale if kind == api.NFC_IN_I16_SQ else 0.0)
             self._batch = int(batch)
 
         def run(self):
             """Stream the source through the path (what ``tb.run()`` does in usrp_nfc.py:170)."""
             step = self._batch * self._per
-            ts = self._trans
             for i in range(0, len(self._data), step):
-                piece = self._data[i:i + step]
-                ts._ctx.push(piece)
-                ts._callback(ts._ctx.transitions() if ts._want_list else [])
-                ts._back._deliver(ts._ctx)
+                self._trans.push_now(self._data[i:i + step])
             return self._back
 
         @property

@@ -1,30 +1,47 @@
 """The reference's ``utilities`` names that the path and the protocol layer use (utilities.py:7-78): status codes and
-pulse lengths as constants, CRC_A through the shared library (csrc/protocol.h: nfc_crc_a), byte <-> bit conversion."""
+pulse lengths as constants, the ISO 14443 CRCs, byte <-> bit conversion."""
 
 
-def _constants(name, doc, **values):
-    return type(name, (object,), dict(values, __doc__=doc))
+class ErrorCode:
+    """in-band decoder status codes (utilities.py:7-14)"""
+    NO_ERROR = 0
+    TOO_SHORT = 2
+    TOO_LONG = 3
+    ENCODING = 4
+    INTERNAL = 5
+    WRONG_DUR = 6
+    GENERAL = 7
 
 
-ErrorCode = _constants('ErrorCode', 'in-band decoder status codes (utilities.py:7-14)',
-                       NO_ERROR=0, TOO_SHORT=2, TOO_LONG=3, ENCODING=4, INTERNAL=5, WRONG_DUR=6, GENERAL=7)
+class PulseLength:
+    """microseconds, with the expressions of utilities.py:17-23 (the doubles must come out the same)"""
+    FULL = 9.44            # one bit period at 106 kbit/s
+    ZERO = 3.00            # a Modified-Miller pause
+    HALF = FULL / 2
+    ZERO_REM = FULL - ZERO
+    ONE_REM = HALF - ZERO
+    ONE_HALF = FULL + HALF
 
-_BIT_US = 9.44     # one bit period at 106 kbit/s
-_PAUSE_US = 3.00   # a Modified-Miller pause
-PulseLength = _constants('PulseLength', 'microseconds, with the expressions of utilities.py:17-23 (the doubles must be the same)',
-                         FULL=_BIT_US, ZERO=_PAUSE_US, HALF=_BIT_US / 2, ZERO_REM=_BIT_US - _PAUSE_US,
-                         ONE_REM=_BIT_US / 2 - _PAUSE_US, ONE_HALF=_BIT_US + _BIT_US / 2)
 
-
-class CRC:   # utilities.py:26-46; only type A is on this path
+class CRC:
+    """ISO/IEC 14443-3 CRCs (utilities.py:26-46): the reflected CCITT polynomial (0x8408), preset 0x6363 for type A, preset
+    0xFFFF and a complemented result for type B; low byte first."""
     CRC_14443_A = 0x6363
+    CRC_14443_B = 0xFFFF
 
     @staticmethod
     def calculate_crc(data, cktp=0x6363):
-        if cktp != CRC.CRC_14443_A:
-            raise ValueError('only CRC_A is implemented')
-        from .fsm import crc_a
-        return crc_a(data)
+        if cktp == CRC.CRC_14443_A:
+            from .fsm import crc_a     # the shared library's (csrc/protocol.h: nfc_crc_a), pinned by the reference's traces
+            return crc_a(data)
+        reg = cktp & 0xFFFF
+        for byte in data:
+            reg ^= byte & 0xFF
+            for _ in range(8):
+                reg = (reg >> 1) ^ 0x8408 if reg & 1 else reg >> 1
+        if cktp == CRC.CRC_14443_B:
+            reg ^= 0xFFFF
+        return [reg & 0xFF, (reg >> 8) & 0xFF]
 
     @staticmethod
     def check_crc(data, cktp=0x6363):
