@@ -150,6 +150,11 @@ int nfc_push(nfc_ctx *ctx, const void *host_samples, size_t n);
 int nfc_push_device(nfc_ctx *ctx, const void *dev_samples, size_t n);
 /* Wait for the device; outputs of the last push are complete after it. */
 int nfc_sync(nfc_ctx *ctx);
+/* The decode and framing stages alone, for a caller that already has transitions (what background.append receives,
+ * background.py:27-28: entries as nfc_read_edges returns them -- v, d in samples, t the route -1 / 0 / 1; idx only labels
+ * the packets): Modified-Miller / Manchester decoding and packet framing on the GPU with the context's decoder and framing
+ * state carried on, results through nfc_read_symbols / nfc_read_packets.  The threshold state is not touched. */
+int nfc_push_edges(nfc_ctx *ctx, const nfc_edge *host_edges, size_t n);
 /* Enqueue this context's work on the caller's HIP stream (hipStream_t; NULL: back to the context's own), so that what the
  * caller enqueues there next -- a collective on the exported boundary states -- needs no host wait in between. */
 int nfc_set_stream(nfc_ctx *ctx, void *stream);

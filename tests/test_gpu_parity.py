@@ -216,3 +216,99 @@ def test_random_parameters_many_chunks(seed):
     check_vs_oracle(iq, params, kind=api.NFC_IN_IQ_F32)
     cuts = sorted(set([0, n] + rng.integers(0, n, 4).tolist() + [int(rng.integers(0, min(n, 3000)))]))
     check_vs_oracle(iq, params, kind=api.NFC_IN_IQ_F32, pushes=cuts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tagname,rate', [('1', 1e6), ('0p5', 2e6), ('0p25', 4e6), ('0p1', 10e6), ('frames_0p5', 2e6), ('frames_0p25', 4e6)])
+def test_decode_kernels_on_decoder_vectors(tagname, rate):
+    # the reference's decoder-only vectors (6 000 random (cur, d) pairs per rate with every error branch, and whole frames)
+    # straight into k_dec_reduce / k_dec_apply / k_frame_write through nfc_push_edges -- interleaved runs of both routes, in
+    # several calls (decoder and framing state carried on the device); symbols against the reference's, packets against its
+    # PacketProcessor restated (oracle)
+    from oracle import py_oracle as po
+    from usrp_nfc_amd import api
+    from tests.golden_util import load_npz
+    z = load_npz('fx_decoder_vectors.npz')
+    dm = z['dm_' + tagname] if 'dm_' + tagname in z else z['d_' + tagname]
+    dt = z['dt_' + tagname] if 'dt_' + tagname in z else z['d_' + tagname]
+    cm, ct = z['curm_' + tagname], z['curt_' + tagname]
+    rng = np.random.default_rng(5)
+    rows, im, it, idx = [], 0, 0, 0
+    while im < len(cm) or it < len(ct):   # runs of 1..40 entries, routes alternating, idle entries sprinkled in
+        for (cur, d, route) in ((cm, dm, 1), (ct, dt, 0)):
+            pos = im if route == 1 else it
+            k = int(rng.integers(1, 41))
+            for j in range(pos, min(pos + k, len(cur))):
+                rows.append((idx, int(d[j]), int(cur[j]), route, 0))
+                idx += 7
+            if route == 1:
+                im = min(pos + k, len(cur))
+            else:
+                it = min(pos + k, len(cur))
+            if rng.random() < 0.3:
+                rows.append((idx, 50, 0, -1, 0))   # an idle heartbeat: dropped by the router (background.py:30-35)
+                idx += 7
+    edges = np.array(rows, dtype=api.EDGE_DTYPE)
+    sink = po.BitSink()
+    mil, man = po.MillerDecoder(sink), po.ManchesterDecoder(sink)
+    factor = 1e6 / rate
+    for r in rows:
+        if r[3] == 1:
+            mil.process_transition([(r[2], r[1] * factor)])
+        elif r[3] == 0:
+            man.process_transition([(r[2], r[1] * factor)])
+    with api.NfcContext(samp_rate=rate, max_len=50) as ctx:
+        sym = {0: [], 1: []}
+        packets = []
+        cuts = [0, 1, 17, len(edges) // 3, len(edges) // 3 + 4097, len(edges)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ctx.push_edges(edges[a:b])
+            for t in (0, 1):
+                sym[t] += ctx.symbols(t).tolist()
+            packets += ctx.packets()
+    assert sym[1] == z['symm_' + tagname].tolist()
+    assert sym[0] == z['symt_' + tagname].tolist()
+    assert sym[1] == sink.symbols[1] and sym[0] == sink.symbols[0]
+    want = [(t, b) for t, b in sink.packets]
+    # packets of the two routes close in stream order of their closing entries
+    assert sorted(packets) == sorted(want) and len(want) >= (10 if tagname.startswith("frames") else 1)
+    assert [p for p in packets if p[0] == 1] == [p for p in want if p[0] == 1]
+    assert [p for p in packets if p[0] == 0] == [p for p in want if p[0] == 0]
+
+
+@pytest.mark.gpu
+def test_window_at_the_upper_bound():
+    # av_window 30000 (the largest nfc_create accepts: ring in global memory), max_len 750, 10 Msps
+    from oracle import c_oracle as co
+    from usrp_nfc_amd import api, synth
+    params = dict(samp_rate=10e6, hi_val=1.1, av_window=30000, max_len=750)
+    frames = synth.txn_frames()
+    m = synth.tiled_profile(synth.modulation_profile(frames, rate_msps=10.0, lead_in=0, tail=0), 1_500_000, lead_in=40000)
+    iq = synth.iq_from_profile(m, seed=3)
+    o = co.COracle(**params)
+    o.push_iq(iq)
+    with api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **params) as ctx:
+        ctx.push(iq[:2 * 700_001])
+        tr = ctx.transitions()
+        pk = ctx.packets()
+        ctx.push(iq[2 * 700_001:])
+        tr += ctx.transitions()
+        pk += ctx.packets()
+    assert tr == o.transitions() and pk == o.packets() and len(pk) > 10
+
+
+@pytest.mark.gpu
+def test_rejected_launch_is_reported(monkeypatch):
+    # a launch the runtime refuses leaves no trace in the stream: without the check behind every launch (launch_check.h) the
+    # push would return the previous batch's totals out of the host's mirror
+    from usrp_nfc_amd import api, synth
+    iq = synth.workload('miller', 300_000)
+    with api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        ctx.push(iq)
+        n_good = len(ctx.edges())
+        monkeypatch.setenv('NFC_DEBUG_BAD_LAUNCH', '1')
+        with pytest.raises(api.NfcError) as e:
+            ctx.push(iq)
+        assert 'kernel launch failed' in str(e.value)
+        monkeypatch.delenv('NFC_DEBUG_BAD_LAUNCH')
+    assert n_good > 1000

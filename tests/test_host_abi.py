@@ -92,3 +92,12 @@ def test_wavfile_source_normalisation_is_the_ieee_quotient():
     sc = np.float32(1.0 / 32768.0)
     got2 = np.array([L.nfc_host_i16_to_float(int(k), float(sc)) for k in v[::257]], np.float32)
     assert np.array_equal(got2, (v[::257].astype(np.float32) * sc).astype(np.float32))
+
+
+def test_window_beyond_the_upper_bound_is_refused():
+    # argument checks come before any device work: this holds without a GPU
+    from usrp_nfc_amd import api
+    for kw in (dict(av_window=30001), dict(av_window=0), dict(max_len=4001), dict(samp_rate=-1.0)):
+        with pytest.raises(api.NfcError) as e:
+            api.NfcContext(**kw)
+        assert 'av_window' in str(e.value) or 'max_len' in str(e.value) or 'samp_rate' in str(e.value)

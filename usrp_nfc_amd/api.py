@@ -77,6 +77,12 @@ class NfcContext(object):
         return n
 
     # -- outputs of the last push -----------------------------------------------
+    def push_edges(self, edges):
+        """Transitions (EDGE_DTYPE rows: idx, d in samples, v, t) through the decode and framing stages alone (nfc_push_edges) --
+        what background.append receives in the reference."""
+        e = np.ascontiguousarray(edges, EDGE_DTYPE)
+        self._chk(self.L.nfc_push_edges(self.h, e.ctypes.data if len(e) else None, len(e)), 'nfc_push_edges')
+
     def counts(self):
         c = _lib.Counts()
         self._chk(self.L.nfc_get_counts(self.h, C.byref(c)), 'nfc_get_counts')

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/nfc_amd.h"
+#include "launch_check.h"
 #include "decode.hip.h"
 #include "decoder_tables.h"
 #include "edges.hip.h"
@@ -115,6 +116,8 @@ struct DevState {
     EdgeCarry ecarry;
     DecCarry dcarry;
     uint8_t totals[TOT_BYTES];
+    uint32_t seq[4];   // seq[0]: the batch the block belongs to, stamped by the batch's first kernel (k_fill): a mirror that
+                       // does not carry the current number was not written by this batch's kernels
 };
 
 struct nfc_ctx {
@@ -144,6 +147,7 @@ struct nfc_ctx {
     DecCarry dirty_dcarry;
     bool cert_pending = false;   // the first certification waits to share a launch with the edge stage (k_certify_and_count)
     CertLaunch cert;
+    uint32_t batch_seq = 0;   // stamped into the state block by every batch's first kernel, checked in the mirror
     int timing = 0;   // 0: no events, 1: the threshold kernels' own start / stop events, 2: + batch total and stages as stream markers (nfc_set_timing)
     hipEvent_t kev[2 * 6] = {};  // start/stop pairs around the first k_threshold launches of a batch
     int n_kev = 0;
@@ -238,7 +242,7 @@ __global__ void k_set_state(DevState *d, Carry a, EdgeCarry b, DecCarry e, int z
         for (int i = 0; i < TOT_BYTES; i++) d->totals[i] = 0;
 }
 inline void launch_set_state(nfc_ctx *c, int zero_totals, bool fill_ring, float fill) {
-    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(256), 0, c->st, (DevState *)c->d_state.p, c->h_carry, c->h_ecarry, c->h_dcarry,
+    NFC_LAUNCH(k_set_state, dim3(1), dim3(256), 0, c->st, (DevState *)c->d_state.p, c->h_carry, c->h_ecarry, c->h_dcarry,
                        zero_totals, fill_ring ? c->d_ring[c->ring_cur].as<float>() : (float *)nullptr, fill_ring && fill != 0.f ? c->L : c->Lpad,
                        fill);
 }
@@ -260,7 +264,7 @@ inline void push_state(nfc_ctx *c, int zero_totals = 0, bool fill_ring = false, 
 }
 inline void flush_state(nfc_ctx *c) {
     if (!c->state_dirty) return;
-    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(256), 0, c->st, (DevState *)c->d_state.p, c->dirty_carry, c->dirty_ecarry, c->dirty_dcarry, 0,
+    NFC_LAUNCH(k_set_state, dim3(1), dim3(256), 0, c->st, (DevState *)c->d_state.p, c->dirty_carry, c->dirty_ecarry, c->dirty_dcarry, 0,
                        c->dirty_fill_ring ? c->d_ring[c->ring_cur].as<float>() : (float *)nullptr,
                        c->dirty_fill_ring && c->dirty_fill != 0.f ? c->L : c->Lpad, c->dirty_fill);
     c->state_dirty = c->dirty_fill_ring = false;
@@ -282,6 +286,24 @@ __global__ void k_pack_state(uint8_t *dst, const float *ring, int L, const uint8
             return fail((c), NFC_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
     } while (0)
 
+// A kernel launch of this batch was rejected by the runtime (launch_check.h), or -- with_mirror -- the host's mirror of the
+// state block was not written by this batch's kernels: nothing the host would read next can be trusted.
+int batch_ok(nfc_ctx *c, bool with_mirror) {
+    LaunchError &le = launch_error();
+    if (le.err != hipSuccess) {
+        const LaunchError e = le;
+        le = LaunchError{};
+        return fail(c, NFC_ERR_DEVICE, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e.err), e.file, e.line);
+    }
+    if (with_mirror && c->hs->seq[0] != c->batch_seq)
+        return fail(c, NFC_ERR_DEVICE, "state mirror is stale (batch %u, mirror %u): a kernel of this batch did not run", c->batch_seq, c->hs->seq[0]);
+    return NFC_OK;
+}
+#define BATCHCHK(c, with_mirror)                                   \
+    do {                                                           \
+        if (int rc__ = batch_ok((c), (with_mirror))) return rc__;  \
+    } while (0)
+
 // Timed launches (nfc_set_timing >= 1) hand the kernel its own start / stop events (hipExtLaunchKernelGGL): the
 // events take the kernel's begin and end, not the position of a marker in the stream, so they neither measure nor add
 // inter-launch gaps.
@@ -291,22 +313,23 @@ void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e
     const uint32_t blocks = (nwork + wpb - 1) / wpb;
     const size_t lds = c->gring ? 0 : (size_t)wpb * c->Lpad * c->lds_per_slot;
     if (e0) {
-        if (c->gring) hipExtLaunchKernelGGL((k_threshold<KIND, 4, true>), dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
-        else hipExtLaunchKernelGGL((k_threshold<KIND, 4, false>), dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
+        if (c->gring) NFC_LAUNCH_EXT((k_threshold<KIND, 4, true>), dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
+        else NFC_LAUNCH_EXT((k_threshold<KIND, 4, false>), dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
         return;
     }
-    if (c->gring) hipLaunchKernelGGL((k_threshold<KIND, 4, true>), dim3(blocks), dim3(64 * wpb), lds, c->st, A);
-    else hipLaunchKernelGGL((k_threshold<KIND, 4, false>), dim3(blocks), dim3(64 * wpb), lds, c->st, A);
+    if (c->gring) NFC_LAUNCH((k_threshold<KIND, 4, true>), dim3(blocks), dim3(64 * wpb), lds, c->st, A);
+    else NFC_LAUNCH((k_threshold<KIND, 4, false>), dim3(blocks), dim3(64 * wpb), lds, c->st, A);
 }
 // Pass 0 with the LDS ring: the lean optimistic kernel (threshold_lean.hip.h); chunks it gives up on are re-run by k_threshold.
 template <int KIND>
 void launch_lean(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipEvent_t e1) {
     const uint32_t wpb = (uint32_t)c->wpb;
     const uint32_t blocks = (nwork + wpb - 1) / wpb;
-    const size_t lds = (size_t)wpb * c->Lpad * c->lds_per_slot;
+    // (NFC_DEBUG_BAD_LAUNCH: a dynamic-LDS request the runtime must reject -- the test of the launch checks)
+    const size_t lds = (size_t)wpb * c->Lpad * c->lds_per_slot + (getenv("NFC_DEBUG_BAD_LAUNCH") ? (size_t)1 << 20 : 0);
     auto go = [&](auto kern) {
-        if (e0) hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
-        else hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, A);
+        if (e0) NFC_LAUNCH_EXT(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
+        else NFC_LAUNCH(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, A);
     };
     switch (c->lean_k) {
     case 2: go(k_threshold_lean<KIND, 2>); break;
@@ -357,18 +380,18 @@ void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n, int nchunks) {
         c->state_dirty = c->dirty_fill_ring = false;
     }
     switch (c->P.input_kind) {
-    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_fill<IN_IQ_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init); break;
-    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_fill<IN_ENV_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init); break;
-    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init); break;
-    default: hipLaunchKernelGGL((k_fill<IN_I16_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init); break;
+    case NFC_IN_IQ_F32: NFC_LAUNCH((k_fill<IN_IQ_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq); break;
+    case NFC_IN_ENV_F32: NFC_LAUNCH((k_fill<IN_ENV_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq); break;
+    case NFC_IN_REAL_F32_SQ: NFC_LAUNCH((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq); break;
+    default: NFC_LAUNCH((k_fill<IN_I16_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq); break;
     }
 }
 void launch_seq_kind(nfc_ctx *c, const SeqArgs &A) {
     switch (c->P.input_kind) {
-    case NFC_IN_IQ_F32: hipLaunchKernelGGL((k_threshold_seq<IN_IQ_F32>), dim3(1), dim3(64), 0, c->st, A); break;
-    case NFC_IN_ENV_F32: hipLaunchKernelGGL((k_threshold_seq<IN_ENV_F32>), dim3(1), dim3(64), 0, c->st, A); break;
-    case NFC_IN_REAL_F32_SQ: hipLaunchKernelGGL((k_threshold_seq<IN_REAL_F32_SQ>), dim3(1), dim3(64), 0, c->st, A); break;
-    default: hipLaunchKernelGGL((k_threshold_seq<IN_I16_SQ>), dim3(1), dim3(64), 0, c->st, A); break;
+    case NFC_IN_IQ_F32: NFC_LAUNCH((k_threshold_seq<IN_IQ_F32>), dim3(1), dim3(64), 0, c->st, A); break;
+    case NFC_IN_ENV_F32: NFC_LAUNCH((k_threshold_seq<IN_ENV_F32>), dim3(1), dim3(64), 0, c->st, A); break;
+    case NFC_IN_REAL_F32_SQ: NFC_LAUNCH((k_threshold_seq<IN_REAL_F32_SQ>), dim3(1), dim3(64), 0, c->st, A); break;
+    default: NFC_LAUNCH((k_threshold_seq<IN_I16_SQ>), dim3(1), dim3(64), 0, c->st, A); break;
     }
 }
 
@@ -593,7 +616,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             // summary in the mirrored state block; later rounds (after re-runs) read the per-chunk flags
             CertSummary *d_sum = (CertSummary *)(tot + TOT_CERT);
             auto launch_certify = [&]() {
-                hipLaunchKernelGGL(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, d_cert,
+                NFC_LAUNCH(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, d_cert,
                                    dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[1 - c->ring_cur].as<float>(), dC(c),
                                    first_round ? d_sum : (CertSummary *)nullptr);
             };
@@ -620,6 +643,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 }
             }
             HIPCHK(c, hipStreamSynchronize(c->st));
+            BATCHCHK(c, true);   // (the verdict summary and the totals are about to be read out of the mirror)
             std::vector<uint32_t> failing;
             if (first_round) {
                 memcpy(&summary, c->hs->totals + TOT_CERT, sizeof summary);
@@ -701,6 +725,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
             HIPCHK(c, mirror_async(c));
             HIPCHK(c, hipStreamSynchronize(c->st));
+            BATCHCHK(c, true);
             std::vector<uint32_t> hv(nch);
             HIPCHK(c, hipMemcpy(hv.data(), c->d_gvtop.p, (size_t)nch * 4, hipMemcpyDeviceToHost));
             for (uint32_t k = 0; k < nch; k++) {
@@ -733,7 +758,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     if (!need_seq) {
         // the end-of-batch ring was resolved beside the last certification unless chunks were re-run after it
         if (passes > 1 || nch == 1)
-            hipLaunchKernelGGL(k_finalize_state, dim3(1), dim3(FIN_BLOCK), 0, c->st, A, c->d_ring[1 - c->ring_cur].as<float>(), dC(c));
+            NFC_LAUNCH(k_finalize_state, dim3(1), dim3(FIN_BLOCK), 0, c->st, A, c->d_ring[1 - c->ring_cur].as<float>(), dC(c));
         c->ring_cur = 1 - c->ring_cur;
         *clean = ran_ahead && passes == 1;
     }
@@ -850,7 +875,7 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
         scan_partials<Last2Op>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials.as<Last2>(), Last2Op::identity(), last2_total);
     if (c->cert_pending && tiles) {
         c->cert_pending = false;
-        hipLaunchKernelGGL(k_certify_and_count, dim3((unsigned)(c->cert.blocks + tiles)), dim3(256), 0, c->st, c->cert, nwords, LoadLast2{E},
+        NFC_LAUNCH(k_certify_and_count, dim3((unsigned)(c->cert.blocks + tiles)), dim3(256), 0, c->st, c->cert, nwords, LoadLast2{E},
                            StoreCtxAndEvents{E, ctx, evm}, c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>(), own, last2_total);
     } else {
         scan_apply_sum<Last2Op, EW_ITEMS, AddU32>(c->st, nwords, nullptr, LoadLast2{E}, StoreCtxAndEvents{E, ctx, evm},
@@ -863,7 +888,7 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     HIPCHK(c, c->d_edges.ensure(((size_t)cap + 1) * sizeof(nfc_edge)));
     HIPCHK(c, c->d_ecode.ensure(((size_t)cap + 8) * 2));
     if (nwords)
-        hipLaunchKernelGGL(k_write_edges, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, ctx, evm,
+        NFC_LAUNCH(k_write_edges, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, ctx, evm,
                            c->d_partials2.as<uint32_t>(), c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), cap, own, edges_total,
                            last2_total, dE(c));
     return NFC_OK;
@@ -929,9 +954,9 @@ int run_decode(nfc_ctx *c) {
     PktCnt *pk_total = (PktCnt *)(tot + TOT_PKT0);
     if (tiles) {
         if (lds_tables)
-            hipLaunchKernelGGL(k_dec_reduce<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
+            NFC_LAUNCH(k_dec_reduce<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
         else
-            hipLaunchKernelGGL(k_dec_reduce<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
+            NFC_LAUNCH(k_dec_reduce<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
     }
     const bool own = tiles <= c->own_prefix_max;   // (scan.hip.h: tile_prefix -- no prefix launches while the tiles are few)
     DecMaps *map_total = (DecMaps *)(tot + TOT_DECMAP);
@@ -940,14 +965,14 @@ int run_decode(nfc_ctx *c) {
     if (!own) scan_partials<ComposeDec>(c->st, tiles, ne_dev, DEC_TILE, dparts, ComposeDec::identity_host(), map_total);
     if (tiles) {
         if (lds_tables)
-            hipLaunchKernelGGL(k_dec_apply<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
+            NFC_LAUNCH(k_dec_apply<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
                                dec_state_in, outw, fparts, c->d_faggs.as<FramePk>(), own, map_total);
         else
-            hipLaunchKernelGGL(k_dec_apply<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
+            NFC_LAUNCH(k_dec_apply<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
                                dec_state_in, outw, fparts, c->d_faggs.as<FramePk>(), own, map_total);
     }
     if (!own) scan_partials<FrameAggOp>(c->st, tiles, ne_dev, DEC_TILE, fparts, FrameAggOp::identity(), frame_total, epi);
-    hipLaunchKernelGGL(k_frame_write, dim3((unsigned)std::max<size_t>(tiles, 1)), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts,
+    NFC_LAUNCH(k_frame_write, dim3((unsigned)std::max<size_t>(tiles, 1)), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts,
                        c->d_faggs.as<FramePk>(), P, own, frame_total, epi);
     const int pn = 1 - c->pend_cur;
     PktFinish F;
@@ -969,7 +994,7 @@ int run_decode(nfc_ctx *c) {
     F.mirror_src = (const uint32_t *)c->d_state.p;   // the stage's last launch also fills the host's mirror of the state block
     F.mirror_dst = (uint32_t *)c->hs_dev;
     F.mirror_words = (uint32_t)(sizeof(DevState) / 4);
-    hipLaunchKernelGGL(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
+    NFC_LAUNCH(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
     return NFC_OK;
 }
 
@@ -1021,7 +1046,7 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     A.mirror_src = (const uint32_t *)c->d_state.p;
     A.mirror_dst = (uint32_t *)c->hs_dev;
     A.mirror_words = (uint32_t)(sizeof(DevState) / 4);
-    hipLaunchKernelGGL(k_small_stage, dim3(1), dim3(SM_BLOCK), 0, c->st, A);
+    NFC_LAUNCH(k_small_stage, dim3(1), dim3(SM_BLOCK), 0, c->st, A);
     return NFC_OK;
 }
 
@@ -1043,6 +1068,8 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         return NFC_OK;
     }
     if (((uintptr_t)d_in & 15u) != 0) return fail(c, NFC_ERR_ARG, "device input must be 16-byte aligned");
+    c->batch_seq++;
+    launch_error() = LaunchError{};   // (a failure nobody reported belongs to an earlier call)
     if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[0], c->st));
 
     uint32_t skip = 0;
@@ -1067,6 +1094,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         }
         HIPCHK(c, mirror_async(c));
         HIPCHK(c, hipStreamSynchronize(c->st));
+        BATCHCHK(c, fills);
         c->h_carry = c->hs->carry;
         c->nseen += n;
         c->have_outputs = true;
@@ -1095,7 +1123,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         if (c->use_small && n <= SM_MAX_SAMPLES) {   // a short batch: one launch for the three stages
             if (c->cert_pending) {   // the certification (and the end-of-batch state) first: the stage's launch is the last, and mirrors the state
                 c->cert_pending = false;
-                hipLaunchKernelGGL(k_certify, dim3(c->cert.blocks), dim3(256), 0, c->st, c->cert.A, c->cert.cert, (CertInfo *)nullptr,
+                NFC_LAUNCH(k_certify, dim3(c->cert.blocks), dim3(256), 0, c->st, c->cert.A, c->cert.cert, (CertInfo *)nullptr,
                                    c->cert.ring_next, c->cert.carry, c->cert.sum);
             }
             const int r = run_small(c, n, skip, g0);
@@ -1121,6 +1149,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
                 if (rc) return rc;
                 HIPCHK(c, hipStreamSynchronize(c->st));
             }
+            BATCHCHK(c, true);
             uint32_t ne, ns[2];
             memcpy(&ne, c->hs->totals + TOT_EDGES, 4);
             memcpy(ns, c->hs->totals + TOT_NSYM, 8);
@@ -1153,6 +1182,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         }
         HIPCHK(c, mirror_async(c));
         HIPCHK(c, hipStreamSynchronize(c->st));
+        BATCHCHK(c, true);
     }
     if (c->timing >= 2) {
         HIPCHK(c, hipEventRecord(c->ev[4], c->st));
@@ -1432,6 +1462,62 @@ int nfc_push(nfc_ctx *c, const void *host_samples, size_t n) {
     return process_batch(c, c->d_in.p, n);
 }
 
+int nfc_push_edges(nfc_ctx *c, const nfc_edge *host_edges, size_t n64) {
+    if (!c) return NFC_ERR_ARG;
+    if (n64 && !host_edges) return fail(c, NFC_ERR_ARG, "null input");
+    if (n64 > 0xFFFFFF00ull) return fail(c, NFC_ERR_ARG, "too many edges for one call");
+    if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
+    const uint32_t n = (uint32_t)n64;
+    c->have_outputs = false;
+    c->pk_ready[0] = c->pk_ready[1] = false;
+    c->n_edges = 0;
+    for (int t = 0; t < 2; t++) c->n_sym[t] = c->n_close[t] = c->n_bits[t] = 0;
+    memset(&c->stats, 0, sizeof c->stats);
+    c->last_n = 0;
+    launch_error() = LaunchError{};
+    flush_state(c);
+    // the entries and their decoder codes (edges.hip.h: edge_code) as the edge stage would have left them
+    std::vector<uint16_t> code(n + 8, 0);
+    const int nd = c->mx + 1;
+    for (uint32_t i = 0; i < n; i++) {
+        const nfc_edge &e = host_edges[i];
+        if (e.v < -1 || e.v > 2 || e.t < -1 || e.t > 1 || e.d < 0) return fail(c, NFC_ERR_ARG, "edge %u out of range", i);
+        const int dd = e.d < nd ? e.d : nd - 1;
+        code[i] = (uint16_t)(((e.v + 1) * nd + dd) | ((e.t + 1) << 14));
+    }
+    c->cap_edges = n;
+    for (int t = 0; t < 2; t++) c->cap_sym[t] = (t == 1 ? 2u : 1u) * n + 16;
+    HIPCHK(c, c->d_edges.ensure(((size_t)n + 1) * sizeof(nfc_edge)));
+    HIPCHK(c, c->d_ecode.ensure(((size_t)n + 8) * 2));
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->d_edges.p, host_edges, (size_t)n * sizeof(nfc_edge), hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->d_ecode.p, code.data(), (size_t)n * 2, hipMemcpyHostToDevice, c->st));
+    }
+    HIPCHK(c, hipMemcpyAsync(dT(c) + TOT_EDGES, &n, 4, hipMemcpyHostToDevice, c->st));
+    const int rc = run_decode(c);   // k_dec_reduce -> k_dec_apply -> k_frame_write -> k_pkt_finish (mirrors the state block)
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    BATCHCHK(c, false);
+    uint32_t ns[2];
+    memcpy(ns, c->hs->totals + TOT_NSYM, 8);
+    c->n_edges = n;
+    c->n_sym[0] = ns[0];
+    c->n_sym[1] = ns[1];
+    const EdgeCarry keep = c->h_ecarry;
+    adopt_mirror(c);
+    c->h_ecarry = keep;
+    uint64_t pk[2];
+    memcpy(&pk[0], c->hs->totals + TOT_PKT0, 8);
+    memcpy(&pk[1], c->hs->totals + TOT_PKT1, 8);
+    for (int t = 0; t < 2; t++) {
+        c->n_bits[t] = (uint32_t)pk[t];
+        c->n_close[t] = (uint32_t)(pk[t] >> 32);
+    }
+    c->pend_cur = 1 - c->pend_cur;
+    c->have_outputs = true;
+    return NFC_OK;
+}
+
 int nfc_sync(nfc_ctx *c) {
     if (!c) return NFC_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->st));
@@ -1610,7 +1696,7 @@ int nfc_export_state(nfc_ctx *c, void *device_dst, size_t cap, size_t *len_out) 
     const size_t p0 = h.n_pending_bits[0], p1 = h.n_pending_bits[1];
     const size_t len = sizeof h + (size_t)c->L * 4 + p0 + p1;
     static_assert(sizeof(nfc_state_header) % 4 == 0, "ring must stay 4-byte aligned behind the header");
-    hipLaunchKernelGGL(k_export_state, dim3(4), dim3(256), 0, c->st, (uint8_t *)device_dst, (uint32_t)len, (int)(16 + len <= cap), h,
+    NFC_LAUNCH(k_export_state, dim3(4), dim3(256), 0, c->st, (uint8_t *)device_dst, (uint32_t)len, (int)(16 + len <= cap), h,
                        c->d_ring[c->ring_cur].as<float>(), c->L, c->d_pending[0][c->pend_cur].as<uint8_t>(), (uint32_t)p0,
                        c->d_pending[1][c->pend_cur].as<uint8_t>(), (uint32_t)p1);
     if (len_out) *len_out = len;
@@ -1637,7 +1723,7 @@ int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap,
     if (ring || (pending && p0 + p1)) {
         // gathered on the device (ring | pending bits of type 0 | of type 1), then one copy and one wait
         HIPCHK(c, c->d_pack.ensure(need + 16));
-        hipLaunchKernelGGL(k_pack_state, dim3(4), dim3(256), 0, c->st, c->d_pack.as<uint8_t>(), c->d_ring[c->ring_cur].as<float>(), c->L,
+        NFC_LAUNCH(k_pack_state, dim3(4), dim3(256), 0, c->st, c->d_pack.as<uint8_t>(), c->d_ring[c->ring_cur].as<float>(), c->L,
                            c->d_pending[0][c->pend_cur].as<uint8_t>(), (uint32_t)p0, c->d_pending[1][c->pend_cur].as<uint8_t>(),
                            (uint32_t)p1);
         HIPCHK(c, hipMemcpyAsync(st, c->d_pack.p, need, hipMemcpyDeviceToHost, c->st));
@@ -1863,9 +1949,9 @@ int nfc_tx_render_device(int device, const nfc_tx_run *runs, size_t n_runs, doub
         const unsigned blocks = (unsigned)n_tiles;
         if (kernel_ms) {
             if (bad(hipEventCreate(&e0), "event") || bad(hipEventCreate(&e1), "event")) break;
-            hipExtLaunchKernelGGL(k_tx_render, dim3(blocks), dim3(TX_BLOCK), 0, nullptr, e0, e1, 0, A);
+            NFC_LAUNCH_EXT(k_tx_render, dim3(blocks), dim3(TX_BLOCK), 0, nullptr, e0, e1, 0, A);
         } else {
-            hipLaunchKernelGGL(k_tx_render, dim3(blocks), dim3(TX_BLOCK), 0, nullptr, A);
+            NFC_LAUNCH(k_tx_render, dim3(blocks), dim3(TX_BLOCK), 0, nullptr, A);
         }
         if (bad(hipGetLastError(), "launch")) break;
         if (bad(hipDeviceSynchronize(), "kernel")) break;

@@ -13,6 +13,8 @@
 // single-workgroup partials pass takes an epilogue for the one-thread bookkeeping that follows a scan.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "launch_check.h"
 #include <stdint.h>
 
 namespace nfc {
@@ -282,11 +284,11 @@ template <class Tr, class Epi = NoEpilogue>
 inline void scan_partials(hipStream_t st, size_t tiles, const uint32_t *n_dev, uint32_t tile, typename Tr::T *partials,
                           typename Tr::T seed, typename Tr::T *total_out, Epi epi = Epi()) {
     if (tiles <= 256 * PART_ITEMS)
-        hipLaunchKernelGGL((k_scan_partials<Tr, 256, Epi>), dim3(1), dim3(256), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
+        NFC_LAUNCH((k_scan_partials<Tr, 256, Epi>), dim3(1), dim3(256), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
     else if (tiles <= 512 * PART_ITEMS)
-        hipLaunchKernelGGL((k_scan_partials<Tr, 512, Epi>), dim3(1), dim3(512), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
+        NFC_LAUNCH((k_scan_partials<Tr, 512, Epi>), dim3(1), dim3(512), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
     else
-        hipLaunchKernelGGL((k_scan_partials<Tr, 1024, Epi>), dim3(1), dim3(1024), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
+        NFC_LAUNCH((k_scan_partials<Tr, 1024, Epi>), dim3(1), dim3(1024), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
 }
 
 // The apply pass: every item gets its exclusive prefix; store() returns a count per item and the tile's sum of them
@@ -339,14 +341,14 @@ template <class Tr, int ITEMS, class Load>
 inline void scan_reduce(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, typename Tr::T *partials) {
     const size_t tiles = scan_num_tiles<ITEMS>(n);
     if (tiles)
-        hipLaunchKernelGGL((k_scan_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load, partials);
+        NFC_LAUNCH((k_scan_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load, partials);
 }
 template <class Tr, int ITEMS, class Tr2, class Load, class Store>
 inline void scan_apply_sum(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, const typename Tr::T *partials,
                            typename Tr2::T *sums, bool own_prefix = false, typename Tr::T *total_out = nullptr) {
     const size_t tiles = scan_num_tiles<ITEMS>(n);
     if (tiles)
-        hipLaunchKernelGGL((k_scan_apply_sum<Tr, ITEMS, Tr2, Load, Store>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev,
+        NFC_LAUNCH((k_scan_apply_sum<Tr, ITEMS, Tr2, Load, Store>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev,
                            load, store, partials, sums, own_prefix, total_out);
 }
 

@@ -1225,11 +1225,13 @@ struct StateInit {
 
 template <int KIND>
 __global__ __launch_bounds__(FILL_BLOCK) void k_fill(const void *in, uint32_t n, float i16_scale, int L, float *ring, Carry *carry,
-                                                     EdgeCarryInit eci, uint8_t *ver, int nchunks, CertSummary *sum, StateInit init) {
+                                                     EdgeCarryInit eci, uint8_t *ver, int nchunks, CertSummary *sum, StateInit init,
+                                                     uint32_t *seq_dst, uint32_t seq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ FillRed red;
     float *lr = (float *)smem;
     const int tid = threadIdx.x;
+    if (tid == 0 && seq_dst) *seq_dst = seq;   // this batch's stamp in the state block (the host checks it in its mirror)
     if (init.apply) {
         if (tid < init.n_words) init.dst[tid] = init.words[tid];
         if (init.fill_ring)
