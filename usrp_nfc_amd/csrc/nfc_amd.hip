@@ -126,7 +126,7 @@ struct nfc_ctx {
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
-    int lean = 1, lean_k = 3, lean_rounds = 1;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
+    int lean = 1, lean_k = 0, lean_rounds = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
     int gring_ok = 0, gring_force = 0, wave_slots_g = 0;   // long windows qualify (NFC_RING=lds|global overrides the choice)
@@ -431,7 +431,12 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     // Long windows: the ring of a chunk in global memory frees the LDS and brings the occupancy back to what the registers
     // allow -- worth it when the batch then fills the machine with chunks of many windows each (a chunk pays one window
     // of speculation and two windows of certification traffic): otherwise the LDS ring, with its fewer, longer chunks.
-    c->gring = c->gring_ok && (c->gring_force || (uint64_t)n >= (uint64_t)c->wave_slots_g * 8u * (uint64_t)c->L);
+    // Measured on configs[3] (10 Msps, av_window 10000, 1e9 samples): the lean kernel on the 40 KB LDS ring -- ONE wave per SIMD,
+    // 1024 chunks -- takes 2.3 ms per pass, k_threshold with the ring in global memory at five waves per SIMD 4.7 ms (the delay
+    // line adds a read and a write per sample; a lone wave is bound by its own instruction stream, which the lean kernel
+    // shortened).  So the global ring is only taken on request (NFC_RING=global) or where the lean kernel does not apply.
+    const bool lean_applies = c->lean && c->P.input_kind != NFC_IN_ENV_F32 && c->mx <= 500;
+    c->gring = c->gring_ok && (c->gring_force || (!lean_applies && (uint64_t)n >= (uint64_t)c->wave_slots_g * 8u * (uint64_t)c->L));
     if (!c->P.chunk_samples) {
         const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : c->wave_slots);
         // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps)
@@ -547,7 +552,8 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
         A.nlist = 0;
         A.mode = 0;
         // the lean kernel wherever it applies (LDS ring, more than one chunk: chunk 0's verdict travels with the certification)
-        const bool lean = c->lean && !c->gring && nch > 1 && c->P.input_kind != NFC_IN_ENV_F32;   // (raw envelopes may be negative: no sign bit to spare)
+        const bool lean = lean_applies && !c->gring && nch > 1;   // (raw envelopes may be negative: no sign bit to spare;
+                                                                    // max_len beyond 500 samples: not exercised, left to k_threshold)
         A.cert = d_cert;
         A.sum = (CertSummary *)(dT(c) + TOT_CERT);
         A.ksteps = c->lean_rounds;
@@ -1284,6 +1290,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     c->rows_per_step = 4;
     c->use_small = getenv("NFC_NO_SMALL") ? 0 : 1;
     if (const char *e = getenv("NFC_LEAN")) c->lean = atoi(e) != 0;
+    c->lean_k = 0;        // chosen below from the occupancy the LDS ring allows, unless set here
+    c->lean_rounds = 0;
     if (const char *e = getenv("NFC_LEAN_K")) c->lean_k = std::min(4, std::max(2, atoi(e)));   // (one step ahead does not survive the compiler: tools/audit_lean_isa.py)
     if (const char *e = getenv("NFC_LEAN_ROUNDS")) c->lean_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("NFC_LEAN_GFAC")) c->lean_gfac = (float)atof(e);
@@ -1352,6 +1360,11 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         const size_t lds_wave = (size_t)c->Lpad * c->lds_per_slot;
         int per_cu = (int)std::min<size_t>(20, (size_t)(160 * 1024) / (lds_wave * c->wpb) * c->wpb);   // LDS- and VGPR-bound
         c->wave_slots = std::max(1, prop.multiProcessorCount * std::max(1, per_cu));
+        // lean kernel: four steps ahead (104 registers) where the LDS ring leaves a SIMD at most four waves anyway, else three
+        // (96: five waves); a superstep long enough that its fixed cost fades -- the drift allowance grows with its length
+        // relative to the window, kept near the default window's (768 samples of 2000)
+        if (!c->lean_k) c->lean_k = per_cu <= 16 ? 4 : 3;
+        if (!c->lean_rounds) c->lean_rounds = std::max(1, (int)(0.4 * c->L / (256.0 * c->lean_k)));
         c->wave_slots_g = prop.multiProcessorCount * 20;   // VGPR-bound: five waves per SIMD
     }
     CRT(hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking));
