@@ -126,7 +126,7 @@ struct nfc_ctx {
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
-    int lean = 1, lean_k = 0, lean_rounds = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
+    int lean = 1, lean_k = 0, lean_rounds = 0, lean_slots = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
     int gring_ok = 0, gring_force = 0, wave_slots_g = 0;   // long windows qualify (NFC_RING=lds|global overrides the choice)
@@ -438,7 +438,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     const bool lean_applies = c->lean && c->P.input_kind != NFC_IN_ENV_F32 && c->mx <= 500;
     c->gring = c->gring_ok && (c->gring_force || (!lean_applies && (uint64_t)n >= (uint64_t)c->wave_slots_g * 8u * (uint64_t)c->L));
     if (!c->P.chunk_samples) {
-        const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : c->wave_slots);
+        const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : (lean_applies ? c->lean_slots : c->wave_slots));
         // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps)
         const int stp = 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
         uint64_t want = ((uint64_t)n + slots - 1) / slots;
@@ -1360,10 +1360,15 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         const size_t lds_wave = (size_t)c->Lpad * c->lds_per_slot;
         int per_cu = (int)std::min<size_t>(20, (size_t)(160 * 1024) / (lds_wave * c->wpb) * c->wpb);   // LDS- and VGPR-bound
         c->wave_slots = std::max(1, prop.multiProcessorCount * std::max(1, per_cu));
-        // lean kernel: four steps ahead (104 registers) where the LDS ring leaves a SIMD at most four waves anyway, else three
-        // (96: five waves); a superstep long enough that its fixed cost fades -- the drift allowance grows with its length
-        // relative to the window, kept near the default window's (768 samples of 2000)
-        if (!c->lean_k) c->lean_k = per_cu <= 16 ? 4 : 3;
+        // lean kernel: four steps ahead (104 registers: at most four waves per SIMD); a superstep long enough that its fixed cost
+        // fades -- the drift allowance grows with its length relative to the window (about half the window at most: beyond, the
+        // widened bands reach the loaded half bits of tag frames)
+        // Measured (configs[1] / [2], 1e8 samples): two waves per SIMD with four steps ahead beat five waves with three --
+        // 0.206 / 0.196 ms against 0.237 / 0.230 on the same box: a chunk's fixed cost (the window before it read and
+        // summarised, its summary written) is paid half as often, and two waves already keep a SIMD's issue slots busy.
+        if (!c->lean_k) c->lean_k = 4;
+        c->lean_slots = std::min(c->wave_slots, prop.multiProcessorCount * 8);
+        if (const char *e = getenv("NFC_LEAN_WAVES")) c->lean_slots = std::min(c->wave_slots, prop.multiProcessorCount * 4 * std::max(1, atoi(e)));
         if (!c->lean_rounds) c->lean_rounds = std::max(1, (int)(0.4 * c->L / (256.0 * c->lean_k)));
         c->wave_slots_g = prop.multiProcessorCount * 20;   // VGPR-bound: five waves per SIMD
     }
