@@ -331,10 +331,10 @@ void launch_lean(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hi
         if (e0) NFC_LAUNCH_EXT(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
         else NFC_LAUNCH(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, A);
     };
+    const bool b16 = (1 << c->nfold) == 16;
     switch (c->lean_k) {
-    case 2: go(k_threshold_lean<KIND, 2>); break;
-    case 3: go(k_threshold_lean<KIND, 3>); break;
-    default: go(k_threshold_lean<KIND, 4>); break;
+    case 2: if (b16) go(k_threshold_lean<KIND, 2, true>); else go(k_threshold_lean<KIND, 2, false>); break;
+    default: if (b16) go(k_threshold_lean<KIND, 4, true>); else go(k_threshold_lean<KIND, 4, false>); break;
     }
 }
 void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, bool lean = false) {
@@ -1292,7 +1292,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     if (const char *e = getenv("NFC_LEAN")) c->lean = atoi(e) != 0;
     c->lean_k = 0;        // chosen below from the occupancy the LDS ring allows, unless set here
     c->lean_rounds = 0;
-    if (const char *e = getenv("NFC_LEAN_K")) c->lean_k = std::min(4, std::max(2, atoi(e)));   // (one step ahead does not survive the compiler: tools/audit_lean_isa.py)
+    if (const char *e = getenv("NFC_LEAN_K")) c->lean_k = atoi(e) <= 2 ? 2 : 4;   // (steps ahead: the two instantiations)
     if (const char *e = getenv("NFC_LEAN_ROUNDS")) c->lean_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("NFC_LEAN_GFAC")) c->lean_gfac = (float)atof(e);
     if (const char *e = getenv("NFC_LEAN_GMIN")) c->lean_gmin = (float)atof(e);
@@ -1386,15 +1386,18 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // decoder LUTs
     DecoderTables t = build_tables(p->samp_rate, c->mx);

@@ -206,6 +206,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // must not be read by a vector instruction within the next two issue slots, and inside an asm statement nobody pads that
 // (measured: the low half of a fresh mask arrived as the previous row's).
 #define PLANE_PUT(pk, dword_of_mask, LANE) asm volatile("s_nop 2\n\tv_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)(dword_of_mask)), "n"(LANE))
+// the same with the lane in a scalar register
+#define PLANE_PUT_AT(pk, dword_of_mask, lane) asm volatile("s_mov_b32 m0, %2\n\ts_nop 2\n\tv_writelane_b32 %0, %1, m0" : "+v"(pk) : "s"((uint32_t)(dword_of_mask)), "s"(__builtin_amdgcn_readfirstlane(lane)) : "m0")   /* (the lane select travels in M0: one SGPR per VALU instruction on the constant bus) */
 // the eight dwords of four masks into lanes LANE0 .. LANE0 + 7 of pk, behind one pad
 #define PLANE_PUT8(pk, m, LANE0)                                                                                                             \
     asm volatile("s_nop 2\n\tv_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %9+1\n\tv_writelane_b32 %0, %3, %9+2\n\tv_writelane_b32 %0, %4, %9+3" \
@@ -406,7 +408,9 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
 
 // The state a chunk starts from: chunk 0 the carried (exact) one; mode 1 the exact one resolved from the predecessors'
 // summaries; otherwise speculated from the L samples before the chunk.
-template <int KIND>
+// PASS0: the caller only ever runs pass 0 (no resolved states, every summary in buffer 0): the look-back code and its
+// dynamically indexed buffer pairs (which the compiler would copy to scratch memory) stay out of that kernel.
+template <int KIND, bool PASS0 = false>
 __device__ __forceinline__ void chunk_incoming(const ThrArgs &A, uint32_t c, int lane, float *ring, const Carry &cr, uint32_t m_chunk,
                                                double &ss0, int &w_nl, int &w_kl, float &eps) {
     const int L = A.L;
@@ -416,7 +420,7 @@ __device__ __forceinline__ void chunk_incoming(const ThrArgs &A, uint32_t c, int
         ss0 = cr.ss;
         w_nl = A.nl0;
         w_kl = A.kl0;
-    } else if (A.mode == 1) {
+    } else if (!PASS0 && A.mode == 1) {
         for (int s = lane; s < L; s += 64) ring[s] = resolve_slot(A, (int)c, s);
         double part = 0;
         #pragma unroll 8
@@ -519,7 +523,7 @@ __device__ __forceinline__ uint32_t chunk_save_in(const ThrArgs &A, uint32_t c, 
 }
 
 // The chunk's summary: ring at its end + touched map, LOW bookkeeping, guard, what the evaluation assumed.
-template <bool SIGN_T>
+template <bool SIGN_T, bool PASS0 = false>
 __device__ __forceinline__ void chunk_publish(const ThrArgs &A, uint32_t c, int lane, const float *ring, const unsigned char *tch, uint32_t emin,
                                               uint32_t emax, uint32_t vmin, uint32_t vmax, float ssf, float eps, uint32_t flags, int chunk_kl,
                                               int chunk_nl, double ss_out, float min_ss, int nl_in, int kl_in, uint32_t all_robust) {
@@ -531,10 +535,10 @@ __device__ __forceinline__ void chunk_publish(const ThrArgs &A, uint32_t c, int 
     }
 
     // ---------------- publish the summary ----------------
-    const int vb_old = A.ver[c];
-    const int vb_new = (A.mode == 1) ? (1 - vb_old) : vb_old;  // pass 0 fills buffer ver[c] directly
-    float *ro = A.ring_out[vb_new] + (size_t)c * L;
-    uint32_t *to = A.touched[vb_new] + (size_t)c * A.twords;
+    // pass 0 fills buffer ver[c] directly -- which is buffer 0 (prepare_batch zeroes the version bytes)
+    const int vb_new = PASS0 ? 0 : ((A.mode == 1) ? (1 - (int)A.ver[c]) : (int)A.ver[c]);
+    float *ro = (PASS0 ? A.ring_out[0] : A.ring_out[vb_new]) + (size_t)c * L;
+    uint32_t *to = (PASS0 ? A.touched[0] : A.touched[vb_new]) + (size_t)c * A.twords;
     uint32_t untouched = 0;
     for (int sbase = 0; sbase < A.twords * 32; sbase += 64) {
         const int s = sbase + lane;
@@ -567,7 +571,7 @@ __device__ __forceinline__ void chunk_publish(const ThrArgs &A, uint32_t c, int 
         ci.emax = emax;
         ci.flags = flags;
         ci.n_untouched = untouched;
-        A.info[vb_new][c] = ci;
+        (PASS0 ? A.info[0] : A.info[vb_new])[c] = ci;
         A.gmin[c] = (uint8_t)emin;
         A.gmax[c] = (uint8_t)emax;
         A.gflags[c] = (uint8_t)(flags | (untouched ? 2u : 0u));

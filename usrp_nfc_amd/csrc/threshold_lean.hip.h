@@ -120,16 +120,16 @@ __device__ __forceinline__ void lean_take(float (&x)[4], float i16_scale) {
 }
 template <int KIND> struct LeanRaw { static constexpr int BYTES = (KIND == IN_IQ_F32) ? 8 : (KIND == IN_I16_SQ) ? 2 : 4; };
 typedef __attribute__((address_space(3))) float lean_lds_f;
-__device__ __forceinline__ float lean_dpp_shl8(float v) {   // lane l <- lane l + 8 of its row of 16 (other lanes: themselves)
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x108, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float lean_dpp_shl15(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x10F, 0xF, 0xF, false));
+typedef __attribute__((address_space(1))) uint32_t lean_g_u32;   // (an address computed from integers must not become a flat access)
+__device__ __forceinline__ uint32_t lean_dpp_shl8(uint32_t v) {   // lane l <- lane l + 8 of its row of 16 (0 where that leaves the row)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xF, 0xF, true);
 }
 
 // PF: steps per superstep = how many steps ahead the raw samples are asked for (a step's registers are refilled, for the
 // step PF later, as soon as its envelopes are taken: PF * 2 KB in flight per wave for IQ input).
-template <int KIND, int PF>
+// BLK16: a LOW run longer than max_len covers an aligned block of 16 samples (max_len 46 .. 93: the default's 50) -- the block test of
+// the LOW-only form is then two DPP instructions per row; otherwise it works on the row's mask (A.blk).
+template <int KIND, int PF, bool BLK16>
 __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     static_assert(KIND != IN_ENV_F32, "raw envelopes may be negative: no sign bit to spare (they take k_threshold)");
     static_assert(PF >= 2 && PF <= 4, "planes of a superstep leave in one store of 16 lanes per step");
@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     const uint32_t m_start = max(m_chunk, A.skip);
     const Carry cr = *A.carry;
     uint64_t *const neg_p = A.neg, *const pos_p = A.pos;   // (by value: a per-lane choice between two kernel-argument FIELDS would be a vector load)
-    const int blk = A.blk;                  // (kernel arguments the loop reads go to registers once: a scalar load in the loop stalls its wave)
+    // this lane's plane for a round's collective store (lane 16 k + i: step k; i < 8 the neg plane, dword i, else the pos plane,
+    // dword i - 8) and for a single step's (lanes 0 .. 7 neg, 8 .. 15 pos): chosen once, as integers
+    const uintptr_t plane_of_lane = (lane & 8) ? (uintptr_t)pos_p : (uintptr_t)neg_p;
     const float i16s = A.i16_scale;
     const float gfac = A.gfac, gfloor = A.gfloor;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     // (measured: a form of this prologue that keeps the whole window in registers -- one pass instead of seven over LDS, at
     // 100 instead of 96 registers -- was 4 % SLOWER on the kernel: all waves run it at once, behind the same burst of loads)
     double ss0;
-    chunk_incoming<KIND>(A, c, lane, ring, cr, m_chunk, ss0, w_nl, w_kl, eps);
+    chunk_incoming<KIND, true>(A, c, lane, ring, cr, m_chunk, ss0, w_nl, w_kl, eps);
     ssf = (float)ss0;
     const uint32_t vtop0 = chunk_save_in<true>(A, c, lane, ring, nullptr, emin, emax);
     ssf = rfl(ssf);
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     constexpr int RB = LeanRaw<KIND>::BYTES;
     const char *const in_lane = (const char *)A.in + (size_t)lane * RB;
     // any step, synchronously (compiler loads): lanes past the batch's end read nothing
-    auto fetch_env = [&](uint32_t b, float (&x)[NR]) {
+    auto fetch_env = [&](uint32_t b, float (&x)[NR]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             const uint32_t m = b + 64u * j + lane;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     uint32_t base = m_chunk;
     while (base + STEPN <= m_start && base < n1) {
         const uint32_t w = (base >> 6) + (uint32_t)(lane & (NR - 1));
-        if (lane < 2 * NR && (size_t)w * 64 < A.n) (lane < NR ? neg_p : pos_p)[w] = 0ull;
+        if (lane < 2 * NR && (size_t)w * 64 < A.n) *(__attribute__((address_space(1))) uint64_t *)((lane < NR ? (uintptr_t)neg_p : (uintptr_t)pos_p) + 8 * (uintptr_t)w) = 0ull;
         base += STEPN;
         slot_step += STEPN;
         slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
@@ -208,18 +210,19 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     float tlo_dn = 0.f, tlo_up = 0.f, thi_dn = 0.f, thi_up = 0.f;
     // deferred per-lane checks of the straight-line step forms (looked at when the superstep closes)
     uint32_t amb_lo = 0xFFFFFFFFu, amb_hi = 0xFFFFFFFFu;   // min of (bits(x) - bits(band bottom)): inside the band iff <= its width
-    float lrun = 3.0e38f;                                  // min over rows of max(x[l], x[l + 8], x[l + 15]) at the lanes that start a 16-block
+    uint32_t lrun = 0x7F7FFFFFu;                           // min over rows of max(x[l], x[l + 8]) at the lanes that start a 16-block (raw bits: x >= 0)
     // LOW bookkeeping of the straight-line forms, made explicit (w_nl, w_kl) only when the general step or the summary needs it
-    unsigned long long lzm[NR] = {0, 0, 0, 0};   // LOW masks of the latest step that had LOW samples ...
-    uint32_t lz_base = 0;                        // ... and its base
+    uint32_t lz_base = 0;                        // base of the latest straight-line step that had LOW samples: its masks are still in the
+                                                 // plane words of its round (pk) or of the round before (pk_prev)
     bool lz_set = false, hot_since = false;      // such a step / any straight-line step since w_nl, w_kl were last explicit
     const int ssl_min = (mx + 1 + (int)STEPN - 1) / (int)STEPN;   // steps without LOW samples after which no LOW sample is in reach of a HIGH one
     int steps_since_low = ((w_kl & 1) && ((int)m_chunk - (w_kl >> 1)) <= mx + 1) ? 0 : ssl_min;
     bool force_general = ((int)m_chunk - 1 - w_nl) > 0;   // the chunk starts inside a LOW run: its first step checks the carried length
-    int pk = 0;   // the superstep's plane words: lanes 16 k .. 16 k + 7 the neg plane of step k (dwords), + 8 .. + 15 the pos plane
+    int pk = 0, pk_prev = 0;   // a round's plane words: lanes 16 k .. 16 k + 7 the neg plane of step k (dwords), + 8 .. + 15 the pos plane
+    uint32_t pk_base = 0, pkp_base = 0xFFFFFFFFu;   // the bases of those rounds' first steps
 
     // thresholds of a superstep from the tracked sum and the allowance; false: the banded test cannot serve
-    auto open_superstep = [&]() -> bool {
+    auto open_superstep = [&]() __attribute__((always_inline)) -> bool {
         if (steps_since_sync >= 256) {   // bound the rounding the f32 sum accumulates: re-derive it from the ring
             double part = 0;
 #pragma unroll 8
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     };
     // was the allowance enough for what the lanes accumulated, did no sample sit inside a band, can no LOW run have reached
     // max_len?  then the sum moves on and the next allowance is set
-    auto close_superstep = [&](bool whole) -> bool {
+    auto close_superstep = [&](bool whole) __attribute__((always_inline)) -> bool {
         const float B = wave_sum_f32(b_acc) * 1.001f;
         const float D = wave_sum_f32(dl_acc);
         b_acc = 0.f;
@@ -249,10 +252,10 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
         if (!(B <= G)) { why = 4u; return false; }
         const uint32_t wlo = __float_as_uint(tlo_up) - __float_as_uint(tlo_dn), whi = __float_as_uint(thi_up) - __float_as_uint(thi_dn);
         const unsigned long long inband = __ballot(amb_lo <= wlo || amb_hi <= whi);
-        const unsigned long long longlow = __ballot(lrun <= tlo_up) & 0x0001000100010001ull;
+        const unsigned long long longlow = __ballot(lrun <= __float_as_uint(tlo_up)) & 0x0001000100010001ull;
         amb_lo = 0xFFFFFFFFu;
         amb_hi = 0xFFFFFFFFu;
-        lrun = 3.0e38f;
+        lrun = 0x7F7FFFFFu;
         if (inband) { why = 2u; return false; }
         if (longlow) { why = 3u; return false; }
         ssf = rfl(ssf + D);
@@ -264,32 +267,60 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     };
     // w_nl / w_kl (last non-LOW index, key of the last LOW sample) as of the step that starts at `base`, from what the
     // straight-line steps left behind
-    auto materialize = [&]() -> bool {
+    auto materialize = [&]() __attribute__((always_inline)) -> bool {
+        // (new values gathered in locals and assigned once, by selects: look-alike blocks of stores to these by-reference
+        // captures get merged into stores through a chosen pointer, which pins them in scratch memory)
+        int nkl = w_kl, nnl = w_nl;
+        bool set_kl = false, set_nl = false, bad = false;
         if (lz_set) {
-            int ll = LL_NONE;
+            int src = pk;
+            uint32_t sb = pk_base;
+            if (lz_base < pk_base) {
+                src = pk_prev;
+                sb = pkp_base;
+            }
+            set_kl = true;
+            if (lz_base >= sb && lz_base - sb < (uint32_t)PF * STEPN) {
+                const int l0 = (int)((lz_base - sb) >> 8) * 16;
+                unsigned long long lm[NR];
 #pragma unroll
-            for (int j = 0; j < NR; j++) ll = lzm[j] ? (int)(lz_base + 64u * j) + last_set(lzm[j]) : ll;
-            w_kl = 2 * ll + 1;   // (a LOW sample of a straight-line step never ends on a time-out: its key is good)
-            chunk_kl = w_kl;
-            if (steps_since_low == 0) {   // that step was the latest one
-                int nl = LL_NONE;
+                for (int j = 0; j < NR; j++)
+                    lm[j] = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(src, l0 + 2 * j) |
+                            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(src, l0 + 2 * j + 1) << 32);
+                int ll = LL_NONE;
 #pragma unroll
-                for (int j = 0; j < NR; j++) nl = (~lzm[j]) ? (int)(lz_base + 64u * j) + last_set(~lzm[j]) : nl;
-                if (nl == LL_NONE) { why = 3u; return false; }   // (256 LOW samples: the block test will have seen it)
-                w_nl = nl;
-                chunk_nl = nl;
+                for (int j = 0; j < NR; j++) ll = lm[j] ? (int)(lz_base + 64u * j) + last_set(lm[j]) : ll;
+                nkl = 2 * ll + 1;   // (a LOW sample of a straight-line step never ends on a time-out: its key is good)
+                if (steps_since_low == 0) {   // that step was the latest one
+                    int nl = LL_NONE;
+#pragma unroll
+                    for (int j = 0; j < NR; j++) nl = (~lm[j]) ? (int)(lz_base + 64u * j) + last_set(~lm[j]) : nl;
+                    bad = nl == LL_NONE;   // (256 LOW samples: the block test will have seen it)
+                    nnl = nl;
+                    set_nl = true;
+                }
+            } else {
+                // its round is gone: more than PF steps (>= 512 samples) back, out of every HIGH sample's reach (max_len <= 500
+                // where this kernel runs).  Any key that is not live stands for it (k_certify, resolve_low_state: a key only
+                // matters while live): the step's last sample.
+                nkl = 2 * (int)(lz_base + STEPN - 1) + 1;
             }
         }
         if (hot_since && (steps_since_low > 0 || !lz_set)) {   // the latest step had no LOW sample
-            w_nl = (int)base - 1;
-            chunk_nl = w_nl;
+            nnl = (int)base - 1;
+            set_nl = true;
         }
+        w_kl = nkl;
+        chunk_kl = set_kl ? nkl : chunk_kl;
+        w_nl = nnl;
+        chunk_nl = set_nl ? nnl : chunk_nl;
         lz_set = false;
         hot_since = false;
-        return true;
+        if (bad) why = 3u;
+        return !bad;
     };
     // plane words of a single step stored at once (masked steps, outside the superstep's collective store)
-    auto store_planes_now = [&](const unsigned long long (&lowm)[NR], const unsigned long long (&posm)[NR]) {
+    auto store_planes_now = [&](const unsigned long long (&lowm)[NR], const unsigned long long (&posm)[NR]) __attribute__((always_inline)) {
         int q = 0;
 #pragma unroll
         for (int k = 0; k < NR; k++) {
@@ -300,16 +331,16 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
         }
         const int h = lane & (2 * NR - 1);
         const uint32_t w = (base >> 6) + (uint32_t)(h >> 1);
-        uint32_t *dst = (uint32_t *)(lane < 2 * NR ? neg_p : pos_p) + 2 * (size_t)(base >> 6) + h;
+        lean_g_u32 *dst = (lean_g_u32 *)(plane_of_lane + 4 * (2 * (uintptr_t)(base >> 6) + (uintptr_t)h));
         if (lane < 4 * NR && (size_t)w * 64 < A.n) *dst = (uint32_t)q;
     };
 
     // ---------------- the general step, on wave masks ----------------
-    // KS >= 0: step KS of a superstep of whole steps (plane words into pk); KS < 0: a masked step on its own -- lanes outside
-    // [m_start, n1) are not samples (the stream's first stable sample, the batch's ragged end).  x: the step's envelopes.
-    auto general_step = [&](auto ks_tag, float (&x)[NR]) -> bool {
-        constexpr int KS = decltype(ks_tag)::value;
-        constexpr bool MASKED = KS < 0;
+    // kslot >= 0: step kslot of a round of whole steps (plane words into pk); kslot < 0: a step on its own (plane words stored at
+    // once).  masked: lanes outside [m_start, n1) are not samples (the stream's first stable sample, the batch's ragged end).
+    // x: the step's envelopes.  Instantiated ONCE in the kernel (its call site is the slow arm of the chunk loop below): the
+    // straight-line forms' registers are not to pay for it.
+    auto general_step = [&](float (&x)[NR], const bool masked, const int kslot) __attribute__((always_inline)) -> bool {
         if (!materialize()) return false;
         float prev[NR];
         uint32_t slot[NR];
@@ -320,8 +351,8 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
             slot[j] = s;
             prev[j] = fabsf(ring[s]);
         }
-        unsigned long long unt[NR], am[NR];
-        if constexpr (MASKED) {
+        unsigned long long unt[NR] = {0, 0, 0, 0}, am[NR] = {~0ull, ~0ull, ~0ull, ~0ull};
+        if (masked) {
             // a lane that is not a sample repeats the value its slot holds (no drift; if "accepted" the slot keeps its
             // value) and the touched flag such a store sets is taken back after the step
 #pragma unroll
@@ -342,11 +373,9 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
             unsigned long long g = (lo1 | lo0) & (hi1 | hi0);
             lowm[j] = lo1;
             posm[j] = hi1;
-            if constexpr (MASKED) {
-                g |= ~am[j];
-                lowm[j] &= am[j];
-                posm[j] &= am[j];
-            }
+            g |= ~am[j];
+            lowm[j] &= am[j];
+            posm[j] &= am[j];
             good &= g;
             anylow |= lowm[j];
             anyhi |= posm[j];
@@ -372,7 +401,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
                 }
             }
             if (hit || ((carry_run > 0) && (carry_run + lead > mx))) { ok = false; why = 3u; }
-            if (MASKED && base < m_start) { ok = false; why = 5u; }   // (a LOW run across the first stable sample: leave it to the exact kernel)
+            if (masked && base < m_start) { ok = false; why = 5u; }   // (a LOW run across the first stable sample: leave it to the exact kernel)
         }
         if (!ok) return false;
         int before = (w_kl & 1) ? (w_kl >> 1) : LL_NONE;  // last LOW before the row (every key here is good)
@@ -394,46 +423,44 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
             vmin = min(vmin, (a && xb != 0u) ? xb : 0xFFFFFFFFu);
             vmax = max(vmax, a ? xb : 0u);
             posm[j] = __ballot(ps);
-            if constexpr (MASKED) posm[j] &= am[j];
+            posm[j] &= am[j];
             before = lowm[j] ? rb + last_set(lowm[j]) : before;
         }
         int step_nl = LL_NONE, step_ll = LL_NONE;
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             const int rb = (int)(base + 64u * j);
-            unsigned long long nonlow = ~lowm[j];
-            if constexpr (MASKED) {
-                nonlow &= am[j];
-                if ((unt[j] >> lane) & 1ull) ring[slot[j]] = __uint_as_float(__float_as_uint(x[j]) | 0x80000000u);
-            }
+            const unsigned long long nonlow = ~lowm[j] & am[j];
+            if ((unt[j] >> lane) & 1ull) ring[slot[j]] = __uint_as_float(__float_as_uint(x[j]) | 0x80000000u);
             step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
             step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
         }
-        if (step_ll != LL_NONE) {
-            w_kl = 2 * step_ll + 1;
-            chunk_kl = w_kl;
-        }
-        if (step_nl != LL_NONE) {
-            w_nl = step_nl;
-            chunk_nl = step_nl;
-        }
+        // (selects, not two look-alike blocks of stores: merged by the optimiser into stores through a chosen POINTER, those would
+        // pin the four variables -- captured by reference -- in scratch memory)
+        w_kl = (step_ll != LL_NONE) ? 2 * step_ll + 1 : w_kl;
+        chunk_kl = (step_ll != LL_NONE) ? w_kl : chunk_kl;
+        w_nl = (step_nl != LL_NONE) ? step_nl : w_nl;
+        chunk_nl = (step_nl != LL_NONE) ? step_nl : chunk_nl;
         steps_since_low = anylow ? 0 : steps_since_low + 1;
-        if constexpr (MASKED) {
+        if (kslot < 0) {
             store_planes_now(lowm, posm);
         } else {
 #pragma unroll
-            for (int k = 0; k < NR; k++) {
-                PLANE_PUT(pk, lowm[k], 16 * KS + 2 * k);
-                PLANE_PUT(pk, (lowm[k] >> 32), 16 * KS + 2 * k + 1);
-                PLANE_PUT(pk, posm[k], 16 * KS + 8 + 2 * k);
-                PLANE_PUT(pk, (posm[k] >> 32), 16 * KS + 8 + 2 * k + 1);
+            for (int k = 0; k < NR; k++) {   // (the lane of a v_writelane may come from a scalar register)
+                PLANE_PUT_AT(pk, lowm[k], 16 * kslot + 2 * k);
+                PLANE_PUT_AT(pk, (lowm[k] >> 32), 16 * kslot + 2 * k + 1);
+                PLANE_PUT_AT(pk, posm[k], 16 * kslot + 8 + 2 * k);
+                PLANE_PUT_AT(pk, (posm[k] >> 32), 16 * kslot + 8 + 2 * k + 1);
             }
         }
         return true;
     };
 
     // ---------------- step KS of a superstep of whole steps ----------------
-    auto step = [&](auto ks_tag) -> bool {
+    // -> 0 done, 1 the wave gives up, 2 the general form has to take this step (its envelopes are left in gx, nothing else of
+    // the step has happened but the refill of its registers)
+    float gx[NR] = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](auto ks_tag) __attribute__((always_inline)) -> int {
         constexpr int KS = decltype(ks_tag)::value;
         float x[NR];
         // this step's samples have landed (the loads of the PF - 1 steps after it may be in flight) ...
@@ -443,14 +470,20 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
         lean_load_step<KIND, KS>(in_lane + (size_t)min(base + (uint32_t)PF * STEPN, last_whole) * RB);
 
         // can anything be LOW / HIGH (or inside those bands) at all?
-        const float xmin = fminf(fminf(x[0], x[1]), fminf(x[2], x[3])), xmax = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
-        const bool lowp = __ballot(!(xmin > tlo_up)) != 0ull;
-        const bool highp = __ballot(!(xmax < thi_dn)) != 0ull;
+        // (envelopes are >= 0: their raw bits order like their values, and integer min / max need no canonicalising of NaNs)
+        const float xmin = __uint_as_float(min(min(__float_as_uint(x[0]), __float_as_uint(x[1])), min(__float_as_uint(x[2]), __float_as_uint(x[3]))));
+        const float xmax = __uint_as_float(max(max(__float_as_uint(x[0]), __float_as_uint(x[1])), max(__float_as_uint(x[2]), __float_as_uint(x[3]))));
+        const unsigned long long lowany = __ballot(!(xmin > tlo_up)), highany = __ballot(!(xmax < thi_dn));
+        const bool lowp = lowany != 0ull, highp = highany != 0ull;
         bool ok = true;
-        if (__builtin_expect((lowp && highp) || force_general || (highp && steps_since_low < ssl_min), 0)) {
+        // which form: 0 nothing classifies, 1 only LOW, 2 only HIGH with no LOW sample in reach, 3 the general step
+        if (__builtin_expect((lowany && highany) || force_general || (highany && steps_since_low < ssl_min), 0)) {
             force_general = false;
-            ok = general_step(ks_tag, x);
-        } else {
+#pragma unroll
+            for (int j = 0; j < NR; j++) gx[j] = x[j];
+            return 2;
+        }
+        {
             // straight-line forms: ring addresses (a step wraps the ring once in L / 256 steps)
             lean_lds_f *pa[NR];
             {
@@ -497,11 +530,11 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
                              min(__float_as_uint(x[1]) - __float_as_uint(tlo_dn), __float_as_uint(x[2]) - __float_as_uint(tlo_dn)));
                 amb_lo = min(amb_lo, __float_as_uint(x[3]) - __float_as_uint(tlo_dn));
                 // a LOW run longer than max_len covers an aligned block of b samples (b = blk)
-                if (blk == 16) {
+                if constexpr (BLK16) {
                     // ... whose first and ninth sample are then LOW: per 16-lane row of the wave, in the lanes
 #pragma unroll
-                    for (int j = 0; j < NR; j++) lrun = fminf(lrun, fmaxf(x[j], lean_dpp_shl8(x[j])));
-                } else if (blk == 64) {
+                    for (int j = 0; j < NR; j++) lrun = min(lrun, max(__float_as_uint(x[j]), lean_dpp_shl8(__float_as_uint(x[j]))));
+                } else if (A.blk == 64) {
                     if ((lw[0] == ~0ull) || (lw[1] == ~0ull) || (lw[2] == ~0ull) || (lw[3] == ~0ull)) { ok = false; why = 3u; }
                 } else {
                     unsigned long long hit = 0;
@@ -514,8 +547,6 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
                     }
                     if (hit) { ok = false; why = 3u; }
                 }
-#pragma unroll
-                for (int j = 0; j < NR; j++) lzm[j] = lw[j];
                 PLANE_PUT8(pk, lw, 16 * KS);
                 lz_base = base;
                 lz_set = true;
@@ -545,86 +576,142 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
         slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
         steps_since_sync++;
         base += STEPN;
-        return ok;
+        return ok ? 0 : 1;
     };
-    // a masked step as a superstep of its own: synchronous loads, general form, plane words stored at once
-    auto masked_superstep = [&]() -> bool {
-        float x[NR];
-        fetch_env(base, x);
-        G = rfl(fminf(fmaxf(G, ssf * 0.00390625f), ssf * 0.125f));
-        if (!open_superstep()) return false;
-        if (!general_step(std::integral_constant<int, -1>{}, x)) return false;
+    // ---------------- the chunk ----------------
+    // Rounds of PF whole steps out of the registers ahead (step k of a round lives in a[8 k ..]), `rounds` rounds to a superstep;
+    // a step that no round can hold -- the one with the stream's first stable sample, fewer than PF whole steps before the
+    // chunk's end (chunk lengths are cut to whole rounds: only a batch's last chunk has them), the batch's ragged end -- is a
+    // superstep of its own on synchronously loaded samples.  One loop, so that the general form has a single call site.
+    const int rounds = max(1, A.ksteps);
+    int k = PF;          // next step of the round in progress (PF: between rounds)
+    int rd = 0;          // rounds done in the superstep in progress
+    bool primed = false, in_round = false, in_super = false;
+    uintptr_t pl_addr = 0;   // this lane's dword of a round's plane store
+    while (good_run) {
+        int gen = -2;    // the general form's job this trip: -2 none, -1 a step on its own, k >= 0 step k of the round
+        if (k == PF) {   // between rounds
+            if (in_round) {   // the round that just ended: its plane words leave
+                if (lane < 16 * PF) *(lean_g_u32 *)pl_addr = (uint32_t)pk;
+                pl_addr += 32 * PF;
+                in_round = false;
+                rd++;
+            }
+            const bool more = base >= m_start && base + (uint32_t)PF * STEPN <= n1;
+            if (in_super && (rd >= rounds || !more)) {
+                if (!close_superstep(true)) { good_run = false; break; }
+                in_super = false;
+                rd = 0;
+            }
+            if (base >= n1) break;
+            if (!more) {
+                gen = -1;
+            } else {
+                if (!primed) {
+                    last_whole = base + (n1 - base - STEPN) / STEPN * STEPN;
+                    lean_load_step<KIND, 0>(in_lane + (size_t)base * RB);
+                    lean_load_step<KIND, 1>(in_lane + (size_t)(base + STEPN) * RB);
+                    if constexpr (PF > 2) lean_load_step<KIND, 2>(in_lane + (size_t)(base + 2 * STEPN) * RB);
+                    if constexpr (PF > 3) lean_load_step<KIND, 3>(in_lane + (size_t)(base + 3 * STEPN) * RB);
+                    // first allowance: sum |x - prev| over the samples of the first round that look acceptable, per such sample,
+                    // for a superstep of acceptable samples only (a guess like any other allowance: the superstep's own B decides)
+                    const float wlo = ssf * loLf * 0.5f, whi = ssf * hiLf * 1.02f;
+                    float b0 = 0.f, n0 = 0.f;
+                    uint32_t sl = slot_step;
+                    auto look = [&](auto kt) {
+                        float xv[NR];
+                        lean_take<KIND, decltype(kt)::value, 0>(xv, i16s);   // (reading leaves the registers as they are: the round takes them again)
+#pragma unroll
+                        for (int j = 0; j < NR; j++) {
+                            uint32_t q = sl + 64u * j + lane;
+                            q = (q >= (uint32_t)L) ? q - (uint32_t)L : q;
+                            const bool in = xv[j] > wlo && xv[j] < whi;
+                            b0 += in ? fabsf(xv[j] - fabsf(ring[q])) : 0.f;
+                            n0 += in ? 1.f : 0.f;
+                        }
+                        sl += STEPN;
+                        sl = (sl >= (uint32_t)L) ? sl - (uint32_t)L : sl;
+                    };
+                    look(std::integral_constant<int, 0>{});
+                    look(std::integral_constant<int, 1>{});
+                    if constexpr (PF > 2) look(std::integral_constant<int, 2>{});
+                    if constexpr (PF > 3) look(std::integral_constant<int, 3>{});
+                    b0 = wave_sum_f32(b0);
+                    n0 = wave_sum_f32(n0);
+                    Bneed = ((n0 >= 64.f) ? b0 / n0 * (float)(PF * STEPN) : ssf * 0.001953125f * (float)PF) * (float)rounds;
+                    G = rfl(fminf(fmaxf(gfac * Bneed, ssf * gfloor), ssf * 0.125f));
+                    pl_addr = plane_of_lane + 4 * (2 * (uintptr_t)(base >> 6) + 8 * (uintptr_t)(lane >> 4) + (uintptr_t)(lane & 7));
+                    pk_base = base;
+                    primed = true;
+                }
+                if (!in_super) {
+                    if (!open_superstep()) { good_run = false; break; }
+                    in_super = true;
+                }
+                pk_prev = pk;
+                pkp_base = pk_base;
+                pk = 0;
+                pk_base = base;
+                in_round = true;
+                k = 0;
+            }
+        }
+        if (gen == -2) {
+            int r = 0;
+            auto stepk = [&](auto kt) -> int {   // (steps beyond the round's length are never instantiated)
+                if constexpr (decltype(kt)::value < PF) return step(kt);
+                else return 0;
+            };
+            switch (k) {
+            case 0:
+                r = stepk(std::integral_constant<int, 0>{});
+                if (r) break;
+                k = 1;
+                [[fallthrough]];
+            case 1:
+                r = stepk(std::integral_constant<int, 1>{});
+                if (r) break;
+                k = 2;
+                if (PF == 2) break;
+                [[fallthrough]];
+            case 2:
+                r = stepk(std::integral_constant<int, 2>{});
+                if (r) break;
+                k = 3;
+                if (PF == 3) break;
+                [[fallthrough]];
+            case 3:
+                r = stepk(std::integral_constant<int, 3>{});
+                if (r) break;
+                k = 4;
+                break;
+            default:
+                break;
+            }
+            if (r == 1) { good_run = false; break; }
+            if (r == 0) continue;   // the round is through
+            gen = k;
+        }
+        // ---- the slow arm: one step in the general form ----
+        const bool own = gen < 0;
+        if (own) {
+            primed = false;   // (the registers ahead belong to another base from here on)
+            fetch_env(base, gx);
+            G = rfl(fminf(fmaxf(G, ssf * 0.00390625f), ssf * 0.125f));
+            if (!open_superstep()) { good_run = false; break; }
+        }
+        if (!general_step(gx, own, gen)) { good_run = false; break; }
         slot_step += STEPN;
         slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
         steps_since_sync++;
         base += STEPN;
-        return close_superstep(false);
-    };
-
-    // (1) the step that holds the stream's first stable sample (chunk 0 of its first batches)
-    if (good_run && base < n1 && base < m_start) good_run = masked_superstep();
-    // (2) whole steps, PF to a superstep; step k of a superstep lives in the accumulator registers a[8 k ..]
-    if (good_run && base + (uint32_t)PF * STEPN <= n1) {
-        last_whole = base + (n1 - base - STEPN) / STEPN * STEPN;
-        lean_load_step<KIND, 0>(in_lane + (size_t)base * RB);
-        lean_load_step<KIND, 1>(in_lane + (size_t)(base + STEPN) * RB);
-        if constexpr (PF > 2) lean_load_step<KIND, 2>(in_lane + (size_t)(base + 2 * STEPN) * RB);
-        if constexpr (PF > 3) lean_load_step<KIND, 3>(in_lane + (size_t)(base + 3 * STEPN) * RB);
-        // first allowance: sum |x - prev| over the samples of the first superstep that look acceptable, per such sample, for a
-        // superstep of acceptable samples only (a guess like any other allowance: the superstep's own B decides)
-        {
-            const float wlo = ssf * loLf * 0.5f, whi = ssf * hiLf * 1.02f;
-            float b0 = 0.f, n0 = 0.f;
-            uint32_t sl = slot_step;
-            auto look = [&](auto kt) {
-                float xv[NR];
-                lean_take<KIND, decltype(kt)::value, 0>(xv, A.i16_scale);   // (reading leaves the registers as they are: the loop takes them again)
-#pragma unroll
-                for (int j = 0; j < NR; j++) {
-                    uint32_t q = sl + 64u * j + lane;
-                    q = (q >= (uint32_t)L) ? q - (uint32_t)L : q;
-                    const bool in = xv[j] > wlo && xv[j] < whi;
-                    b0 += in ? fabsf(xv[j] - fabsf(ring[q])) : 0.f;
-                    n0 += in ? 1.f : 0.f;
-                }
-                sl += STEPN;
-                sl = (sl >= (uint32_t)L) ? sl - (uint32_t)L : sl;
-            };
-            look(std::integral_constant<int, 0>{});
-            look(std::integral_constant<int, 1>{});
-            if constexpr (PF > 2) look(std::integral_constant<int, 2>{});
-            if constexpr (PF > 3) look(std::integral_constant<int, 3>{});
-            b0 = wave_sum_f32(b0);
-            n0 = wave_sum_f32(n0);
-            Bneed = ((n0 >= 64.f) ? b0 / n0 * (float)(PF * STEPN) : ssf * 0.001953125f * (float)PF) * (float)max(1, A.ksteps);
-            G = rfl(fminf(fmaxf(gfac * Bneed, ssf * gfloor), ssf * 0.125f));
+        if (own) {
+            if (!close_superstep(false)) { good_run = false; break; }
+        } else {
+            k = gen + 1;
         }
-        // this lane's dword of the superstep's plane store: lane 16 k + i -> step k, i < 8 the neg plane (dword i), else pos
-        uint32_t *pl_ptr = (uint32_t *)((lane & 8) ? pos_p : neg_p) + 2 * (size_t)(base >> 6) + 8 * (size_t)(lane >> 4) + (lane & 7);
-        // a superstep is `rounds` trips through the PF unrolled steps (thresholds, reductions and checks once per superstep;
-        // the plane words leave once per trip)
-        const int rounds = max(1, A.ksteps);
-        while (good_run && base + (uint32_t)PF * STEPN <= n1) {
-            if (!open_superstep()) { good_run = false; break; }
-            bool okk = true;
-            for (int rd = 0; rd < rounds && okk && base + (uint32_t)PF * STEPN <= n1; rd++) {
-                pk = 0;
-                okk = step(std::integral_constant<int, 0>{});
-                okk = okk && step(std::integral_constant<int, 1>{});
-                if constexpr (PF > 2) okk = okk && step(std::integral_constant<int, 2>{});
-                if constexpr (PF > 3) okk = okk && step(std::integral_constant<int, 3>{});
-                if (okk) {
-                    if (lane < 16 * PF) *pl_ptr = (uint32_t)pk;
-                    pl_ptr += 8 * PF;
-                }
-            }
-            if (!okk || !close_superstep(true)) { good_run = false; break; }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the loop's is left in flight)
     }
-    // (3) fewer than PF whole steps left (chunk lengths are cut to multiples of PF steps: only a batch's last chunk has
-    // them), and the batch's ragged end: one at a time, each loading its own samples
-    while (good_run && base < n1) good_run = masked_superstep();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the rounds' loads is left in flight)
     if (good_run) good_run = materialize();
 
     if (A.dbg_clk) clk2 = clock64();
@@ -633,7 +720,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
         A.cert[0] = good_run ? 1 : 0;
         if (!good_run) atomicAdd(&A.sum->n_fail, 1u);
     }
-    chunk_publish<true>(A, c, lane, ring, nullptr, emin, emax, vmin, vmax, ssf, eps, good_run ? 0u : (4u | (why << 4)), chunk_kl, chunk_nl,
+    chunk_publish<true, true>(A, c, lane, ring, nullptr, emin, emax, vmin, vmax, ssf, eps, good_run ? 0u : (4u | (why << 4)), chunk_kl, chunk_nl,
                         (double)ssf, min_ss, nl_in, kl_in, all_robust);
     if (A.dbg_clk && lane == 0) {
         A.dbg_clk[4 * (size_t)c + 0] = clk0;
