@@ -329,7 +329,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
 struct FrameOut {
     uint8_t *sym[2];        // [0] Manchester / tag, [1] Miller / reader
     uint32_t cap_sym[2];    // buffer capacities (an overflow is seen by the host in the totals, the stage repeated)
-    const nfc_edge *edges;
+    const uint32_t *epos;   // per edge: batch-local sample position (edges.hip.h); its index is g0 + position ...
+    uint64_t g0;
+    const uint64_t *idx64;  // ... unless the caller brought the edges with indices of its own (nfc_push_edges)
     uint8_t *bits[2];       // appended bits per type, starting with the pending ones of earlier batches
     uint32_t *close_end[2]; // per close: number of bits appended before it (= end offset of the packet)
     uint64_t *close_idx[2]; // per close: sample index of the closing edge
@@ -371,7 +373,7 @@ __device__ __forceinline__ void frame_write(const FrameOut &P, const FrameAgg &p
                 const uint32_t j = co + (uint32_t)__popc(closes & (low - 1u));
                 if (j < P.cap_close[t]) {
                     P.close_end[t][j] = bo + (uint32_t)__popc(appended & (low - 1u));
-                    P.close_idx[t][j] = P.edges[base + k].idx;
+                    P.close_idx[t][j] = P.idx64 ? P.idx64[base + k] : P.g0 + (uint64_t)P.epos[base + k];
                 }
             }
         }

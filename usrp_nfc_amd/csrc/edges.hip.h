@@ -14,6 +14,17 @@
 // run's first sample -- in a 64-bit event mask; after a prefix sum over the popcounts one thread per
 // ENTRY rebuilds the three values before its sample from the closed form, takes the reference's step
 // for that one sample (transition_sink.py:84-99) and writes the entry: stores are dense and in order.
+//
+// The number of entries before a position is a closed form too: the val changes before it, plus
+// floor((length - 1) / max_len) time-outs per finished run, plus those of the run in progress.  So ONE
+// scan (EdgeAgg: first change, last two changes, entries of the runs that begin and end inside the span)
+// gives a tile both what the old two scans did -- the change positions before it and where its entries go.
+// Two launches: a reduce over the planes (16 bytes per tile), and the writer, which re-reads its tile's
+// planes, folds its predecessors' aggregates itself and needs no per-word arrays from global memory.
+//
+// An entry is stored as its sample position (u32, batch-local) and its 16-bit code (LUT row | route):
+// 6 bytes instead of the 16 of nfc_edge.  (v, d, t) decode from the code, the index is g0 + position;
+// nfc_read_edges builds the records on the host from these.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,6 +75,17 @@ struct EdgeArgs {
         return (int)(r >= (uint32_t)mx ? r - (uint32_t)mx : r);
     }
 
+    __device__ __forceinline__ uint32_t div_mx(int x) const {   // floor(x / max_len) for 0 <= x < 2^31
+        const uint32_t q = __umulhi((uint32_t)x, mx_magic);   // the quotient or one less
+        const uint32_t r = (uint32_t)x - q * (uint32_t)mx;
+        return q + (r >= (uint32_t)mx ? 1u : 0u);
+    }
+    // time-outs of a run whose first sample is s, before position e: samples s + k max_len (k >= 1) below e
+    __device__ __forceinline__ uint32_t timeouts_between(int32_t s, int32_t e) const {
+        const int x = e - s - 1;
+        return x > 0 ? div_mx(x) : 0u;
+    }
+
     __device__ __forceinline__ int val_at(int32_t p) const {
         if ((neg[p >> 6] >> (p & 63)) & 1ull) return -1;
         return (int)((pos[p >> 6] >> (p & 63)) & 1ull);
@@ -80,6 +102,10 @@ struct EdgeArgs {
             pn = neg[w - 1] >> 63;
             pp = pos[w - 1] >> 63;
         }
+        return change_mask_of(w, ng, ps, pn, pp);
+    }
+    // the same from planes already loaded: pn / pp = the LOW / HIGH bit of the sample before the word
+    __device__ __forceinline__ uint64_t change_mask_of(size_t w, uint64_t ng, uint64_t ps, uint64_t pn, uint64_t pp) const {
         uint64_t m = (ng ^ ((ng << 1) | pn)) | (ps ^ ((ps << 1) | pp));
         const long long first = (long long)w * 64;
         const long long lo = (long long)skip - first, hi = (long long)n - first;
@@ -182,135 +208,282 @@ __device__ __forceinline__ void event_entry(const EdgeArgs &A, int32_t w0, int b
     event_entry(A, w0, b, ng, ps, m, ctx, v, d, t, [&A](int32_t q) { return A.val_at(q); });
 }
 
-// ---- scan 1: last two change positions before every word; its apply also marks the word's events and
-// sums their counts per tile (the aggregates of scan 2: where each word's entries go) ----
-struct LoadLast2 {
-    EdgeArgs A;
-    __device__ __forceinline__ Last2 operator()(size_t w) const {
-        uint64_t ng, ps;
-        const uint64_t m = A.change_mask(w, ng, ps);
-        if (!m) return Last2{POS_NONE, POS_NONE};
-        const int b1 = 63 - __clzll((long long)m);
-        const uint64_t m2 = m & ~(1ull << b1);
-        return Last2{(int32_t)(w * 64) + b1, m2 ? (int32_t)(w * 64) + (63 - __clzll((long long)m2)) : POS_NONE};
+// ---- the stage's scan ------------------------------------------------------------------------------------------
+// A span of words: where its first val change is, its last two, and the entries it is sure of whatever surrounds it --
+// its val changes and the time-outs of the runs that begin AND end in it.  The time-outs of the run that enters the span
+// and of the one that leaves it depend on the neighbours: the operator adds them when two spans meet (the run between
+// a's last change and b's first), entries_before() adds the two at the ends.
+struct EdgeAgg {
+    int32_t first;   // POS_NONE: no change in the span
+    Last2 l;
+    uint32_t sum;
+};
+struct EdgeAggOp {
+    using T = EdgeAgg;
+    int32_t mx;
+    uint32_t mx_magic;
+    __host__ __device__ __forceinline__ T identity() const { return T{POS_NONE, Last2{POS_NONE, POS_NONE}, 0u}; }
+    __device__ __forceinline__ T operator()(const T &a, const T &b) const {
+        if (b.first == POS_NONE) return a;
+        if (a.first == POS_NONE) return b;
+        const int x = b.first - a.l.s1 - 1;   // (> = 0: b follows a)
+        uint32_t tmo = 0u;
+        if (x > 0) {
+            const uint32_t q = __umulhi((uint32_t)x, mx_magic);
+            const uint32_t r = (uint32_t)x - q * (uint32_t)mx;
+            tmo = q + (r >= (uint32_t)mx ? 1u : 0u);
+        }
+        return T{a.first, b.l.s2 != POS_NONE ? b.l : Last2{b.l.s1, a.l.s1}, a.sum + b.sum + tmo};
     }
 };
-struct StoreCtxAndEvents {
-    EdgeArgs A;
-    Last2 *ctx;
-    uint64_t *evm;
-    __device__ __forceinline__ uint32_t operator()(size_t w, Last2 excl, Last2) const {   // returns the word's entry count
-        uint64_t ng, ps;
-        const uint64_t m = A.change_mask(w, ng, ps);
-        const uint64_t e = event_mask(A, w, excl, m);
-        ctx[w] = excl;
-        evm[w] = e;
-        return (uint32_t)__popcll(e);
+// one word's aggregate from its change mask (w0: its first sample)
+__device__ __forceinline__ EdgeAgg word_agg(const EdgeArgs &A, int32_t w0, uint64_t m) {
+    if (!m) return EdgeAgg{POS_NONE, Last2{POS_NONE, POS_NONE}, 0u};
+    const int b0 = __ffsll((long long)m) - 1, b1 = 63 - __clzll((long long)m);
+    const uint64_t m2 = m & ~(1ull << b1);
+    uint32_t sum = (uint32_t)__popcll(m);
+    if (b1 - b0 > A.mx) {   // a run inside the word may be long enough to time out
+        uint64_t rest = m & (m - 1);
+        int prev = b0;
+        while (rest) {
+            const int b = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            sum += A.timeouts_between(prev, b);
+            prev = b;
+        }
     }
-};
+    return EdgeAgg{w0 + b0, Last2{w0 + b1, m2 ? w0 + (63 - __clzll((long long)m2)) : POS_NONE}, sum};
+}
+// Entries before position T (the first sample of a word), from the aggregate of all the words before it: what the
+// aggregate is sure of, the time-outs of the run carried into the batch (up to the first change), and those of the run
+// in progress at T.  (A carried run "starts" where its carried _dur puts it: skip - dur_in.)
+__device__ __forceinline__ uint32_t entries_before(const EdgeArgs &A, const EdgeAgg &pre, int32_t T) {
+    const int32_t s0 = (int32_t)A.skip - A.dur_in;
+    uint32_t c = pre.sum;
+    if (pre.first != POS_NONE) c += A.timeouts_between(s0, pre.first);
+    return c + A.timeouts_between(pre.l.s1 != POS_NONE ? pre.l.s1 : s0, T);
+}
+
+// A thread's consecutive words of the planes and their change masks; 16-byte loads when the words are all there.
+template <int ITEMS>
+__device__ __forceinline__ void load_words(const EdgeArgs &A, size_t w, size_t nwords, uint64_t (&ng)[ITEMS], uint64_t (&ps)[ITEMS],
+                                           uint64_t (&m)[ITEMS]) {
+    static_assert(ITEMS % 2 == 0, "pairs of words");
+    if (w + ITEMS <= nwords) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i += 2) {
+            const uint4 a = *(const uint4 *)(A.neg + w + i), b = *(const uint4 *)(A.pos + w + i);
+            ng[i] = (uint64_t)a.x | ((uint64_t)a.y << 32);
+            ng[i + 1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+            ps[i] = (uint64_t)b.x | ((uint64_t)b.y << 32);
+            ps[i + 1] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            ng[i] = (w + i < nwords) ? A.neg[w + i] : 0ull;
+            ps[i] = (w + i < nwords) ? A.pos[w + i] : 0ull;
+        }
+    }
+    uint64_t pn, pp;
+    if (w == 0) {
+        pn = A.last_bit_in == -1 ? 1ull : 0ull;
+        pp = A.last_bit_in == 1 ? 1ull : 0ull;
+    } else if (w <= nwords) {
+        pn = A.neg[w - 1] >> 63;
+        pp = A.pos[w - 1] >> 63;
+    } else {
+        pn = pp = 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        m[i] = (w + i < nwords) ? A.change_mask_of(w + i, ng[i], ps[i], pn, pp) : 0ull;
+        pn = ng[i] >> 63;
+        pp = ps[i] >> 63;
+    }
+}
+
+#ifndef NFC_EW_ITEMS
+#define NFC_EW_ITEMS 4
+#endif
+constexpr int EW_ITEMS = NFC_EW_ITEMS;               // words per thread
+constexpr int EW_WORDS = SCAN_BLOCK * EW_ITEMS;      // words per tile, in both launches of the stage
+#ifndef NFC_EW_CAP
+#define NFC_EW_CAP 8192
+#endif
+inline size_t edge_num_tiles(size_t nwords) { return (nwords + EW_WORDS - 1) / EW_WORDS; }
+
+// ---- launch 1: one aggregate per tile ----
+__device__ __forceinline__ void edge_reduce_block(const EdgeArgs &A, size_t nwords, uint32_t tile, EdgeAgg *partials) {
+    __shared__ EdgeAgg lds[SCAN_WAVES];
+    const EdgeAggOp op{A.mx, A.mx_magic};
+    const size_t w = (size_t)tile * EW_WORDS + (size_t)threadIdx.x * EW_ITEMS;
+    uint64_t ng[EW_ITEMS], ps[EW_ITEMS], m[EW_ITEMS];
+    load_words<EW_ITEMS>(A, w, nwords, ng, ps, m);
+    EdgeAgg agg = op.identity();
+#pragma unroll
+    for (int i = 0; i < EW_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w + i) * 64), m[i]));
+    EdgeAgg total;
+    (void)block_exclusive_with<SCAN_WAVES>(op, agg, lds, total);
+    if (threadIdx.x == 0) partials[tile] = total;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_edge_reduce(EdgeArgs A, size_t nwords, EdgeAgg *partials) {
+    edge_reduce_block(A, nwords, blockIdx.x, partials);
+}
 
 // per edge, for the decoders: LUT row (v + 1) * nd + d in the low 14 bits, route in the top two
-// (0 dropped, 1 Manchester / tag->reader, 2 Miller / reader->tag; background.py:30-35)
+// (0 dropped, 1 Manchester / tag->reader, 2 Miller / reader->tag; background.py:30-35).  d <= max_len = nd - 1 on
+// every path of event_entry, so the code holds the whole entry.
 __device__ __forceinline__ uint16_t edge_code(int v, int d, int t, int nd) {
     const int dd = d < nd ? d : nd - 1;
     return (uint16_t)(((v + 1) * nd + dd) | ((t + 1) << 14));
 }
+// ... and back (host: nfc_read_edges)
+inline void edge_decode(uint16_t code, int nd, int &v, int &d, int &t) {
+    const int li = code & 0x3FFF;
+    v = li / nd - 1;
+    d = li % nd;
+    t = (int)(code >> 14) - 1;
+}
 
-// carried (_last_bit, _dur, _current_state) after the batch, from the scan-1 total; runs once after the entry-count
-// scan: as the epilogue of its prefix launch, or in the workgroup of the last tile of k_write_edges
-struct EdgeCarryEpilogue {
+// carried (_last_bit, _dur, _current_state) after the batch, from the last two change positions of the whole batch
+__device__ __forceinline__ void edge_carry_out(const EdgeArgs &A, Last2 total, EdgeCarry *carry) {
+    if (A.skip >= A.n) return;  // nothing but fill samples: unchanged
+    int lb, dur, st;
+    A.state_before((int32_t)A.n, total, lb, dur, st);
+    carry->last_bit = lb;
+    carry->dur = dur;
+    carry->state = st;
+}
+// long batches: the epilogue of the prefix launch over the tile aggregates publishes the totals and the carry
+struct EdgeTotalEpilogue {
     EdgeArgs A;
-    const Last2 *total;
+    uint32_t *edges_total;
+    Last2 *last2_total;
     EdgeCarry *carry;
-    __device__ __forceinline__ void operator()(uint32_t) const {
-        if (A.skip >= A.n) return;  // nothing but fill samples: unchanged
-        int lb, dur, st;
-        A.state_before((int32_t)A.n, *total, lb, dur, st);
-        carry->last_bit = lb;
-        carry->dur = dur;
-        carry->state = st;
+    __device__ __forceinline__ void operator()(const EdgeAgg &tot) const {
+        *edges_total = entries_before(A, tot, (int32_t)A.n);
+        *last2_total = tot.l;
+        edge_carry_out(A, tot.l, carry);
     }
 };
 
-// The writer: a workgroup owns 512 consecutive words (two per thread).  It places its entries with a block
-// scan, lists them as (word, bit) in LDS, and then works one thread per entry, so that consecutive lanes
-// store consecutive 16-byte entries.
-constexpr int EW_ITEMS = 2;
-constexpr int EW_WORDS = SCAN_BLOCK * EW_ITEMS;
-constexpr int EW_CAP = 4096;   // entries listed per round (a tile holds 2150 on the bench workloads, 32768 at most)
-__global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const Last2 *ctx, const uint64_t *evm,
-                                                           const uint32_t *tile_base, nfc_edge *edges, uint16_t *ecode,
-                                                           uint32_t cap, bool own_prefix, uint32_t *total_out, const Last2 *last2_total,
-                                                           EdgeCarry *carry_out) {
-    __shared__ uint64_t s_ng[EW_WORDS], s_ps[EW_WORDS], s_m[EW_WORDS];
-    __shared__ Last2 s_ctx[EW_WORDS];
-    __shared__ uint16_t s_ev[EW_CAP];
-    __shared__ uint32_t s_scan[SCAN_WAVES];
-    const int wl0 = (int)threadIdx.x * EW_ITEMS;
+// ---- launch 2: the writer.  A workgroup owns EW_WORDS consecutive words; a thread walks its EW_ITEMS words' entries in
+// stream order, which is the reference's own loop restricted to the samples that emit (transition_sink.py:84-99): between
+// entries everything it carries has a closed form, so the walk keeps
+//   lb      _last_bit: val of the run in progress
+//   q       the sample where _dur last restarted: the run's first sample or its latest time-out (_dur = p - q)
+//   timed   the run has timed out at least once
+//   left    _current_state the previous run left (a val-0 run that has not timed out keeps it)
+// and needs no division per entry.  Where a thread starts comes from ONE block scan of EdgeAgg on top of the tile's
+// prefix: the two changes before its first word AND, by entries_before(), the offset of its first entry.  Entries go to
+// LDS at their offsets and leave the workgroup as whole rows of positions and codes.
+constexpr int EW_CAP = NFC_EW_CAP;   // entries staged per round (a tile of 1024 words holds 4300 on the bench workloads, 65536 at most)
+struct EdgeWalk {
+    int lb, left;
+    int32_t q;
+    bool timed, carried;
+};
+__global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const EdgeAgg *partials, uint32_t *epos,
+                                                           uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
+                                                           Last2 *last2_total, EdgeCarry *carry_out) {
+    __shared__ uint32_t s_pos[EW_CAP];
+    __shared__ uint16_t s_code[EW_CAP];
+    __shared__ EdgeAgg s_agg[SCAN_WAVES];
     const size_t wt = (size_t)blockIdx.x * EW_WORDS;   // first word of the tile
-    uint64_t ev[EW_ITEMS];
-    uint32_t mine = 0;
+    const size_t w_first = wt + (size_t)threadIdx.x * EW_ITEMS;
+    // own_prefix: partials still holds the tiles' aggregates and the workgroup folds its predecessors' itself
+    // (first, while few registers are live); the last tile then publishes the totals and the carry
+    const EdgeAggOp op{A.mx, A.mx_magic};
+    const EdgeAgg pre = own_prefix ? tile_prefix_with<SCAN_BLOCK>(op, partials, blockIdx.x, s_agg) : partials[blockIdx.x];
+    const uint32_t gbase = entries_before(A, pre, (int32_t)(wt * 64));
+    uint64_t ng[EW_ITEMS], ps[EW_ITEMS], m[EW_ITEMS];
+    load_words<EW_ITEMS>(A, w_first, nwords, ng, ps, m);
+    EdgeAgg agg = op.identity();
 #pragma unroll
-    for (int i = 0; i < EW_ITEMS; i++) {
-        const size_t w = wt + wl0 + i;
-        ev[i] = 0ull;
-        if (w < nwords) {
-            uint64_t ng, ps;
-            s_m[wl0 + i] = A.change_mask(w, ng, ps);
-            s_ng[wl0 + i] = ng;
-            s_ps[wl0 + i] = ps;
-            s_ctx[wl0 + i] = ctx[w];
-            ev[i] = evm[w];
-        }
-        mine += (uint32_t)__popcll(ev[i]);
-    }
-    uint32_t total;
-    const uint32_t off = block_exclusive<AddU32>(mine, s_scan, total);
-    // own_prefix: tile_base still holds the tiles' entry counts; the last tile publishes the total and the carry
-    const uint32_t gbase = own_prefix ? tile_prefix<AddU32, SCAN_BLOCK>(tile_base, blockIdx.x, s_scan) : tile_base[blockIdx.x];
+    for (int i = 0; i < EW_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w_first + i) * 64), m[i]));
+    EdgeAgg tile_total;
+    const EdgeAgg before = op(pre, block_exclusive_with<SCAN_WAVES>(op, agg, s_agg, tile_total));
+    const EdgeAgg all = op(pre, tile_total);
+    const int32_t T = (int32_t)min(w_first * 64, (size_t)A.n), tile_end = (int32_t)min((wt + EW_WORDS) * 64, (size_t)A.n);
+    const uint32_t off = entries_before(A, before, T) - gbase;
+    const uint32_t total = entries_before(A, all, tile_end) - gbase;
     if (own_prefix && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         *total_out = gbase + total;
-        EdgeCarryEpilogue{A, last2_total, carry_out}(gbase + total);
+        *last2_total = all.l;
+        edge_carry_out(A, all.l, carry_out);
     }
-    for (uint32_t rbase = 0; rbase < total; rbase += EW_CAP) {
+    // where the walk stands at the thread's first sample
+    EdgeWalk W0;
+    {
+        const Last2 c = before.l;
+        W0.carried = c.s1 == POS_NONE;
+        const int32_t s = W0.carried ? (int32_t)A.skip - A.dur_in : c.s1;
+        const int32_t k = (int32_t)A.timeouts_between(s, T);   // time-outs of the run so far
+        W0.q = s + k * A.mx;
+        W0.timed = k > 0;
+        W0.left = A.state_in;
+        if (W0.carried) {
+            W0.lb = A.last_bit_in;
+        } else {
+            // (no change between c.s1 and T: val at T - 1 is the run's; T - 1 lies in the word before the thread's)
+            const size_t wp = (size_t)(T - 1) >> 6;
+            const int sh = (T - 1) & 63;
+            W0.lb = ((A.neg[wp] >> sh) & 1ull) ? -1 : (int)((A.pos[wp] >> sh) & 1ull);
+            if (W0.lb == 0 && !W0.timed) {   // a val-0 run that has not timed out keeps what the previous run left
+                int lb, dur;
+                A.state_before(T, c, lb, dur, W0.left);
+            }
+        }
+    }
+    for (uint32_t rbase = 0; rbase < total; rbase += EW_CAP) {   // (a second round walks again: only tiles denser than EW_CAP)
+        EdgeWalk W = W0;
         uint32_t k = off - rbase;   // wraps below the round: the unsigned compare drops those
+        auto emit = [&](int32_t p, int v, int d, int t) {
+            if (k < (uint32_t)EW_CAP) {
+                s_pos[k] = (uint32_t)p;
+                s_code[k] = edge_code(v, d, t, A.nd);
+            }
+            k++;
+        };
 #pragma unroll
         for (int i = 0; i < EW_ITEMS; i++) {
-            uint64_t e = ev[i];
-            while (e) {
-                if (k < (uint32_t)EW_CAP) s_ev[k] = (uint16_t)(((wl0 + i) << 6) | (__ffsll((long long)e) - 1));
-                e &= e - 1;
-                k++;
+            const int32_t w0 = (int32_t)((w_first + i) * 64);
+            const int32_t end = min(w0 + 64, (int32_t)A.n);
+            uint64_t mm = m[i];
+            while (true) {
+                const int b = mm ? __ffsll((long long)mm) - 1 : 64;
+                const int32_t c = min(w0 + b, end);   // the next change, or the end of the word
+                const int32_t nt = W.q + A.mx;        // the run's next time-out
+                if (nt < c) {   // _dur exceeds max_len (transition_sink.py:95-99)
+                    const int cs = (W.lb == -1) ? 2 : ((W.lb == 1) ? 1 : (W.timed ? 0 : W.left));
+                    emit(nt, cs == 2 ? W.lb + 1 : W.lb, A.mx, cs - 1);
+                    W.q = nt;
+                    W.timed = true;
+                    continue;
+                }
+                if (!mm) break;
+                // val changes here (transition_sink.py:86-92)
+                const int val = ((ng[i] >> b) & 1ull) ? -1 : (int)((ps[i] >> b) & 1ull);
+                int prev_st = (W.lb != 0) ? ((W.timed && W.q == c - 1) ? 0 : (W.lb == -1 ? 2 : 1)) : (W.timed ? 0 : W.left);
+                if (W.carried && c == (int32_t)A.skip) prev_st = A.state_in;   // the first stable sample: the carried value itself
+                const int st = (val == -1) ? 2 : ((val == 1) ? 1 : prev_st);
+                emit(c, st == 2 ? W.lb + 1 : W.lb, prev_st == 0 ? A.mx : c - W.q, st - 1);
+                W.left = prev_st;
+                W.lb = val;
+                W.q = c;
+                W.timed = false;
+                W.carried = false;
+                mm &= mm - 1;
             }
         }
         __syncthreads();
         const uint32_t cnt = min((uint32_t)EW_CAP, total - rbase);
         for (uint32_t j = threadIdx.x; j < cnt; j += SCAN_BLOCK) {
-            const uint32_t code = s_ev[j];
-            const int wl = (int)(code >> 6), b = (int)(code & 63u);
-            const int32_t w0 = (int32_t)((wt + wl) * 64);
-            int v, d, t;
-            // val at an earlier change position: from the staged planes when it lies in this tile (nearly always)
-            auto val = [&](int32_t q) {
-                const long long ql = (long long)(q >> 6) - (long long)wt;
-                if (ql >= 0) {
-                    const int sh = q & 63;
-                    if ((s_ng[ql] >> sh) & 1ull) return -1;
-                    return (int)((s_ps[ql] >> sh) & 1ull);
-                }
-                return A.val_at(q);
-            };
-            event_entry(A, w0, b, s_ng[wl], s_ps[wl], s_m[wl], s_ctx[wl], v, d, t, val);
             const uint32_t g = gbase + rbase + j;
             if (g < cap) {
-                nfc_edge o;
-                o.idx = A.g0 + (uint64_t)(w0 + b);
-                o.d = d;
-                o.v = (int8_t)v;
-                o.t = (int8_t)t;
-                o.pad = 0;
-                edges[g] = o;
-                ecode[g] = edge_code(v, d, t, A.nd);
+                epos[g] = s_pos[j];
+                ecode[g] = s_code[j];
             }
         }
         __syncthreads();

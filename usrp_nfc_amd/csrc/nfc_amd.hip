@@ -5,7 +5,7 @@
 //   k_fill (first av_window samples, then the per-batch preparation)
 //   -> k_threshold pass 0 (speculate) -> k_certify (+ end-of-batch state, verdict summary)
 //      [-> re-runs from the exact state | k_threshold_seq over a prefix, then another attempt]      (run_threshold)
-//   -> last-two-changes scan -> event masks + entry counts -> entry offsets -> k_write_edges        (run_edges)
+//   -> tile aggregates (first / last two changes, entries) -> k_write_edges                         (run_edges)
 //   -> k_dec_reduce -> tile prefixes -> k_dec_apply -> symbol / bit / close offsets and framing states (one scan)
 //   -> k_frame_write -> k_pkt_finish (both packet types in each launch; fills the host's mirror of the state) (run_decode)
 //   (batches up to 2^18 samples: the three stages after the threshold stage in ONE launch, small.hip.h)
@@ -44,9 +44,9 @@ namespace {
 
 std::string g_create_error;
 
-// The first certification of a batch and the edge stage's counting pass both depend on k_threshold only, so they share
+// The first certification of a batch and the edge stage's reduce pass both depend on k_threshold only, so they share
 // a launch: the first cert_blocks workgroups certify (the last of them resolves the end-of-batch state), the others
-// count the entries of their 512 words.  (Sequentially they were 22 + 23 us.)
+// reduce their tile of the planes to its aggregate (edges.hip.h).
 struct CertLaunch {
     ThrArgs A;
     uint8_t *cert;
@@ -55,14 +55,12 @@ struct CertLaunch {
     CertSummary *sum;
     uint32_t blocks;
 };
-__global__ __launch_bounds__(256) void k_certify_and_count(CertLaunch C, size_t nwords, LoadLast2 load, StoreCtxAndEvents store,
-                                                           const Last2 *partials, uint32_t *sums, bool own_prefix, Last2 *total_out) {
+__global__ __launch_bounds__(256) void k_certify_and_reduce(CertLaunch C, EdgeArgs E, size_t nwords, EdgeAgg *partials) {
     if (blockIdx.x < C.blocks) {
         certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, blockIdx.x, C.blocks);
         return;
     }
-    scan_apply_sum_block<Last2Op, EW_ITEMS, AddU32, LoadLast2, StoreCtxAndEvents>(nwords, nullptr, load, store, partials, sums,
-                                                                                    blockIdx.x - C.blocks, own_prefix, total_out);
+    edge_reduce_block(E, nwords, blockIdx.x - C.blocks, partials);
 }
 
 struct DevBuf {
@@ -174,8 +172,10 @@ struct nfc_ctx {
     // batch buffers
     DevBuf d_certinfo;
     DevBuf d_in, d_neg, d_pos, d_ringout[2], d_touched[2], d_info[2], d_ringin, d_meta, d_ver, d_cflags, d_list;
-    DevBuf d_ctx, d_wcnt, d_ecode;
-    DevBuf d_edges, d_states, d_sym[2], d_bits[2], d_pending[2][2], d_close_end[2],
+    DevBuf d_ecode, d_epos, d_eidx;   // per entry: code, batch-local sample position (edges.hip.h); caller's own indices (nfc_push_edges)
+    bool edges_from_host = false;
+    std::vector<nfc_edge> h_pushed;   // the entries of the last nfc_push_edges, as nfc_read_edges hands them back
+    DevBuf d_states, d_sym[2], d_bits[2], d_pending[2][2], d_close_end[2],
         d_close_idx[2];
     DevBuf d_partials, d_partials2, d_aggs, d_faggs;  // scan scratch
     DevBuf d_pack;                           // nfc_get_state staging
@@ -862,41 +862,32 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     E.mx_magic = c->mx > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c->mx) : 0xFFFFFFFFu;
     E.per_mask = 0;
     for (int b = 0; b < 64; b += c->mx) E.per_mask |= 1ull << b;
-    HIPCHK(c, c->d_ctx.ensure((nwords + 1) * sizeof(Last2)));
-    HIPCHK(c, c->d_wcnt.ensure((nwords + 1) * 8));
-    const size_t tiles = scan_num_tiles<EW_ITEMS>(nwords);   // 512 words per tile in every pass of the stage
-    HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(Last2)));
-    HIPCHK(c, c->d_partials2.ensure((tiles + 1) * sizeof(uint32_t)));
-    Last2 *ctx = c->d_ctx.as<Last2>();
-    uint64_t *evm = c->d_wcnt.as<uint64_t>();   // event masks
-    // scan 1: the two latest val changes before every 64-sample word; each word then marks its entries, and the
-    // tiles' entry counts are the aggregates of scan 2 (entry offsets per tile)
-    // While the tiles are few, each tile's workgroup folds its predecessors' aggregates itself (scan.hip.h: tile_prefix)
-    // and the two single-workgroup prefix launches of the stage are not needed.
+    const size_t tiles = edge_num_tiles(nwords);   // EW_WORDS words per tile in both launches of the stage
+    HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(EdgeAgg)));
+    EdgeAgg *parts = c->d_partials.as<EdgeAgg>();
+    // launch 1: one aggregate per tile (first change, last two changes, entries it is sure of).  While the tiles are few,
+    // each tile's workgroup of the writer folds its predecessors' aggregates itself (scan.hip.h: tile_prefix) and the
+    // single-workgroup prefix launch is not needed.
     const bool own = tiles <= c->own_prefix_max;
     Last2 *last2_total = (Last2 *)(tot + TOT_LAST2);
     uint32_t *edges_total = (uint32_t *)(tot + TOT_EDGES);
-    scan_reduce<Last2Op, EW_ITEMS>(c->st, nwords, nullptr, LoadLast2{E}, c->d_partials.as<Last2>());
-    if (!own)
-        scan_partials<Last2Op>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials.as<Last2>(), Last2Op::identity(), last2_total);
+    const EdgeAggOp op{E.mx, E.mx_magic};
     if (c->cert_pending && tiles) {
         c->cert_pending = false;
-        NFC_LAUNCH(k_certify_and_count, dim3((unsigned)(c->cert.blocks + tiles)), dim3(256), 0, c->st, c->cert, nwords, LoadLast2{E},
-                           StoreCtxAndEvents{E, ctx, evm}, c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>(), own, last2_total);
-    } else {
-        scan_apply_sum<Last2Op, EW_ITEMS, AddU32>(c->st, nwords, nullptr, LoadLast2{E}, StoreCtxAndEvents{E, ctx, evm},
-                                                  c->d_partials.as<Last2>(), c->d_partials2.as<uint32_t>(), own, last2_total);
+        NFC_LAUNCH(k_certify_and_reduce, dim3((unsigned)(c->cert.blocks + tiles)), dim3(256), 0, c->st, c->cert, E, nwords, parts);
+    } else if (tiles) {
+        NFC_LAUNCH(k_edge_reduce, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, parts);
     }
-    if (!own)
-        scan_partials<AddU32>(c->st, tiles, nullptr, SCAN_BLOCK * EW_ITEMS, c->d_partials2.as<uint32_t>(), 0u, edges_total,
-                              EdgeCarryEpilogue{E, last2_total, dE(c)});
+    if (!own || !tiles)
+        scan_partials_with(c->st, op, tiles, nullptr, (uint32_t)EW_WORDS, parts, op.identity(), (EdgeAgg *)nullptr,
+                           EdgeTotalEpilogue{E, edges_total, last2_total, dE(c)});
     const uint32_t cap = c->cap_edges;
-    HIPCHK(c, c->d_edges.ensure(((size_t)cap + 1) * sizeof(nfc_edge)));
+    HIPCHK(c, c->d_epos.ensure(((size_t)cap + 8) * 4));
     HIPCHK(c, c->d_ecode.ensure(((size_t)cap + 8) * 2));
-    if (nwords)
-        NFC_LAUNCH(k_write_edges, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, ctx, evm,
-                           c->d_partials2.as<uint32_t>(), c->d_edges.as<nfc_edge>(), c->d_ecode.as<uint16_t>(), cap, own, edges_total,
-                           last2_total, dE(c));
+    if (tiles)
+        NFC_LAUNCH(k_write_edges, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, parts, c->d_epos.as<uint32_t>(),
+                   c->d_ecode.as<uint16_t>(), cap, own, edges_total, last2_total, dE(c));
+    c->edges_from_host = false;
     return NFC_OK;
 }
 
@@ -908,7 +899,9 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
 int frame_out(nfc_ctx *c, FrameOut &P, const bool (&enabled)[2]) {
     memset(&P, 0, sizeof P);
     const int pn = 1 - c->pend_cur;
-    P.edges = c->d_edges.as<nfc_edge>();
+    P.epos = c->d_epos.as<uint32_t>();
+    P.g0 = c->last_g0;
+    P.idx64 = c->edges_from_host ? c->d_eidx.as<uint64_t>() : nullptr;
     for (int t = 0; t < 2; t++) {
         const uint32_t cs = c->cap_sym[t];
         HIPCHK(c, c->d_sym[t].ensure((size_t)cs + 16));
@@ -1025,9 +1018,10 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     for (int b = 0; b < 64; b += c->mx) A.E.per_mask |= 1ull << b;
     A.nwords = ((size_t)n + 63) / 64;
     const uint32_t ce = c->cap_edges;
-    HIPCHK(c, c->d_edges.ensure(((size_t)ce + 1) * sizeof(nfc_edge)));
+    HIPCHK(c, c->d_epos.ensure(((size_t)ce + 8) * 4));
     HIPCHK(c, c->d_ecode.ensure(((size_t)ce + 8) * 2));
-    A.edges = c->d_edges.as<nfc_edge>();
+    c->edges_from_host = false;
+    A.epos = c->d_epos.as<uint32_t>();
     A.ecode = c->d_ecode.as<uint16_t>();
     A.cap_edges = ce;
     A.T = c->T;
@@ -1450,7 +1444,7 @@ void nfc_destroy(nfc_ctx *c) {
     else (void)hipDeviceSynchronize();   // on a caller's stream (nfc_set_stream): the handle may be gone by now
     DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_state,
                      &c->d_ring[0], &c->d_ring[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
-                     &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ctx, &c->d_wcnt, &c->d_ecode, &c->d_edges, &c->d_states, &c->d_sym[0], &c->d_sym[1],
+                     &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ecode, &c->d_epos, &c->d_eidx, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
                      &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_gring, &c->d_pack, &c->d_gvtop, &c->d_seqout};
@@ -1508,10 +1502,15 @@ int nfc_push_edges(nfc_ctx *c, const nfc_edge *host_edges, size_t n64) {
     }
     c->cap_edges = n;
     for (int t = 0; t < 2; t++) c->cap_sym[t] = (t == 1 ? 2u : 1u) * n + 16;
-    HIPCHK(c, c->d_edges.ensure(((size_t)n + 1) * sizeof(nfc_edge)));
+    HIPCHK(c, c->d_eidx.ensure(((size_t)n + 1) * 8));
     HIPCHK(c, c->d_ecode.ensure(((size_t)n + 8) * 2));
+    HIPCHK(c, c->d_epos.ensure(8 * 4));
+    c->h_pushed.assign(host_edges, host_edges + n);
+    c->edges_from_host = true;   // (the packets are labelled with the caller's indices)
+    std::vector<uint64_t> idx(n);
+    for (uint32_t i = 0; i < n; i++) idx[i] = host_edges[i].idx;
     if (n) {
-        HIPCHK(c, hipMemcpyAsync(c->d_edges.p, host_edges, (size_t)n * sizeof(nfc_edge), hipMemcpyHostToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->d_eidx.p, idx.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->st));
         HIPCHK(c, hipMemcpyAsync(c->d_ecode.p, code.data(), (size_t)n * 2, hipMemcpyHostToDevice, c->st));
     }
     HIPCHK(c, hipMemcpyAsync(dT(c) + TOT_EDGES, &n, 4, hipMemcpyHostToDevice, c->st));
@@ -1580,9 +1579,38 @@ static int read_range(nfc_ctx *c, const void *dev, size_t total, size_t esz, siz
     return NFC_OK;
 }
 
+// The device keeps an entry as (sample position, code): 6 bytes (edges.hip.h).  The records are built here.
 int nfc_read_edges(nfc_ctx *c, size_t first, nfc_edge *out, size_t cap, size_t *n_out) {
     if (!c) return NFC_ERR_ARG;
-    return read_range(c, c->d_edges.p, c->n_edges, sizeof(nfc_edge), first, out, cap, n_out);
+    if (!c->have_outputs) return fail(c, NFC_ERR_STATE, "no completed batch");
+    size_t n = 0;
+    if (first < c->n_edges) n = std::min(cap, (size_t)c->n_edges - first);
+    if (n && !out) return fail(c, NFC_ERR_ARG, "null output");
+    if (n_out) *n_out = n;
+    if (!n) return NFC_OK;
+    if (c->edges_from_host) {
+        memcpy(out, c->h_pushed.data() + first, n * sizeof(nfc_edge));
+        return NFC_OK;
+    }
+    std::vector<uint32_t> pos(n);
+    std::vector<uint16_t> code(n);
+    HIPCHK(c, hipMemcpy(pos.data(), c->d_epos.as<uint32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(code.data(), c->d_ecode.as<uint16_t>() + first, n * 2, hipMemcpyDeviceToHost));
+    const int nd = c->mx + 1;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t p = pos[i];
+        const uint16_t cd = code[i];
+        int v, d, t;
+        edge_decode(cd, nd, v, d, t);
+        nfc_edge o;
+        o.idx = c->last_g0 + (uint64_t)p;
+        o.d = d;
+        o.v = (int8_t)v;
+        o.t = (int8_t)t;
+        o.pad = 0;
+        out[i] = o;
+    }
+    return NFC_OK;
 }
 
 int nfc_read_symbols(nfc_ctx *c, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out) {
@@ -1759,6 +1787,9 @@ int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size
                   size_t pending_len) {
     if (!c || !h || !ring) return NFC_ERR_ARG;
     if (h->av_window != c->L || ring_len != (size_t)c->L) return fail(c, NFC_ERR_ARG, "state was taken with another av_window");
+    // (_dur is 0 after the fill and 1 .. max_len after a sample: transition_sink.py:95-99, 123; the entry codes rely on it)
+    if (h->dur < 0 || h->dur > c->mx || h->last_bit < -1 || h->last_bit > 1 || h->cur_state < 0 || h->cur_state > 2)
+        return fail(c, NFC_ERR_ARG, "edge-timing state out of range (dur %d, last_bit %d, cur_state %d)", h->dur, h->last_bit, h->cur_state);
     const size_t p0 = h->n_pending_bits[0], p1 = h->n_pending_bits[1];
     if (p0 + p1 != pending_len || ((p0 + p1) && !pending)) return fail(c, NFC_ERR_ARG, "pending bits do not match the header");
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");

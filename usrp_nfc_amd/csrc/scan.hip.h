@@ -114,46 +114,67 @@ __device__ __forceinline__ T dpp_move(const T &old, const T &v) {
     __builtin_memcpy(&out, r, sizeof(T));
     return out;
 }
+// The helpers below take the operator as an OBJECT (type T, identity(), operator()(a, b)), so that an operator may carry
+// values (edges.hip.h: EdgeAggOp divides by max_len); the trait forms (static identity / op) wrap into StaticOp.
 template <class Tr>
-__device__ __forceinline__ typename Tr::T wave_inclusive(typename Tr::T x) {
+struct StaticOp {
     using T = typename Tr::T;
-    const T id = Tr::identity();
-    x = Tr::op(dpp_move<0x111, 0xF>(id, x), x);   // row_shr:1   (rows of 16 lanes)
-    x = Tr::op(dpp_move<0x112, 0xF>(id, x), x);   // row_shr:2
-    x = Tr::op(dpp_move<0x114, 0xF>(id, x), x);   // row_shr:4
-    x = Tr::op(dpp_move<0x118, 0xF>(id, x), x);   // row_shr:8
-    x = Tr::op(dpp_move<0x142, 0xA>(id, x), x);   // row_bcast:15 -> rows 1 and 3
-    x = Tr::op(dpp_move<0x143, 0xC>(id, x), x);   // row_bcast:31 -> rows 2 and 3
+    __device__ __forceinline__ T identity() const { return Tr::identity(); }
+    __device__ __forceinline__ T operator()(const T &a, const T &b) const { return Tr::op(a, b); }
+};
+template <class Op>
+__device__ __forceinline__ typename Op::T wave_inclusive_with(const Op &op, typename Op::T x) {
+    using T = typename Op::T;
+    const T id = op.identity();
+    x = op(dpp_move<0x111, 0xF>(id, x), x);   // row_shr:1   (rows of 16 lanes)
+    x = op(dpp_move<0x112, 0xF>(id, x), x);   // row_shr:2
+    x = op(dpp_move<0x114, 0xF>(id, x), x);   // row_shr:4
+    x = op(dpp_move<0x118, 0xF>(id, x), x);   // row_shr:8
+    x = op(dpp_move<0x142, 0xA>(id, x), x);   // row_bcast:15 -> rows 1 and 3
+    x = op(dpp_move<0x143, 0xC>(id, x), x);   // row_bcast:31 -> rows 2 and 3
     return x;
 }
+template <class Tr>
+__device__ __forceinline__ typename Tr::T wave_inclusive(typename Tr::T x) {
+    return wave_inclusive_with(StaticOp<Tr>{}, x);
+}
 // the inclusive value of the lane below (identity in lane 0)
+template <class Op>
+__device__ __forceinline__ typename Op::T wave_shift_up1_with(const Op &op, const typename Op::T &inc) {
+    return dpp_move<0x138, 0xF>(op.identity(), inc);   // wave_shr:1
+}
 template <class Tr>
 __device__ __forceinline__ typename Tr::T wave_shift_up1(const typename Tr::T &inc) {
-    return dpp_move<0x138, 0xF>(Tr::identity(), inc);   // wave_shr:1
+    return wave_shift_up1_with(StaticOp<Tr>{}, inc);
 }
 
 // ---- block-level helpers ----------------------------------------------------
 // Inclusive scan of one value per thread across the block; returns the exclusive
 // prefix of this thread and the block total.  lds must hold WAVES entries.
-template <class Tr, int WAVES = SCAN_WAVES>
-__device__ __forceinline__ typename Tr::T block_exclusive(typename Tr::T v, typename Tr::T *lds,
-                                                          typename Tr::T &block_total) {
-    using T = typename Tr::T;
+template <int WAVES, class Op>
+__device__ __forceinline__ typename Op::T block_exclusive_with(const Op &op, typename Op::T v, typename Op::T *lds,
+                                                               typename Op::T &block_total) {
+    using T = typename Op::T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const T inc = wave_inclusive<Tr>(v);
+    const T inc = wave_inclusive_with(op, v);
     if (lane == 63) lds[wave] = inc;
     __syncthreads();
-    T wave_prefix = Tr::identity();
-    T total = Tr::identity();
+    T wave_prefix = op.identity();
+    T total = op.identity();
 #pragma unroll
     for (int w = 0; w < WAVES; w++) {
         T x = lds[w];
-        if (w < wave) wave_prefix = Tr::op(wave_prefix, x);
-        total = Tr::op(total, x);
+        if (w < wave) wave_prefix = op(wave_prefix, x);
+        total = op(total, x);
     }
     __syncthreads();
     block_total = total;
-    return Tr::op(wave_prefix, wave_shift_up1<Tr>(inc));
+    return op(wave_prefix, wave_shift_up1_with(op, inc));
+}
+template <class Tr, int WAVES = SCAN_WAVES>
+__device__ __forceinline__ typename Tr::T block_exclusive(typename Tr::T v, typename Tr::T *lds,
+                                                          typename Tr::T &block_total) {
+    return block_exclusive_with<WAVES>(StaticOp<Tr>{}, v, lds, block_total);
 }
 // Block total of a commutative sum, valid in every thread.
 template <class Tr, int WAVES = SCAN_WAVES>
@@ -177,23 +198,27 @@ __device__ __forceinline__ typename Tr::T block_sum(typename Tr::T v, typename T
 // single-workgroup prefix launch between two passes (5-10 us each, plus the boundary); the total traffic is
 // quadratic in the tile count, so long batches keep the launch (OWN_PREFIX_MAX_TILES).
 constexpr uint32_t OWN_PREFIX_MAX_TILES = 4096;
-template <class Tr, int BLOCK = 256>
-__device__ __forceinline__ typename Tr::T tile_prefix(const typename Tr::T *aggs, uint32_t b, typename Tr::T *lds) {
-    using T = typename Tr::T;
+template <int BLOCK, class Op>
+__device__ __forceinline__ typename Op::T tile_prefix_with(const Op &op, const typename Op::T *aggs, uint32_t b, typename Op::T *lds) {
+    using T = typename Op::T;
     const uint32_t per = (b + BLOCK - 1) / BLOCK;
     const uint32_t lo = min(b, (uint32_t)threadIdx.x * per), hi = min(b, lo + per);
-    T acc = Tr::identity();
+    T acc = op.identity();
     constexpr int G = sizeof(T) <= 8 ? 8 : 4;   // loads in flight per thread: the fold must not wait for them one by one
     for (uint32_t i = lo; i < hi; i += G) {
         T v[G];
 #pragma unroll
-        for (int k = 0; k < G; k++) v[k] = (i + k < hi) ? aggs[i + k] : Tr::identity();
+        for (int k = 0; k < G; k++) v[k] = (i + k < hi) ? aggs[i + k] : op.identity();
 #pragma unroll
-        for (int k = 0; k < G; k++) acc = Tr::op(acc, v[k]);
+        for (int k = 0; k < G; k++) acc = op(acc, v[k]);
     }
     T total;
-    (void)block_exclusive<Tr, BLOCK / 64>(acc, lds, total);
+    (void)block_exclusive_with<BLOCK / 64>(op, acc, lds, total);
     return total;
+}
+template <class Tr, int BLOCK = 256>
+__device__ __forceinline__ typename Tr::T tile_prefix(const typename Tr::T *aggs, uint32_t b, typename Tr::T *lds) {
+    return tile_prefix_with<BLOCK>(StaticOp<Tr>{}, aggs, b, lds);
 }
 
 // tiles of BLOCK*ITEMS items
@@ -231,11 +256,11 @@ struct NoEpilogue {
     template <class T>
     __device__ __forceinline__ void operator()(const T &) const {}
 };
-template <class Tr, int BLOCK, class Epi>
+template <class Op, int BLOCK, class Epi>
 __global__ __launch_bounds__(BLOCK) void k_scan_partials(size_t nparts, const uint32_t *n_dev, uint32_t tile,
-                                                        typename Tr::T *partials, typename Tr::T seed,
-                                                        typename Tr::T *total_out, Epi epi) {
-    using T = typename Tr::T;
+                                                        typename Op::T *partials, typename Op::T seed,
+                                                        typename Op::T *total_out, Epi epi, Op op) {
+    using T = typename Op::T;
     constexpr int WAVES = BLOCK / 64;
     if (n_dev) nparts = min(nparts, ((size_t)*n_dev + tile - 1) / tile);
     __shared__ T lds[WAVES + 1];
@@ -245,34 +270,28 @@ __global__ __launch_bounds__(BLOCK) void k_scan_partials(size_t nparts, const ui
         const size_t i0 = base + (size_t)threadIdx.x * PART_ITEMS;
         T v[PART_ITEMS];
 #pragma unroll
-        for (int k = 0; k < PART_ITEMS; k++) v[k] = (i0 + k < nparts) ? partials[i0 + k] : Tr::identity();
+        for (int k = 0; k < PART_ITEMS; k++) v[k] = (i0 + k < nparts) ? partials[i0 + k] : op.identity();
         T inc = v[0];
 #pragma unroll
-        for (int k = 1; k < PART_ITEMS; k++) inc = Tr::op(inc, v[k]);
-        inc = wave_inclusive<Tr>(inc);
-        const T excl = wave_shift_up1<Tr>(inc);
+        for (int k = 1; k < PART_ITEMS; k++) inc = op(inc, v[k]);
+        inc = wave_inclusive_with(op, inc);
+        const T excl = wave_shift_up1_with(op, inc);
         if (lane == 63) lds[wave] = inc;
         __syncthreads();
-        if (wave == 0) {   // scan of the wave totals
-            T x = (lane < WAVES) ? lds[lane] : Tr::identity();
-#pragma unroll
-            for (int d = 1; d < WAVES; d <<= 1) {
-                T up = Tr::shfl_up(x, d);
-                if (lane >= d) x = Tr::op(up, x);
-            }
-            T ex = Tr::shfl_up(x, 1);
-            if (lane == 0) ex = Tr::identity();
+        if (wave == 0) {   // scan of the wave totals (lanes past them hold the identity)
+            const T x = wave_inclusive_with(op, (lane < WAVES) ? lds[lane] : op.identity());
+            const T ex = wave_shift_up1_with(op, x);
             if (lane < WAVES) lds[lane] = ex;
             if (lane == WAVES - 1) lds[WAVES] = x;
         }
         __syncthreads();
-        T run = Tr::op(carry, Tr::op(lds[wave], excl));
-        carry = Tr::op(carry, lds[WAVES]);
+        T run = op(carry, op(lds[wave], excl));
+        carry = op(carry, lds[WAVES]);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PART_ITEMS; k++) {
             if (i0 + k < nparts) partials[i0 + k] = run;
-            run = Tr::op(run, v[k]);
+            run = op(run, v[k]);
         }
     }
     if (threadIdx.x == 0) {
@@ -280,15 +299,20 @@ __global__ __launch_bounds__(BLOCK) void k_scan_partials(size_t nparts, const ui
         epi(carry);
     }
 }
+template <class Op, class Epi = NoEpilogue>
+inline void scan_partials_with(hipStream_t st, Op op, size_t tiles, const uint32_t *n_dev, uint32_t tile, typename Op::T *partials,
+                               typename Op::T seed, typename Op::T *total_out, Epi epi = Epi()) {
+    if (tiles <= 256 * PART_ITEMS)
+        NFC_LAUNCH((k_scan_partials<Op, 256, Epi>), dim3(1), dim3(256), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi, op);
+    else if (tiles <= 512 * PART_ITEMS)
+        NFC_LAUNCH((k_scan_partials<Op, 512, Epi>), dim3(1), dim3(512), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi, op);
+    else
+        NFC_LAUNCH((k_scan_partials<Op, 1024, Epi>), dim3(1), dim3(1024), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi, op);
+}
 template <class Tr, class Epi = NoEpilogue>
 inline void scan_partials(hipStream_t st, size_t tiles, const uint32_t *n_dev, uint32_t tile, typename Tr::T *partials,
                           typename Tr::T seed, typename Tr::T *total_out, Epi epi = Epi()) {
-    if (tiles <= 256 * PART_ITEMS)
-        NFC_LAUNCH((k_scan_partials<Tr, 256, Epi>), dim3(1), dim3(256), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
-    else if (tiles <= 512 * PART_ITEMS)
-        NFC_LAUNCH((k_scan_partials<Tr, 512, Epi>), dim3(1), dim3(512), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
-    else
-        NFC_LAUNCH((k_scan_partials<Tr, 1024, Epi>), dim3(1), dim3(1024), 0, st, tiles, n_dev, tile, partials, seed, total_out, epi);
+    scan_partials_with(st, StaticOp<Tr>{}, tiles, n_dev, tile, partials, seed, total_out, epi);
 }
 
 // The apply pass: every item gets its exclusive prefix; store() returns a count per item and the tile's sum of them

@@ -23,12 +23,12 @@ constexpr uint32_t SM_MAX_SAMPLES = 1u << 18;   // batches up to this length tak
 struct SmallArgs {
     EdgeArgs E;
     size_t nwords;
-    nfc_edge *edges;
+    uint32_t *epos;         // entries as (batch-local sample position, code): edges.hip.h
     uint16_t *ecode;
     uint32_t cap_edges;
     DecTables T;
     uint32_t dec_state_in;
-    FrameOut P;             // (edges: the array this launch writes)
+    FrameOut P;             // (epos: the array this launch writes)
     int32_t enabled[2];
     uint8_t *pending_next[2];
     uint32_t pending_cap[2];
@@ -101,13 +101,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
                     event_entry(A.E, p0, b, s_ng[wl], s_ps[wl], s_m[wl], s_ctx[wl], v, d, t);
                     const uint32_t g = n_edges_all + rbase + j;
                     if (g < A.cap_edges) {
-                        nfc_edge o;
-                        o.idx = A.E.g0 + (uint64_t)(p0 + b);
-                        o.d = d;
-                        o.v = (int8_t)v;
-                        o.t = (int8_t)t;
-                        o.pad = 0;
-                        A.edges[g] = o;
+                        A.epos[g] = (uint32_t)(p0 + b);
                         A.ecode[g] = edge_code(v, d, t, A.E.nd);
                     }
                 }

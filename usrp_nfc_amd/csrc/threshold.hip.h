@@ -207,7 +207,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // (measured: the low half of a fresh mask arrived as the previous row's).
 #define PLANE_PUT(pk, dword_of_mask, LANE) asm volatile("s_nop 2\n\tv_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"((uint32_t)(dword_of_mask)), "n"(LANE))
 // the same with the lane in a scalar register
-#define PLANE_PUT_AT(pk, dword_of_mask, lane) asm volatile("s_mov_b32 m0, %2\n\ts_nop 2\n\tv_writelane_b32 %0, %1, m0" : "+v"(pk) : "s"((uint32_t)(dword_of_mask)), "s"(__builtin_amdgcn_readfirstlane(lane)) : "m0")   /* (the lane select travels in M0: one SGPR per VALU instruction on the constant bus) */
+// (the lane select travels in M0 -- one SGPR per VALU instruction on the constant bus -- which is saved and put back here)
+#define PLANE_PUT_AT(pk, dword_of_mask, lane)                                                                                    \
+    do {                                                                                                                         \
+        uint32_t m0_keep_;                                                                                                       \
+        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"             \
+                     : "+v"(pk), "=&s"(m0_keep_)                                                                                 \
+                     : "s"((uint32_t)(dword_of_mask)), "s"(__builtin_amdgcn_readfirstlane(lane)));                               \
+    } while (0)
 // the eight dwords of four masks into lanes LANE0 .. LANE0 + 7 of pk, behind one pad
 #define PLANE_PUT8(pk, m, LANE0)                                                                                                             \
     asm volatile("s_nop 2\n\tv_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %9+1\n\tv_writelane_b32 %0, %3, %9+2\n\tv_writelane_b32 %0, %4, %9+3" \
