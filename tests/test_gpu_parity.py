@@ -154,6 +154,33 @@ def test_synthetic_workloads_2M(name, kw):
     assert len(r['packets']) > 100
 
 
+@pytest.mark.parametrize('max_len', [1, 7, 31, 32, 50, 62, 63, 64, 200])
+def test_edge_stage_dense_and_long_runs(monkeypatch, max_len):
+    # The multi-launch edge stage (edges.hip.h) on a short batch: samples that flicker between LOW, accepted and HIGH from one
+    # sample to the next (more entries per tile than the writer stages in one round), runs of every length around max_len
+    # and its multiples (time-outs inside a word, across words, across tiles and across pushes), for max_len on both
+    # sides of the 32 / 63 boundaries where the in-word time-out count changes form.
+    monkeypatch.setenv('NFC_NO_SMALL', '1')
+    rng = np.random.default_rng(7000 + max_len)
+    n = 150_000
+    x = (0.25 * (1 + 0.002 * rng.standard_normal(n))).astype(np.float32)
+    lv = np.array([0.01, 0.25, 0.25 * 1.3], np.float32)
+    for s in (3000, 40_000, 90_000):   # dense stretches: 35 000 samples of flicker
+        k = 35_000 if s == 40_000 else 2500
+        x[s:s + k] = lv[rng.integers(0, 3, k)]
+    pos = 8000
+    for ln in [max_len - 1, max_len, max_len + 1, 2 * max_len, 2 * max_len + 1, 3 * max_len + 2, 70, 5 * max_len + 3]:
+        for level in (0.01, 0.25 * 1.3):
+            if ln > 0:
+                x[pos:pos + ln] = level
+            pos += ln + int(rng.integers(1, 40))
+    x[130_000:131_000] = 0.01   # a long LOW run near the end
+    params = dict(hi_val=1.1, av_window=500, max_len=max_len)
+    check_vs_oracle(x, params)
+    cuts = sorted(set([0, n, 40_000 + 64 * 7 + 13, 57_344, 57_345, 130_500] + rng.integers(600, n, 4).tolist()))
+    check_vs_oracle(x, params, pushes=cuts)
+
+
 @pytest.mark.parametrize('own_prefix_max', ['0', '3'])
 def test_prefix_launch_path(monkeypatch, own_prefix_max):
     # Few tiles: every tile's workgroup folds its predecessors' aggregates itself; long batches keep the single-workgroup

@@ -223,17 +223,18 @@ struct EdgeAggOp {
     int32_t mx;
     uint32_t mx_magic;
     __host__ __device__ __forceinline__ T identity() const { return T{POS_NONE, Last2{POS_NONE, POS_NONE}, 0u}; }
-    __device__ __forceinline__ T operator()(const T &a, const T &b) const {
-        if (b.first == POS_NONE) return a;
-        if (a.first == POS_NONE) return b;
-        const int x = b.first - a.l.s1 - 1;   // (> = 0: b follows a)
-        uint32_t tmo = 0u;
-        if (x > 0) {
-            const uint32_t q = __umulhi((uint32_t)x, mx_magic);
-            const uint32_t r = (uint32_t)x - q * (uint32_t)mx;
-            tmo = q + (r >= (uint32_t)mx ? 1u : 0u);
-        }
-        return T{a.first, b.l.s2 != POS_NONE ? b.l : Last2{b.l.s1, a.l.s1}, a.sum + b.sum + tmo};
+    __device__ __forceinline__ T operator()(const T &a, const T &b) const {   // (selects, no branches: it runs inside scans)
+        const bool ae = a.first == POS_NONE, be = b.first == POS_NONE;
+        const int x = (int)((uint32_t)b.first - (uint32_t)a.l.s1 - 1u);   // samples between a's last change and b's first
+        const uint32_t q = __umulhi((uint32_t)x, mx_magic);
+        const uint32_t r = (uint32_t)x - q * (uint32_t)mx;
+        const uint32_t tmo = (ae || be || x <= 0) ? 0u : q + (r >= (uint32_t)mx ? 1u : 0u);
+        T o;
+        o.first = ae ? b.first : a.first;
+        o.l.s1 = be ? a.l.s1 : b.l.s1;
+        o.l.s2 = be ? a.l.s2 : (b.l.s2 != POS_NONE ? b.l.s2 : a.l.s1);
+        o.sum = a.sum + b.sum + tmo;
+        return o;
     }
 };
 // one word's aggregate from its change mask (w0: its first sample)
@@ -242,7 +243,21 @@ __device__ __forceinline__ EdgeAgg word_agg(const EdgeArgs &A, int32_t w0, uint6
     const int b0 = __ffsll((long long)m) - 1, b1 = 63 - __clzll((long long)m);
     const uint64_t m2 = m & ~(1ull << b1);
     uint32_t sum = (uint32_t)__popcll(m);
-    if (b1 - b0 > A.mx) {   // a run inside the word may be long enough to time out
+    if (A.mx >= 32) {
+        if (A.mx < 63) {
+            // a run inside the word can time out at most once (2 max_len > 63): count the stretches of max_len or more
+            // samples without a change between the word's first and last change.  x marks the samples that begin
+            // max_len change-free samples (and-ing shifted copies, doubling the proven length); a stretch of r such
+            // samples (max_len <= r < 2 max_len) leaves r - max_len + 1 marks in a row.
+            uint64_t x = ~m & ((1ull << b1) - 1ull) & ~((2ull << b0) - 1ull);
+            for (int have = 1; have < A.mx;) {
+                const int sh = min(have, A.mx - have);
+                x &= x >> sh;
+                have += sh;
+            }
+            sum += (uint32_t)__popcll(x & ~(x >> 1));
+        }
+    } else if (b1 - b0 > A.mx) {   // short max_len: walk the runs
         uint64_t rest = m & (m - 1);
         int prev = b0;
         while (rest) {
@@ -266,8 +281,8 @@ __device__ __forceinline__ uint32_t entries_before(const EdgeArgs &A, const Edge
 
 // A thread's consecutive words of the planes and their change masks; 16-byte loads when the words are all there.
 template <int ITEMS>
-__device__ __forceinline__ void load_words(const EdgeArgs &A, size_t w, size_t nwords, uint64_t (&ng)[ITEMS], uint64_t (&ps)[ITEMS],
-                                           uint64_t (&m)[ITEMS]) {
+__device__ __forceinline__ int load_words(const EdgeArgs &A, size_t w, size_t nwords, uint64_t (&ng)[ITEMS], uint64_t (&ps)[ITEMS],
+                                          uint64_t (&m)[ITEMS]) {   // returns val of the sample before the first word
     static_assert(ITEMS % 2 == 0, "pairs of words");
     if (w + ITEMS <= nwords) {
 #pragma unroll
@@ -295,21 +310,24 @@ __device__ __forceinline__ void load_words(const EdgeArgs &A, size_t w, size_t n
     } else {
         pn = pp = 0ull;
     }
+    const int val_before = pn ? -1 : (int)pp;
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         m[i] = (w + i < nwords) ? A.change_mask_of(w + i, ng[i], ps[i], pn, pp) : 0ull;
         pn = ng[i] >> 63;
         pp = ps[i] >> 63;
     }
+    return val_before;
 }
 
 #ifndef NFC_EW_ITEMS
-#define NFC_EW_ITEMS 4
+#define NFC_EW_ITEMS 2
 #endif
-constexpr int EW_ITEMS = NFC_EW_ITEMS;               // words per thread
+constexpr int EW_ITEMS = NFC_EW_ITEMS;               // words per thread (2, with 4096 staged entries: 25 KB of LDS, six workgroups
+                                                     // per CU; 4 with 8192 measured 52 vs 47 us on the bench workload)
 constexpr int EW_WORDS = SCAN_BLOCK * EW_ITEMS;      // words per tile, in both launches of the stage
 #ifndef NFC_EW_CAP
-#define NFC_EW_CAP 8192
+#define NFC_EW_CAP 4096
 #endif
 inline size_t edge_num_tiles(size_t nwords) { return (nwords + EW_WORDS - 1) / EW_WORDS; }
 
@@ -378,7 +396,7 @@ struct EdgeTotalEpilogue {
 // and needs no division per entry.  Where a thread starts comes from ONE block scan of EdgeAgg on top of the tile's
 // prefix: the two changes before its first word AND, by entries_before(), the offset of its first entry.  Entries go to
 // LDS at their offsets and leave the workgroup as whole rows of positions and codes.
-constexpr int EW_CAP = NFC_EW_CAP;   // entries staged per round (a tile of 1024 words holds 4300 on the bench workloads, 65536 at most)
+constexpr int EW_CAP = NFC_EW_CAP;   // entries staged per round (a tile of 512 words holds 2150 on the bench workloads, 32768 at most)
 struct EdgeWalk {
     int lb, left;
     int32_t q;
@@ -394,11 +412,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
     const size_t w_first = wt + (size_t)threadIdx.x * EW_ITEMS;
     // own_prefix: partials still holds the tiles' aggregates and the workgroup folds its predecessors' itself
     // (first, while few registers are live); the last tile then publishes the totals and the carry
+    // (the tile's words are requested first: their latency passes under the prefix)
     const EdgeAggOp op{A.mx, A.mx_magic};
+    uint64_t ng[EW_ITEMS], ps[EW_ITEMS], m[EW_ITEMS];
+    const int val_before = load_words<EW_ITEMS>(A, w_first, nwords, ng, ps, m);
     const EdgeAgg pre = own_prefix ? tile_prefix_with<SCAN_BLOCK>(op, partials, blockIdx.x, s_agg) : partials[blockIdx.x];
     const uint32_t gbase = entries_before(A, pre, (int32_t)(wt * 64));
-    uint64_t ng[EW_ITEMS], ps[EW_ITEMS], m[EW_ITEMS];
-    load_words<EW_ITEMS>(A, w_first, nwords, ng, ps, m);
     EdgeAgg agg = op.identity();
 #pragma unroll
     for (int i = 0; i < EW_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w_first + i) * 64), m[i]));
@@ -426,10 +445,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
         if (W0.carried) {
             W0.lb = A.last_bit_in;
         } else {
-            // (no change between c.s1 and T: val at T - 1 is the run's; T - 1 lies in the word before the thread's)
-            const size_t wp = (size_t)(T - 1) >> 6;
-            const int sh = (T - 1) & 63;
-            W0.lb = ((A.neg[wp] >> sh) & 1ull) ? -1 : (int)((A.pos[wp] >> sh) & 1ull);
+            // (no change between c.s1 and T: val at T - 1 is the run's; T - 1 is the last sample of the word before the
+            // thread's, or -- past the end of the batch -- nothing the walk will use)
+            W0.lb = val_before;
             if (W0.lb == 0 && !W0.timed) {   // a val-0 run that has not timed out keeps what the previous run left
                 int lb, dur;
                 A.state_before(T, c, lb, dur, W0.left);
@@ -455,26 +473,24 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
                 const int b = mm ? __ffsll((long long)mm) - 1 : 64;
                 const int32_t c = min(w0 + b, end);   // the next change, or the end of the word
                 const int32_t nt = W.q + A.mx;        // the run's next time-out
-                if (nt < c) {   // _dur exceeds max_len (transition_sink.py:95-99)
-                    const int cs = (W.lb == -1) ? 2 : ((W.lb == 1) ? 1 : (W.timed ? 0 : W.left));
-                    emit(nt, cs == 2 ? W.lb + 1 : W.lb, A.mx, cs - 1);
-                    W.q = nt;
-                    W.timed = true;
-                    continue;
-                }
-                if (!mm) break;
-                // val changes here (transition_sink.py:86-92)
-                const int val = ((ng[i] >> b) & 1ull) ? -1 : (int)((ps[i] >> b) & 1ull);
-                int prev_st = (W.lb != 0) ? ((W.timed && W.q == c - 1) ? 0 : (W.lb == -1 ? 2 : 1)) : (W.timed ? 0 : W.left);
-                if (W.carried && c == (int32_t)A.skip) prev_st = A.state_in;   // the first stable sample: the carried value itself
-                const int st = (val == -1) ? 2 : ((val == 1) ? 1 : prev_st);
-                emit(c, st == 2 ? W.lb + 1 : W.lb, prev_st == 0 ? A.mx : c - W.q, st - 1);
-                W.left = prev_st;
+                const bool is_to = nt < c;            // _dur exceeds max_len first (transition_sink.py:95-99)
+                if (!is_to && !mm) break;
+                const int32_t p = is_to ? nt : c;
+                // _current_state before sample p
+                const int run_st = (W.lb == -1) ? 2 : 1;            // inside a LOW / HIGH run ...
+                const int zero_st = W.timed ? 0 : W.left;           // inside a val-0 run
+                int prev_st = (W.lb != 0) ? ((W.timed && W.q == p - 1) ? 0 : run_st) : zero_st;   // ... unless p - 1 timed out
+                if (W.carried && p == (int32_t)A.skip) prev_st = A.state_in;   // the first stable sample: the carried value itself
+                // a time-out keeps val and takes the run's state; a change (transition_sink.py:86-92) takes the new val's
+                const int val = is_to ? W.lb : (((ng[i] >> b) & 1ull) ? -1 : (int)((ps[i] >> b) & 1ull));
+                const int st = is_to ? ((W.lb != 0) ? run_st : zero_st) : ((val == -1) ? 2 : ((val == 1) ? 1 : prev_st));
+                emit(p, st == 2 ? W.lb + 1 : W.lb, (is_to || prev_st == 0) ? A.mx : p - W.q, st - 1);
+                W.left = is_to ? W.left : prev_st;
                 W.lb = val;
-                W.q = c;
-                W.timed = false;
-                W.carried = false;
-                mm &= mm - 1;
+                W.q = p;
+                W.timed = is_to;
+                W.carried = W.carried && is_to;
+                if (!is_to) mm &= mm - 1;
             }
         }
         __syncthreads();
