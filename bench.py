@@ -234,7 +234,8 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
     if rank == 0:
         k_avg = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
         thr_bytes = 8.0 * n                              # 8 B per sample read by the envelope + threshold kernel ...
-        edge_bytes = 16.0 * n_edges                      # ... 16 B per emitted edge, written by the edge stage
+        edge_bytes = 16.0 * n_edges                      # ... 16 B per emitted edge (the nfc_edge record) in SURVEY's count; the edge
+        stored_bytes = 6.0 * n_edges                     # stage now keeps 6 B per entry (u32 position + u16 code), records built on read
         achieved = thr_bytes / (k_avg * 1e-3) / 1e9
         traffic, tsrc = hbm_traffic(workload, n)
         out = {
@@ -251,9 +252,10 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                          'launches_per_step': float(np.mean(n_pass)) if n_pass else None,
                          'algorithmic_bytes_per_launch': thr_bytes,
                          'note': '8 B/sample only: the 16 B/edge of SURVEY 8(d) are written by the edge stage, listed under edge_stage'},
-            'edge_stage': {'algorithmic_bytes': edge_bytes, 'stage_ms': st.ms_edges,
+            'edge_stage': {'algorithmic_bytes': edge_bytes, 'bytes_stored': stored_bytes, 'stage_ms': st.ms_edges,
                            'achieved_GBs': (edge_bytes / (st.ms_edges * 1e-3) / 1e9) if st.ms_edges > 0 else None,
-                           'note': 'all kernels of the edge stage of the extra, marker-timed step (scan, count, write)'},
+                           'note': 'all kernels of the edge stage of the extra, marker-timed step (tile aggregates, writer); algorithmic_bytes '
+                                   'is SURVEY 8(d)\'s 16 B per edge, the stage stores 6 B per entry and nfc_read_edges builds the 16-byte records'},
             'whole_path': {'algorithmic_bytes': thr_bytes + edge_bytes,
                            'achieved_GBs': (thr_bytes + edge_bytes) / (dt / steps) / 1e9, 'frac': (thr_bytes + edge_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS},
             'stage_ms_extra_step': {'total_device': st.ms_total, 'threshold': st.ms_threshold, 'edges': st.ms_edges,
@@ -340,7 +342,7 @@ def cpu_baseline(own, flags, params):
 def end_to_end(workload, own, flags):
     """Host IQ in, decoded commands out (SURVEY.md 8(d) "separately end-to-end"): pinned host samples -> H2D in pieces (a second
     thread uploads piece k + 1 while piece k decodes) -> GPU path -> edges, packet tables and packet bits D2H -> packets to
-    bytes / commands on the host (fsm.process_packets, C).  Which link bounds it: PCIe (8 B per sample in, 16 B per edge out)."""
+    bytes / commands on the host (fsm.process_packets, C).  Which link bounds it: PCIe (8 B per sample in, 6 B per transition out)."""
     import ctypes as C
     import numpy as np
     from usrp_nfc_amd import api, fsm, _lib
@@ -368,7 +370,7 @@ def end_to_end(workload, own, flags):
             th = threading.Thread(target=upload, args=(k + 1,))
             th.start()
         ctx.push_device(bufs[k & 1], m)
-        n_edges += len(ctx.edges())
+        n_edges += len(ctx.edges_compact()[0])
         tabs = [ctx.packet_table(t) for t in (0, 1)]
         bits = [ctx.packet_bits(t) for t in (0, 1)]
         table = np.concatenate(tabs)
@@ -384,9 +386,9 @@ def end_to_end(workload, own, flags):
     L.nfc_host_free_pinned(pin)
     return {'value': n / dt / 1e6, 'unit': 'Msamples/s', 'ms_total': dt * 1e3, 'samples': n, 'edges_to_host': n_edges,
             'commands': n_frames, 'piece_samples': piece,
-            'what': 'pinned host IQ -> H2D (overlapped, second thread) -> GPU path -> edges + packets D2H -> fsm (C) on the host',
-            'bound': 'PCIe: %.0f MB in + %.0f MB out per pass = %.1f GB/s over the link' % (8 * n / 1e6, 16 * n_edges / 1e6,
-                                                                                           (8 * n + 16 * n_edges) / dt / 1e9)}
+            'what': 'pinned host IQ -> H2D (overlapped, second thread) -> GPU path -> transitions (compact: 6 B each) + packets D2H -> fsm (C) on the host',
+            'bound': 'PCIe: %.0f MB in + %.0f MB out per pass = %.1f GB/s over the link' % (8 * n / 1e6, 6 * n_edges / 1e6,
+                                                                                           (8 * n + 6 * n_edges) / dt / 1e9)}
 
 
 def rank_main(a):

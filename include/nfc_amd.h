@@ -161,7 +161,14 @@ int nfc_set_stream(nfc_ctx *ctx, void *stream);
 
 /* Outputs of the LAST push (valid until the next push). */
 int nfc_get_counts(nfc_ctx *ctx, nfc_counts *out);
+/* The transitions of the batch (transition_sink.py:89-90,97).  On the device an entry is its batch-local sample position
+ * (u32) and a 16-bit code; nfc_read_edges fetches those and builds the 16-byte records on the host.  A caller that can use
+ * the compact form directly (6 bytes per entry over the link instead of 16) reads it with nfc_read_edges_compact:
+ *   pos   sample index in the batch (stream index = n_seen before the push + pos)
+ *   code  ((v + 1) * (max_len + 1) + d) | (t + 1) << 14     -- v, d, t as in nfc_edge
+ * (not after nfc_push_edges, whose entries keep the caller's own indices). */
 int nfc_read_edges(nfc_ctx *ctx, size_t first, nfc_edge *out, size_t cap, size_t *n_out);
+int nfc_read_edges_compact(nfc_ctx *ctx, size_t first, uint32_t *pos_out, uint16_t *code_out, size_t cap, size_t *n_out);
 /* symbols handed to CombinedPacketProcessor.append_bit(bit, type): 0/1 or an ErrorCode (utilities.py:7-14) */
 int nfc_read_symbols(nfc_ctx *ctx, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out);
 /* closed packets of one type in stream order, and their bits (one byte per bit) */

@@ -154,6 +154,31 @@ def test_synthetic_workloads_2M(name, kw):
     assert len(r['packets']) > 100
 
 
+def test_compact_transitions_are_the_records():
+    # nfc_read_edges_compact hands out what the device keeps (position, code); nfc_read_edges the records built from it
+    import ctypes as C
+    c = Case('fx_ultralight_txn')
+    with api.NfcContext(input_kind=api.NFC_IN_ENV_F32, **c.params) as ctx:
+        half = len(c.x) // 2
+        for a, b in ((0, half), (half, len(c.x))):
+            ctx.push(c.x[a:b])
+            e = ctx.edges()
+            pos, code = ctx.edges_compact()
+            nd = c.params.get('max_len', 50) + 1
+            li = (code & 0x3FFF).astype(np.int64)
+            assert (e['idx'] == a + pos.astype(np.uint64)).all()
+            assert (e['v'] == li // nd - 1).all() and (e['d'] == li % nd).all() and (e['t'] == (code >> 14).astype(np.int64) - 1).all()
+            # a range in the middle, through both readers
+            if len(e) > 12:
+                sub = np.zeros(7, api.EDGE_DTYPE)
+                got = C.c_size_t(0)
+                assert ctx.L.nfc_read_edges(ctx.h, 5, sub.ctypes.data, 7, C.byref(got)) == 0 and got.value == 7
+                assert (sub == e[5:12]).all()
+                p7, c7 = np.zeros(7, np.uint32), np.zeros(7, np.uint16)
+                assert ctx.L.nfc_read_edges_compact(ctx.h, 5, p7.ctypes.data, c7.ctypes.data, 7, C.byref(got)) == 0 and got.value == 7
+                assert (p7 == pos[5:12]).all() and (c7 == code[5:12]).all()
+
+
 @pytest.mark.parametrize('max_len', [1, 7, 31, 32, 50, 62, 63, 64, 200])
 def test_edge_stage_dense_and_long_runs(monkeypatch, max_len):
     # The multi-launch edge stage (edges.hip.h) on a short batch: samples that flicker between LOW, accepted and HIGH from one

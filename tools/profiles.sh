@@ -1,20 +1,21 @@
 #!/bin/bash
 # Regenerates the files under profiles/ on the GPU box (outputs land in gpurun_out/prof, copy what is judged).
 # usage: tools/profiles.sh <round-tag>
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o $tag -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity > $out/${tag}_bench_under_rocprof.json 2> $out/stats.log
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2> $out/fetch.log
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2> $out/write.log
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o $tag -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity --no-extras > $out/${tag}_bench_under_rocprof.json 2> $out/stats.log
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras > /dev/null 2> $out/fetch.log
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras > /dev/null 2> $out/write.log
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $out/sq -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-extras > /dev/null 2> $out/sq.log
 timeout 400 python3 bench.py > $out/${tag}_bench.json 2> $out/bench.log
 python3 - <<PY
 import csv, json, collections
 out = "$out"; tag = "$tag"
 rows = list(csv.DictReader(open(f"{out}/stats/{tag}_kernel_stats.csv")))
 thr = [r for r in rows if "k_threshold" in r["Name"]]
-nstep = int(thr[0]["Calls"]) if thr else 1
+nstep = sum(int(r["Calls"]) for r in thr) if thr else 1
 lines = []; tot = 0
 for r in rows:
     per = float(r["TotalDurationNs"]) / nstep / 1e3; tot += per
@@ -27,11 +28,25 @@ def pmc(d, name):
     for r in rs: byd[r["Dispatch_Id"]] += float(r["Counter_Value"])
     v = sorted(byd.values()); return v[len(v) // 2]
 f, w = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
-rec = {"workload": "miller", "samples": 100000000, "kernel": "k_threshold<0,4>", "FETCH_SIZE_kb": round(f), "WRITE_SIZE_kb": round(w),
+kname = sorted({r["Kernel_Name"] for r in csv.DictReader(open(f"{out}/fetch/p_counter_collection.csv")) if "k_threshold" in r["Kernel_Name"]})
+rec = {"workload": "miller", "samples": 100000000, "kernel": ", ".join(k.replace("void nfc::", "").split("(")[0] for k in kname), "FETCH_SIZE_kb": round(f), "WRITE_SIZE_kb": round(w),
        "correction": "FETCH_SIZE x2 (gfx950: TCC_EA0_RDREQ counted at 64 B per 128-B request, MI355X_MICROARCH.md section HBM); WRITE_SIZE as reported",
        "bytes_per_launch": int((2 * f + w) * 1024),
-       "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity   (and the same with --pmc WRITE_SIZE); median over the launches"}
+       "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras   (and the same with --pmc WRITE_SIZE); median over the launches"}
 json.dump(rec, open(f"{out}/hbm_traffic.json", "w"), indent=1)
+# instruction counts per wave of every kernel of a step (one --pmc pass of SQ counters)
+rows = list(csv.DictReader(open(f"{out}/sq/p_counter_collection.csv")))
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); nd = collections.defaultdict(set)
+for r in rows:
+    k = r["Kernel_Name"].replace("void nfc::", "").replace("nfc::", "").split("(")[0][:60]
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); nd[k].add(r["Dispatch_Id"])
+with open(f"{out}/{tag}_sq_counters.txt", "w") as fh:
+    fh.write("per dispatch: waves, and VALU / SALU / LDS / VMEM-read / VMEM-write instructions per wave\n")
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"]):
+        n = len(nd[k]); wv = max(v["SQ_WAVES"] / n, 1)
+        fh.write("%-62s dispatches %3d waves %8d  valu %7.0f salu %7.0f lds %6.0f vmem_rd %6.1f vmem_wr %6.1f\n" % (
+            k, n, wv, v["SQ_INSTS_VALU"] / n / wv, v["SQ_INSTS_SALU"] / n / wv, v["SQ_INSTS_LDS"] / n / wv, v["SQ_INSTS_VMEM_RD"] / n / wv, v["SQ_INSTS_VMEM_WR"] / n / wv))
+print(open(f"{out}/{tag}_sq_counters.txt").read())
 print(rec)
 print(open(f"{out}/{tag}_kernel_stats_per_step.txt").read())
 PY

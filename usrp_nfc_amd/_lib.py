@@ -60,7 +60,7 @@ PACKET_DTYPE = np.dtype([('idx', '<u8'), ('bit_off', '<u8'), ('n_bits', '<u4'), 
 
 # every symbol include/nfc_amd.h declares
 SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', 'nfc_last_error', 'nfc_push',
-           'nfc_push_device', 'nfc_push_edges', 'nfc_sync', 'nfc_set_stream', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_symbols', 'nfc_read_packets',
+           'nfc_push_device', 'nfc_push_edges', 'nfc_sync', 'nfc_set_stream', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_edges_compact', 'nfc_read_symbols', 'nfc_read_packets',
            'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_prime', 'nfc_export_state', 'nfc_get_stats', 'nfc_set_timing',
            'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_stream_create', 'nfc_stream_destroy',
            'nfc_stream_sync', 'nfc_device_download_async', 'nfc_device_fill', 'nfc_host_alloc_pinned', 'nfc_host_free_pinned', 'nfc_host_decode_lut', 'nfc_host_decode_steps', 'nfc_host_i16_to_float',
@@ -96,6 +96,7 @@ def load():
     L.nfc_set_stream.argtypes = [vp, vp]
     L.nfc_get_counts.argtypes = [vp, C.POINTER(Counts)]
     L.nfc_read_edges.argtypes = [vp, sz, vp, sz, psz]
+    L.nfc_read_edges_compact.argtypes = [vp, sz, vp, vp, sz, psz]
     L.nfc_read_symbols.argtypes = [vp, C.c_int, sz, vp, sz, psz]
     L.nfc_read_packets.argtypes = [vp, C.c_int, vp, sz, psz]
     L.nfc_read_packet_bits.argtypes = [vp, C.c_int, sz, vp, sz, psz]

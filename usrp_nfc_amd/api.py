@@ -108,6 +108,17 @@ class NfcContext(object):
     def edges(self):
         return self._read(self.L.nfc_read_edges, self.counts().n_edges, EDGE_DTYPE, 0)
 
+    def edges_compact(self):
+        """(pos, code) of the batch's transitions as the device keeps them (nfc_read_edges_compact): batch-local sample
+        position, and ((v + 1) * (max_len + 1) + d) | (t + 1) << 14."""
+        n = int(self.counts().n_edges)
+        pos, code = np.zeros(n, np.uint32), np.zeros(n, np.uint16)
+        got = C.c_size_t(0)
+        if n:
+            self._chk(self.L.nfc_read_edges_compact(self.h, 0, pos.ctypes.data, code.ctypes.data, n, C.byref(got)), 'nfc_read_edges_compact')
+            assert got.value == n
+        return pos, code
+
     def transitions(self):
         """The list transition_sink hands to its callback: [((v, d*factor), t), ...]."""
         e = self.edges()

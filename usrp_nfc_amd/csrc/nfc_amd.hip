@@ -161,6 +161,9 @@ struct nfc_ctx {
     void *hs_dev = nullptr;        // the same memory as the device addresses it (kernels may fill the mirror themselves)
     uint8_t *h_stage = nullptr;    // pinned staging for nfc_get_state
     size_t h_stage_cap = 0;
+    uint8_t *h_edge_stage = nullptr;   // pinned staging for nfc_read_edges / nfc_read_edges_compact (two pieces)
+    size_t h_edge_stage_cap = 0;
+    std::vector<uint64_t> edge_lut;    // per LUT row: the (d, v) half of an nfc_edge record
     uint8_t *h_cflags = nullptr;   // pinned mirror of the per-chunk flag sections
     size_t h_cflags_cap = 0;
     int ring_cur = 0;
@@ -1451,6 +1454,7 @@ void nfc_destroy(nfc_ctx *c) {
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_edge_stage) (void)hipHostFree(c->h_edge_stage);
     if (c->h_cflags) (void)hipHostFree(c->h_cflags);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1579,38 +1583,100 @@ static int read_range(nfc_ctx *c, const void *dev, size_t total, size_t esz, siz
     return NFC_OK;
 }
 
-// The device keeps an entry as (sample position, code): 6 bytes (edges.hip.h).  The records are built here.
-int nfc_read_edges(nfc_ctx *c, size_t first, nfc_edge *out, size_t cap, size_t *n_out) {
-    if (!c) return NFC_ERR_ARG;
+// The device keeps an entry as (sample position, code): 6 bytes (edges.hip.h).  Both readers fetch them through a pinned
+// staging area in pieces, the copy of one piece under the unpacking of the one before.
+extern "C++" {
+namespace {
+constexpr size_t EDGE_PIECE = 1u << 20;   // entries per piece
+template <class Consume>
+int fetch_entries(nfc_ctx *c, size_t first, size_t n, Consume consume) {   // consume(pos, code, count, offset)
+    const size_t need = 2 * EDGE_PIECE * 6 + 64;
+    if (c->h_edge_stage_cap < need) {
+        if (c->h_edge_stage) (void)hipHostFree(c->h_edge_stage);
+        c->h_edge_stage = nullptr;
+        c->h_edge_stage_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_edge_stage, need, hipHostMallocDefault));
+        c->h_edge_stage_cap = need;
+    }
+    auto pos_of = [&](int b) { return (uint32_t *)(c->h_edge_stage + (size_t)b * EDGE_PIECE * 6); };
+    auto code_of = [&](int b) { return (uint16_t *)(c->h_edge_stage + (size_t)b * EDGE_PIECE * 6 + EDGE_PIECE * 4); };
+    auto request = [&](size_t off, int b) -> hipError_t {
+        const size_t cnt = std::min(EDGE_PIECE, n - off);
+        hipError_t e = hipMemcpyAsync(pos_of(b), c->d_epos.as<uint32_t>() + first + off, cnt * 4, hipMemcpyDeviceToHost, c->st);
+        if (e == hipSuccess) e = hipMemcpyAsync(code_of(b), c->d_ecode.as<uint16_t>() + first + off, cnt * 2, hipMemcpyDeviceToHost, c->st);
+        if (e == hipSuccess) e = hipEventRecord(c->ev[6 + b], c->st);
+        return e;
+    };
+    HIPCHK(c, request(0, 0));
+    int b = 0;
+    for (size_t off = 0; off < n; off += EDGE_PIECE, b ^= 1) {
+        if (off + EDGE_PIECE < n) HIPCHK(c, request(off + EDGE_PIECE, b ^ 1));
+        HIPCHK(c, hipEventSynchronize(c->ev[6 + b]));
+        consume(pos_of(b), code_of(b), std::min(EDGE_PIECE, n - off), off);
+    }
+    return NFC_OK;
+}
+int edge_range(nfc_ctx *c, size_t first, const void *out, size_t cap, size_t *n_out, size_t &n) {
     if (!c->have_outputs) return fail(c, NFC_ERR_STATE, "no completed batch");
-    size_t n = 0;
+    n = 0;
     if (first < c->n_edges) n = std::min(cap, (size_t)c->n_edges - first);
     if (n && !out) return fail(c, NFC_ERR_ARG, "null output");
     if (n_out) *n_out = n;
-    if (!n) return NFC_OK;
+    return NFC_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int nfc_read_edges(nfc_ctx *c, size_t first, nfc_edge *out, size_t cap, size_t *n_out) {
+    if (!c) return NFC_ERR_ARG;
+    size_t n;
+    const int rc = edge_range(c, first, out, cap, n_out, n);
+    if (rc || !n) return rc;
     if (c->edges_from_host) {
         memcpy(out, c->h_pushed.data() + first, n * sizeof(nfc_edge));
         return NFC_OK;
     }
-    std::vector<uint32_t> pos(n);
-    std::vector<uint16_t> code(n);
-    HIPCHK(c, hipMemcpy(pos.data(), c->d_epos.as<uint32_t>() + first, n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(code.data(), c->d_ecode.as<uint16_t>() + first, n * 2, hipMemcpyDeviceToHost));
+    // the second half of a record -- d, v, t -- per LUT row (edges.hip.h: edge_code), built once
+    static_assert(sizeof(nfc_edge) == 16, "record layout");
     const int nd = c->mx + 1;
-    for (size_t i = 0; i < n; i++) {
-        const uint32_t p = pos[i];
-        const uint16_t cd = code[i];
-        int v, d, t;
-        edge_decode(cd, nd, v, d, t);
-        nfc_edge o;
-        o.idx = c->last_g0 + (uint64_t)p;
-        o.d = d;
-        o.v = (int8_t)v;
-        o.t = (int8_t)t;
-        o.pad = 0;
-        out[i] = o;
+    if (c->edge_lut.empty()) {
+        c->edge_lut.assign((size_t)4 * nd, 0);
+        for (int li = 0; li < 4 * nd; li++) {
+            nfc_edge e;
+            memset(&e, 0, sizeof e);
+            e.d = li % nd;
+            e.v = (int8_t)(li / nd - 1);
+            memcpy(&c->edge_lut[li], (const char *)&e + 8, 8);
+        }
     }
-    return NFC_OK;
+    const uint64_t g0 = c->last_g0;
+    const uint64_t *lut = c->edge_lut.data();
+    const size_t rows = c->edge_lut.size();
+    return fetch_entries(c, first, n, [&](const uint32_t *pos, const uint16_t *code, size_t cnt, size_t off) {
+        nfc_edge *o = out + off;
+        for (size_t i = 0; i < cnt; i++) {
+            const uint32_t li = code[i] & 0x3FFFu;
+            nfc_edge e;
+            e.idx = g0 + pos[i];
+            const uint64_t hi = li < rows ? lut[li] : 0;
+            memcpy((char *)&e + 8, &hi, 8);
+            e.t = (int8_t)((int)(code[i] >> 14) - 1);
+            o[i] = e;
+        }
+    });
+}
+
+int nfc_read_edges_compact(nfc_ctx *c, size_t first, uint32_t *pos_out, uint16_t *code_out, size_t cap, size_t *n_out) {
+    if (!c) return NFC_ERR_ARG;
+    size_t n;
+    int rc = edge_range(c, first, pos_out, cap, n_out, n);
+    if (rc || !n) return rc;
+    if (!code_out) return fail(c, NFC_ERR_ARG, "null output");
+    if (c->edges_from_host) return fail(c, NFC_ERR_STATE, "the entries of nfc_push_edges carry the caller's indices: use nfc_read_edges");
+    return fetch_entries(c, first, n, [&](const uint32_t *pos, const uint16_t *code, size_t cnt, size_t off) {
+        memcpy(pos_out + off, pos, cnt * 4);
+        memcpy(code_out + off, code, cnt * 2);
+    });
 }
 
 int nfc_read_symbols(nfc_ctx *c, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out) {
