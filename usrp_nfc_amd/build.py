@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(HERE, 'libnfc_amd.so')
 SOURCES = ['nfc_amd.hip']
-DEPS = ['nfc_amd.hip', 'threshold.hip.h', 'threshold_lean.hip.h', 'edges.hip.h', 'decode.hip.h', 'scan.hip.h', 'small.hip.h', 'tx.hip.h', 'decoder_tables.h', 'protocol.h',
+DEPS = ['nfc_amd.hip', 'launch_check.h', 'threshold.hip.h', 'threshold_lean.hip.h', 'edges.hip.h', 'decode.hip.h', 'scan.hip.h', 'small.hip.h', 'tx.hip.h', 'decoder_tables.h', 'protocol.h',
         os.path.join('..', '..', 'include', 'nfc_amd.h')]
 
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
@@ -31,6 +31,15 @@ def build(force=False, verbose=False):
         print(' '.join(cmd))
     subprocess.check_call(cmd)
     return SO
+
+
+def device_isa(out_path):
+    """The device-side assembly of the same sources with the same flags (what tools/audit_lean_isa.py reads)."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    flags = [f for f in FLAGS if f not in ('-fPIC', '-shared')]
+    subprocess.check_call([hipcc] + flags + ['-S', '--cuda-device-only', os.path.join(CSRC, SOURCES[0]), '-o', out_path],
+                          stderr=subprocess.DEVNULL)
+    return out_path
 
 
 if __name__ == '__main__':
