@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the end-to-end figure and the other configurations')
+    ap.add_argument('--sync-steps', action='store_true', help='one GPU: every step a fresh stream pushed synchronously (nfc_push_device), as the sharded steps are; '
+                    'default: the steps are consecutive batches of ONE stream, each submitted before the one before it is waited for')
     return ap.parse_args()
 
 
@@ -205,28 +207,72 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
             comm.barrier()
         ctx.sync()
 
-    for _ in range(warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
+    # One GPU, no exchange: the steps are consecutive batches of ONE stream -- the capture again and again, the stream state
+    # carried on -- and batch k + 1 is submitted before batch k is waited for (nfc_submit_device / nfc_wait): its threshold
+    # stage then runs beside the edge and decode stages of batch k.  Sharded runs (and --sync-steps) decode a fresh stream
+    # per step: reset / prime, overlap, own chunk, boundary exchange.
+    ahead = world == 1 and not force_exchange and not a.sync_steps
     kernel_ms, n_pass = [], []
-    for k in range(steps):
-        # every 8th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
-        # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are)
-        timed = k % 8 == 0
-        if timed or k % 8 == 1:
-            ctx.set_timing(1 if timed else 0)
-        one_step()
-        if timed:
-            st = ctx.stats()
-            kernel_ms += [st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed)]
-            n_pass.append(st.threshold_passes)
+    n_ahead = [0]
+
+    def stream_steps(count, timed_every):
+        """count consecutive batches of the stream, two in flight; timed_every: every that-many-th threshold launch carries
+        its own start / stop HIP events (nfc_set_timing; a timed launch costs the step a few us, so not all of them are)"""
+        if not count:
+            return
+        want = lambda j: bool(timed_every) and j % timed_every == 0
+        cur = [None]
+
+        def submit(j):
+            t = 1 if want(j) else 0
+            if t != cur[0]:
+                ctx.set_timing(t)
+                cur[0] = t
+            ctx.submit_device(res.buf, n)
+        submit(0)
+        for k in range(count):
+            if k + 1 < count:
+                submit(k + 1)
+            ctx.wait()
+            if timed_every:
+                st = ctx.stats()
+                n_ahead[0] += int(st.ran_ahead)
+                if st.n_threshold_timed:
+                    kernel_ms.extend(st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed))
+                    n_pass.append(st.threshold_passes)
+        ctx.set_timing(0)
+
+    if ahead:
+        ctx.reset()
+        stream_steps(warmup, 0)
+        barrier()
+        t0 = time.perf_counter()
+        stream_steps(steps, 8)
+    else:
+        for _ in range(warmup):
+            one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            # every 8th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
+            # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are)
+            timed = k % 8 == 0
+            if timed or k % 8 == 1:
+                ctx.set_timing(1 if timed else 0)
+            one_step()
+            if timed:
+                st = ctx.stats()
+                kernel_ms += [st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed)]
+                n_pass.append(st.threshold_passes)
     barrier()
     dt = time.perf_counter() - t0
     if hasattr(comm, 'max_over_ranks'):
         dt = comm.max_over_ranks(dt)
-    ctx.set_timing(2)   # one more, untimed, step for the per-stage split reported beside the headline
-    one_step()
+    ctx.set_timing(2)   # one more, untimed, step for the per-stage split reported beside the headline (synchronous: stream markers)
+    if ahead:
+        ctx.push_device(res.buf, n)
+    else:
+        one_step()
     st = ctx.stats()
     cnt = ctx.counts()
     n_edges = int(cnt.n_edges)
@@ -245,7 +291,9 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                        'time_chunks': int(st.n_chunks), 'parallelism': 'time-chunk x%d' % world, 'edges_per_gpu': n_edges,
                        'symbols_reader': int(cnt.n_symbols[1]), 'symbols_tag': int(cnt.n_symbols[0]),
                        'packets': int(cnt.n_packets[0] + cnt.n_packets[1]), 'boundary_redos': redo[0],
-                       'shard_overlap_samples': capture_overlap(workload) if world > 1 else 0, 'exchange': backend if world > 1 else 'none'},
+                       'shard_overlap_samples': capture_overlap(workload) if world > 1 else 0, 'exchange': backend if world > 1 else 'none',
+                       'steps_are': ('consecutive batches of one stream, batch k + 1 submitted before batch k is waited for (%d of %d timed steps ran ahead)' % (n_ahead[0], steps))
+                                    if ahead else 'a fresh stream per step, pushed synchronously'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_lean / k_threshold (fused envelope + gated-mean threshold)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': tsrc, 'avg_launch_ms': k_avg, 'launches_timed': len(kernel_ms),
@@ -262,13 +310,17 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                                     'decode': st.ms_decode, 'used_sequential': int(st.used_sequential)},
         }
         if want_parity:
-            out['parity'] = parity_check(workload, own, flags, n)
-            # the context the timed loop ran in must have produced the same decode (rank 0's shard starts the stream)
-            same = bool(n_edges == out['parity']['n_edges'] and int(cnt.n_packets[0] + cnt.n_packets[1]) == out['parity']['n_packets'])
-            out['parity']['timed_loop_counts_equal'] = same
-            if not same:
-                raise SystemExit('bench: the timed loop decoded %d edges / %d packets, the oracle %d / %d' % (
-                    n_edges, int(cnt.n_packets[0] + cnt.n_packets[1]), out['parity']['n_edges'], out['parity']['n_packets']))
+            out['parity'] = parity_check(workload, own, flags, n, ahead)
+            # the context the timed loop ran in must have produced the same decode: a fresh stream per step / rank 0's shard
+            # starts the stream; or, with consecutive batches of one stream, its steady state (when the rounds repeat)
+            if ahead and not out['parity'].get('stationary'):
+                out['parity']['timed_loop_counts_equal'] = None
+            else:
+                same = bool(n_edges == out['parity']['n_edges'] and int(cnt.n_packets[0] + cnt.n_packets[1]) == out['parity']['n_packets'])
+                out['parity']['timed_loop_counts_equal'] = same
+                if not same:
+                    raise SystemExit('bench: the timed loop decoded %d edges / %d packets, the oracle %d / %d' % (
+                        n_edges, int(cnt.n_packets[0] + cnt.n_packets[1]), out['parity']['n_edges'], out['parity']['n_packets']))
     ctx.set_stream(None)   # back on its own stream before the communicator's goes away
     ctx.close()
     return out, own, flags
@@ -287,19 +339,34 @@ def hbm_traffic(workload, n):
     return None, None
 
 
-def parity_check(workload, own, flags, n):
-    """Rank 0's chunk decoded from a fresh stream, GPU vs the pinned C oracle, full size (a tiled capture: tile by tile)."""
+def parity_check(workload, own, flags, n, ahead=False):
+    """Rank 0's chunk, GPU vs the pinned C oracle, full size, every pass compared in full (edges, symbols, packets).
+    A tiled capture goes tile by tile.  ahead: as the timed loop does it -- ONE stream, the capture again and again, batch
+    k + 1 submitted before batch k is waited for; three rounds (two for a tiled capture), so that a batch that follows a
+    synchronous one and a batch that follows one that ran ahead are both compared; the counts reported are the last round's."""
     import numpy as np
     from oracle import c_oracle as co
     from usrp_nfc_amd import api
     tile = len(own) // 2
     reps = (n + tile - 1) // tile
+    rounds = (3 if reps == 1 else 2) if ahead else 1
     ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **stream_params(workload), **flags)
     o = co.COracle(**stream_params(workload), **flags)
     ok_edges = ok_sym = ok_pk = True
-    n_edges = n_packets = 0
-    for _ in range(reps):   # the stream carries over from tile to tile on both sides; outputs are compared per tile
-        ctx.push(own)
+    per_round = []
+    n_ahead = 0
+    buf = api.DeviceBuffer(own) if ahead else None
+    total = rounds * reps
+    if ahead:
+        ctx.submit_device(buf, tile)
+    for k in range(total):   # the stream carries over from pass to pass on both sides; outputs are compared per pass
+        if ahead:
+            if k + 1 < total:
+                ctx.submit_device(buf, tile)
+            ctx.wait()
+            n_ahead += int(ctx.stats().ran_ahead)
+        else:
+            ctx.push(own)
         o.clear_outputs()
         o.push_iq(own)
         ge, oe = ctx.edges(), o.edges()
@@ -308,11 +375,18 @@ def parity_check(workload, own, flags, n):
         ok_sym &= all(np.array_equal(ctx.symbols(t), o.symbols(t)) for t in (0, 1))
         gp = ctx.packets()
         ok_pk &= gp == o.packets()
-        n_edges += len(oe)
-        n_packets += len(gp)
+        if k % reps == 0:
+            per_round.append([0, 0])
+        per_round[-1][0] += len(oe)
+        per_round[-1][1] += len(gp)
     ctx.close()
-    return {'vs': 'oracle/nfc_oracle.c on the same %d samples' % n, 'edges_equal': bool(ok_edges), 'symbols_equal': bool(ok_sym),
-            'packets_equal': bool(ok_pk), 'n_edges': int(n_edges), 'n_packets': int(n_packets), 'tiles': reps}
+    out = {'vs': 'oracle/nfc_oracle.c on the same %d samples' % n, 'edges_equal': bool(ok_edges), 'symbols_equal': bool(ok_sym),
+           'packets_equal': bool(ok_pk), 'n_edges': int(per_round[-1][0]), 'n_packets': int(per_round[-1][1]), 'tiles': reps}
+    if ahead:
+        out.update({'passes': 'one stream, %d rounds over the capture, batches submitted ahead (%d of %d ran ahead)' % (rounds, n_ahead, total),
+                    'first_round': {'n_edges': int(per_round[0][0]), 'n_packets': int(per_round[0][1])},
+                    'stationary': bool(per_round[-1] == per_round[-2])})
+    return out
 
 
 def cpu_baseline(own, flags, params):

@@ -113,6 +113,8 @@ typedef struct {
     double ms_threshold_kernel[6]; /* hipEvent duration of each k_threshold launch of the last batch (first 6) */
     uint32_t n_threshold_timed;
     uint32_t chunk_samples;   /* time-chunk length the threshold kernel used for the last batch */
+    uint32_t ran_ahead;       /* 1: the last batch's threshold stage ran ahead of the batch before it (nfc_submit_device) */
+    uint32_t redone_total;    /* submitted batches of this context that had to be processed again synchronously */
 } nfc_stats;
 
 /* Everything a successor time chunk needs from its predecessor:
@@ -155,6 +157,20 @@ int nfc_sync(nfc_ctx *ctx);
  * the packets): Modified-Miller / Manchester decoding and packet framing on the GPU with the context's decoder and framing
  * state carried on, results through nfc_read_symbols / nfc_read_packets.  The threshold state is not touched. */
 int nfc_push_edges(nfc_ctx *ctx, const nfc_edge *host_edges, size_t n);
+/* Batches submitted ahead.  nfc_submit_device enqueues a batch and returns; nfc_wait completes the OLDEST submitted batch,
+ * after which its outputs are read as after nfc_push_device -- valid until the next nfc_submit_device / nfc_wait / nfc_push*.
+ * At most two batches may be in flight, so the steady state of a stream is
+ *     submit(0);  loop k: submit(k + 1); wait(k); read the outputs of k
+ * and the threshold stage of batch k + 1 runs on the GPU beside the edge and decode stages of batch k (which need nothing of
+ * it, and leave it most of the machine's issue slots).  The input buffer of a submitted batch must stay untouched until
+ * its nfc_wait returns.  Results are identical to nfc_push_device's: what runs ahead is checked in nfc_wait (certification
+ * verdict, exactness guard, buffer capacities) and a batch that fails a check is processed again synchronously from the
+ * state before it.  A batch that does not qualify (window not full yet, a short batch, state just set from the host, ...)
+ * is simply processed inside its nfc_wait.  No other call that touches the stream state is accepted while batches are in
+ * flight (NFC_ERR_STATE).  No reference counterpart: the reference is one synchronous work() call after another. */
+int nfc_submit_device(nfc_ctx *ctx, const void *dev_samples, size_t n);
+int nfc_wait(nfc_ctx *ctx);
+int nfc_submitted(nfc_ctx *ctx); /* batches submitted and not yet waited for (0, 1 or 2) */
 /* Enqueue this context's work on the caller's HIP stream (hipStream_t; NULL: back to the context's own), so that what the
  * caller enqueues there next -- a collective on the exported boundary states -- needs no host wait in between. */
 int nfc_set_stream(nfc_ctx *ctx, void *stream);

@@ -31,7 +31,8 @@ class Stats(C.Structure):
     _fields_ = [('ms_total', C.c_double), ('ms_threshold', C.c_double), ('ms_edges', C.c_double),
                 ('ms_decode', C.c_double), ('threshold_passes', C.c_uint32), ('chunks_rerun', C.c_uint32),
                 ('used_sequential', C.c_uint32), ('n_chunks', C.c_uint32), ('bytes_in', C.c_uint64),
-                ('ms_threshold_kernel', C.c_double * 6), ('n_threshold_timed', C.c_uint32), ('chunk_samples', C.c_uint32)]
+                ('ms_threshold_kernel', C.c_double * 6), ('n_threshold_timed', C.c_uint32), ('chunk_samples', C.c_uint32),
+                ('ran_ahead', C.c_uint32), ('redone_total', C.c_uint32)]
 
 
 class Frame(C.Structure):   # nfc_frame
@@ -60,7 +61,7 @@ PACKET_DTYPE = np.dtype([('idx', '<u8'), ('bit_off', '<u8'), ('n_bits', '<u4'), 
 
 # every symbol include/nfc_amd.h declares
 SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', 'nfc_last_error', 'nfc_push',
-           'nfc_push_device', 'nfc_push_edges', 'nfc_sync', 'nfc_set_stream', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_edges_compact', 'nfc_read_symbols', 'nfc_read_packets',
+           'nfc_push_device', 'nfc_submit_device', 'nfc_wait', 'nfc_submitted', 'nfc_push_edges', 'nfc_sync', 'nfc_set_stream', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_edges_compact', 'nfc_read_symbols', 'nfc_read_packets',
            'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_prime', 'nfc_export_state', 'nfc_get_stats', 'nfc_set_timing',
            'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_stream_create', 'nfc_stream_destroy',
            'nfc_stream_sync', 'nfc_device_download_async', 'nfc_device_fill', 'nfc_host_alloc_pinned', 'nfc_host_free_pinned', 'nfc_host_decode_lut', 'nfc_host_decode_steps', 'nfc_host_i16_to_float',
@@ -91,6 +92,9 @@ def load():
     L.nfc_last_error.restype = C.c_char_p
     L.nfc_push.argtypes = [vp, vp, sz]
     L.nfc_push_device.argtypes = [vp, vp, sz]
+    L.nfc_submit_device.argtypes = [vp, vp, sz]
+    L.nfc_wait.argtypes = [vp]
+    L.nfc_submitted.argtypes = [vp]
     L.nfc_sync.argtypes = [vp]
     L.nfc_push_edges.argtypes = [vp, vp, sz]
     L.nfc_set_stream.argtypes = [vp, vp]

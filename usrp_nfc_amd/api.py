@@ -76,6 +76,19 @@ class NfcContext(object):
         self._chk(self.L.nfc_push_device(self.h, ptr, n), 'nfc_push_device')
         return n
 
+    def submit_device(self, dev_ptr, n):
+        """Enqueue a batch and return (nfc_submit_device); at most two in flight.  The buffer stays untouched until its wait()."""
+        ptr = dev_ptr.ptr if isinstance(dev_ptr, DeviceBuffer) else C.c_void_p(int(dev_ptr))
+        self._chk(self.L.nfc_submit_device(self.h, ptr, n), 'nfc_submit_device')
+        return n
+
+    def wait(self):
+        """Complete the oldest submitted batch (nfc_wait): its outputs are then read like those of a push."""
+        self._chk(self.L.nfc_wait(self.h), 'nfc_wait')
+
+    def submitted(self):
+        return int(self.L.nfc_submitted(self.h))
+
     # -- outputs of the last push -----------------------------------------------
     def push_edges(self, edges):
         """Transitions (EDGE_DTYPE rows: idx, d in samples, v, t) through the decode and framing stages alone (nfc_push_edges) --

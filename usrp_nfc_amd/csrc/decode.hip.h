@@ -451,6 +451,7 @@ struct PktFinish {
     const uint32_t *mirror_src;   // the device state block, or NULL
     uint32_t *mirror_dst;         // the host mirror as the device sees it
     uint32_t mirror_words;
+    uint32_t stamp_word, stamp;   // the batch's number, written into word stamp_word of the mirror: this launch wrote it
 };
 __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
     for (int t = 0; t < 2; t++) {
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
     if (F.mirror_src) {
         __threadfence();
         __syncthreads();   // thread 0's carry words are part of the block
-        for (uint32_t i = threadIdx.x; i < F.mirror_words; i += blockDim.x) F.mirror_dst[i] = F.mirror_src[i];
+        for (uint32_t i = threadIdx.x; i < F.mirror_words; i += blockDim.x) F.mirror_dst[i] = (i == F.stamp_word) ? F.stamp : F.mirror_src[i];
     }
 }
 

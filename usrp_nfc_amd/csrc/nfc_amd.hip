@@ -156,7 +156,8 @@ struct nfc_ctx {
     DecTables T;
 
     // carried state
-    DevBuf d_state, d_ring[2];
+    DevBuf d_state, d_ring[3];   // the window: the carried one, the one the batch in work writes, and -- with a batch submitted
+                                 // ahead (nfc_submit_device) -- the one THAT batch writes; they rotate
     DevState *hs = nullptr;        // pinned host mirror of d_state
     void *hs_dev = nullptr;        // the same memory as the device addresses it (kernels may fill the mirror themselves)
     uint8_t *h_stage = nullptr;    // pinned staging for nfc_get_state
@@ -167,6 +168,28 @@ struct nfc_ctx {
     uint8_t *h_cflags = nullptr;   // pinned mirror of the per-chunk flag sections
     size_t h_cflags_cap = 0;
     int ring_cur = 0;
+    // ---- a batch submitted ahead (nfc_submit_device / nfc_wait): its threshold stage runs on st_a beside the edge and
+    // decode stages of the batch before it on st
+    hipStream_t st_a = nullptr;
+    DevBuf d_neg_alt, d_pos_alt;               // that batch's planes (they become d_neg / d_pos when its edge stage is enqueued)
+    DevState *hs_a[2] = {nullptr, nullptr};    // pinned snapshots of the state block taken right after a submitted batch's certification
+    hipEvent_t ev_a[2] = {}, ev_b[2] = {};     // its threshold stage / its last stage done
+    hipEvent_t kev_sub[2][2] = {};             // start / stop of its threshold kernel (nfc_set_timing >= 1)
+    struct Submitted {
+        const void *d_in = nullptr;
+        uint32_t n = 0, seq = 0, nch = 0, chunk = 0;
+        uint64_t g0 = 0;
+        int slot = 0, ring_in = 0, timing = 0;   // (timing: nfc_set_timing's level when the batch was submitted)
+        bool fast = false, b_enqueued = false, timed = false;
+    } sub[2];
+    int sub_count = 0;             // batches submitted and not yet waited for (sub[0] the older)
+    uint32_t slot_next = 0;
+    bool low_valid = false;        // Carry.low_nl / low_kl on the device describe the end of the last completed batch
+    size_t lean_lds_per_cu = 0;
+    uint32_t stamp_b = 0;          // the batch number the decode stage's last launch writes into the mirror (seq[1])
+    bool in_wait = false;
+    uint32_t dbg_fast_waits = 0;
+    uint32_t stats_redo_submitted = 0;   // submitted batches that had to go through the synchronous path after all
     Carry h_carry;
     EdgeCarry h_ecarry;
     DecCarry h_dcarry;
@@ -340,10 +363,14 @@ void launch_lean(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hi
     default: if (b16) go(k_threshold_lean<KIND, 4, true>); else go(k_threshold_lean<KIND, 4, false>); break;
     }
 }
-void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, bool lean = false) {
-    const bool timed = c->timing >= 1 && c->n_kev < 6;
+void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, bool lean = false, hipEvent_t *own_events = nullptr) {
+    const bool timed = !own_events && c->timing >= 1 && c->n_kev < 6;
     hipEvent_t e0 = timed ? c->kev[2 * c->n_kev] : nullptr, e1 = timed ? c->kev[2 * c->n_kev + 1] : nullptr;
     if (timed) c->n_kev++;
+    if (own_events) {
+        e0 = own_events[0];
+        e1 = own_events[1];
+    }
     if (lean) {
         switch (c->P.input_kind) {
         case NFC_IN_IQ_F32: launch_lean<IN_IQ_F32>(c, A, nwork, e0, e1); break;
@@ -359,8 +386,8 @@ void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, bool le
     default: launch_threshold<IN_I16_SQ>(c, A, nwork, e0, e1); break;
     }
 }
-void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n, int nchunks) {
-    float *ring = c->d_ring[c->ring_cur].as<float>();
+void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n, int nchunks, int ring_idx = -1) {
+    float *ring = c->d_ring[ring_idx < 0 ? c->ring_cur : ring_idx].as<float>();
     Carry *cr = dC(c);
     EdgeCarryInit eci{(int32_t *)dE(c), c->L % c->mx};
     uint8_t *ver = c->d_ver.as<uint8_t>();
@@ -419,16 +446,33 @@ double elapsed_ms(hipEvent_t a, hipEvent_t b) {
 // One parallel attempt at the samples [base, n_all) of the batch (base a multiple of the step; the planes, the ring and
 // the carried sums already hold everything before base).  *need_seq: the attempt cannot vouch for its sums (or the
 // sequential kernel was asked for): nothing of it stands and the caller replays sequentially.
-static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint32_t skip_all, uint32_t base, const EdgeCarry &ec,
-                          const std::function<int()> *ahead, bool *clean, bool *need_seq_out) {
-    bool ran_ahead = false;
-    *clean = false;
+// Every fp64 sum of a batch is exact -- hence independent of the order it was added in -- when all
+// operands are multiples of 2^low and no sum reaches 2^(low + 53).  Operands: ring values (24-bit mantissas)
+// and the carried ss / delta (their lowest set bits); sums: the window sums (bounded by the kernel from the sums
+// it tracked) and the carried ss itself.  hc: the carried values after the batch; emin / emax / vtop: what its chunks measured.
+static bool sums_exact(const Carry &hc, int emin, int emax, uint32_t vtop) {
+    int low = emin - 23;
+    if (hc.ss_emin != 255) low = std::min(low, hc.ss_emin);
+    float vtf;
+    memcpy(&vtf, &vtop, 4);
+    int high = 255 + 64;   // vtop: f32 bits of an upper bound of every window sum the batch saw
+    if (std::isfinite(vtf) && vtf >= 0.f) high = vtf > 0.f ? std::ilogb((double)vtf) + 127 : 0;
+    high = std::max(high, hc.ss_emax);
+    return (emax < 255) && (high - low <= 52);
+}
+
+// What one parallel attempt at [base, n_all) needs before anything is launched: the chunking, room in every per-chunk
+// buffer, and the kernels' argument block.  (Shared by the synchronous path and by a batch submitted ahead, which works
+// on the other pair of planes, from the window the batch before it leaves, with the LOW bookkeeping read on the device.)
+struct ThrPlan {
+    uint32_t nch;
+    bool lean_applies;
+    uint8_t *d_cert, *d_gflags, *d_gmin, *d_gmax;
+    const uint8_t *h_cert, *h_gflags, *h_gmin, *h_gmax;
+};
+static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all, uint32_t skip, uint32_t base, uint64_t nseen,
+                       const EdgeCarry &ec, int ring_in, DevBuf &planes_neg, DevBuf &planes_pos, bool low_on_device, ThrArgs &A, ThrPlan &P) {
     const int L = c->L;
-    const uint32_t n = n_all - base;
-    const uint32_t skip = skip_all > base ? skip_all - base : 0u;
-    const void *d_in = (const char *)d_in_all + (size_t)base * c->in_bytes_per_sample;
-    const uint64_t nseen = c->nseen + base;
-    uint32_t passes = 0;
     // Chunk length for this batch: one wave per chunk, and a chunk's latency is what the launch takes, so
     // aim at one full round of resident waves (no second, half-empty round), never below the configured size.
     // Long windows: the ring of a chunk in global memory frees the LDS and brings the occupancy back to what the registers
@@ -453,8 +497,8 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     c->stats.n_chunks = nch;
     c->stats.chunk_samples = (uint32_t)c->C;
     const size_t nwords = ((size_t)n_all + 63) / 64 + 8;
-    HIPCHK(c, c->d_neg.ensure(nwords * 8));
-    HIPCHK(c, c->d_pos.ensure(nwords * 8));
+    HIPCHK(c, planes_neg.ensure(nwords * 8));
+    HIPCHK(c, planes_pos.ensure(nwords * 8));
     for (int b = 0; b < 2; b++) {
         HIPCHK(c, c->d_ringout[b].ensure((size_t)nch * L * sizeof(float)));
         HIPCHK(c, c->d_touched[b].ensure((size_t)nch * c->twords * sizeof(uint32_t)));
@@ -492,13 +536,6 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
         kl0 = KEY_NONE;
     }
 
-    // fill (if the window is not full yet) + per-batch preparation (delta, guard span, version bytes): one launch
-    launch_fill_kind(c, d_in, n, (int)nch);
-
-    // a 256-sample step must not wrap the ring onto itself: short windows take the sequential kernel
-    const bool force_seq = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0 || L < STEP;
-    bool need_seq = force_seq;
-    ThrArgs A;
     memset(&A, 0, sizeof A);
     A.gring = c->d_gring.p;
     A.in = d_in;
@@ -521,10 +558,11 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     A.fast_ok = c->fast_ok;
     A.i16_scale = c->i16_scale;
     A.eps = c->eps;
-    A.ring_carry = c->d_ring[c->ring_cur].as<float>();
+    A.ring_carry = c->d_ring[ring_in].as<float>();
     A.carry = dC(c);
     A.nl0 = nl0;
     A.kl0 = kl0;
+    A.low_src = low_on_device ? dC(c) : nullptr;
     A.lo_L = c->P.lo_val / (double)L;
     A.hi_L = c->P.hi_val / (double)L;
     for (int f = 0; f < 6; f++) A.fold_sh[f] = (f < c->nfold) ? (1 << f) : 0;
@@ -543,12 +581,48 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     A.gmax = d_gmax;
     A.gflags = d_gflags;
     A.gvtop = c->d_gvtop.as<uint32_t>();
-    A.neg = c->d_neg.as<uint64_t>() + base / 64;
-    A.pos = c->d_pos.as<uint64_t>() + base / 64;
+    A.neg = planes_neg.as<uint64_t>() + base / 64;
+    A.pos = planes_pos.as<uint64_t>() + base / 64;
     A.twords = c->twords;
     A.off = (int32_t)off;
     A.nrows = (L + 63) / 64;
+    P.nch = nch;
+    P.lean_applies = lean_applies;
+    P.d_cert = d_cert;
+    P.d_gflags = d_gflags;
+    P.d_gmin = d_gmin;
+    P.d_gmax = d_gmax;
+    P.h_cert = h_cert;
+    P.h_gflags = h_gflags;
+    P.h_gmin = h_gmin;
+    P.h_gmax = h_gmax;
+    return NFC_OK;
+}
 
+static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint32_t skip_all, uint32_t base, const EdgeCarry &ec,
+                          const std::function<int()> *ahead, bool *clean, bool *need_seq_out) {
+    bool ran_ahead = false;
+    *clean = false;
+    const int L = c->L;
+    const uint32_t n = n_all - base;
+    const uint32_t skip = skip_all > base ? skip_all - base : 0u;
+    const void *d_in = (const char *)d_in_all + (size_t)base * c->in_bytes_per_sample;
+    const uint64_t nseen = c->nseen + base;
+    uint32_t passes = 0;
+    ThrArgs A;
+    ThrPlan P;
+    if (int rc = thr_prepare(c, d_in, n, n_all, skip, base, nseen, ec, c->ring_cur, c->d_neg, c->d_pos, false, A, P)) return rc;
+    const uint32_t nch = P.nch;
+    const bool lean_applies = P.lean_applies;
+    uint8_t *d_cert = P.d_cert;
+    const uint8_t *h_cert = P.h_cert, *h_gflags = P.h_gflags, *h_gmin = P.h_gmin, *h_gmax = P.h_gmax;
+
+    // fill (if the window is not full yet) + per-batch preparation (delta, guard span, version bytes): one launch
+    launch_fill_kind(c, d_in, n, (int)nch);
+
+    // a 256-sample step must not wrap the ring onto itself: short windows take the sequential kernel
+    const bool force_seq = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0 || L < STEP;
+    bool need_seq = force_seq;
     if (!force_seq) {
         // pass 0: every chunk from a speculated incoming state (chunk 0: the carried, exact one)
         A.list = nullptr;
@@ -626,12 +700,12 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             CertSummary *d_sum = (CertSummary *)(tot + TOT_CERT);
             auto launch_certify = [&]() {
                 NFC_LAUNCH(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, d_cert,
-                                   dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[1 - c->ring_cur].as<float>(), dC(c),
+                                   dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[(c->ring_cur + 1) % 3].as<float>(), dC(c),
                                    first_round ? d_sum : (CertSummary *)nullptr);
             };
             if (first_round && ahead && !dbg) {
                 // the stages that follow are enqueued now; their first full-width kernel takes the certification along
-                c->cert = CertLaunch{A, d_cert, c->d_ring[1 - c->ring_cur].as<float>(), dC(c), d_sum, (np + 3) / 4 + 1};
+                c->cert = CertLaunch{A, d_cert, c->d_ring[(c->ring_cur + 1) % 3].as<float>(), dC(c), d_sum, (np + 3) / 4 + 1};
                 c->cert_pending = true;
                 const int rc = (*ahead)();
                 if (c->cert_pending) {   // (a short batch's one-launch stage, or no edge stage at all: on its own then)
@@ -746,20 +820,9 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
         }
         c->h_carry = c->hs->carry;
         carry_apply_fin(c->h_carry);
-        // Every fp64 sum of the batch is exact -- hence independent of the order it was added in -- when all
-        // operands are multiples of 2^low and no sum reaches 2^(low + 53).  Operands: ring values (24-bit mantissas)
-        // and the carried ss / delta (their lowest set bits); sums: the window sums (bounded by the kernel from the sums
-        // it tracked) and the carried ss itself.
-        int low = emin - 23;
-        if (c->h_carry.ss_emin != 255) low = std::min(low, c->h_carry.ss_emin);
-        float vtf;
-        memcpy(&vtf, &vtop, 4);
-        int high = 255 + 64;   // vtop: f32 bits of an upper bound of every window sum the batch saw
-        if (std::isfinite(vtf) && vtf >= 0.f) high = vtf > 0.f ? std::ilogb((double)vtf) + 127 : 0;
-        high = std::max(high, c->h_carry.ss_emax);
-        const bool exact = (emax < 255) && (high - low <= 52);
-        if (dbg) fprintf(stderr, "[nfc] guard: emin %d emax %d ss_emin %d ss_emax %d low %d high %d flagged %d exact %d\n", emin, emax,
-                         c->h_carry.ss_emin, c->h_carry.ss_emax, low, high, (int)flagged, (int)exact);
+        const bool exact = sums_exact(c->h_carry, emin, emax, vtop);
+        if (dbg) fprintf(stderr, "[nfc] guard: emin %d emax %d ss_emin %d ss_emax %d flagged %d exact %d\n", emin, emax,
+                         c->h_carry.ss_emin, c->h_carry.ss_emax, (int)flagged, (int)exact);
         if (!exact || flagged) need_seq = true;
     }
 
@@ -767,8 +830,8 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     if (!need_seq) {
         // the end-of-batch ring was resolved beside the last certification unless chunks were re-run after it
         if (passes > 1 || nch == 1)
-            NFC_LAUNCH(k_finalize_state, dim3(1), dim3(FIN_BLOCK), 0, c->st, A, c->d_ring[1 - c->ring_cur].as<float>(), dC(c));
-        c->ring_cur = 1 - c->ring_cur;
+            NFC_LAUNCH(k_finalize_state, dim3(1), dim3(FIN_BLOCK), 0, c->st, A, c->d_ring[(c->ring_cur + 1) % 3].as<float>(), dC(c));
+        c->ring_cur = (c->ring_cur + 1) % 3;
         *clean = ran_ahead && passes == 1;
     }
     return NFC_OK;
@@ -996,6 +1059,8 @@ int run_decode(nfc_ctx *c) {
     F.mirror_src = (const uint32_t *)c->d_state.p;   // the stage's last launch also fills the host's mirror of the state block
     F.mirror_dst = (uint32_t *)c->hs_dev;
     F.mirror_words = (uint32_t)(sizeof(DevState) / 4);
+    F.stamp_word = (uint32_t)(offsetof(DevState, seq) / 4 + 1);
+    F.stamp = c->stamp_b;
     NFC_LAUNCH(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
     return NFC_OK;
 }
@@ -1049,11 +1114,35 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     A.mirror_src = (const uint32_t *)c->d_state.p;
     A.mirror_dst = (uint32_t *)c->hs_dev;
     A.mirror_words = (uint32_t)(sizeof(DevState) / 4);
+    A.stamp_word = (uint32_t)(offsetof(DevState, seq) / 4 + 1);
+    A.stamp = c->stamp_b;
     NFC_LAUNCH(k_small_stage, dim3(1), dim3(SM_BLOCK), 0, c->st, A);
     return NFC_OK;
 }
 
+// capacity estimates from the densities of the previous batches (batches of very different lengths alternate
+// when a capture is sharded: a short overlap, then the shard), with head-room
+void size_capacities(nfc_ctx *c, uint32_t n) {
+    const uint64_t ce = (uint64_t)((double)n * c->edge_rate * 1.25) + 65536;
+    c->cap_edges = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ce, c->cap_edges_floor), 0xFFFFFF00u);
+    for (int t = 0; t < 2; t++) {
+        const uint64_t ub = (t == 1 ? 2ull : 1ull) * c->cap_edges + 16;   // <= 2 (Miller) / 1 (Manchester) symbols per edge
+        const uint64_t cs = (uint64_t)((double)c->cap_edges * c->sym_rate[t] * 1.1) + 65536;
+        c->cap_sym[t] = (uint32_t)std::min<uint64_t>(std::min(ub, std::max<uint64_t>(cs, c->cap_sym_floor[t])), 0xFFFFFF00u);
+    }
+}
+// densities for the next batch's estimates
+void update_estimates(nfc_ctx *c, uint32_t n) {
+    c->cap_edges_floor = 0;
+    c->cap_sym_floor[0] = c->cap_sym_floor[1] = 0;
+    c->edge_rate = std::max({(double)c->n_edges / (double)n, c->edge_rate * 0.9, 1.0 / 64});
+    for (int t = 0; t < 2; t++)
+        if (c->n_edges) c->sym_rate[t] = std::max((double)c->n_sym[t] / (double)c->n_edges, c->sym_rate[t] * 0.9);
+}
+
 int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
+    if (c->sub_count && !c->in_wait) return fail(c, NFC_ERR_STATE, "batches submitted with nfc_submit_device are in flight: nfc_wait for them first");
+    c->low_valid = false;
     c->have_outputs = false;
     c->pk_ready[0] = c->pk_ready[1] = false;
     c->n_edges = 0;
@@ -1072,6 +1161,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     }
     if (((uintptr_t)d_in & 15u) != 0) return fail(c, NFC_ERR_ARG, "device input must be 16-byte aligned");
     c->batch_seq++;
+    c->stamp_b = c->batch_seq;
     launch_error() = LaunchError{};   // (a failure nobody reported belongs to an earlier call)
     if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[0], c->st));
 
@@ -1108,17 +1198,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     const bool want_edges = !(c->P.flags & NFC_FLAG_NO_EDGES);
     const EdgeCarry ecarry_in = c->h_ecarry;
     const uint64_t g0 = c->nseen;
-    auto size_caps = [&]() {
-        // capacity estimates from the densities of the previous batches (batches of very different lengths alternate
-        // when a capture is sharded: a short overlap, then the shard), with head-room
-        const uint64_t ce = (uint64_t)((double)n * c->edge_rate * 1.25) + 65536;
-        c->cap_edges = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ce, c->cap_edges_floor), 0xFFFFFF00u);
-        for (int t = 0; t < 2; t++) {
-            const uint64_t ub = (t == 1 ? 2ull : 1ull) * c->cap_edges + 16;   // <= 2 (Miller) / 1 (Manchester) symbols per edge
-            const uint64_t cs = (uint64_t)((double)c->cap_edges * c->sym_rate[t] * 1.1) + 65536;
-            c->cap_sym[t] = (uint32_t)std::min<uint64_t>(std::min(ub, std::max<uint64_t>(cs, c->cap_sym_floor[t])), 0xFFFFFF00u);
-        }
-    };
+    auto size_caps = [&]() { size_capacities(c, n); };
     bool ev3_done = false;
     auto edges_and_decode = [&]() -> int {
         size_caps();
@@ -1170,13 +1250,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
             c->cap_sym_floor[0] = (uint64_t)ns[0] * 5 / 4 + 65536;
             c->cap_sym_floor[1] = (uint64_t)ns[1] * 5 / 4 + 65536;
         }
-        // next batch's estimates
-        // densities for the next batch's estimates
-        c->cap_edges_floor = 0;
-        c->cap_sym_floor[0] = c->cap_sym_floor[1] = 0;
-        c->edge_rate = std::max({(double)c->n_edges / (double)n, c->edge_rate * 0.9, 1.0 / 64});
-        for (int t = 0; t < 2; t++)
-            if (c->n_edges) c->sym_rate[t] = std::max((double)c->n_sym[t] / (double)c->n_edges, c->sym_rate[t] * 0.9);
+        update_estimates(c, n);
         c->pend_cur = 1 - c->pend_cur;
     } else {
         if (c->timing >= 2) {
@@ -1215,6 +1289,251 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     c->nseen += n;
     c->last_in = d_in;
     c->have_outputs = true;
+    // (the end-of-batch LOW bookkeeping on the device is what a batch submitted ahead may start from: only when the whole
+    // batch went through one parallel attempt, whose last certification workgroup or k_finalize_state wrote it)
+    c->low_valid = skip == 0 && c->stats.used_sequential == 0 && c->h_carry.stable;
+    return NFC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// batches submitted ahead (nfc_submit_device / nfc_wait)
+// ---------------------------------------------------------------------------
+// The threshold stage of batch k + 1 needs nothing the edge and decode stages of batch k produce -- the window, the sums
+// and the LOW bookkeeping it starts from are left on the device by batch k's own threshold stage -- so it is enqueued on
+// a second stream as soon as it is submitted and runs beside them (it leaves two thirds of a SIMD's issue slots idle; they
+// are bound by exactly those).  Its edge and decode stages take the carried values of theirs BY VALUE from the host
+// mirror, so they are enqueued when batch k has been waited for -- at the next submit / wait call, not in nfc_wait
+// itself, so that the outputs of batch k stay readable in between.  Everything optimistic is checked in nfc_wait (the
+// certification verdict, the exactness guard, the capacities, the stamps of both mirrors); a batch that fails any check
+// is simply processed again by the synchronous path from the state before it (host mirrors + the third window buffer),
+// and the batch submitted behind it, which started from a state that does not stand, is enqueued again.
+// Not for long windows: with a 40 KB ring per wave the threshold kernel holds ALL of a CU's LDS, the other stages'
+// workgroups cannot start beside it, and the two streams only get in each other's way (configs[3], 1e9 samples: 3.8 ms per
+// batch submitted ahead against 2.7 ms one after the other) -- such batches take the synchronous path inside nfc_wait.
+bool submit_fast_ok(const nfc_ctx *c, uint32_t n) {
+    return c->h_carry.stable && !(c->P.flags & (NFC_FLAG_NO_EDGES | NFC_FLAG_FORCE_SEQUENTIAL)) && c->L >= STEP && c->timing < 2 &&
+           !(c->use_small && n <= SM_MAX_SAMPLES) && n > 0 && c->lean_lds_per_cu <= 96 * 1024 && !getenv("NFC_DEBUG") && !getenv("NFC_DEBUG_CLK") && !getenv("NFC_NO_SUBMIT_AHEAD");
+}
+
+// the threshold stage of a submitted batch, on st_a; b.fast is cleared when the batch turns out not to qualify
+int enqueue_threshold_ahead(nfc_ctx *c, nfc_ctx::Submitted &b) {
+    ThrArgs A;
+    ThrPlan P;
+    const EdgeCarry unused{0, 0, 0, 0};
+    if (int rc = thr_prepare(c, b.d_in, b.n, b.n, 0u, 0u, b.g0, unused, b.ring_in, c->d_neg_alt, c->d_pos_alt, true, A, P)) return rc;
+    if (!P.lean_applies || c->gring || P.nch < 2) {   // (the general kernel's passes keep the synchronous path)
+        b.fast = false;
+        return NFC_OK;
+    }
+    b.nch = P.nch;
+    b.chunk = (uint32_t)c->C;
+    hipStream_t keep = c->st;
+    c->st = c->st_a;
+    c->batch_seq = b.seq;
+    launch_fill_kind(c, b.d_in, b.n, (int)P.nch, b.ring_in);
+    A.list = nullptr;
+    A.nlist = 0;
+    A.mode = 0;
+    A.cert = P.d_cert;
+    A.sum = (CertSummary *)(dT(c) + TOT_CERT);
+    A.ksteps = c->lean_rounds;
+    A.gfac = c->lean_gfac;
+    A.gfloor = c->lean_gmin;
+    A.blk = 1 << c->nfold;
+    b.timed = c->timing >= 1;
+    launch_threshold_kind(c, A, P.nch, true, b.timed ? c->kev_sub[b.slot] : nullptr);
+    const uint32_t np = P.nch - 1;
+    A.nlist = np;
+    NFC_LAUNCH(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, P.d_cert, (CertInfo *)nullptr,
+               c->d_ring[(b.ring_in + 1) % 3].as<float>(), dC(c), A.sum);
+    hipError_t e = hipMemcpyAsync(c->hs_a[b.slot], c->d_state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->st);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_a[b.slot], c->st);
+    c->st = keep;
+    if (e != hipSuccess) return fail(c, NFC_ERR_DEVICE, "submitting the threshold stage failed: %s", hipGetErrorString(e));
+    return NFC_OK;
+}
+
+// its edge and decode stages, on st behind its threshold stage; from here on the context's per-batch fields are this batch's
+int enqueue_stages_behind(nfc_ctx *c, nfc_ctx::Submitted &b) {
+    HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_a[b.slot], 0));
+    std::swap(c->d_neg, c->d_neg_alt);
+    std::swap(c->d_pos, c->d_pos_alt);
+    c->have_outputs = false;
+    c->pk_ready[0] = c->pk_ready[1] = false;
+    c->n_edges = 0;
+    for (int t = 0; t < 2; t++) c->n_sym[t] = c->n_close[t] = c->n_bits[t] = 0;
+    memset(&c->stats, 0, sizeof c->stats);
+    c->n_kev = 0;
+    c->last_n = b.n;
+    c->last_g0 = b.g0;
+    c->last_skip = 0;
+    c->stats.bytes_in = (uint64_t)b.n * c->in_bytes_per_sample;
+    c->stats.n_chunks = b.nch;
+    c->stats.chunk_samples = b.chunk;
+    c->stats.threshold_passes = 1;
+    c->stats.ran_ahead = 1;
+    c->stamp_b = b.seq;
+    c->cert_pending = false;
+    size_capacities(c, b.n);
+    int rc = run_edges(c, b.n, 0u, b.g0);
+    if (!rc) rc = run_decode(c);   // (its last launch mirrors the state block and stamps it)
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_b[b.slot], c->st));
+    b.b_enqueued = true;
+    return NFC_OK;
+}
+
+int submit_batch(nfc_ctx *c, const void *d_in, size_t n64) {
+    if (c->sub_count == 2) return fail(c, NFC_ERR_STATE, "two batches are in flight: nfc_wait for the older one first");
+    if (n64 > (1ull << 30)) return fail(c, NFC_ERR_ARG, "batch of %zu samples exceeds 2^30; push it in pieces", n64);
+    if (n64 && ((uintptr_t)d_in & 15u) != 0) return fail(c, NFC_ERR_ARG, "device input must be 16-byte aligned");
+    const uint32_t n = (uint32_t)n64;
+    nfc_ctx::Submitted *front = c->sub_count ? &c->sub[0] : nullptr;
+    // the older batch's edge / decode stages first: they were held back while the outputs of the batch before it could be read
+    if (front && front->fast && !front->b_enqueued)
+        if (int rc = enqueue_stages_behind(c, *front)) return rc;
+    nfc_ctx::Submitted b;
+    b.d_in = d_in;
+    b.n = n;
+    b.slot = (int)(c->slot_next++ & 1u);
+    b.timing = c->timing;
+    if (front) {
+        b.g0 = front->g0 + front->n;
+        b.ring_in = (front->ring_in + 1) % 3;
+        b.fast = front->fast && submit_fast_ok(c, n);   // (behind a batch that takes the synchronous path nothing is known yet)
+    } else {
+        b.g0 = c->nseen;
+        b.ring_in = c->ring_cur;
+        b.fast = c->low_valid && !c->state_dirty && submit_fast_ok(c, n);
+    }
+    if (b.fast) {
+        b.seq = c->batch_seq + 1;
+        if (!front) launch_error() = LaunchError{};
+        if (int rc = enqueue_threshold_ahead(c, b)) return rc;
+    }
+    c->sub[c->sub_count++] = b;
+    return NFC_OK;
+}
+
+int wait_batch(nfc_ctx *c) {
+    if (!c->sub_count) return fail(c, NFC_ERR_STATE, "nothing was submitted");
+    nfc_ctx::Submitted b = c->sub[0];
+    auto pop = [&]() {
+        c->sub[0] = c->sub[1];
+        c->sub_count--;
+    };
+    struct Scope {   // process_batch refuses to run beside submitted batches unless it is this function that calls it
+        nfc_ctx *c;
+        explicit Scope(nfc_ctx *c_) : c(c_) { c->in_wait = true; }
+        ~Scope() { c->in_wait = false; }
+    } scope(c);
+    if (!b.fast) {
+        pop();
+        const int keep_timing = c->timing;
+        c->timing = b.timing;
+        const int rc = process_batch(c, b.d_in, b.n);
+        c->timing = keep_timing;
+        if (rc) {
+            c->sub_count = 0;
+            return rc;
+        }
+        if (c->sub_count) {   // the batch behind it can start now that its state is known
+            nfc_ctx::Submitted &nb = c->sub[0];
+            nb.g0 = c->nseen;
+            nb.ring_in = c->ring_cur;
+            nb.fast = c->low_valid && !c->state_dirty && submit_fast_ok(c, nb.n);
+            if (nb.fast) {
+                nb.seq = c->batch_seq + 1;
+                if (int r2 = enqueue_threshold_ahead(c, nb)) return r2;
+            }
+        }
+        return NFC_OK;
+    }
+    if (!b.b_enqueued) {
+        if (int rc = enqueue_stages_behind(c, b)) return rc;
+        c->sub[0] = b;
+    }
+    HIPCHK(c, hipEventSynchronize(c->ev_b[b.slot]));
+    bool regular = true;
+    const char *why = "";
+    {
+        LaunchError &le = launch_error();
+        if (le.err != hipSuccess) {
+            const LaunchError e = le;
+            le = LaunchError{};
+            c->sub_count = 0;
+            return fail(c, NFC_ERR_DEVICE, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e.err), e.file, e.line);
+        }
+    }
+    const DevState *sa = c->hs_a[b.slot];
+    if (sa->seq[0] != b.seq || c->hs->seq[1] != b.seq) {
+        c->sub_count = 0;
+        return fail(c, NFC_ERR_DEVICE, "state mirror is stale (batch %u, mirrors %u / %u): a kernel of this batch did not run", b.seq, sa->seq[0], c->hs->seq[1]);
+    }
+    CertSummary summary;
+    memcpy(&summary, sa->totals + TOT_CERT, sizeof summary);
+    Carry after = sa->carry;
+    carry_apply_fin(after);
+    uint32_t ne, ns[2];
+    memcpy(&ne, c->hs->totals + TOT_EDGES, 4);
+    memcpy(ns, c->hs->totals + TOT_NSYM, 8);
+    if (summary.n_fail != 0) regular = false, why = "a chunk was not certified";
+    else if (summary.flagged || !sums_exact(after, (int)summary.emin, (int)summary.emax, summary.vtop)) regular = false, why = "sums not provably exact";
+    else if (!(ne <= c->cap_edges && ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1])) regular = false, why = "a capacity estimate was too small";
+    if (getenv("NFC_DEBUG_REDO_SUBMITTED") && (c->dbg_fast_waits++ % 3u) == 2u) regular = false, why = "test hook";   // every third batch that ran ahead
+    if (regular) {
+        c->h_carry = after;
+        c->h_ecarry = c->hs->ecarry;
+        c->h_dcarry = c->hs->dcarry;
+        c->n_edges = ne;
+        c->n_sym[0] = ns[0];
+        c->n_sym[1] = ns[1];
+        update_estimates(c, b.n);
+        c->pend_cur = 1 - c->pend_cur;
+        uint64_t pk[2];
+        memcpy(&pk[0], c->hs->totals + TOT_PKT0, 8);
+        memcpy(&pk[1], c->hs->totals + TOT_PKT1, 8);
+        for (int t = 0; t < 2; t++) {
+            c->n_bits[t] = (uint32_t)pk[t];
+            c->n_close[t] = (uint32_t)(pk[t] >> 32);
+        }
+        if (b.timed) {
+            c->stats.ms_threshold_kernel[0] = elapsed_ms(c->kev_sub[b.slot][0], c->kev_sub[b.slot][1]);
+            c->stats.n_threshold_timed = 1;
+        }
+        c->ring_cur = (b.ring_in + 1) % 3;
+        c->nseen = b.g0 + b.n;
+        c->last_in = b.d_in;
+        c->have_outputs = true;
+        c->low_valid = true;
+        pop();
+        return NFC_OK;
+    }
+    // The optimistic result does not stand: everything in flight is drained, the batch goes through the synchronous path
+    // from the state before it (the host mirrors were last adopted there; its window buffer was not written since), and
+    // the batch behind it starts again from what that leaves.
+    if (getenv("NFC_TRACE")) fprintf(stderr, "[nfc] submitted batch %u processed again: %s\n", b.seq, why);
+    HIPCHK(c, hipStreamSynchronize(c->st_a));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->stats_redo_submitted++;
+    push_state(c);
+    pop();
+    const int rc = process_batch(c, b.d_in, b.n);
+    if (rc) {
+        c->sub_count = 0;
+        return rc;
+    }
+    if (c->sub_count) {
+        nfc_ctx::Submitted &nb = c->sub[0];
+        nb.g0 = c->nseen;
+        nb.ring_in = c->ring_cur;
+        nb.b_enqueued = false;
+        nb.fast = c->low_valid && !c->state_dirty && submit_fast_ok(c, nb.n);
+        if (nb.fast) {
+            nb.seq = c->batch_seq + 1;
+            if (int r2 = enqueue_threshold_ahead(c, nb)) return r2;
+        }
+    }
     return NFC_OK;
 }
 
@@ -1368,11 +1687,23 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         if (const char *e = getenv("NFC_LEAN_WAVES")) c->lean_slots = std::min(c->wave_slots, prop.multiProcessorCount * 4 * std::max(1, atoi(e)));
         if (!c->lean_rounds) c->lean_rounds = std::max(1, (int)(0.4 * c->L / (256.0 * c->lean_k)));
         c->wave_slots_g = prop.multiProcessorCount * 20;   // VGPR-bound: five waves per SIMD
+        // LDS the lean kernel's resident waves hold per CU: a batch is only run ahead of its predecessor's edge / decode stages
+        // (nfc_submit_device) while those stages' workgroups (25 KB each) still fit beside it
+        c->lean_lds_per_cu = (size_t)((c->lean_slots + prop.multiProcessorCount - 1) / prop.multiProcessorCount) * lds_wave;
     }
     CRT(hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking));
     c->st = c->own_st;
     for (auto &e : c->ev) CRT(hipEventCreate(&e));
     for (auto &e : c->kev) CRT(hipEventCreate(&e));
+    CRT(hipStreamCreateWithFlags(&c->st_a, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+        CRT(hipEventCreateWithFlags(&c->ev_a[b], hipEventDisableTiming));
+        CRT(hipEventCreateWithFlags(&c->ev_b[b], hipEventDisableTiming));
+        CRT(hipEventCreate(&c->kev_sub[b][0]));
+        CRT(hipEventCreate(&c->kev_sub[b][1]));
+        CRT(hipHostMalloc((void **)&c->hs_a[b], sizeof(DevState), hipHostMallocDefault));
+        memset(c->hs_a[b], 0, sizeof(DevState));
+    }
     const size_t lds = (size_t)c->wpb * c->Lpad * c->lds_per_slot;
     if (lds > 160 * 1024) {
         nfc_destroy(c);
@@ -1427,9 +1758,11 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     CRT(hipHostMalloc((void **)&c->hs, sizeof(DevState), hipHostMallocMapped));
     memset(c->hs, 0, sizeof(DevState));
     CRT(hipHostGetDevicePointer(&c->hs_dev, c->hs, 0));
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < 3; b++) {
         CRT(c->d_ring[b].ensure((size_t)c->Lpad * 4));
         CRT(hipMemset(c->d_ring[b].p, 0, (size_t)c->Lpad * 4));
+    }
+    for (int b = 0; b < 2; b++) {
         CRT(c->d_pending[b][0].ensure(1024));
         CRT(c->d_pending[b][1].ensure(1024));
     }
@@ -1443,10 +1776,11 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
 void nfc_destroy(nfc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->P.device);
+    if (c->st_a) (void)hipStreamSynchronize(c->st_a);
     if (c->st && c->st == c->own_st) (void)hipStreamSynchronize(c->st);
     else (void)hipDeviceSynchronize();   // on a caller's stream (nfc_set_stream): the handle may be gone by now
     DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_state,
-                     &c->d_ring[0], &c->d_ring[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
+                     &c->d_ring[0], &c->d_ring[1], &c->d_ring[2], &c->d_neg_alt, &c->d_pos_alt, &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ecode, &c->d_epos, &c->d_eidx, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
@@ -1460,6 +1794,14 @@ void nfc_destroy(nfc_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->kev)
         if (e) (void)hipEventDestroy(e);
+    for (int b = 0; b < 2; b++) {
+        if (c->ev_a[b]) (void)hipEventDestroy(c->ev_a[b]);
+        if (c->ev_b[b]) (void)hipEventDestroy(c->ev_b[b]);
+        if (c->kev_sub[b][0]) (void)hipEventDestroy(c->kev_sub[b][0]);
+        if (c->kev_sub[b][1]) (void)hipEventDestroy(c->kev_sub[b][1]);
+        if (c->hs_a[b]) (void)hipHostFree(c->hs_a[b]);
+    }
+    if (c->st_a) (void)hipStreamDestroy(c->st_a);
     if (c->own_st) (void)hipStreamDestroy(c->own_st);
     delete c;
 }
@@ -1471,8 +1813,29 @@ int nfc_push_device(nfc_ctx *c, const void *dev_samples, size_t n) {
     return process_batch(c, dev_samples, n);
 }
 
+int nfc_submit_device(nfc_ctx *c, const void *dev_samples, size_t n) {
+    if (!c) return NFC_ERR_ARG;
+    if (n && !dev_samples) return fail(c, NFC_ERR_ARG, "null input");
+    if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
+    return submit_batch(c, dev_samples, n);
+}
+
+int nfc_wait(nfc_ctx *c) {
+    if (!c) return NFC_ERR_ARG;
+    if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
+    return wait_batch(c);
+}
+
+int nfc_submitted(nfc_ctx *c) { return c ? c->sub_count : 0; }
+
+#define NOSUB(c)                                                                                                                     \
+    do {                                                                                                                             \
+        if ((c)->sub_count) return fail((c), NFC_ERR_STATE, "batches submitted with nfc_submit_device are in flight: nfc_wait first"); \
+    } while (0)
+
 int nfc_push(nfc_ctx *c, const void *host_samples, size_t n) {
     if (!c) return NFC_ERR_ARG;
+    NOSUB(c);
     if (n && !host_samples) return fail(c, NFC_ERR_ARG, "null input");
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
     const size_t bytes = n * c->in_bytes_per_sample;
@@ -1483,6 +1846,7 @@ int nfc_push(nfc_ctx *c, const void *host_samples, size_t n) {
 
 int nfc_push_edges(nfc_ctx *c, const nfc_edge *host_edges, size_t n64) {
     if (!c) return NFC_ERR_ARG;
+    NOSUB(c);
     if (n64 && !host_edges) return fail(c, NFC_ERR_ARG, "null input");
     if (n64 > 0xFFFFFF00ull) return fail(c, NFC_ERR_ARG, "too many edges for one call");
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
@@ -1550,6 +1914,7 @@ int nfc_sync(nfc_ctx *c) {
 
 int nfc_set_stream(nfc_ctx *c, void *stream) {
     if (!c) return NFC_ERR_ARG;
+    NOSUB(c);
     HIPCHK(c, hipStreamSynchronize(c->st));   // nothing of this context is left on the stream it leaves
     c->st = stream ? (hipStream_t)stream : c->own_st;
     return NFC_OK;
@@ -1747,6 +2112,7 @@ int nfc_set_timing(nfc_ctx *c, int level) {
 
 int nfc_reset(nfc_ctx *c) {
     if (!c) return NFC_ERR_ARG;
+    NOSUB(c);
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
     init_carried(c);
     c->have_outputs = false;
@@ -1756,6 +2122,7 @@ int nfc_reset(nfc_ctx *c) {
 
 int nfc_prime(nfc_ctx *c, uint64_t start_index, float level) {
     if (!c || !(level >= 0.f) || !std::isfinite(level)) return NFC_ERR_ARG;
+    NOSUB(c);
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
     init_carried(c);
     c->nseen = start_index;
@@ -1804,6 +2171,7 @@ __global__ void k_export_state(uint8_t *dst, uint32_t len, int fits, nfc_state_h
 
 int nfc_export_state(nfc_ctx *c, void *device_dst, size_t cap, size_t *len_out) {
     if (!c || !device_dst || cap < 16 || ((uintptr_t)device_dst & 15u)) return NFC_ERR_ARG;
+    NOSUB(c);
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
     flush_state(c);   // (a reset / prime that has not reached the device yet)
     nfc_state_header h;
@@ -1820,6 +2188,7 @@ int nfc_export_state(nfc_ctx *c, void *device_dst, size_t cap, size_t *len_out) 
 
 int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap, uint8_t *pending, size_t pending_cap) {
     if (!c || !h) return NFC_ERR_ARG;
+    NOSUB(c);
     flush_state(c);
     HIPCHK(c, hipStreamSynchronize(c->st));
     fill_state_header(c, h);
@@ -1852,6 +2221,7 @@ int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap,
 int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size_t ring_len, const uint8_t *pending,
                   size_t pending_len) {
     if (!c || !h || !ring) return NFC_ERR_ARG;
+    NOSUB(c);
     if (h->av_window != c->L || ring_len != (size_t)c->L) return fail(c, NFC_ERR_ARG, "state was taken with another av_window");
     // (_dur is 0 after the fill and 1 .. max_len after a sample: transition_sink.py:95-99, 123; the entry codes rely on it)
     if (h->dur < 0 || h->dur > c->mx || h->last_bit < -1 || h->last_bit > 1 || h->cur_state < 0 || h->cur_state > 2)
@@ -1886,6 +2256,7 @@ int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size
 int nfc_get_stats(nfc_ctx *c, nfc_stats *out) {
     if (!c || !out) return NFC_ERR_ARG;
     *out = c->stats;
+    out->redone_total = c->stats_redo_submitted;
     return NFC_OK;
 }
 

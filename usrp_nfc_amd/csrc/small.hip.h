@@ -43,6 +43,7 @@ struct SmallArgs {
     const uint32_t *mirror_src;   // the device state block -> the host's mapped mirror (decode.hip.h: PktFinish), or NULL
     uint32_t *mirror_dst;
     uint32_t mirror_words;
+    uint32_t stamp_word, stamp;   // (decode.hip.h: PktFinish)
 };
 
 __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
     if (A.mirror_src) {   // the batch's last launch: the state block goes to the host's mirror from here
         __threadfence();
         __syncthreads();
-        for (uint32_t i = tid; i < A.mirror_words; i += SM_BLOCK) A.mirror_dst[i] = A.mirror_src[i];
+        for (uint32_t i = tid; i < A.mirror_words; i += SM_BLOCK) A.mirror_dst[i] = (i == A.stamp_word) ? A.stamp : A.mirror_src[i];
     }
 }
 

@@ -56,6 +56,9 @@ struct Carry {
     int32_t fin_valid; // ss_fin holds the sum at the end of the last batch (applied by the next batch's preparation)
     double ss_fin;     // The end-of-batch sum does NOT overwrite ss: a batch whose sums cannot be proven exact is replayed
                        // by the sequential kernel from the batch-start ss after the parallel attempt has already finalized.
+    int32_t low_nl, low_kl;   // the "HIGH ignored" bookkeeping (below) at the end of the batch, in the NEXT batch's sample
+                              // indices (<= -1): what a batch enqueued before this one's results are read starts from
+                              // (ThrArgs.low_src; the synchronous path derives the same from the edge stage's carried values)
 };
 __host__ __device__ inline void carry_apply_fin(Carry &c) {
     if (c.fin_valid) {
@@ -104,7 +107,8 @@ struct ThrArgs {
     float eps;             // certification margin of pass 0
     const float *ring_carry;
     const Carry *carry;
-    int32_t nl0, kl0;      // carried last-non-LOW index and LOW key at the batch start (batch-local, <= -1)
+    int32_t nl0, kl0;      // carried last-non-LOW index and LOW key at the batch start (batch-local, <= -1) ...
+    const Carry *low_src;  // ... or, when not null, where the previous batch's kernels left them (Carry.low_nl / low_kl)
     double lo_L, hi_L;     // lo / L, hi / L (the fast path's thresholds carry 2^-20 of slack)
     int32_t fold_sh[6];    // long-LOW-run detector: shifts of the six folds (0 = fold disabled) ...
     int32_t probe_mid, probe_end;   // ... pre-filter probes: b/2 and b-1 for aligned blocks of b samples
@@ -312,13 +316,15 @@ __device__ __forceinline__ void classify_one(const ThrArgs &A, double x64, doubl
 // LOW bookkeeping at a chunk start.  A LOW key only matters within max_len + 1 samples and a chunk is longer
 // than that, so only the predecessor's key can be live; the last non-LOW index needs a deeper look only when
 // whole chunks were LOW.
+__device__ __forceinline__ int carried_nl(const ThrArgs &A) { return A.low_src ? A.low_src->low_nl : A.nl0; }
+__device__ __forceinline__ int carried_kl(const ThrArgs &A) { return A.low_src ? A.low_src->low_kl : A.kl0; }
 __device__ __forceinline__ void resolve_low_state(const ThrArgs &A, int c, int &nl, int &kl) {
     const ChunkInfo p = A.info[A.ver[c - 1]][c - 1];
     kl = p.low_key;
     nl = p.last_nonlow;
     for (int cc = c - 2; cc >= 0 && nl == LL_NONE; cc--) nl = A.info[A.ver[cc]][cc].last_nonlow;
-    if (nl == LL_NONE) nl = A.nl0;
-    if (c == 1 && kl == KEY_NONE) kl = A.kl0;
+    if (nl == LL_NONE) nl = carried_nl(A);
+    if (c == 1 && kl == KEY_NONE) kl = carried_kl(A);
 }
 
 // exact incoming ring value of slot s for chunk c: latest predecessor that accepted a sample into it
@@ -425,8 +431,8 @@ __device__ __forceinline__ void chunk_incoming(const ThrArgs &A, uint32_t c, int
         #pragma unroll 8
         for (int s = lane; s < L; s += 64) ring[s] = A.ring_carry[s];
         ss0 = cr.ss;
-        w_nl = A.nl0;
-        w_kl = A.kl0;
+        w_nl = carried_nl(A);
+        w_kl = carried_kl(A);
     } else if (!PASS0 && A.mode == 1) {
         for (int s = lane; s < L; s += 64) ring[s] = resolve_slot(A, (int)c, s);
         double part = 0;
@@ -1063,6 +1069,16 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
         }
         carry->ss_fin = S + carry->delta;
         carry->fin_valid = 1;
+        // the LOW bookkeeping a chunk after the last one would start from, rebased to the next batch's sample 0.  (Only the
+        // run's phase modulo max_len and "longer than max_len + 1" matter of a last-non-LOW index far back: it is brought
+        // within 2^29 in whole multiples of max_len, so that batch after batch of LOW samples cannot overflow it.)
+        int nl, kl;
+        resolve_low_state(A, A.nchunks, nl, kl);
+        long long rel = (long long)nl - (long long)A.n;
+        const long long floor_ = -(1ll << 29);
+        if (rel < floor_) rel += ((floor_ - rel + A.mx - 1) / A.mx) * (long long)A.mx;
+        carry->low_nl = (int32_t)rel;
+        carry->low_kl = (kl == KEY_NONE || (long long)(kl >> 1) - (long long)A.n < floor_) ? KEY_NONE : kl - 2 * (int32_t)A.n;
         if (sum) {
             sum->emin = mn;
             sum->emax = mx;
