@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the end-to-end figure and the other configurations')
+    ap.add_argument('--in-flight', type=int, default=2, choices=[1, 2, 3], help='one GPU: batches submitted and not yet waited for')
     ap.add_argument('--sync-steps', action='store_true', help='one GPU: every step a fresh stream pushed synchronously (nfc_push_device), as the sharded steps are; '
                     'default: the steps are consecutive batches of ONE stream, each submitted before the one before it is waited for')
     return ap.parse_args()
@@ -229,10 +230,11 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                 ctx.set_timing(t)
                 cur[0] = t
             ctx.submit_device(res.buf, n)
-        submit(0)
+        nxt = 0
         for k in range(count):
-            if k + 1 < count:
-                submit(k + 1)
+            while nxt < count and nxt < k + a.in_flight:   # (three in flight: the threshold stage of batch k + 2 queued behind k + 1's)
+                submit(nxt)
+                nxt += 1
             ctx.wait()
             if timed_every:
                 st = ctx.stats()
@@ -268,6 +270,30 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
     dt = time.perf_counter() - t0
     if hasattr(comm, 'max_over_ranks'):
         dt = comm.max_over_ranks(dt)
+    # beside the headline: the same batches one after the other (nfc_push_device, nothing in flight beside them) -- what a
+    # step costs then, and the threshold kernel's duration with the machine to itself
+    alone = None
+    if ahead and not a.no_extras:
+        k_alone = []
+        for _ in range(5):
+            ctx.push_device(res.buf, n)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for k in range(steps):
+            timed = k % 8 == 0
+            if timed or k % 8 == 1:
+                ctx.set_timing(1 if timed else 0)
+            ctx.push_device(res.buf, n)
+            if timed:
+                st = ctx.stats()
+                k_alone += [st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed)]
+        ctx.sync()
+        dt1 = time.perf_counter() - t1
+        ka = float(np.mean(k_alone)) if k_alone else float('nan')
+        alone = {'ms_per_step': dt1 / steps * 1e3, 'value': n * steps / dt1 / 1e6, 'unit': 'Msamples/s', 'steps': steps,
+                 'roofline': {'bound': 'hbm', 'achieved': 8.0 * n / (ka * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': 8.0 * n / (ka * 1e-3) / 1e9 / HBM_PEAK_GBS, 'avg_launch_ms': ka, 'launches_timed': len(k_alone)},
+                 'what': 'the same stream, each batch pushed synchronously (nfc_push_device): nothing runs beside the threshold kernel'}
     ctx.set_timing(2)   # one more, untimed, step for the per-stage split reported beside the headline (synchronous: stream markers)
     if ahead:
         ctx.push_device(res.buf, n)
@@ -292,20 +318,23 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                        'symbols_reader': int(cnt.n_symbols[1]), 'symbols_tag': int(cnt.n_symbols[0]),
                        'packets': int(cnt.n_packets[0] + cnt.n_packets[1]), 'boundary_redos': redo[0],
                        'shard_overlap_samples': capture_overlap(workload) if world > 1 else 0, 'exchange': backend if world > 1 else 'none',
-                       'steps_are': ('consecutive batches of one stream, batch k + 1 submitted before batch k is waited for (%d of %d timed steps ran ahead)' % (n_ahead[0], steps))
+                       'steps_are': ('consecutive batches of one stream, %d in flight: batch k + %d is submitted before batch k is waited for (%d of %d timed steps ran ahead)' % (a.in_flight, a.in_flight - 1, n_ahead[0], steps))
                                     if ahead else 'a fresh stream per step, pushed synchronously'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_lean / k_threshold (fused envelope + gated-mean threshold)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': tsrc, 'avg_launch_ms': k_avg, 'launches_timed': len(kernel_ms),
                          'launches_per_step': float(np.mean(n_pass)) if n_pass else None,
                          'algorithmic_bytes_per_launch': thr_bytes,
-                         'note': '8 B/sample only: the 16 B/edge of SURVEY 8(d) are written by the edge stage, listed under edge_stage'},
+                         'note': '8 B/sample only: the 16 B/edge of SURVEY 8(d) are written by the edge stage, listed under edge_stage'
+                                 + ('; the launches of the timed region run BESIDE the previous batch\'s edge and decode stages (batches submitted ahead) and '
+                                    'share the SIMDs\' issue slots with them: one_batch_at_a_time.roofline is the same kernel with the machine to itself' if ahead else '')},
             'edge_stage': {'algorithmic_bytes': edge_bytes, 'bytes_stored': stored_bytes, 'stage_ms': st.ms_edges,
                            'achieved_GBs': (edge_bytes / (st.ms_edges * 1e-3) / 1e9) if st.ms_edges > 0 else None,
                            'note': 'all kernels of the edge stage of the extra, marker-timed step (tile aggregates, writer); algorithmic_bytes '
                                    'is SURVEY 8(d)\'s 16 B per edge, the stage stores 6 B per entry and nfc_read_edges builds the 16-byte records'},
             'whole_path': {'algorithmic_bytes': thr_bytes + edge_bytes,
                            'achieved_GBs': (thr_bytes + edge_bytes) / (dt / steps) / 1e9, 'frac': (thr_bytes + edge_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS},
+            'one_batch_at_a_time': alone,
             'stage_ms_extra_step': {'total_device': st.ms_total, 'threshold': st.ms_threshold, 'edges': st.ms_edges,
                                     'decode': st.ms_decode, 'used_sequential': int(st.used_sequential)},
         }
@@ -342,14 +371,14 @@ def hbm_traffic(workload, n):
 def parity_check(workload, own, flags, n, ahead=False):
     """Rank 0's chunk, GPU vs the pinned C oracle, full size, every pass compared in full (edges, symbols, packets).
     A tiled capture goes tile by tile.  ahead: as the timed loop does it -- ONE stream, the capture again and again, batch
-    k + 1 submitted before batch k is waited for; three rounds (two for a tiled capture), so that a batch that follows a
+    k + 2 submitted before batch k is waited for; four rounds (two for a tiled capture), so that a batch that follows a
     synchronous one and a batch that follows one that ran ahead are both compared; the counts reported are the last round's."""
     import numpy as np
     from oracle import c_oracle as co
     from usrp_nfc_amd import api
     tile = len(own) // 2
     reps = (n + tile - 1) // tile
-    rounds = (3 if reps == 1 else 2) if ahead else 1
+    rounds = (4 if reps == 1 else 2) if ahead else 1
     ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **stream_params(workload), **flags)
     o = co.COracle(**stream_params(workload), **flags)
     ok_edges = ok_sym = ok_pk = True
@@ -357,12 +386,12 @@ def parity_check(workload, own, flags, n, ahead=False):
     n_ahead = 0
     buf = api.DeviceBuffer(own) if ahead else None
     total = rounds * reps
-    if ahead:
-        ctx.submit_device(buf, tile)
+    nxt = 0
     for k in range(total):   # the stream carries over from pass to pass on both sides; outputs are compared per pass
         if ahead:
-            if k + 1 < total:
+            while nxt < total and nxt < k + 3:
                 ctx.submit_device(buf, tile)
+                nxt += 1
             ctx.wait()
             n_ahead += int(ctx.stats().ran_ahead)
         else:

@@ -159,10 +159,10 @@ int nfc_sync(nfc_ctx *ctx);
 int nfc_push_edges(nfc_ctx *ctx, const nfc_edge *host_edges, size_t n);
 /* Batches submitted ahead.  nfc_submit_device enqueues a batch and returns; nfc_wait completes the OLDEST submitted batch,
  * after which its outputs are read as after nfc_push_device -- valid until the next nfc_submit_device / nfc_wait / nfc_push*.
- * At most two batches may be in flight, so the steady state of a stream is
- *     submit(0);  loop k: submit(k + 1); wait(k); read the outputs of k
+ * At most three batches may be in flight, so the steady state of a stream is
+ *     submit(0); submit(1);  loop k: submit(k + 2); wait(k); read the outputs of k
  * and the threshold stage of batch k + 1 runs on the GPU beside the edge and decode stages of batch k (which need nothing of
- * it, and leave it most of the machine's issue slots).  The input buffer of a submitted batch must stay untouched until
+ * it, and leave it most of the machine's issue slots), with batch k + 2's queued right behind it.  The input buffer of a submitted batch must stay untouched until
  * its nfc_wait returns.  Results are identical to nfc_push_device's: what runs ahead is checked in nfc_wait (certification
  * verdict, exactness guard, buffer capacities) and a batch that fails a check is processed again synchronously from the
  * state before it.  A batch that does not qualify (window not full yet, a short batch, state just set from the host, ...)
@@ -170,7 +170,7 @@ int nfc_push_edges(nfc_ctx *ctx, const nfc_edge *host_edges, size_t n);
  * flight (NFC_ERR_STATE).  No reference counterpart: the reference is one synchronous work() call after another. */
 int nfc_submit_device(nfc_ctx *ctx, const void *dev_samples, size_t n);
 int nfc_wait(nfc_ctx *ctx);
-int nfc_submitted(nfc_ctx *ctx); /* batches submitted and not yet waited for (0, 1 or 2) */
+int nfc_submitted(nfc_ctx *ctx); /* batches submitted and not yet waited for (0 .. 3) */
 /* Enqueue this context's work on the caller's HIP stream (hipStream_t; NULL: back to the context's own), so that what the
  * caller enqueues there next -- a collective on the exported boundary states -- needs no host wait in between. */
 int nfc_set_stream(nfc_ctx *ctx, void *stream);

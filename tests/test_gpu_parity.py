@@ -154,14 +154,18 @@ def test_synthetic_workloads_2M(name, kw):
     assert len(r['packets']) > 100
 
 
-def _run_submitted(ctx, iq, cuts):
-    """The stream in batches, each submitted before the one before it is waited for (nfc_submit_device / nfc_wait)."""
+def _run_submitted(ctx, iq, cuts, depth=2):
+    """The stream in batches, each submitted before the batches before it are waited for (nfc_submit_device / nfc_wait):
+    `depth` batches in flight."""
     bufs = [api.DeviceBuffer(iq[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    lens = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
     tr, s0, s1, pk, ahead = [], [], [], [], 0
-    ctx.submit_device(bufs[0], cuts[1] - cuts[0])
+    nxt = 0
     for k in range(len(bufs)):
-        if k + 1 < len(bufs):
-            ctx.submit_device(bufs[k + 1], cuts[k + 2] - cuts[k + 1])
+        while nxt < len(bufs) and nxt < k + depth:
+            ctx.submit_device(bufs[nxt], lens[nxt])
+            nxt += 1
+        assert ctx.submitted() == nxt - k
         ctx.wait()
         tr += ctx.transitions()
         s0 += ctx.symbols(0).tolist()
@@ -172,8 +176,8 @@ def _run_submitted(ctx, iq, cuts):
     return tr, s0, s1, pk, ahead
 
 
-@pytest.mark.parametrize('hook', ['', 'redo'])
-def test_batches_submitted_ahead(monkeypatch, hook):
+@pytest.mark.parametrize('hook,depth', [('', 2), ('', 3), ('redo', 2), ('redo', 3)])
+def test_batches_submitted_ahead(monkeypatch, hook, depth):
     # batch k + 1's threshold stage runs beside batch k's edge / decode stages, starting from the LOW bookkeeping, window and
     # sums batch k's own threshold stage left on the device; the result must be the single stream's.  With the test hook every
     # third submitted batch is declared irregular in nfc_wait and goes through the synchronous path again (and the batch behind
@@ -185,7 +189,11 @@ def test_batches_submitted_ahead(monkeypatch, hook):
     o = oracle_run(iq, dict(hi_val=1.1), api.NFC_IN_IQ_F32)
     cuts = [0, 300_000, 700_000, 1_000_003, 1_400_000, 1_800_001, 2_100_000, 2_400_000, 2_700_000, n]
     with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
-        tr, s0, s1, pk, ahead = _run_submitted(ctx, iq, cuts)
+        tr, s0, s1, pk, ahead = _run_submitted(ctx, iq, cuts, depth)
+        with pytest.raises(api.NfcError):   # nothing else touches the stream while batches are in flight
+            ctx.submit_device(api.DeviceBuffer(iq[:600_000]), 300_000)
+            ctx.reset()
+        ctx.wait()
         st = ctx.stats()
     d = first_diff(tr, o.transitions())
     assert d is None, 'transition %s' % (d,)
@@ -237,7 +245,7 @@ def test_batches_submitted_ahead_cut_inside_frames(name, kw):
     cuts = [0, 300_000] + sorted((300_000 + 290_000 * (k + 1) + int(rng.integers(0, 20_000))) for k in range(8)) + [n]
     o = oracle_run(iq, dict(hi_val=1.1, **kw), api.NFC_IN_IQ_F32)
     with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32, **kw) as ctx:
-        tr, s0, s1, pk, ahead = _run_submitted(ctx, iq, cuts)
+        tr, s0, s1, pk, ahead = _run_submitted(ctx, iq, cuts, 3)
         st = ctx.stats()
     d = first_diff(tr, o.transitions())
     assert d is None, 'transition %s' % (d,)

@@ -77,7 +77,7 @@ class NfcContext(object):
         return n
 
     def submit_device(self, dev_ptr, n):
-        """Enqueue a batch and return (nfc_submit_device); at most two in flight.  The buffer stays untouched until its wait()."""
+        """Enqueue a batch and return (nfc_submit_device); at most three in flight.  The buffer stays untouched until its wait()."""
         ptr = dev_ptr.ptr if isinstance(dev_ptr, DeviceBuffer) else C.c_void_p(int(dev_ptr))
         self._chk(self.L.nfc_submit_device(self.h, ptr, n), 'nfc_submit_device')
         return n

@@ -118,6 +118,9 @@ struct DevState {
                        // does not carry the current number was not written by this batch's kernels
 };
 
+constexpr int NRING = 4;   // window buffers: the carried one + one per batch that may be in flight (they rotate)
+constexpr int NSUB = 3;    // batches that may be submitted and not yet waited for
+
 struct nfc_ctx {
     nfc_params P;
     int L, mx, C, Lpad, wpb, twords;
@@ -156,8 +159,8 @@ struct nfc_ctx {
     DecTables T;
 
     // carried state
-    DevBuf d_state, d_ring[3];   // the window: the carried one, the one the batch in work writes, and -- with a batch submitted
-                                 // ahead (nfc_submit_device) -- the one THAT batch writes; they rotate
+    DevBuf d_state, d_ring[NRING];   // the window: the carried one, the one the batch in work writes, and -- with batches submitted
+                                     // ahead (nfc_submit_device) -- the ones THOSE write; they rotate
     DevState *hs = nullptr;        // pinned host mirror of d_state
     void *hs_dev = nullptr;        // the same memory as the device addresses it (kernels may fill the mirror themselves)
     uint8_t *h_stage = nullptr;    // pinned staging for nfc_get_state
@@ -171,18 +174,20 @@ struct nfc_ctx {
     // ---- a batch submitted ahead (nfc_submit_device / nfc_wait): its threshold stage runs on st_a beside the edge and
     // decode stages of the batch before it on st
     hipStream_t st_a = nullptr;
-    DevBuf d_neg_alt, d_pos_alt;               // that batch's planes (they become d_neg / d_pos when its edge stage is enqueued)
-    DevState *hs_a[2] = {nullptr, nullptr};    // pinned snapshots of the state block taken right after a submitted batch's certification
-    hipEvent_t ev_a[2] = {}, ev_b[2] = {};     // its threshold stage / its last stage done
-    hipEvent_t kev_sub[2][2] = {};             // start / stop of its threshold kernel (nfc_set_timing >= 1)
+    DevBuf d_neg_alt[NSUB - 1], d_pos_alt[NSUB - 1];   // planes of the batches whose edge stage is not enqueued yet (a set becomes
+                                                       // d_neg / d_pos then, and the retired set takes its place in the pool)
+    uint32_t alt_free = (1u << (NSUB - 1)) - 1u;       // which of them are free
+    DevState *hs_a[NSUB] = {};                 // pinned snapshots of the state block taken right after a submitted batch's certification
+    hipEvent_t ev_a[NSUB] = {}, ev_b[NSUB] = {};   // its threshold stage / its last stage done
+    hipEvent_t kev_sub[NSUB][2] = {};          // start / stop of its threshold kernel (nfc_set_timing >= 1)
     struct Submitted {
         const void *d_in = nullptr;
         uint32_t n = 0, seq = 0, nch = 0, chunk = 0;
         uint64_t g0 = 0;
-        int slot = 0, ring_in = 0, timing = 0;   // (timing: nfc_set_timing's level when the batch was submitted)
+        int slot = 0, planes = -1, ring_in = 0, timing = 0;   // (timing: nfc_set_timing's level when the batch was submitted)
         bool fast = false, b_enqueued = false, timed = false;
-    } sub[2];
-    int sub_count = 0;             // batches submitted and not yet waited for (sub[0] the older)
+    } sub[NSUB];
+    int sub_count = 0;             // batches submitted and not yet waited for (sub[0] the oldest)
     uint32_t slot_next = 0;
     bool low_valid = false;        // Carry.low_nl / low_kl on the device describe the end of the last completed batch
     size_t lean_lds_per_cu = 0;
@@ -700,12 +705,12 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             CertSummary *d_sum = (CertSummary *)(tot + TOT_CERT);
             auto launch_certify = [&]() {
                 NFC_LAUNCH(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, d_cert,
-                                   dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[(c->ring_cur + 1) % 3].as<float>(), dC(c),
+                                   dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c),
                                    first_round ? d_sum : (CertSummary *)nullptr);
             };
             if (first_round && ahead && !dbg) {
                 // the stages that follow are enqueued now; their first full-width kernel takes the certification along
-                c->cert = CertLaunch{A, d_cert, c->d_ring[(c->ring_cur + 1) % 3].as<float>(), dC(c), d_sum, (np + 3) / 4 + 1};
+                c->cert = CertLaunch{A, d_cert, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c), d_sum, (np + 3) / 4 + 1};
                 c->cert_pending = true;
                 const int rc = (*ahead)();
                 if (c->cert_pending) {   // (a short batch's one-launch stage, or no edge stage at all: on its own then)
@@ -830,8 +835,8 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
     if (!need_seq) {
         // the end-of-batch ring was resolved beside the last certification unless chunks were re-run after it
         if (passes > 1 || nch == 1)
-            NFC_LAUNCH(k_finalize_state, dim3(1), dim3(FIN_BLOCK), 0, c->st, A, c->d_ring[(c->ring_cur + 1) % 3].as<float>(), dC(c));
-        c->ring_cur = (c->ring_cur + 1) % 3;
+            NFC_LAUNCH(k_finalize_state, dim3(1), dim3(FIN_BLOCK), 0, c->st, A, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c));
+        c->ring_cur = (c->ring_cur + 1) % NRING;
         *clean = ran_ahead && passes == 1;
     }
     return NFC_OK;
@@ -1315,14 +1320,22 @@ bool submit_fast_ok(const nfc_ctx *c, uint32_t n) {
            !(c->use_small && n <= SM_MAX_SAMPLES) && n > 0 && c->lean_lds_per_cu <= 96 * 1024 && !getenv("NFC_DEBUG") && !getenv("NFC_DEBUG_CLK") && !getenv("NFC_NO_SUBMIT_AHEAD");
 }
 
-// the threshold stage of a submitted batch, on st_a; b.fast is cleared when the batch turns out not to qualify
+// the threshold stage of a submitted batch, on st_a, into a free set of planes; b.fast is cleared when the batch turns out
+// not to qualify
 int enqueue_threshold_ahead(nfc_ctx *c, nfc_ctx::Submitted &b) {
+    if (b.planes < 0) {
+        if (!c->alt_free) return fail(c, NFC_ERR_INTERNAL, "no free set of planes");
+        b.planes = __builtin_ctz(c->alt_free);
+        c->alt_free &= ~(1u << b.planes);
+    }
     ThrArgs A;
     ThrPlan P;
     const EdgeCarry unused{0, 0, 0, 0};
-    if (int rc = thr_prepare(c, b.d_in, b.n, b.n, 0u, 0u, b.g0, unused, b.ring_in, c->d_neg_alt, c->d_pos_alt, true, A, P)) return rc;
+    if (int rc = thr_prepare(c, b.d_in, b.n, b.n, 0u, 0u, b.g0, unused, b.ring_in, c->d_neg_alt[b.planes], c->d_pos_alt[b.planes], true, A, P)) return rc;
     if (!P.lean_applies || c->gring || P.nch < 2) {   // (the general kernel's passes keep the synchronous path)
         b.fast = false;
+        c->alt_free |= 1u << b.planes;
+        b.planes = -1;
         return NFC_OK;
     }
     b.nch = P.nch;
@@ -1340,12 +1353,12 @@ int enqueue_threshold_ahead(nfc_ctx *c, nfc_ctx::Submitted &b) {
     A.gfac = c->lean_gfac;
     A.gfloor = c->lean_gmin;
     A.blk = 1 << c->nfold;
-    b.timed = c->timing >= 1;
+    b.timed = b.timing >= 1;
     launch_threshold_kind(c, A, P.nch, true, b.timed ? c->kev_sub[b.slot] : nullptr);
     const uint32_t np = P.nch - 1;
     A.nlist = np;
     NFC_LAUNCH(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, P.d_cert, (CertInfo *)nullptr,
-               c->d_ring[(b.ring_in + 1) % 3].as<float>(), dC(c), A.sum);
+               c->d_ring[(b.ring_in + 1) % NRING].as<float>(), dC(c), A.sum);
     hipError_t e = hipMemcpyAsync(c->hs_a[b.slot], c->d_state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->st);
     if (e == hipSuccess) e = hipEventRecord(c->ev_a[b.slot], c->st);
     c->st = keep;
@@ -1353,11 +1366,18 @@ int enqueue_threshold_ahead(nfc_ctx *c, nfc_ctx::Submitted &b) {
     return NFC_OK;
 }
 
+// The planes of the oldest submitted batch become the context's; the retired set goes back to the pool.
+void take_planes(nfc_ctx *c, nfc_ctx::Submitted &b) {
+    std::swap(c->d_neg, c->d_neg_alt[b.planes]);
+    std::swap(c->d_pos, c->d_pos_alt[b.planes]);
+    c->alt_free |= 1u << b.planes;
+    b.planes = -1;
+}
+
 // its edge and decode stages, on st behind its threshold stage; from here on the context's per-batch fields are this batch's
 int enqueue_stages_behind(nfc_ctx *c, nfc_ctx::Submitted &b) {
     HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_a[b.slot], 0));
-    std::swap(c->d_neg, c->d_neg_alt);
-    std::swap(c->d_pos, c->d_pos_alt);
+    if (b.planes >= 0) take_planes(c, b);
     c->have_outputs = false;
     c->pk_ready[0] = c->pk_ready[1] = false;
     c->n_edges = 0;
@@ -1383,34 +1403,66 @@ int enqueue_stages_behind(nfc_ctx *c, nfc_ctx::Submitted &b) {
     return NFC_OK;
 }
 
+// (Re)start every submitted batch from the context's current state: after the batch before them went through the
+// synchronous path, what they were enqueued on -- if they were -- does not stand.
+int restart_submitted(nfc_ctx *c) {
+    uint64_t g0 = c->nseen;
+    int ring = c->ring_cur;
+    bool fast = c->low_valid && !c->state_dirty;
+    for (int i = 0; i < c->sub_count; i++) {
+        nfc_ctx::Submitted &nb = c->sub[i];
+        nb.g0 = g0;
+        nb.ring_in = ring;
+        nb.b_enqueued = false;
+        nb.fast = fast && submit_fast_ok(c, nb.n);
+        if (nb.fast) {
+            nb.seq = c->batch_seq + 1;
+            if (int rc = enqueue_threshold_ahead(c, nb)) return rc;
+        }
+        if (!nb.fast && nb.planes >= 0) {
+            c->alt_free |= 1u << nb.planes;
+            nb.planes = -1;
+        }
+        fast = nb.fast;
+        g0 += nb.n;
+        ring = (ring + 1) % NRING;
+    }
+    return NFC_OK;
+}
+
 int submit_batch(nfc_ctx *c, const void *d_in, size_t n64) {
-    if (c->sub_count == 2) return fail(c, NFC_ERR_STATE, "two batches are in flight: nfc_wait for the older one first");
+    if (c->sub_count == NSUB) return fail(c, NFC_ERR_STATE, "%d batches are in flight: nfc_wait for the oldest one first", NSUB);
     if (n64 > (1ull << 30)) return fail(c, NFC_ERR_ARG, "batch of %zu samples exceeds 2^30; push it in pieces", n64);
     if (n64 && ((uintptr_t)d_in & 15u) != 0) return fail(c, NFC_ERR_ARG, "device input must be 16-byte aligned");
     const uint32_t n = (uint32_t)n64;
-    nfc_ctx::Submitted *front = c->sub_count ? &c->sub[0] : nullptr;
-    // the older batch's edge / decode stages first: they were held back while the outputs of the batch before it could be read
-    if (front && front->fast && !front->b_enqueued)
-        if (int rc = enqueue_stages_behind(c, *front)) return rc;
+    nfc_ctx::Submitted *oldest = c->sub_count ? &c->sub[0] : nullptr;
+    nfc_ctx::Submitted *prev = c->sub_count ? &c->sub[c->sub_count - 1] : nullptr;
     nfc_ctx::Submitted b;
     b.d_in = d_in;
     b.n = n;
-    b.slot = (int)(c->slot_next++ & 1u);
+    b.slot = (int)(c->slot_next++ % (uint32_t)NSUB);
     b.timing = c->timing;
-    if (front) {
-        b.g0 = front->g0 + front->n;
-        b.ring_in = (front->ring_in + 1) % 3;
-        b.fast = front->fast && submit_fast_ok(c, n);   // (behind a batch that takes the synchronous path nothing is known yet)
+    if (prev) {
+        b.g0 = prev->g0 + prev->n;
+        b.ring_in = (prev->ring_in + 1) % NRING;
+        b.fast = prev->fast && submit_fast_ok(c, n);   // (behind a batch that takes the synchronous path nothing is known yet)
     } else {
         b.g0 = c->nseen;
         b.ring_in = c->ring_cur;
         b.fast = c->low_valid && !c->state_dirty && submit_fast_ok(c, n);
     }
+    // The oldest batch's edge / decode stages were held back while the outputs of the batch before it could be read; they
+    // are enqueued now -- AFTER the new batch's threshold stage, whose stream is the one that must not run dry.  The planes
+    // change hands first: the oldest batch's become the context's, the retired set is free for the new batch.
+    const bool behind = oldest && oldest->fast && !oldest->b_enqueued;
+    if (behind) take_planes(c, *oldest);
     if (b.fast) {
         b.seq = c->batch_seq + 1;
-        if (!front) launch_error() = LaunchError{};
+        if (!prev) launch_error() = LaunchError{};
         if (int rc = enqueue_threshold_ahead(c, b)) return rc;
     }
+    if (behind)
+        if (int rc = enqueue_stages_behind(c, *oldest)) return rc;
     c->sub[c->sub_count++] = b;
     return NFC_OK;
 }
@@ -1419,8 +1471,12 @@ int wait_batch(nfc_ctx *c) {
     if (!c->sub_count) return fail(c, NFC_ERR_STATE, "nothing was submitted");
     nfc_ctx::Submitted b = c->sub[0];
     auto pop = [&]() {
-        c->sub[0] = c->sub[1];
+        for (int i = 1; i < c->sub_count; i++) c->sub[i - 1] = c->sub[i];
         c->sub_count--;
+    };
+    auto abandon = [&]() {   // an error: nothing submitted stands
+        c->sub_count = 0;
+        c->alt_free = (1u << (NSUB - 1)) - 1u;
     };
     struct Scope {   // process_batch refuses to run beside submitted batches unless it is this function that calls it
         nfc_ctx *c;
@@ -1434,23 +1490,16 @@ int wait_batch(nfc_ctx *c) {
         const int rc = process_batch(c, b.d_in, b.n);
         c->timing = keep_timing;
         if (rc) {
-            c->sub_count = 0;
+            abandon();
             return rc;
         }
-        if (c->sub_count) {   // the batch behind it can start now that its state is known
-            nfc_ctx::Submitted &nb = c->sub[0];
-            nb.g0 = c->nseen;
-            nb.ring_in = c->ring_cur;
-            nb.fast = c->low_valid && !c->state_dirty && submit_fast_ok(c, nb.n);
-            if (nb.fast) {
-                nb.seq = c->batch_seq + 1;
-                if (int r2 = enqueue_threshold_ahead(c, nb)) return r2;
-            }
-        }
-        return NFC_OK;
+        return restart_submitted(c);   // the batches behind it can start now that their state is known
     }
     if (!b.b_enqueued) {
-        if (int rc = enqueue_stages_behind(c, b)) return rc;
+        if (int rc = enqueue_stages_behind(c, b)) {
+            abandon();
+            return rc;
+        }
         c->sub[0] = b;
     }
     HIPCHK(c, hipEventSynchronize(c->ev_b[b.slot]));
@@ -1461,13 +1510,13 @@ int wait_batch(nfc_ctx *c) {
         if (le.err != hipSuccess) {
             const LaunchError e = le;
             le = LaunchError{};
-            c->sub_count = 0;
+            abandon();
             return fail(c, NFC_ERR_DEVICE, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e.err), e.file, e.line);
         }
     }
     const DevState *sa = c->hs_a[b.slot];
     if (sa->seq[0] != b.seq || c->hs->seq[1] != b.seq) {
-        c->sub_count = 0;
+        abandon();
         return fail(c, NFC_ERR_DEVICE, "state mirror is stale (batch %u, mirrors %u / %u): a kernel of this batch did not run", b.seq, sa->seq[0], c->hs->seq[1]);
     }
     CertSummary summary;
@@ -1501,7 +1550,7 @@ int wait_batch(nfc_ctx *c) {
             c->stats.ms_threshold_kernel[0] = elapsed_ms(c->kev_sub[b.slot][0], c->kev_sub[b.slot][1]);
             c->stats.n_threshold_timed = 1;
         }
-        c->ring_cur = (b.ring_in + 1) % 3;
+        c->ring_cur = (b.ring_in + 1) % NRING;
         c->nseen = b.g0 + b.n;
         c->last_in = b.d_in;
         c->have_outputs = true;
@@ -1511,30 +1560,22 @@ int wait_batch(nfc_ctx *c) {
     }
     // The optimistic result does not stand: everything in flight is drained, the batch goes through the synchronous path
     // from the state before it (the host mirrors were last adopted there; its window buffer was not written since), and
-    // the batch behind it starts again from what that leaves.
+    // the batches behind it start again from what that leaves.
     if (getenv("NFC_TRACE")) fprintf(stderr, "[nfc] submitted batch %u processed again: %s\n", b.seq, why);
     HIPCHK(c, hipStreamSynchronize(c->st_a));
     HIPCHK(c, hipStreamSynchronize(c->st));
     c->stats_redo_submitted++;
     push_state(c);
     pop();
+    const int keep_timing = c->timing;
+    c->timing = b.timing;
     const int rc = process_batch(c, b.d_in, b.n);
+    c->timing = keep_timing;
     if (rc) {
-        c->sub_count = 0;
+        abandon();
         return rc;
     }
-    if (c->sub_count) {
-        nfc_ctx::Submitted &nb = c->sub[0];
-        nb.g0 = c->nseen;
-        nb.ring_in = c->ring_cur;
-        nb.b_enqueued = false;
-        nb.fast = c->low_valid && !c->state_dirty && submit_fast_ok(c, nb.n);
-        if (nb.fast) {
-            nb.seq = c->batch_seq + 1;
-            if (int r2 = enqueue_threshold_ahead(c, nb)) return r2;
-        }
-    }
-    return NFC_OK;
+    return restart_submitted(c);
 }
 
 int build_packets(nfc_ctx *c, int t) {
@@ -1696,7 +1737,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     for (auto &e : c->ev) CRT(hipEventCreate(&e));
     for (auto &e : c->kev) CRT(hipEventCreate(&e));
     CRT(hipStreamCreateWithFlags(&c->st_a, hipStreamNonBlocking));
-    for (int b = 0; b < 2; b++) {
+    static_assert(NRING == 4 && NSUB == 3, "the buffer list of nfc_destroy names them");
+    for (int b = 0; b < NSUB; b++) {
         CRT(hipEventCreateWithFlags(&c->ev_a[b], hipEventDisableTiming));
         CRT(hipEventCreateWithFlags(&c->ev_b[b], hipEventDisableTiming));
         CRT(hipEventCreate(&c->kev_sub[b][0]));
@@ -1758,7 +1800,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     CRT(hipHostMalloc((void **)&c->hs, sizeof(DevState), hipHostMallocMapped));
     memset(c->hs, 0, sizeof(DevState));
     CRT(hipHostGetDevicePointer(&c->hs_dev, c->hs, 0));
-    for (int b = 0; b < 3; b++) {
+    for (int b = 0; b < NRING; b++) {
         CRT(c->d_ring[b].ensure((size_t)c->Lpad * 4));
         CRT(hipMemset(c->d_ring[b].p, 0, (size_t)c->Lpad * 4));
     }
@@ -1780,7 +1822,7 @@ void nfc_destroy(nfc_ctx *c) {
     if (c->st && c->st == c->own_st) (void)hipStreamSynchronize(c->st);
     else (void)hipDeviceSynchronize();   // on a caller's stream (nfc_set_stream): the handle may be gone by now
     DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_state,
-                     &c->d_ring[0], &c->d_ring[1], &c->d_ring[2], &c->d_neg_alt, &c->d_pos_alt, &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
+                     &c->d_ring[0], &c->d_ring[1], &c->d_ring[2], &c->d_ring[3], &c->d_neg_alt[0], &c->d_pos_alt[0], &c->d_neg_alt[1], &c->d_pos_alt[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ecode, &c->d_epos, &c->d_eidx, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
@@ -1794,7 +1836,7 @@ void nfc_destroy(nfc_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->kev)
         if (e) (void)hipEventDestroy(e);
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < NSUB; b++) {
         if (c->ev_a[b]) (void)hipEventDestroy(c->ev_a[b]);
         if (c->ev_b[b]) (void)hipEventDestroy(c->ev_b[b]);
         if (c->kev_sub[b][0]) (void)hipEventDestroy(c->kev_sub[b][0]);
