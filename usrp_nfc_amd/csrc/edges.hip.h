@@ -323,11 +323,10 @@ __device__ __forceinline__ int load_words(const EdgeArgs &A, size_t w, size_t nw
 #ifndef NFC_EW_ITEMS
 #define NFC_EW_ITEMS 2
 #endif
-constexpr int EW_ITEMS = NFC_EW_ITEMS;               // words per thread (2, with 4096 staged entries: 25 KB of LDS, six workgroups
-                                                     // per CU; 4 with 8192 measured 52 vs 47 us on the bench workload)
+constexpr int EW_ITEMS = NFC_EW_ITEMS;               // words per thread (2; 4 with twice the staged entries measured 52 vs 47 us)
 constexpr int EW_WORDS = SCAN_BLOCK * EW_ITEMS;      // words per tile, in both launches of the stage
 #ifndef NFC_EW_CAP
-#define NFC_EW_CAP 4096
+#define NFC_EW_CAP 3072
 #endif
 inline size_t edge_num_tiles(size_t nwords) { return (nwords + EW_WORDS - 1) / EW_WORDS; }
 
@@ -396,7 +395,10 @@ struct EdgeTotalEpilogue {
 // and needs no division per entry.  Where a thread starts comes from ONE block scan of EdgeAgg on top of the tile's
 // prefix: the two changes before its first word AND, by entries_before(), the offset of its first entry.  Entries go to
 // LDS at their offsets and leave the workgroup as whole rows of positions and codes.
-constexpr int EW_CAP = NFC_EW_CAP;   // entries staged per round (a tile of 512 words holds 2150 on the bench workloads, 32768 at most)
+constexpr int EW_CAP = NFC_EW_CAP;   // entries staged per round (a tile of 512 words holds 2150 on the bench workloads, 32768 at most).
+// 3072 entries of 2 + 2 bytes: 12 KB per workgroup -- six of them fit in the 96 KB of LDS a CU has left while the threshold
+// kernel of the next batch runs on it (batches submitted ahead), which is when this kernel's occupancy matters most.
+static_assert(EW_WORDS * 64 <= 65536, "tile-local positions are staged in 16 bits");
 struct EdgeWalk {
     int lb, left;
     int32_t q;
@@ -405,7 +407,7 @@ struct EdgeWalk {
 __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const EdgeAgg *partials, uint32_t *epos,
                                                            uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
                                                            Last2 *last2_total, EdgeCarry *carry_out) {
-    __shared__ uint32_t s_pos[EW_CAP];
+    __shared__ uint16_t s_pos[EW_CAP];   // (tile-local sample position: a tile is EW_WORDS * 64 <= 65536 samples)
     __shared__ uint16_t s_code[EW_CAP];
     __shared__ EdgeAgg s_agg[SCAN_WAVES];
     const size_t wt = (size_t)blockIdx.x * EW_WORDS;   // first word of the tile
@@ -454,12 +456,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
             }
         }
     }
+    const int32_t tile_p0 = (int32_t)(wt * 64);
     for (uint32_t rbase = 0; rbase < total; rbase += EW_CAP) {   // (a second round walks again: only tiles denser than EW_CAP)
         EdgeWalk W = W0;
         uint32_t k = off - rbase;   // wraps below the round: the unsigned compare drops those
         auto emit = [&](int32_t p, int v, int d, int t) {
             if (k < (uint32_t)EW_CAP) {
-                s_pos[k] = (uint32_t)p;
+                s_pos[k] = (uint16_t)(p - tile_p0);
                 s_code[k] = edge_code(v, d, t, A.nd);
             }
             k++;
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
         for (uint32_t j = threadIdx.x; j < cnt; j += SCAN_BLOCK) {
             const uint32_t g = gbase + rbase + j;
             if (g < cap) {
-                epos[g] = s_pos[j];
+                epos[g] = (uint32_t)tile_p0 + s_pos[j];
                 ecode[g] = s_code[j];
             }
         }
