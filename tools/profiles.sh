@@ -5,10 +5,13 @@ tag=${1:-r02}
 out=gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o $tag -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity --no-extras > $out/${tag}_bench_under_rocprof.json 2> $out/stats.log
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras > /dev/null 2> $out/fetch.log
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras > /dev/null 2> $out/write.log
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $out/sq -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-extras > /dev/null 2> $out/sq.log
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o $tag -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity --no-extras --sync-steps > $out/${tag}_bench_under_rocprof.json 2> $out/stats.log
+# the same with batches submitted ahead (the default): the threshold stage of batch k + 1 beside the later stages of batch k
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_ahead -o ${tag}a -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity --no-extras > $out/${tag}_bench_ahead_under_rocprof.json 2> $out/stats_ahead.log
+python3 tools/timeline2.py $out/stats_ahead/${tag}a_kernel_trace.csv 60 22 > $out/${tag}_timeline_ahead.txt 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/fetch.log
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/write.log
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $out/sq -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/sq.log
 timeout 400 python3 bench.py > $out/${tag}_bench.json 2> $out/bench.log
 python3 - <<PY
 import csv, json, collections
@@ -20,8 +23,18 @@ lines = []; tot = 0
 for r in rows:
     per = float(r["TotalDurationNs"]) / nstep / 1e3; tot += per
     lines.append("%-90s calls/step %5.2f  avg %8.1f us  per-step %8.1f us" % (r["Name"].replace("nfc::", "").replace("void ", "")[:88], int(r["Calls"]) / nstep, float(r["AverageNs"]) / 1e3, per))
-lines.append("total per step %.1f us over %d steps (incl. warm-up and the untimed extra step)" % (tot, nstep))
+lines.append("total per step %.1f us over %d steps (incl. warm-up and the untimed extra step); --sync-steps: one batch at a time" % (tot, nstep))
 open(f"{out}/{tag}_kernel_stats_per_step.txt", "w").write("\n".join(lines) + "\n")
+# the same table for the run with batches submitted ahead (kernels of consecutive batches overlap: durations are longer, the step shorter)
+rows = list(csv.DictReader(open(f"{out}/stats_ahead/{tag}a_kernel_stats.csv")))
+thr = [r for r in rows if "k_threshold" in r["Name"]]
+nstep = sum(int(r["Calls"]) for r in thr) if thr else 1
+lines = []; tot = 0
+for r in rows:
+    per = float(r["TotalDurationNs"]) / nstep / 1e3; tot += per
+    lines.append("%-90s calls/step %5.2f  avg %8.1f us  per-step %8.1f us" % (r["Name"].replace("nfc::", "").replace("void ", "")[:88], int(r["Calls"]) / nstep, float(r["AverageNs"]) / 1e3, per))
+lines.append("sum of kernel durations per step %.1f us over %d steps -- they overlap (two queues): see the timeline" % (tot, nstep))
+open(f"{out}/{tag}_kernel_stats_ahead_per_step.txt", "w").write("\n".join(lines) + "\n")
 def pmc(d, name):
     rs = [r for r in csv.DictReader(open(f"{out}/{d}/p_counter_collection.csv")) if "k_threshold" in r["Kernel_Name"] and r["Counter_Name"] == name]
     byd = collections.defaultdict(float)
@@ -32,7 +45,7 @@ kname = sorted({r["Kernel_Name"] for r in csv.DictReader(open(f"{out}/fetch/p_co
 rec = {"workload": "miller", "samples": 100000000, "kernel": ", ".join(k.replace("void nfc::", "").split("(")[0] for k in kname), "FETCH_SIZE_kb": round(f), "WRITE_SIZE_kb": round(w),
        "correction": "FETCH_SIZE x2 (gfx950: TCC_EA0_RDREQ counted at 64 B per 128-B request, MI355X_MICROARCH.md section HBM); WRITE_SIZE as reported",
        "bytes_per_launch": int((2 * f + w) * 1024),
-       "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras   (and the same with --pmc WRITE_SIZE); median over the launches"}
+       "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps   (and the same with --pmc WRITE_SIZE); median over the launches"}
 json.dump(rec, open(f"{out}/hbm_traffic.json", "w"), indent=1)
 # instruction counts per wave of every kernel of a step (one --pmc pass of SQ counters)
 rows = list(csv.DictReader(open(f"{out}/sq/p_counter_collection.csv")))
