@@ -208,11 +208,15 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
             comm.barrier()
         ctx.sync()
 
-    # One GPU, no exchange: the steps are consecutive batches of ONE stream -- the capture again and again, the stream state
-    # carried on -- and batch k + 1 is submitted before batch k is waited for (nfc_submit_device / nfc_wait): its threshold
-    # stage then runs beside the edge and decode stages of batch k.  Sharded runs (and --sync-steps) decode a fresh stream
-    # per step: reset / prime, overlap, own chunk, boundary exchange.
-    ahead = world == 1 and not force_exchange and not a.sync_steps
+    # The steps are consecutive batches of ONE stream per rank -- the rank's slice of the capture again and again, the stream
+    # state carried on -- and batch k + 1 is submitted before batch k is waited for (nfc_submit_device / nfc_wait): its
+    # threshold stage then runs beside the edge and decode stages of batch k.  With several ranks the rank's time shard IS that
+    # stream: `steps` batches long, primed and warmed up on the overlap before it, its speculated start state checked against
+    # the predecessor's true end state in ONE exchange after the last batch (a mismatch re-decodes the shard).  --sync-steps:
+    # every step a fresh stream, pushed synchronously -- with several ranks the whole protocol per step (reset / prime,
+    # overlap, own chunk, exchange).
+    ahead = not a.sync_steps
+    sharded = world > 1 or force_exchange
     kernel_ms, n_pass = [], []
     n_ahead = [0]
 
@@ -244,7 +248,17 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                     n_pass.append(st.threshold_passes)
         ctx.set_timing(0)
 
-    if ahead:
+    if ahead and sharded:
+        def shard(count, timed_every):
+            redo[0] += sharding.decode_shard(ctx, comm, lambda: ctx.push_device(d_ov, n_ov), lambda: stream_steps(count, timed_every),
+                                             g_lo - n_ov, level, force_exchange=force_exchange)
+        if warmup:
+            shard(warmup, 0)
+        redo[0] = 0
+        barrier()
+        t0 = time.perf_counter()
+        shard(steps, 8)
+    elif ahead:
         ctx.reset()
         stream_steps(warmup, 0)
         barrier()
@@ -273,7 +287,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
     # beside the headline: the same batches one after the other (nfc_push_device, nothing in flight beside them) -- what a
     # step costs then, and the threshold kernel's duration with the machine to itself
     alone = None
-    if ahead and not a.no_extras:
+    if ahead and not sharded and not a.no_extras:
         k_alone = []
         for _ in range(5):
             ctx.push_device(res.buf, n)
@@ -319,6 +333,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                        'packets': int(cnt.n_packets[0] + cnt.n_packets[1]), 'boundary_redos': redo[0],
                        'shard_overlap_samples': capture_overlap(workload) if world > 1 else 0, 'exchange': backend if world > 1 else 'none',
                        'steps_are': ('consecutive batches of one stream, %d in flight: batch k + %d is submitted before batch k is waited for (%d of %d timed steps ran ahead)' % (a.in_flight, a.in_flight - 1, n_ahead[0], steps))
+                                    + ('; the rank\'s time shard is that stream: one boundary exchange after its last batch' if sharded else '')
                                     if ahead else 'a fresh stream per step, pushed synchronously'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_lean / k_threshold (fused envelope + gated-mean threshold)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
