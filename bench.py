@@ -44,7 +44,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the end-to-end figure and the other configurations')
-    ap.add_argument('--in-flight', type=int, default=2, choices=[1, 2, 3], help='one GPU: batches submitted and not yet waited for')
+    ap.add_argument('--in-flight', type=int, default=3, choices=[1, 2, 3], help='one GPU: batches submitted and not yet waited for')
     ap.add_argument('--sync-steps', action='store_true', help='one GPU: every step a fresh stream pushed synchronously (nfc_push_device), as the sharded steps are; '
                     'default: the steps are consecutive batches of ONE stream, each submitted before the one before it is waited for')
     return ap.parse_args()
@@ -404,7 +404,7 @@ def parity_check(workload, own, flags, n, ahead=False):
     nxt = 0
     for k in range(total):   # the stream carries over from pass to pass on both sides; outputs are compared per pass
         if ahead:
-            while nxt < total and nxt < k + 3:
+            while nxt < total and nxt < k + 3:   # (three in flight, as the timed loop)
                 ctx.submit_device(buf, tile)
                 nxt += 1
             ctx.wait()
