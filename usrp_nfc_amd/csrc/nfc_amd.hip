@@ -1455,13 +1455,17 @@ int submit_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     // are enqueued now -- AFTER the new batch's threshold stage, whose stream is the one that must not run dry.  The planes
     // change hands first: the oldest batch's become the context's, the retired set is free for the new batch.
     const bool behind = oldest && oldest->fast && !oldest->b_enqueued;
+    // (with a threshold stage already queued behind the running one that stream has work for a while: the held-back stages go first then)
+    const bool stages_first = behind && c->sub_count >= 2;
     if (behind) take_planes(c, *oldest);
+    if (stages_first)
+        if (int rc = enqueue_stages_behind(c, *oldest)) return rc;
     if (b.fast) {
         b.seq = c->batch_seq + 1;
         if (!prev) launch_error() = LaunchError{};
         if (int rc = enqueue_threshold_ahead(c, b)) return rc;
     }
-    if (behind)
+    if (behind && !stages_first)
         if (int rc = enqueue_stages_behind(c, *oldest)) return rc;
     c->sub[c->sub_count++] = b;
     return NFC_OK;
