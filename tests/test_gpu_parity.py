@@ -253,6 +253,36 @@ def test_batches_submitted_ahead_cut_inside_frames(name, kw):
     assert ahead >= 7 and st.redone_total == 0, (ahead, st.redone_total)
 
 
+def test_batches_submitted_ahead_int16_and_misuse():
+    # 16-bit PCM (the WAV branch: scaled and squared on the fly) through batches submitted ahead; and what the calls refuse
+    iq = synth.workload('all', 2_400_000)
+    env = np.sqrt(synth.envelope_f32(iq))
+    pcm = np.clip(np.round(env / env.max() * 30000.0), -32768, 32767).astype(np.int16)
+    params = dict(hi_val=1.09)
+    o = co.COracle(trace=False, **params)
+    o.push_i16(pcm) if hasattr(o, 'push_i16') else o.push_real_sq((pcm.astype(np.float32) / np.float32(32767.0)).astype(np.float32))
+    cuts = [0, 400_000, 800_000, 1_200_000, 1_600_000, 2_000_000, len(pcm)]
+    with api.NfcContext(input_kind=api.NFC_IN_I16_SQ, **params) as ctx:
+        bufs = [api.DeviceBuffer(pcm[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        with pytest.raises(api.NfcError):
+            ctx.wait()                                  # nothing submitted
+        tr, pk, ahead = [], [], 0
+        for k, b in enumerate(bufs):
+            ctx.submit_device(b, cuts[k + 1] - cuts[k])
+            if k == 2:
+                with pytest.raises(api.NfcError):
+                    ctx.push_device(b, 10)              # a synchronous push beside batches in flight
+                with pytest.raises(api.NfcError):
+                    ctx.state_blob()
+            ctx.wait()
+            tr += ctx.transitions()
+            pk += ctx.packets()
+            ahead += int(ctx.stats().ran_ahead)
+        # one at a time nothing runs beside anything, but the path is the same: threshold stage from the device-side state
+        assert ahead >= 3
+    assert first_diff(tr, o.transitions()) is None and pk == o.packets()
+
+
 def test_compact_transitions_are_the_records():
     # nfc_read_edges_compact hands out what the device keeps (position, code); nfc_read_edges the records built from it
     import ctypes as C
