@@ -29,6 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+STREAM_CEILING_GBS = 6070.0   # what a read-only kernel with the threshold kernel's access pattern (one wave per 49 152-sample chunk,
+                              # 2 KB per wave and step) reaches on this machine: tools/ubench/stream_chunks.hip, profiles/r02_stream_ceiling.txt
 
 
 def parse():
@@ -340,6 +342,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                          'traffic': traffic, 'traffic_source': tsrc, 'avg_launch_ms': k_avg, 'launches_timed': len(kernel_ms),
                          'launches_per_step': float(np.mean(n_pass)) if n_pass else None,
                          'algorithmic_bytes_per_launch': thr_bytes,
+                         'streaming_read_ceiling': STREAM_CEILING_GBS, 'frac_of_streaming_ceiling': achieved / STREAM_CEILING_GBS,
                          'note': '8 B/sample only: the 16 B/edge of SURVEY 8(d) are written by the edge stage, listed under edge_stage'
                                  + ('; the launches of the timed region run BESIDE the previous batch\'s edge and decode stages (batches submitted ahead) and '
                                     'share the SIMDs\' issue slots with them: one_batch_at_a_time.roofline is the same kernel with the machine to itself' if ahead else '')},

@@ -86,7 +86,7 @@ int main() {
     hipMalloc(&o, 4);
     hipMemset(d, 0, n * 8);
     const double gb = n * 8 / 1e9;
-    for (int lds : {32000, 16000}) {
+    for (int lds : {80000, 32000}) {
         const uint32_t waves = 256 * (160 * 1024 / lds) * 4;
         uint32_t C = (uint32_t)((n + waves - 1) / waves);
         C = (C + 1023) / 1024 * 1024;
@@ -102,6 +102,9 @@ int main() {
         printf("wave chunks (C %u, %u waves, LDS %d) PF 2: %.3f ms  %.2f TB/s\n", C, nch, lds, ms, gb / ms);
         ms = timeit([&] { hipLaunchKernelGGL(k_chunks<4>, dim3(blocks), dim3(256), lds, 0, d, n, C, o); });
         printf("wave chunks (C %u, %u waves, LDS %d) PF 4: %.3f ms  %.2f TB/s\n", C, nch, lds, ms, gb / ms);
+        hipFuncSetAttribute((const void *)k_chunks<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        ms = timeit([&] { hipLaunchKernelGGL(k_chunks<8>, dim3(blocks), dim3(256), lds, 0, d, n, C, o); });
+        printf("wave chunks (C %u, %u waves, LDS %d) PF 8: %.3f ms  %.2f TB/s\n", C, nch, lds, ms, gb / ms);
     }
     {
         const int lds = 32000;
