@@ -253,6 +253,30 @@ def test_batches_submitted_ahead_cut_inside_frames(name, kw):
     assert ahead >= 7 and st.redone_total == 0, (ahead, st.redone_total)
 
 
+def test_state_set_from_the_host_is_not_run_ahead_of():
+    # After nfc_set_state (here: a state taken mid-stream and put back) the device-side LOW bookkeeping is not the stream's:
+    # the next submitted batch must take the synchronous path, the ones after it may run ahead again
+    iq = synth.workload('miller', 1_600_000)
+    o = oracle_run(iq, dict(hi_val=1.1, tag=False), api.NFC_IN_IQ_F32)
+    cuts = [0, 400_000, 800_000, 1_200_000, 1_600_000]
+    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32, tag=False) as ctx:
+        bufs = [api.DeviceBuffer(iq[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        tr, pk, flags = [], [], []
+        for k, b in enumerate(bufs):
+            if k == 2:
+                blob = ctx.state_blob()
+                ctx.reset()
+                ctx.set_state_blob(blob)
+                ctx.state_blob()              # (flushes the pending state to the device: nothing "dirty" is left to notice)
+            ctx.submit_device(b, cuts[k + 1] - cuts[k])
+            ctx.wait()
+            tr += ctx.transitions()
+            pk += ctx.packets()
+            flags.append(int(ctx.stats().ran_ahead))
+    assert first_diff(tr, o.transitions()) is None and pk == o.packets()
+    assert flags == [0, 0, 0, 1], flags
+
+
 def test_batches_submitted_ahead_int16_and_misuse():
     # 16-bit PCM (the WAV branch: scaled and squared on the fly) through batches submitted ahead; and what the calls refuse
     iq = synth.workload('all', 2_400_000)

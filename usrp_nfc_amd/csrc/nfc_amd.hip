@@ -280,6 +280,7 @@ inline void launch_set_state(nfc_ctx *c, int zero_totals, bool fill_ring, float 
 // The host values become the device state lazily: with the next batch's first launch (k_fill takes them along), or
 // right away when something reads the device state first (flush_state).
 inline void push_state(nfc_ctx *c, int zero_totals = 0, bool fill_ring = false, float fill = 0.f) {
+    c->low_valid = false;   // (the LOW bookkeeping a submitted batch would read on the device is not part of what the host sets)
     if (zero_totals) {
         launch_set_state(c, zero_totals, fill_ring, fill);
         c->state_dirty = false;
@@ -1331,7 +1332,10 @@ int enqueue_threshold_ahead(nfc_ctx *c, nfc_ctx::Submitted &b) {
     ThrArgs A;
     ThrPlan P;
     const EdgeCarry unused{0, 0, 0, 0};
-    if (int rc = thr_prepare(c, b.d_in, b.n, b.n, 0u, 0u, b.g0, unused, b.ring_in, c->d_neg_alt[b.planes], c->d_pos_alt[b.planes], true, A, P)) return rc;
+    const nfc_stats keep_stats = c->stats;   // (the context's statistics are those of the last completed batch until this one is)
+    const int rc_prep = thr_prepare(c, b.d_in, b.n, b.n, 0u, 0u, b.g0, unused, b.ring_in, c->d_neg_alt[b.planes], c->d_pos_alt[b.planes], true, A, P);
+    c->stats = keep_stats;
+    if (rc_prep) return rc_prep;
     if (!P.lean_applies || c->gring || P.nch < 2) {   // (the general kernel's passes keep the synchronous path)
         b.fast = false;
         c->alt_free |= 1u << b.planes;
