@@ -1,16 +1,16 @@
 // scan.hip.h -- device-wide ordered exclusive scan for gfx950 (wave64), generic in
 // the (possibly non-commutative) operator.  Reduce-then-scan:
-//   k_scan_reduce   : one aggregate per tile of BLOCK*ITEMS items
+//   a stage's first kernel: one aggregate per tile (k_edge_reduce, k_dec_reduce; a pass may also leave the aggregates of the
+//                     NEXT scan, as k_dec_apply does for the framing scan)
 //   tile prefixes   : while the tiles are few, every tile's workgroup folds its predecessors' aggregates itself
 //                     (tile_prefix); beyond OWN_PREFIX_MAX_TILES one workgroup does it in a launch (k_scan_partials)
-//   k_scan_apply_sum: re-reads the items, hands each its exclusive prefix
-// Items are produced by a Load functor (so a stage can compute its item on the
-// fly from whatever it reads) and consumed by a Store functor.  A blocked
-// arrangement (thread t owns ITEMS consecutive items) keeps the order, which the
+//   the stage's later kernels re-read their items and give each its exclusive prefix.
+// A blocked arrangement (thread t owns consecutive items) keeps the order, which the
 // transducer compositions need.
-// Every launch costs a few microseconds whatever it does, so stages chain their scans: an apply pass may
-// return a value per item whose tile sums are the next scan's aggregates (k_scan_apply_sum), and the
-// single-workgroup partials pass takes an epilogue for the one-thread bookkeeping that follows a scan.
+// Every launch costs a few microseconds whatever it does, so stages chain their scans (a pass leaves the tile aggregates of
+// the next scan), and the single-workgroup partials pass takes an epilogue for the one-thread bookkeeping that follows a scan.
+// (Measured and dropped: long batches folding in two levels -- groups of tiles, then the own group -- instead of the partials
+// launch: every tile's workgroup then pays two more block scans, 0.315 vs 0.260 ms for the edge stage of a 1e9-sample batch.)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -28,26 +28,6 @@ struct AddU32 {
     static __device__ __forceinline__ T identity() { return 0u; }
     static __device__ __forceinline__ T op(T a, T b) { return a + b; }
     static __device__ __forceinline__ T shfl_up(T v, int d) { return (T)__shfl_up((int)v, d, 64); }
-    static __device__ __forceinline__ T shfl(T v, int l) { return (T)__shfl((int)v, l, 64); }
-    static __device__ __forceinline__ T shfl_xor(T v, int d) { return (T)__shfl_xor((int)v, d, 64); }
-};
-
-struct AddU64 {  // also used as two packed u32 counters (no carry between halves while each < 2^32)
-    using T = uint64_t;
-    static __device__ __forceinline__ T identity() { return 0ull; }
-    static __device__ __forceinline__ T op(T a, T b) { return a + b; }
-    static __device__ __forceinline__ T shfl_up(T v, int d) {
-        int lo = __shfl_up((int)(uint32_t)v, d, 64), hi = __shfl_up((int)(uint32_t)(v >> 32), d, 64);
-        return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-    }
-    static __device__ __forceinline__ T shfl(T v, int l) {
-        int lo = __shfl((int)(uint32_t)v, l, 64), hi = __shfl((int)(uint32_t)(v >> 32), l, 64);
-        return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-    }
-    static __device__ __forceinline__ T shfl_xor(T v, int d) {
-        int lo = __shfl_xor((int)(uint32_t)v, d, 64), hi = __shfl_xor((int)(uint32_t)(v >> 32), d, 64);
-        return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-    }
 };
 
 // ---- finite-state maps ---------------------------------------------------------
@@ -176,22 +156,6 @@ __device__ __forceinline__ typename Tr::T block_exclusive(typename Tr::T v, type
                                                           typename Tr::T &block_total) {
     return block_exclusive_with<WAVES>(StaticOp<Tr>{}, v, lds, block_total);
 }
-// Block total of a commutative sum, valid in every thread.
-template <class Tr, int WAVES = SCAN_WAVES>
-__device__ __forceinline__ typename Tr::T block_sum(typename Tr::T v, typename Tr::T *lds) {
-    using T = typename Tr::T;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = Tr::op(v, Tr::shfl_xor(v, d));
-    if (lane == 0) lds[wave] = v;
-    __syncthreads();
-    T total = Tr::identity();
-#pragma unroll
-    for (int w = 0; w < WAVES; w++) total = Tr::op(total, lds[w]);
-    __syncthreads();
-    return total;
-}
-
 // A tile's exclusive prefix from the aggregates of its predecessors, computed by the tile's OWN workgroup: every
 // thread folds a contiguous share of aggs[0 .. b), one ordered block reduction joins the shares.  The aggregates
 // are a few tens of KB and stay in L2, so while there are only a few thousand tiles this is cheaper than a
@@ -221,32 +185,7 @@ __device__ __forceinline__ typename Tr::T tile_prefix(const typename Tr::T *aggs
     return tile_prefix_with<BLOCK>(StaticOp<Tr>{}, aggs, b, lds);
 }
 
-// tiles of BLOCK*ITEMS items
-template <int ITEMS>
-inline size_t scan_num_tiles(size_t n) {
-    const size_t tile = (size_t)SCAN_BLOCK * ITEMS;
-    return (n + tile - 1) / tile;
-}
-
-// ---- the three kernels --------------------------------------------------------
-template <class Tr, int ITEMS, class Load>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(size_t n, const uint32_t *n_dev, Load load, typename Tr::T *partials) {
-    using T = typename Tr::T;
-    if (n_dev) n = min(n, (size_t)*n_dev);   // the item count may live on the device (n is then the capacity)
-    if ((size_t)blockIdx.x * SCAN_BLOCK * ITEMS >= n) return;
-    __shared__ T lds[SCAN_WAVES];
-    const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * ITEMS;
-    T agg = Tr::identity();
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const size_t idx = base + i;
-        if (idx < n) agg = Tr::op(agg, load(idx));
-    }
-    T total;
-    (void)block_exclusive<Tr>(agg, lds, total);
-    if (threadIdx.x == 0) partials[blockIdx.x] = total;
-}
-
+// ---- the prefix launch of long batches ------------------------------------------
 // partials[i] <- op(seed, exclusive prefix of partials)[i]; the total (with the seed) goes to *total_out and
 // to the epilogue, which thread 0 runs once (carried-state bookkeeping that would otherwise be a launch).
 // One workgroup, eight consecutive partials per thread, so that every load of a round is in flight at once;
@@ -313,67 +252,6 @@ template <class Tr, class Epi = NoEpilogue>
 inline void scan_partials(hipStream_t st, size_t tiles, const uint32_t *n_dev, uint32_t tile, typename Tr::T *partials,
                           typename Tr::T seed, typename Tr::T *total_out, Epi epi = Epi()) {
     scan_partials_with(st, StaticOp<Tr>{}, tiles, n_dev, tile, partials, seed, total_out, epi);
-}
-
-// The apply pass: every item gets its exclusive prefix; store() returns a count per item and the tile's sum of them
-// lands in sums[tile] -- the aggregates of the next scan (over the same tiling), which then needs no reduce launch of its own.
-template <class Tr, int ITEMS, class Tr2, class Load, class Store>
-__device__ __forceinline__ void scan_apply_sum_block(size_t n, const uint32_t *n_dev, const Load &load, const Store &store,
-                                                     const typename Tr::T *partials, typename Tr2::T *sums, uint32_t bid,
-                                                     bool own_prefix = false, typename Tr::T *total_out = nullptr) {
-    using T = typename Tr::T;
-    using T2 = typename Tr2::T;
-    if (n_dev) n = min(n, (size_t)*n_dev);
-    if ((size_t)bid * SCAN_BLOCK * ITEMS >= n) return;
-    __shared__ T lds[SCAN_WAVES];
-    __shared__ T2 lds2[SCAN_WAVES];
-    const size_t base = ((size_t)bid * SCAN_BLOCK + threadIdx.x) * ITEMS;
-    T item[ITEMS];
-    T agg = Tr::identity();
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const size_t idx = base + i;
-        item[i] = (idx < n) ? load(idx) : Tr::identity();
-        agg = Tr::op(agg, item[i]);
-    }
-    T total;
-    T excl = block_exclusive<Tr>(agg, lds, total);
-    // own_prefix: `partials` still holds the tiles' aggregates (no prefix launch ran); the last tile publishes the total
-    const T pre = own_prefix ? tile_prefix<Tr, SCAN_BLOCK>(partials, bid, lds) : partials[bid];
-    if (own_prefix && total_out && threadIdx.x == 0 && ((size_t)bid + 1) * SCAN_BLOCK * ITEMS >= n) *total_out = Tr::op(pre, total);
-    T run = Tr::op(pre, excl);
-    T2 mine = Tr2::identity();
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const size_t idx = base + i;
-        if (idx < n) mine = Tr2::op(mine, store(idx, run, item[i]));
-        run = Tr::op(run, item[i]);
-    }
-    const T2 sum = block_sum<Tr2>(mine, lds2);
-    if (threadIdx.x == 0) sums[bid] = sum;
-}
-template <class Tr, int ITEMS, class Tr2, class Load, class Store>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply_sum(size_t n, const uint32_t *n_dev, Load load, Store store,
-                                                              const typename Tr::T *partials, typename Tr2::T *sums, bool own_prefix,
-                                                              typename Tr::T *total_out) {
-    scan_apply_sum_block<Tr, ITEMS, Tr2, Load, Store>(n, n_dev, load, store, partials, sums, blockIdx.x, own_prefix, total_out);
-}
-
-// Host-side drivers.  `partials` must hold scan_num_tiles<ITEMS>(n) entries.
-// n_dev != nullptr: the true item count is *n_dev on the device and n is only the capacity the grid is sized for.
-template <class Tr, int ITEMS, class Load>
-inline void scan_reduce(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, typename Tr::T *partials) {
-    const size_t tiles = scan_num_tiles<ITEMS>(n);
-    if (tiles)
-        NFC_LAUNCH((k_scan_reduce<Tr, ITEMS, Load>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev, load, partials);
-}
-template <class Tr, int ITEMS, class Tr2, class Load, class Store>
-inline void scan_apply_sum(hipStream_t st, size_t n, const uint32_t *n_dev, Load load, Store store, const typename Tr::T *partials,
-                           typename Tr2::T *sums, bool own_prefix = false, typename Tr::T *total_out = nullptr) {
-    const size_t tiles = scan_num_tiles<ITEMS>(n);
-    if (tiles)
-        NFC_LAUNCH((k_scan_apply_sum<Tr, ITEMS, Tr2, Load, Store>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, st, n, n_dev,
-                           load, store, partials, sums, own_prefix, total_out);
 }
 
 }  // namespace nfc
