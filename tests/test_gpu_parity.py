@@ -372,7 +372,7 @@ def test_prefix_launch_path(monkeypatch, own_prefix_max):
 @pytest.mark.parametrize('window,max_len,rate', [(2000, 50, 2.0), (4000, 100, 4.0), (10000, 250, 10.0)])
 def test_ring_in_global_memory(monkeypatch, window, max_len, rate):
     # Long windows keep a chunk's ring in global memory when the batch is long enough to fill the machine that way
-    # (nfc_amd.hip: threshold_span); NFC_RING=global forces that kernel on batches of test size, for every window
+    # (host_threshold.h: threshold_span); NFC_RING=global forces that kernel on batches of test size, for every window
     monkeypatch.setenv('NFC_RING', 'global')
     period = synth.modulation_profile(synth.txn_frames(), rate_msps=rate, lead_in=0, tail=0)
     iq = synth.iq_from_profile(synth.tiled_profile(period, 1_300_000, lead_in=window + 700), seed=11)

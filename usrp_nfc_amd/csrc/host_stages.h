@@ -1,0 +1,399 @@
+// host_stages.h -- edge stage, decode + framing stage, the one-launch form of short batches, process_batch
+// (part of nfc_amd.hip: included there, in this order, into one translation unit)
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// edge stage
+// ---------------------------------------------------------------------------
+// Both stages run without a host round trip: buffers and grids are sized from capacity estimates (last batch's
+// counts with head-room), the true counts stay on the device, and the caller checks them after the batch's
+// final sync -- on overflow the two stages are simply repeated with larger estimates (they are idempotent:
+// carried values come in by value and go out to write-only slots).
+int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
+    uint8_t *tot = dT(c);
+    const size_t nwords = ((size_t)n + 63) / 64;
+    EdgeArgs E;
+    E.neg = c->d_neg.as<uint64_t>();
+    E.pos = c->d_pos.as<uint64_t>();
+    E.n = n;
+    E.skip = skip;
+    E.mx = c->mx;
+    E.dur_in = c->h_ecarry.dur;
+    E.last_bit_in = c->h_ecarry.last_bit;
+    E.state_in = c->h_ecarry.state;
+    E.nd = c->mx + 1;
+    E.g0 = g0;
+    E.mx_magic = c->mx > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c->mx) : 0xFFFFFFFFu;
+    E.per_mask = 0;
+    for (int b = 0; b < 64; b += c->mx) E.per_mask |= 1ull << b;
+    const size_t tiles = edge_num_tiles(nwords);   // EW_WORDS words per tile in both launches of the stage
+    HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(EdgeAgg)));
+    EdgeAgg *parts = c->d_partials.as<EdgeAgg>();
+    // launch 1: one aggregate per tile (first change, last two changes, entries it is sure of).  While the tiles are few,
+    // each tile's workgroup of the writer folds its predecessors' aggregates itself (scan.hip.h: tile_prefix) and the
+    // single-workgroup prefix launch is not needed.
+    const bool own = tiles <= c->own_prefix_max;
+    Last2 *last2_total = (Last2 *)(tot + TOT_LAST2);
+    uint32_t *edges_total = (uint32_t *)(tot + TOT_EDGES);
+    const EdgeAggOp op{E.mx, E.mx_magic};
+    if (c->cert_pending && tiles) {
+        c->cert_pending = false;
+        NFC_LAUNCH(k_certify_and_reduce, dim3((unsigned)(c->cert.blocks + tiles)), dim3(256), 0, c->st, c->cert, E, nwords, parts);
+    } else if (tiles) {
+        NFC_LAUNCH(k_edge_reduce, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, parts);
+    }
+    if (!own || !tiles)
+        scan_partials_with(c->st, op, tiles, nullptr, (uint32_t)EW_WORDS, parts, op.identity(), (EdgeAgg *)nullptr,
+                           EdgeTotalEpilogue{E, edges_total, last2_total, dE(c)});
+    const uint32_t cap = c->cap_edges;
+    HIPCHK(c, c->d_epos.ensure(((size_t)cap + 8) * 4));
+    HIPCHK(c, c->d_ecode.ensure(((size_t)cap + 8) * 2));
+    if (tiles)
+        NFC_LAUNCH(k_write_edges, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, parts, c->d_epos.as<uint32_t>(),
+                   c->d_ecode.as<uint16_t>(), cap, own, edges_total, last2_total, dE(c));
+    c->edges_from_host = false;
+    return NFC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// decode + framing
+// ---------------------------------------------------------------------------
+// what both forms of the stage write through: symbol, bit and close arrays sized from the estimates; the open packets'
+// bits of earlier batches go in front of this batch's (the other half of the double buffer takes the next ones)
+int frame_out(nfc_ctx *c, FrameOut &P, const bool (&enabled)[2]) {
+    memset(&P, 0, sizeof P);
+    const int pn = 1 - c->pend_cur;
+    P.epos = c->d_epos.as<uint32_t>();
+    P.g0 = c->last_g0;
+    P.idx64 = c->edges_from_host ? c->d_eidx.as<uint64_t>() : nullptr;
+    for (int t = 0; t < 2; t++) {
+        const uint32_t cs = c->cap_sym[t];
+        HIPCHK(c, c->d_sym[t].ensure((size_t)cs + 16));
+        P.sym[t] = c->d_sym[t].as<uint8_t>();
+        P.cap_sym[t] = cs;
+        P.started_in[t] = (uint32_t)c->h_dcarry.pkt_started[t];
+        if (!enabled[t]) continue;   // no symbols of this type (background.py:17-25); its carry stays
+        const uint32_t pend = c->h_dcarry.pending[t];
+        HIPCHK(c, c->d_bits[t].ensure((size_t)pend + cs + 16));
+        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend + cs + 16));
+        HIPCHK(c, c->d_close_end[t].ensure(((size_t)cs + 4) * 4));
+        HIPCHK(c, c->d_close_idx[t].ensure(((size_t)cs + 4) * 8));
+        P.bits[t] = c->d_bits[t].as<uint8_t>();
+        P.close_end[t] = c->d_close_end[t].as<uint32_t>();
+        P.close_idx[t] = c->d_close_idx[t].as<uint64_t>();
+        P.cap_bits[t] = pend + cs;
+        P.cap_close[t] = cs;
+        P.pending[t] = c->d_pending[t][c->pend_cur].as<uint8_t>();
+        P.pend[t] = pend;
+    }
+    return NFC_OK;
+}
+
+int run_decode(nfc_ctx *c) {
+    uint8_t *tot = dT(c);
+    const uint32_t ce = c->cap_edges;                      // capacity; the count is on the device
+    const uint32_t *ne_dev = (const uint32_t *)(tot + TOT_EDGES);
+    const size_t tiles = dec_num_tiles(ce);
+    HIPCHK(c, c->d_states.ensure((size_t)ce + 16));   // one out-byte per edge
+    HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(DecMaps)));
+    HIPCHK(c, c->d_partials2.ensure((tiles + 1) * sizeof(FrameAgg)));
+    HIPCHK(c, c->d_aggs.ensure((tiles * SCAN_BLOCK + 1) * sizeof(DecMaps)));
+    HIPCHK(c, c->d_faggs.ensure((tiles * SCAN_BLOCK + 1) * sizeof(FramePk)));
+    const bool enabled[2] = {c->T.tag != 0, c->T.reader != 0};
+    FrameOut P;
+    const int rf = frame_out(c, P, enabled);
+    if (rf) return rf;
+
+    // decoder states: tile maps -> tile prefixes -> every thread walks its edges.  What the walk emits stays per edge
+    // (one byte); a tile's symbol counts, framing map and bit / close counts are the aggregates of ONE more scan, whose
+    // prefixes place the symbols, the packet bits and the packet ends in a single pass.
+    const uint16_t *ecode = c->d_ecode.as<uint16_t>();
+    uint8_t *outw = c->d_states.as<uint8_t>();
+    const uint32_t dec_state_in = (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4);
+    const bool lds_tables = 4 * c->T.nd <= DEC_LDS_ROWS;
+    DecMaps *dparts = c->d_partials.as<DecMaps>(), *daggs = c->d_aggs.as<DecMaps>();
+    FrameAgg *fparts = c->d_partials2.as<FrameAgg>();
+    FrameAgg *frame_total = (FrameAgg *)(tot + TOT_FRAME);
+    PktCnt *pk_total = (PktCnt *)(tot + TOT_PKT0);
+    if (tiles) {
+        if (lds_tables)
+            NFC_LAUNCH(k_dec_reduce<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
+        else
+            NFC_LAUNCH(k_dec_reduce<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
+    }
+    const bool own = tiles <= c->own_prefix_max;   // (scan.hip.h: tile_prefix -- no prefix launches while the tiles are few)
+    DecMaps *map_total = (DecMaps *)(tot + TOT_DECMAP);
+    const DecCarryEpilogue epi{map_total, dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM), pk_total,
+                               {P.pend[0], P.pend[1]}, {P.started_in[0], P.started_in[1]}};
+    if (!own) scan_partials<ComposeDec>(c->st, tiles, ne_dev, DEC_TILE, dparts, ComposeDec::identity_host(), map_total);
+    if (tiles) {
+        if (lds_tables)
+            NFC_LAUNCH(k_dec_apply<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
+                               dec_state_in, outw, fparts, c->d_faggs.as<FramePk>(), own, map_total);
+        else
+            NFC_LAUNCH(k_dec_apply<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
+                               dec_state_in, outw, fparts, c->d_faggs.as<FramePk>(), own, map_total);
+    }
+    if (!own) scan_partials<FrameAggOp>(c->st, tiles, ne_dev, DEC_TILE, fparts, FrameAggOp::identity(), frame_total, epi);
+    NFC_LAUNCH(k_frame_write, dim3((unsigned)std::max<size_t>(tiles, 1)), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts,
+                       c->d_faggs.as<FramePk>(), P, own, frame_total, epi);
+    const int pn = 1 - c->pend_cur;
+    PktFinish F;
+    memset(&F, 0, sizeof F);
+    for (int t = 0; t < 2; t++) {
+        F.enabled[t] = enabled[t] ? 1 : 0;
+        F.bits[t] = P.bits[t];
+        F.pending_next[t] = c->d_pending[t][pn].as<uint8_t>();
+        F.close_end[t] = P.close_end[t];
+        F.started_in[t] = (int32_t)P.started_in[t];
+        F.pending_cap[t] = (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu);
+        F.cap_bits[t] = P.cap_bits[t];
+        F.cap_close[t] = P.cap_close[t];
+    }
+    F.totals = pk_total;
+    F.frame_total = frame_total;
+    F.carry = dD(c);
+    static_assert(sizeof(DevState) % 4 == 0, "whole words");
+    F.mirror_src = (const uint32_t *)c->d_state.p;   // the stage's last launch also fills the host's mirror of the state block
+    F.mirror_dst = (uint32_t *)c->hs_dev;
+    F.mirror_words = (uint32_t)(sizeof(DevState) / 4);
+    F.stamp_word = (uint32_t)(offsetof(DevState, seq) / 4 + 1);
+    F.stamp = c->stamp_b;
+    NFC_LAUNCH(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
+    return NFC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// short batches: edges, decoders and framing in one launch (small.hip.h)
+// ---------------------------------------------------------------------------
+int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
+    uint8_t *tot = dT(c);
+    SmallArgs A;
+    memset(&A, 0, sizeof A);
+    A.E.neg = c->d_neg.as<uint64_t>();
+    A.E.pos = c->d_pos.as<uint64_t>();
+    A.E.n = n;
+    A.E.skip = skip;
+    A.E.mx = c->mx;
+    A.E.dur_in = c->h_ecarry.dur;
+    A.E.last_bit_in = c->h_ecarry.last_bit;
+    A.E.state_in = c->h_ecarry.state;
+    A.E.nd = c->mx + 1;
+    A.E.g0 = g0;
+    A.E.mx_magic = c->mx > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c->mx) : 0xFFFFFFFFu;
+    for (int b = 0; b < 64; b += c->mx) A.E.per_mask |= 1ull << b;
+    A.nwords = ((size_t)n + 63) / 64;
+    const uint32_t ce = c->cap_edges;
+    HIPCHK(c, c->d_epos.ensure(((size_t)ce + 8) * 4));
+    HIPCHK(c, c->d_ecode.ensure(((size_t)ce + 8) * 2));
+    c->edges_from_host = false;
+    A.epos = c->d_epos.as<uint32_t>();
+    A.ecode = c->d_ecode.as<uint16_t>();
+    A.cap_edges = ce;
+    A.T = c->T;
+    A.dec_state_in = (uint32_t)c->h_dcarry.mil_state | ((uint32_t)c->h_dcarry.man_state << 4);
+    const bool enabled[2] = {c->T.tag != 0, c->T.reader != 0};
+    const int rf = frame_out(c, A.P, enabled);
+    if (rf) return rf;
+    const int pn = 1 - c->pend_cur;
+    for (int t = 0; t < 2; t++) {
+        A.enabled[t] = enabled[t] ? 1 : 0;
+        A.pending_next[t] = c->d_pending[t][pn].as<uint8_t>();
+        A.pending_cap[t] = (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu);
+    }
+    A.tot_last2 = (Last2 *)(tot + TOT_LAST2);
+    A.tot_edges = (uint32_t *)(tot + TOT_EDGES);
+    A.tot_decmap = (DecMaps *)(tot + TOT_DECMAP);
+    A.tot_frame = (FrameAgg *)(tot + TOT_FRAME);
+    A.tot_pk = (PktCnt *)(tot + TOT_PKT0);
+    A.tot_nsym = (uint32_t *)(tot + TOT_NSYM);
+    A.ecarry = dE(c);
+    A.dcarry = dD(c);
+    A.mirror_src = (const uint32_t *)c->d_state.p;
+    A.mirror_dst = (uint32_t *)c->hs_dev;
+    A.mirror_words = (uint32_t)(sizeof(DevState) / 4);
+    A.stamp_word = (uint32_t)(offsetof(DevState, seq) / 4 + 1);
+    A.stamp = c->stamp_b;
+    NFC_LAUNCH(k_small_stage, dim3(1), dim3(SM_BLOCK), 0, c->st, A);
+    return NFC_OK;
+}
+
+// capacity estimates from the densities of the previous batches (batches of very different lengths alternate
+// when a capture is sharded: a short overlap, then the shard), with head-room
+void size_capacities(nfc_ctx *c, uint32_t n) {
+    const uint64_t ce = (uint64_t)((double)n * c->edge_rate * 1.25) + 65536;
+    c->cap_edges = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ce, c->cap_edges_floor), 0xFFFFFF00u);
+    for (int t = 0; t < 2; t++) {
+        const uint64_t ub = (t == 1 ? 2ull : 1ull) * c->cap_edges + 16;   // <= 2 (Miller) / 1 (Manchester) symbols per edge
+        const uint64_t cs = (uint64_t)((double)c->cap_edges * c->sym_rate[t] * 1.1) + 65536;
+        c->cap_sym[t] = (uint32_t)std::min<uint64_t>(std::min(ub, std::max<uint64_t>(cs, c->cap_sym_floor[t])), 0xFFFFFF00u);
+    }
+}
+// densities for the next batch's estimates
+void update_estimates(nfc_ctx *c, uint32_t n) {
+    c->cap_edges_floor = 0;
+    c->cap_sym_floor[0] = c->cap_sym_floor[1] = 0;
+    c->edge_rate = std::max({(double)c->n_edges / (double)n, c->edge_rate * 0.9, 1.0 / 64});
+    for (int t = 0; t < 2; t++)
+        if (c->n_edges) c->sym_rate[t] = std::max((double)c->n_sym[t] / (double)c->n_edges, c->sym_rate[t] * 0.9);
+}
+
+int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
+    if (c->sub_count && !c->in_wait) return fail(c, NFC_ERR_STATE, "batches submitted with nfc_submit_device are in flight: nfc_wait for them first");
+    c->low_valid = false;
+    c->have_outputs = false;
+    c->pk_ready[0] = c->pk_ready[1] = false;
+    c->n_edges = 0;
+    for (int t = 0; t < 2; t++) c->n_sym[t] = c->n_close[t] = c->n_bits[t] = 0;
+    memset(&c->stats, 0, sizeof c->stats);
+    c->n_kev = 0;
+    if (n64 > (1ull << 30)) return fail(c, NFC_ERR_ARG, "batch of %zu samples exceeds 2^30; push it in pieces", n64);
+    const uint32_t n = (uint32_t)n64;
+    c->last_n = n;
+    c->last_g0 = c->nseen;
+    c->last_skip = 0;
+    c->stats.bytes_in = (uint64_t)n * c->in_bytes_per_sample;
+    if (n == 0) {
+        c->have_outputs = true;
+        return NFC_OK;
+    }
+    if (((uintptr_t)d_in & 15u) != 0) return fail(c, NFC_ERR_ARG, "device input must be 16-byte aligned");
+    c->batch_seq++;
+    c->stamp_b = c->batch_seq;
+    launch_error() = LaunchError{};   // (a failure nobody reported belongs to an earlier call)
+    if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[0], c->st));
+
+    uint32_t skip = 0;
+    bool fills = false;
+    if (!c->h_carry.stable) {
+        fills = true;
+        skip = (uint32_t)std::min<uint64_t>(n, (uint64_t)(c->L - c->h_carry.filled));
+        c->h_carry.filled += (int)skip;
+        if (c->h_carry.filled == c->L) {
+            c->h_carry.stable = 1;
+            c->h_ecarry.state = 0;
+            c->h_ecarry.last_bit = 0;
+            c->h_ecarry.dur = c->L % c->mx;  // transition_sink.py:123 (k_fill sets the device copy)
+        }
+    }
+    c->last_skip = skip;
+    if (!c->h_carry.stable || skip == n) {
+        // the whole batch went into the averaging window: no callback content (transition_sink.py:109-125)
+        if (fills) {
+            HIPCHK(c, c->d_ver.ensure(16));
+            launch_fill_kind(c, d_in, n, 0);
+        }
+        HIPCHK(c, mirror_async(c));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        BATCHCHK(c, fills);
+        c->h_carry = c->hs->carry;
+        c->nseen += n;
+        c->have_outputs = true;
+        return NFC_OK;
+    }
+
+    if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[1], c->st));
+    const bool want_edges = !(c->P.flags & NFC_FLAG_NO_EDGES);
+    const EdgeCarry ecarry_in = c->h_ecarry;
+    const uint64_t g0 = c->nseen;
+    auto size_caps = [&]() { size_capacities(c, n); };
+    bool ev3_done = false;
+    auto edges_and_decode = [&]() -> int {
+        size_caps();
+        if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[2], c->st));
+        if (c->use_small && n <= SM_MAX_SAMPLES) {   // a short batch: one launch for the three stages
+            if (c->cert_pending) {   // the certification (and the end-of-batch state) first: the stage's launch is the last, and mirrors the state
+                c->cert_pending = false;
+                NFC_LAUNCH(k_certify, dim3(c->cert.blocks), dim3(256), 0, c->st, c->cert.A, c->cert.cert, (CertInfo *)nullptr,
+                                   c->cert.ring_next, c->cert.carry, c->cert.sum);
+            }
+            const int r = run_small(c, n, skip, g0);
+            if (r) return r;
+            if (!ev3_done && c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+            ev3_done = true;
+            return NFC_OK;
+        }
+        int r = run_edges(c, n, skip, g0);
+        if (r) return r;
+        if (!ev3_done && c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+        ev3_done = true;
+        return run_decode(c);   // (its last launch mirrors the state block)
+    };
+    const std::function<int()> ahead = edges_and_decode;
+    bool clean = false;
+    int rc = run_threshold(c, d_in, n, skip, want_edges ? &ahead : nullptr, &clean);
+    if (rc) return rc;
+    if (want_edges) {
+        for (int attempt = 0;; attempt++) {
+            if (attempt > 0 || !clean) {
+                rc = edges_and_decode();
+                if (rc) return rc;
+                HIPCHK(c, hipStreamSynchronize(c->st));
+            }
+            BATCHCHK(c, true);
+            uint32_t ne, ns[2];
+            memcpy(&ne, c->hs->totals + TOT_EDGES, 4);
+            memcpy(ns, c->hs->totals + TOT_NSYM, 8);
+            const bool fit = ne <= c->cap_edges && ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1];
+            if (fit) {
+                c->n_edges = ne;
+                c->n_sym[0] = ns[0];
+                c->n_sym[1] = ns[1];
+                break;
+            }
+            // a buffer was too small: the stages read carried values by value and wrote only write-only slots, so
+            // they can simply run again with room for what was counted
+            if (attempt >= 3) return fail(c, NFC_ERR_INTERNAL, "edge / symbol capacity did not settle");
+            c->cap_edges_floor = (uint64_t)std::max(ne, c->cap_edges) * 5 / 4 + 65536;
+            c->cap_sym_floor[0] = (uint64_t)ns[0] * 5 / 4 + 65536;
+            c->cap_sym_floor[1] = (uint64_t)ns[1] * 5 / 4 + 65536;
+        }
+        update_estimates(c, n);
+        c->pend_cur = 1 - c->pend_cur;
+    } else {
+        if (c->timing >= 2) {
+            HIPCHK(c, hipEventRecord(c->ev[2], c->st));
+            HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+        }
+        HIPCHK(c, mirror_async(c));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        BATCHCHK(c, true);
+    }
+    if (c->timing >= 2) {
+        HIPCHK(c, hipEventRecord(c->ev[4], c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+    }
+    {
+        adopt_mirror(c);
+        if (c->P.flags & NFC_FLAG_NO_EDGES) c->h_ecarry = ecarry_in;
+        else {
+            uint64_t pk[2];
+            memcpy(&pk[0], c->hs->totals + TOT_PKT0, 8);
+            memcpy(&pk[1], c->hs->totals + TOT_PKT1, 8);
+            for (int t = 0; t < 2; t++) {
+                c->n_bits[t] = (uint32_t)pk[t];
+                c->n_close[t] = (uint32_t)(pk[t] >> 32);
+            }
+        }
+    }
+    if (c->timing >= 2) {
+        c->stats.ms_total = elapsed_ms(c->ev[0], c->ev[4]);
+        c->stats.ms_threshold = elapsed_ms(c->ev[1], c->ev[2]);
+        c->stats.ms_edges = elapsed_ms(c->ev[2], c->ev[3]);
+        c->stats.ms_decode = elapsed_ms(c->ev[3], c->ev[4]);
+    }
+    for (int i = 0; i < c->n_kev; i++) c->stats.ms_threshold_kernel[i] = elapsed_ms(c->kev[2 * i], c->kev[2 * i + 1]);
+    c->stats.n_threshold_timed = (uint32_t)c->n_kev;
+    c->nseen += n;
+    c->last_in = d_in;
+    c->have_outputs = true;
+    // (the end-of-batch LOW bookkeeping on the device is what a batch submitted ahead may start from: only when the whole
+    // batch went through one parallel attempt, whose last certification workgroup or k_finalize_state wrote it)
+    c->low_valid = skip == 0 && c->stats.used_sequential == 0 && c->h_carry.stable;
+    return NFC_OK;
+}
+
+
+}  // namespace

@@ -1,0 +1,475 @@
+// host_threshold.h -- the threshold stage of a batch: plan, pass 0, certification rounds, sequential fallback
+// (part of nfc_amd.hip: included there, in this order, into one translation unit)
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// threshold stage
+// ---------------------------------------------------------------------------
+// `ahead`, when given, enqueues the stages that follow (edges, decode) behind the first certification WITHOUT
+// waiting for its verdict: certification almost always succeeds, so the host round trip that reads the verdict
+// overlaps those stages instead of idling the GPU.  *clean reports that the verdict let that work stand.
+// One parallel attempt at the samples [base, n_all) of the batch (base a multiple of the step; the planes, the ring and
+// the carried sums already hold everything before base).  *need_seq: the attempt cannot vouch for its sums (or the
+// sequential kernel was asked for): nothing of it stands and the caller replays sequentially.
+// Every fp64 sum of a batch is exact -- hence independent of the order it was added in -- when all
+// operands are multiples of 2^low and no sum reaches 2^(low + 53).  Operands: ring values (24-bit mantissas)
+// and the carried ss / delta (their lowest set bits); sums: the window sums (bounded by the kernel from the sums
+// it tracked) and the carried ss itself.  hc: the carried values after the batch; emin / emax / vtop: what its chunks measured.
+static bool sums_exact(const Carry &hc, int emin, int emax, uint32_t vtop) {
+    int low = emin - 23;
+    if (hc.ss_emin != 255) low = std::min(low, hc.ss_emin);
+    float vtf;
+    memcpy(&vtf, &vtop, 4);
+    int high = 255 + 64;   // vtop: f32 bits of an upper bound of every window sum the batch saw
+    if (std::isfinite(vtf) && vtf >= 0.f) high = vtf > 0.f ? std::ilogb((double)vtf) + 127 : 0;
+    high = std::max(high, hc.ss_emax);
+    return (emax < 255) && (high - low <= 52);
+}
+
+// What one parallel attempt at [base, n_all) needs before anything is launched: the chunking, room in every per-chunk
+// buffer, and the kernels' argument block.  (Shared by the synchronous path and by a batch submitted ahead, which works
+// on the other pair of planes, from the window the batch before it leaves, with the LOW bookkeeping read on the device.)
+struct ThrPlan {
+    uint32_t nch;
+    bool lean_applies;
+    uint8_t *d_cert, *d_gflags, *d_gmin, *d_gmax;
+    const uint8_t *h_cert, *h_gflags, *h_gmin, *h_gmax;
+};
+static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all, uint32_t skip, uint32_t base, uint64_t nseen,
+                       const EdgeCarry &ec, int ring_in, DevBuf &planes_neg, DevBuf &planes_pos, bool low_on_device, ThrArgs &A, ThrPlan &P) {
+    const int L = c->L;
+    // Chunk length for this batch: one wave per chunk, and a chunk's latency is what the launch takes, so
+    // aim at one full round of resident waves (no second, half-empty round), never below the configured size.
+    // Long windows: the ring of a chunk in global memory frees the LDS and brings the occupancy back to what the registers
+    // allow -- worth it when the batch then fills the machine with chunks of many windows each (a chunk pays one window
+    // of speculation and two windows of certification traffic): otherwise the LDS ring, with its fewer, longer chunks.
+    // Measured on configs[3] (10 Msps, av_window 10000, 1e9 samples): the lean kernel on the 40 KB LDS ring -- ONE wave per SIMD,
+    // 1024 chunks -- takes 2.3 ms per pass, k_threshold with the ring in global memory at five waves per SIMD 4.7 ms (the delay
+    // line adds a read and a write per sample; a lone wave is bound by its own instruction stream, which the lean kernel
+    // shortened).  So the global ring is only taken on request (NFC_RING=global) or where the lean kernel does not apply.
+    const bool lean_applies = c->lean && c->P.input_kind != NFC_IN_ENV_F32 && c->mx <= 500;
+    c->gring = c->gring_ok && (c->gring_force || (!lean_applies && (uint64_t)n >= (uint64_t)c->wave_slots_g * 8u * (uint64_t)c->L));
+    if (!c->P.chunk_samples) {
+        const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : (lean_applies ? c->lean_slots : c->wave_slots));
+        // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps)
+        const int stp = 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
+        uint64_t want = ((uint64_t)n + slots - 1) / slots;
+        want = (want + stp - 1) / stp * stp;
+        c->C = (int)std::max<uint64_t>(want, (uint64_t)c->C_min);
+    }
+    const uint32_t off = 0u;   // (chunk c covers samples [c*C - off, (c+1)*C - off): the kernels here use off = 0)
+    const uint32_t nch = (uint32_t)(((uint64_t)n + off + c->C - 1) / c->C);
+    c->stats.n_chunks = nch;
+    c->stats.chunk_samples = (uint32_t)c->C;
+    const size_t nwords = ((size_t)n_all + 63) / 64 + 8;
+    HIPCHK(c, planes_neg.ensure(nwords * 8));
+    HIPCHK(c, planes_pos.ensure(nwords * 8));
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(c, c->d_ringout[b].ensure((size_t)nch * L * sizeof(float)));
+        HIPCHK(c, c->d_touched[b].ensure((size_t)nch * c->twords * sizeof(uint32_t)));
+        HIPCHK(c, c->d_info[b].ensure((size_t)nch * sizeof(ChunkInfo)));
+    }
+    HIPCHK(c, c->d_ringin.ensure((size_t)nch * L * sizeof(float)));
+    HIPCHK(c, c->d_meta.ensure((size_t)nch * sizeof(RunMeta)));
+    HIPCHK(c, c->d_ver.ensure(nch));
+    HIPCHK(c, c->d_cflags.ensure((size_t)4 * nch));   // sections: cert | gflags | gmin | gmax
+    if (c->h_cflags_cap < (size_t)4 * nch) {
+        if (c->h_cflags) (void)hipHostFree(c->h_cflags);
+        c->h_cflags_cap = (size_t)4 * nch + 4096;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_cflags, c->h_cflags_cap, hipHostMallocDefault));
+    }
+    uint8_t *d_cert = c->d_cflags.as<uint8_t>(), *d_gflags = d_cert + nch, *d_gmin = d_cert + 2 * (size_t)nch,
+            *d_gmax = d_cert + 3 * (size_t)nch;
+    const uint8_t *h_cert = c->h_cflags, *h_gflags = c->h_cflags + nch, *h_gmin = c->h_cflags + 2 * (size_t)nch,
+                  *h_gmax = c->h_cflags + 3 * (size_t)nch;
+    HIPCHK(c, c->d_list.ensure((size_t)nch * 4));
+    HIPCHK(c, c->d_gvtop.ensure((size_t)nch * 4));
+    if (c->gring) HIPCHK(c, c->d_gring.ensure((size_t)nch * c->Lpad * c->lds_per_slot));
+    c->h_ver.assign(nch, 0);
+
+    // carried "HIGH ignored" bookkeeping from (_current_state, _last_bit, _dur) at the first stable sample
+    const int s0 = (int)skip;
+    int nl0, kl0;
+    if (ec.last_bit == -1) {
+        nl0 = s0 - ec.dur - 1;
+        kl0 = 2 * (s0 - 1) + (ec.state == 2 ? 1 : 0);
+    } else if (ec.state == 2) {
+        nl0 = s0 - 1;
+        kl0 = 2 * (s0 - ec.dur - 1) + 1;
+    } else {
+        nl0 = s0 - 1;
+        kl0 = KEY_NONE;
+    }
+
+    memset(&A, 0, sizeof A);
+    A.gring = c->d_gring.p;
+    A.in = d_in;
+    A.n = n;
+    A.skip = skip;
+    A.g0modL = (uint32_t)(nseen % (uint64_t)L);
+    A.L = L;
+    A.Lpad = c->Lpad;
+    A.mx = c->mx;
+    A.C = c->C;
+    A.nchunks = (int)nch;
+    A.lo = c->P.lo_val;
+    A.hi = c->P.hi_val;
+    A.hi_plus = c->hi_plus;
+    A.lo_a = c->lo_a;
+    A.lo_b = c->lo_b;
+    A.hi_a = c->hi_a;
+    A.hi_b = c->hi_b;
+    A.bands_ok = c->bands_ok;
+    A.fast_ok = c->fast_ok;
+    A.i16_scale = c->i16_scale;
+    A.eps = c->eps;
+    A.ring_carry = c->d_ring[ring_in].as<float>();
+    A.carry = dC(c);
+    A.nl0 = nl0;
+    A.kl0 = kl0;
+    A.low_src = low_on_device ? dC(c) : nullptr;
+    A.lo_L = c->P.lo_val / (double)L;
+    A.hi_L = c->P.hi_val / (double)L;
+    for (int f = 0; f < 6; f++) A.fold_sh[f] = (f < c->nfold) ? (1 << f) : 0;
+    A.probe_mid = (1 << c->nfold) / 2;
+    A.probe_end = (1 << c->nfold) - 1;
+    A.selmask = c->selmask;
+    for (int b = 0; b < 2; b++) {
+        A.ring_out[b] = c->d_ringout[b].as<float>();
+        A.touched[b] = c->d_touched[b].as<uint32_t>();
+        A.info[b] = c->d_info[b].as<ChunkInfo>();
+    }
+    A.ver = c->d_ver.as<uint8_t>();
+    A.ring_in = c->d_ringin.as<float>();
+    A.meta = c->d_meta.as<RunMeta>();
+    A.gmin = d_gmin;
+    A.gmax = d_gmax;
+    A.gflags = d_gflags;
+    A.gvtop = c->d_gvtop.as<uint32_t>();
+    A.neg = planes_neg.as<uint64_t>() + base / 64;
+    A.pos = planes_pos.as<uint64_t>() + base / 64;
+    A.twords = c->twords;
+    A.off = (int32_t)off;
+    A.nrows = (L + 63) / 64;
+    P.nch = nch;
+    P.lean_applies = lean_applies;
+    P.d_cert = d_cert;
+    P.d_gflags = d_gflags;
+    P.d_gmin = d_gmin;
+    P.d_gmax = d_gmax;
+    P.h_cert = h_cert;
+    P.h_gflags = h_gflags;
+    P.h_gmin = h_gmin;
+    P.h_gmax = h_gmax;
+    return NFC_OK;
+}
+
+static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint32_t skip_all, uint32_t base, const EdgeCarry &ec,
+                          const std::function<int()> *ahead, bool *clean, bool *need_seq_out) {
+    bool ran_ahead = false;
+    *clean = false;
+    const int L = c->L;
+    const uint32_t n = n_all - base;
+    const uint32_t skip = skip_all > base ? skip_all - base : 0u;
+    const void *d_in = (const char *)d_in_all + (size_t)base * c->in_bytes_per_sample;
+    const uint64_t nseen = c->nseen + base;
+    uint32_t passes = 0;
+    ThrArgs A;
+    ThrPlan P;
+    if (int rc = thr_prepare(c, d_in, n, n_all, skip, base, nseen, ec, c->ring_cur, c->d_neg, c->d_pos, false, A, P)) return rc;
+    const uint32_t nch = P.nch;
+    const bool lean_applies = P.lean_applies;
+    uint8_t *d_cert = P.d_cert;
+    const uint8_t *h_cert = P.h_cert, *h_gflags = P.h_gflags, *h_gmin = P.h_gmin, *h_gmax = P.h_gmax;
+
+    // fill (if the window is not full yet) + per-batch preparation (delta, guard span, version bytes): one launch
+    launch_fill_kind(c, d_in, n, (int)nch);
+
+    // a 256-sample step must not wrap the ring onto itself: short windows take the sequential kernel
+    const bool force_seq = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0 || L < STEP;
+    bool need_seq = force_seq;
+    if (!force_seq) {
+        // pass 0: every chunk from a speculated incoming state (chunk 0: the carried, exact one)
+        A.list = nullptr;
+        A.nlist = 0;
+        A.mode = 0;
+        // the lean kernel wherever it applies (LDS ring, more than one chunk: chunk 0's verdict travels with the certification)
+        const bool lean = lean_applies && !c->gring && nch > 1;   // (raw envelopes may be negative: no sign bit to spare;
+                                                                    // max_len beyond 500 samples: not exercised, left to k_threshold)
+        A.cert = d_cert;
+        A.sum = (CertSummary *)(dT(c) + TOT_CERT);
+        A.ksteps = c->lean_rounds;
+        A.gfac = c->lean_gfac;
+        A.gfloor = c->lean_gmin;
+        A.blk = 1 << c->nfold;
+        const bool dbg_clk = lean && getenv("NFC_DEBUG_CLK") != nullptr;
+        if (dbg_clk) {
+            HIPCHK(c, c->d_certinfo.ensure((size_t)nch * 32));
+            A.dbg_clk = c->d_certinfo.as<unsigned long long>();
+        }
+        launch_threshold_kind(c, A, nch, lean);
+        if (dbg_clk) {
+            std::vector<unsigned long long> h((size_t)nch * 4);
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            HIPCHK(c, hipMemcpy(h.data(), c->d_certinfo.p, (size_t)nch * 32, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            double pro = 0, loop = 0, epi = 0, maxtot = 0, maxstart = 0;
+            for (uint32_t k = 0; k < nch; k++) {
+                t0 = std::min(t0, h[4 * k]);
+                t1 = std::max(t1, h[4 * k + 3]);
+            }
+            for (uint32_t k = 0; k < nch; k++) {
+                pro += (double)(h[4 * k + 1] - h[4 * k]);
+                loop += (double)(h[4 * k + 2] - h[4 * k + 1]);
+                epi += (double)(h[4 * k + 3] - h[4 * k + 2]);
+                maxtot = std::max(maxtot, (double)(h[4 * k + 3] - h[4 * k]));
+                maxstart = std::max(maxstart, (double)(h[4 * k] - t0));
+            }
+            fprintf(stderr, "[nfc] lean kernel, %u chunks, s_memtime ticks: first start .. last end %llu; per wave: incoming state %.0f, loop %.0f, "
+                    "summary %.0f, longest wave %.0f, latest start %.0f\n", nch, t1 - t0, pro / nch, loop / nch, epi / nch, maxtot, maxstart);
+            if (const char *path = getenv("NFC_DEBUG_CLK")) {
+                if (path[0] == '/' || path[0] == '.' || path[0] == 'g') {   // a file name: the raw stamps, for tools/clk_hist.py
+                    if (FILE *f = fopen(path, "wb")) {
+                        fwrite(h.data(), 8, h.size(), f);
+                        fclose(f);
+                    }
+                }
+            }
+            A.dbg_clk = nullptr;
+        }
+        c->stats.threshold_passes++;
+        passes++;
+
+        // certify; re-run what cannot be proven from the exact (look-back) state; certify again what can
+        // see a re-run chunk.  Every round makes at least the first pending chunk final.
+        const bool dbg = getenv("NFC_DEBUG") != nullptr;
+        bool first_round = true;
+        c->h_list.clear();
+        for (uint32_t k = 1; k < nch; k++) c->h_list.push_back(k);
+        int rounds = 0;
+        bool have_summary = false;
+        CertSummary summary{};
+        uint8_t *tot = dT(c);
+        while (!c->h_list.empty()) {
+            const uint32_t np = (uint32_t)c->h_list.size();
+            if (first_round) {
+                A.list = nullptr;   // k_certify: chunks 1 .. nch-1
+            } else {
+                HIPCHK(c, hipMemcpyAsync(c->d_list.p, c->h_list.data(), (size_t)np * 4, hipMemcpyHostToDevice, c->st));
+                A.list = c->d_list.as<uint32_t>();
+            }
+            A.nlist = np;
+            if (dbg) HIPCHK(c, c->d_certinfo.ensure((size_t)nch * sizeof(CertInfo)));
+            // the first round also resolves the end-of-batch state (last workgroup) and leaves its verdict as a
+            // summary in the mirrored state block; later rounds (after re-runs) read the per-chunk flags
+            CertSummary *d_sum = (CertSummary *)(tot + TOT_CERT);
+            auto launch_certify = [&]() {
+                NFC_LAUNCH(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, d_cert,
+                                   dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c),
+                                   first_round ? d_sum : (CertSummary *)nullptr);
+            };
+            if (first_round && ahead && !dbg) {
+                // the stages that follow are enqueued now; their first full-width kernel takes the certification along
+                c->cert = CertLaunch{A, d_cert, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c), d_sum, (np + 3) / 4 + 1};
+                c->cert_pending = true;
+                const int rc = (*ahead)();
+                if (c->cert_pending) {   // (a short batch's one-launch stage, or no edge stage at all: on its own then)
+                    c->cert_pending = false;
+                    launch_certify();
+                    HIPCHK(c, mirror_async(c));
+                }
+                if (rc) return rc;
+                ran_ahead = true;
+            } else {
+                launch_certify();
+                if (!first_round) HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
+                HIPCHK(c, mirror_async(c));
+                if (first_round && ahead) {
+                    const int rc = (*ahead)();
+                    if (rc) return rc;
+                    ran_ahead = true;
+                }
+            }
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            BATCHCHK(c, true);   // (the verdict summary and the totals are about to be read out of the mirror)
+            std::vector<uint32_t> failing;
+            if (first_round) {
+                memcpy(&summary, c->hs->totals + TOT_CERT, sizeof summary);
+                if (summary.n_fail == 0 && !dbg) {
+                    have_summary = true;
+                    break;
+                }
+                HIPCHK(c, hipMemcpy(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost));
+            }
+            if (first_round && lean && !h_cert[0]) failing.push_back(0);   // chunk 0 gave up: re-run from the carried state
+            for (uint32_t k : c->h_list)
+                if (!h_cert[k]) failing.push_back(k);
+            if (getenv("NFC_TRACE")) {
+                fprintf(stderr, "[nfc] round %d: n_fail %u, %zu failing of %u pending (cert[0] %d):", rounds, summary.n_fail, failing.size(), np, (int)h_cert[0]);
+                for (size_t i = 0; i < failing.size() && i < 12; i++) fprintf(stderr, " %u", failing[i]);
+                fprintf(stderr, "\n");
+            }
+            if (dbg) {
+                std::vector<CertInfo> ci(nch);
+                HIPCHK(c, hipMemcpy(ci.data(), c->d_certinfo.p, (size_t)nch * sizeof(CertInfo), hipMemcpyDeviceToHost));
+                double worst = 0;
+                for (uint32_t k : c->h_list) worst = std::max(worst, (double)ci[k].d / std::max(1e-30f, ci[k].allowed));
+                fprintf(stderr, "[nfc] certify round %d: %u pending, %zu failing, worst d/allowed %.3f\n", rounds, np,
+                        failing.size(), worst);
+                if (first_round && lean) {
+                    std::vector<ChunkInfo> inf(nch);
+                    HIPCHK(c, hipMemcpy(inf.data(), c->d_info[0].p, (size_t)nch * sizeof(ChunkInfo), hipMemcpyDeviceToHost));
+                    int why[8] = {0};
+                    for (uint32_t k : failing) why[(inf[k].flags >> 4) & 7]++;
+                    fprintf(stderr, "[nfc]   lean gave up: range %d, band %d, low run %d, allowance %d, first sample %d; not lean %d\n", why[1], why[2],
+                            why[3], why[4], why[5], why[0]);
+                }
+                for (size_t i = 0; i < failing.size() && i < 8; i++) {
+                    const CertInfo &x = ci[failing[i]];
+                    fprintf(stderr, "[nfc]   chunk %u: d %.6g allowed %.6g all_robust %u low_ok %u\n", failing[i], x.d,
+                            x.allowed, x.all_robust, x.low_ok);
+                }
+            }
+            if (failing.empty()) break;
+            first_round = false;
+            HIPCHK(c, hipMemcpyAsync(c->d_list.p, failing.data(), failing.size() * 4, hipMemcpyHostToDevice, c->st));
+            A.list = c->d_list.as<uint32_t>();
+            A.nlist = (uint32_t)failing.size();
+            A.mode = 1;
+            launch_threshold_kind(c, A, A.nlist);
+            c->stats.threshold_passes++;
+            passes++;
+            c->stats.chunks_rerun += A.nlist;
+            HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            std::vector<uint8_t> ran(nch, 0);
+            for (uint32_t k : failing) {
+                ran[k] = 1;
+                c->h_ver[k] ^= 1;
+            }
+            HIPCHK(c, hipMemcpyAsync(c->d_ver.p, c->h_ver.data(), nch, hipMemcpyHostToDevice, c->st));
+            // pending: the re-run chunks (a predecessor may have been re-run beside them) and every
+            // chunk that can see one of them through predecessors that left ring slots untouched
+            c->h_list.clear();
+            bool vis = false;
+            for (uint32_t k = 0; k < nch; k++) {
+                if (vis || ran[k]) c->h_list.push_back(k);
+                const bool full = !(h_gflags[k] & 2);
+                vis = ran[k] || (vis && !full);
+            }
+            if (++rounds > (int)nch + 2) return fail(c, NFC_ERR_INTERNAL, "threshold passes did not converge");
+        }
+
+        // can every fp64 sum of this batch be proven exact?  (otherwise the summation order matters)
+        int emin = 255, emax = 0;
+        bool flagged = false;
+        uint32_t vtop = 0;
+        if (have_summary && passes == 1) {
+            emin = (int)summary.emin;
+            emax = (int)summary.emax;
+            flagged = summary.flagged != 0;
+            vtop = summary.vtop;
+        } else {
+            HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, mirror_async(c));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            BATCHCHK(c, true);
+            std::vector<uint32_t> hv(nch);
+            HIPCHK(c, hipMemcpy(hv.data(), c->d_gvtop.p, (size_t)nch * 4, hipMemcpyDeviceToHost));
+            for (uint32_t k = 0; k < nch; k++) {
+                emin = std::min(emin, (int)h_gmin[k]);
+                emax = std::max(emax, (int)h_gmax[k]);
+                if (h_gflags[k] & 1) flagged = true;
+                vtop = std::max(vtop, hv[k]);
+            }
+        }
+        c->h_carry = c->hs->carry;
+        carry_apply_fin(c->h_carry);
+        const bool exact = sums_exact(c->h_carry, emin, emax, vtop);
+        if (dbg) fprintf(stderr, "[nfc] guard: emin %d emax %d ss_emin %d ss_emax %d flagged %d exact %d\n", emin, emax,
+                         c->h_carry.ss_emin, c->h_carry.ss_emax, (int)flagged, (int)exact);
+        if (!exact || flagged) need_seq = true;
+    }
+
+    *need_seq_out = need_seq;
+    if (!need_seq) {
+        // the end-of-batch ring was resolved beside the last certification unless chunks were re-run after it
+        if (passes > 1 || nch == 1)
+            NFC_LAUNCH(k_finalize_state, dim3(1), dim3(FIN_BLOCK), 0, c->st, A, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c));
+        c->ring_cur = (c->ring_cur + 1) % NRING;
+        *clean = ran_ahead && passes == 1;
+    }
+    return NFC_OK;
+}
+
+// The literal loop on one lane over the samples [base, base + len) of the batch (exact whatever the sums look like).
+// ec_out (optional): (_current_state, _last_bit, _dur) after the last of them, for the attempt that follows.
+static int sequential_span(nfc_ctx *c, const void *d_in_all, uint32_t skip_all, uint32_t base, uint32_t len, const EdgeCarry &ec,
+                           EdgeCarry *ec_out) {
+    SeqArgs S;
+    memset(&S, 0, sizeof S);
+    S.in = (const char *)d_in_all + (size_t)base * c->in_bytes_per_sample;
+    S.n = len;
+    S.skip = skip_all > base ? std::min(skip_all - base, len) : 0u;
+    S.g0modL = (uint32_t)((c->nseen + base) % (uint64_t)c->L);
+    S.L = c->L;
+    S.mx = c->mx;
+    S.lo = c->P.lo_val;
+    S.hi = c->P.hi_val;
+    S.hi_plus = c->hi_plus;
+    S.i16_scale = c->i16_scale;
+    S.ring = c->d_ring[c->ring_cur].as<float>();
+    S.carry = dC(c);
+    S.state = ec.state;
+    S.last_bit = ec.last_bit;
+    S.dur = ec.dur;
+    S.neg = c->d_neg.as<uint64_t>() + base / 64;
+    S.pos = c->d_pos.as<uint64_t>() + base / 64;
+    HIPCHK(c, c->d_seqout.ensure(64));
+    S.out = c->d_seqout.as<int32_t>();
+    launch_seq_kind(c, S);
+    c->stats.used_sequential = 1;
+    if (ec_out) {
+        int32_t o[3];
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        HIPCHK(c, hipMemcpy(o, c->d_seqout.p, sizeof o, hipMemcpyDeviceToHost));
+        ec_out->state = o[0];
+        ec_out->last_bit = o[1];
+        ec_out->dur = o[2];
+    }
+    return NFC_OK;
+}
+
+// The threshold stage of a batch.  Almost always one parallel attempt.  When an attempt cannot prove its fp64 sums
+// exact -- typically a stream that starts inside a transaction: the fill phase stored pause-level samples, and while
+// they sit in the window the reference's own running sum rounds -- the sequential kernel replays a PREFIX (a few
+// windows, until those values have been overwritten) and the rest of the batch gets another parallel attempt.
+int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const std::function<int()> *ahead, bool *clean) {
+    *clean = false;
+    c->stats.threshold_passes = 0;
+    c->stats.chunks_rerun = 0;
+    c->stats.used_sequential = 0;
+    const uint32_t span = (uint32_t)std::min<uint64_t>(((uint64_t)8 * c->L + STEP - 1) / STEP * STEP, 1u << 30);   // prefix per round
+    EdgeCarry ec = c->h_ecarry;
+    uint32_t base = 0;
+    for (int round = 0;; round++) {
+        bool need_seq = false, span_clean = false;
+        const int rc = threshold_span(c, d_in, n, skip, base, ec, base == 0 ? ahead : nullptr, &span_clean, &need_seq);
+        if (rc) return rc;
+        if (!need_seq) {
+            *clean = span_clean && base == 0;
+            return NFC_OK;
+        }
+        const bool forced = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0 || c->L < STEP;
+        const uint32_t left = n - base;
+        if (forced || round >= 6 || left <= 4 * span) return sequential_span(c, d_in, skip, base, left, ec, nullptr);
+        const int rs = sequential_span(c, d_in, skip, base, span, ec, &ec);
+        if (rs) return rs;
+        base += span;
+    }
+}
+
+
+}  // namespace
