@@ -253,6 +253,57 @@ def test_batches_submitted_ahead_cut_inside_frames(name, kw):
     assert ahead >= 7 and st.redone_total == 0, (ahead, st.redone_total)
 
 
+def test_batches_submitted_ahead_mixed_with_batches_that_do_not_qualify():
+    # long batches (run ahead), short ones (<= 2^18 samples: the one-launch stage, processed inside nfc_wait), a tiny one and
+    # an empty one, three in flight: whatever mixture, the stream is the single stream's
+    iq = synth.workload('all', 3_000_000)
+    n = len(iq) // 2
+    o = oracle_run(iq, dict(hi_val=1.1), api.NFC_IN_IQ_F32)
+    sizes = [300_000, 100_000, 500_000, 50_000, 400_000, 400_000, 10, 0, 400_000, 300_017, 7, 280_000]
+    cuts = [0]
+    for z in sizes:
+        cuts.append(cuts[-1] + z)
+    cuts.append(n)
+    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        bufs = [api.DeviceBuffer(iq[2 * a:2 * b] if b > a else np.zeros(4, np.float32)) for a, b in zip(cuts[:-1], cuts[1:])]
+        lens = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+        tr, s0, s1, pk, flags = [], [], [], [], []
+        nxt = 0
+        for k in range(len(bufs)):
+            while nxt < len(bufs) and nxt < k + 3:
+                ctx.submit_device(bufs[nxt], lens[nxt])
+                nxt += 1
+            ctx.wait()
+            tr += ctx.transitions()
+            s0 += ctx.symbols(0).tolist()
+            s1 += ctx.symbols(1).tolist()
+            pk += ctx.packets()
+            flags.append(int(ctx.stats().ran_ahead))
+    d = first_diff(tr, o.transitions())
+    assert d is None, 'transition %s' % (d,)
+    assert s0 == o.symbols(0).tolist() and s1 == o.symbols(1).tolist() and pk == o.packets()
+    assert sum(flags) >= 3 and flags[1] == 0 and flags[3] == 0, flags   # the short ones never run ahead
+
+
+def test_submit_and_wait_where_nothing_can_run_ahead():
+    # an envelope input (the general threshold kernel: no device-side hand-over) through the same two calls
+    c = Case('fx_ultralight_txn')
+    x = np.tile(c.x, 12)   # 380 000 samples
+    o = oracle_run(x, c.params, api.NFC_IN_ENV_F32)
+    with api.NfcContext(input_kind=api.NFC_IN_ENV_F32, **c.params) as ctx:
+        cut = 300_000
+        a, b = api.DeviceBuffer(x[:cut]), api.DeviceBuffer(x[cut:])
+        ctx.submit_device(a, cut)
+        ctx.submit_device(b, len(x) - cut)
+        tr, pk = [], []
+        for _ in range(2):
+            ctx.wait()
+            tr += ctx.transitions()
+            pk += ctx.packets()
+            assert ctx.stats().ran_ahead == 0
+    assert first_diff(tr, o.transitions()) is None and pk == o.packets()
+
+
 def test_state_set_from_the_host_is_not_run_ahead_of():
     # After nfc_set_state (here: a state taken mid-stream and put back) the device-side LOW bookkeeping is not the stream's:
     # the next submitted batch must take the synchronous path, the ones after it may run ahead again
