@@ -47,8 +47,10 @@ def parse():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the end-to-end figure and the other configurations')
     ap.add_argument('--in-flight', type=int, default=3, choices=[1, 2, 3], help='one GPU: batches submitted and not yet waited for')
-    ap.add_argument('--sync-steps', action='store_true', help='one GPU: every step a fresh stream pushed synchronously (nfc_push_device), as the sharded steps are; '
-                    'default: the steps are consecutive batches of ONE stream, each submitted before the one before it is waited for')
+    ap.add_argument('--primary', default='sync', choices=['sync', 'ahead'], help='what the headline steps are -- sync: every step a fresh stream pushed synchronously '
+                    '(the threshold kernel with the machine to itself); ahead: consecutive batches of one stream, submitted ahead (nfc_submit_device / nfc_wait). '
+                    'The other one is measured beside it unless --no-extras')
+    ap.add_argument('--sync-steps', action='store_true', help='(same as --primary sync --no-extras for the stepping: kept for the profiling scripts)')
     return ap.parse_args()
 
 
@@ -210,24 +212,24 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
             comm.barrier()
         ctx.sync()
 
-    # The steps are consecutive batches of ONE stream per rank -- the rank's slice of the capture again and again, the stream
-    # state carried on -- and batch k + 1 is submitted before batch k is waited for (nfc_submit_device / nfc_wait): its
-    # threshold stage then runs beside the edge and decode stages of batch k.  With several ranks the rank's time shard IS that
-    # stream: `steps` batches long, primed and warmed up on the overlap before it, its speculated start state checked against
-    # the predecessor's true end state in ONE exchange after the last batch (a mismatch re-decodes the shard).  --sync-steps:
-    # every step a fresh stream, pushed synchronously -- with several ranks the whole protocol per step (reset / prime,
-    # overlap, own chunk, exchange).
-    ahead = not a.sync_steps
+    # Two ways to step, both measured (the other one lands beside the headline unless --no-extras):
+    #  sync   every step a fresh stream pushed synchronously (nfc_push_device) -- with several ranks the whole sharding
+    #         protocol per step (reset / prime, overlap, own chunk, boundary exchange).  Nothing runs beside the threshold
+    #         kernel: its launches are the kernel with the machine to itself.  The headline unless --primary ahead.
+    #  ahead  the steps are consecutive batches of ONE stream per rank -- the rank's slice of the capture again and again,
+    #         the stream state carried on -- and batch k + 1 is submitted before batch k is waited for (nfc_submit_device /
+    #         nfc_wait): its threshold stage then runs beside the edge and decode stages of batch k.  With several ranks
+    #         the rank's time shard IS that stream: `steps` batches long, primed and warmed up on the overlap before it,
+    #         its speculated start state checked against the predecessor's true end state in ONE exchange after the last
+    #         batch (a mismatch re-decodes the shard).
     sharded = world > 1 or force_exchange
-    kernel_ms, n_pass = [], []
-    n_ahead = [0]
 
-    def stream_steps(count, timed_every):
-        """count consecutive batches of the stream, two in flight; timed_every: every that-many-th threshold launch carries
-        its own start / stop HIP events (nfc_set_timing; a timed launch costs the step a few us, so not all of them are)"""
+    def stream_steps(count, timed_every, acc):
+        """count consecutive batches of the stream, a.in_flight in flight; timed_every: every that-many-th threshold launch
+        carries its own start / stop HIP events (nfc_set_timing; a timed launch costs the step a few us, so not all of them are)"""
         if not count:
             return
-        want = lambda j: bool(timed_every) and j % timed_every == 0
+        want = lambda j: bool(timed_every) and j % timed_every == 3   # (not the region's very first launches)
         cur = [None]
 
         def submit(j):
@@ -244,72 +246,77 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
             ctx.wait()
             if timed_every:
                 st = ctx.stats()
-                n_ahead[0] += int(st.ran_ahead)
+                acc['n_ahead'] += int(st.ran_ahead)
                 if st.n_threshold_timed:
-                    kernel_ms.extend(st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed))
-                    n_pass.append(st.threshold_passes)
+                    acc['kernel_ms'].extend(st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed))
+                    acc['n_pass'].append(st.threshold_passes)
         ctx.set_timing(0)
 
-    if ahead and sharded:
-        def shard(count, timed_every):
-            redo[0] += sharding.decode_shard(ctx, comm, lambda: ctx.push_device(d_ov, n_ov), lambda: stream_steps(count, timed_every),
-                                             g_lo - n_ov, level, force_exchange=force_exchange)
-        if warmup:
-            shard(warmup, 0)
+    def region(mode):
+        """warm-up + exactly `steps` timed steps in the given mode, bracketed by barrier + device sync; max over ranks"""
+        acc = {'kernel_ms': [], 'n_pass': [], 'n_ahead': 0, 'mode': mode}
         redo[0] = 0
+        if mode == 'ahead' and sharded:
+            def shard(count, timed_every):
+                redo[0] += sharding.decode_shard(ctx, comm, lambda: ctx.push_device(d_ov, n_ov), lambda: stream_steps(count, timed_every, acc),
+                                                 g_lo - n_ov, level, force_exchange=force_exchange)
+            if warmup:
+                shard(warmup, 0)
+            redo[0] = 0
+            barrier()
+            t0 = time.perf_counter()
+            shard(steps, 8)
+        elif mode == 'ahead':
+            ctx.reset()
+            stream_steps(warmup, 0, acc)
+            barrier()
+            t0 = time.perf_counter()
+            stream_steps(steps, 8, acc)
+        else:
+            for _ in range(warmup):
+                one_step()
+            redo[0] = 0
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                # every 8th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
+                # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are)
+                timed = k % 8 == 3   # (not the region's very first launches)
+                if timed or k % 8 == 4:
+                    ctx.set_timing(1 if timed else 0)
+                one_step()
+                if timed:
+                    st = ctx.stats()
+                    acc['kernel_ms'] += [st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed)]
+                    acc['n_pass'].append(st.threshold_passes)
+            ctx.set_timing(0)
         barrier()
-        t0 = time.perf_counter()
-        shard(steps, 8)
-    elif ahead:
-        ctx.reset()
-        stream_steps(warmup, 0)
-        barrier()
-        t0 = time.perf_counter()
-        stream_steps(steps, 8)
-    else:
-        for _ in range(warmup):
-            one_step()
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            # every 8th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
-            # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are)
-            timed = k % 8 == 0
-            if timed or k % 8 == 1:
-                ctx.set_timing(1 if timed else 0)
-            one_step()
-            if timed:
-                st = ctx.stats()
-                kernel_ms += [st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed)]
-                n_pass.append(st.threshold_passes)
-    barrier()
-    dt = time.perf_counter() - t0
-    if hasattr(comm, 'max_over_ranks'):
-        dt = comm.max_over_ranks(dt)
-    # beside the headline: the same batches one after the other (nfc_push_device, nothing in flight beside them) -- what a
-    # step costs then, and the threshold kernel's duration with the machine to itself
-    alone = None
-    if ahead and not sharded and not a.no_extras:
-        k_alone = []
-        for _ in range(5):
-            ctx.push_device(res.buf, n)
-        ctx.sync()
-        t1 = time.perf_counter()
-        for k in range(steps):
-            timed = k % 8 == 0
-            if timed or k % 8 == 1:
-                ctx.set_timing(1 if timed else 0)
-            ctx.push_device(res.buf, n)
-            if timed:
-                st = ctx.stats()
-                k_alone += [st.ms_threshold_kernel[i] for i in range(st.n_threshold_timed)]
-        ctx.sync()
-        dt1 = time.perf_counter() - t1
-        ka = float(np.mean(k_alone)) if k_alone else float('nan')
-        alone = {'ms_per_step': dt1 / steps * 1e3, 'value': n * steps / dt1 / 1e6, 'unit': 'Msamples/s', 'steps': steps,
-                 'roofline': {'bound': 'hbm', 'achieved': 8.0 * n / (ka * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': 8.0 * n / (ka * 1e-3) / 1e9 / HBM_PEAK_GBS, 'avg_launch_ms': ka, 'launches_timed': len(k_alone)},
-                 'what': 'the same stream, each batch pushed synchronously (nfc_push_device): nothing runs beside the threshold kernel'}
+        dt = time.perf_counter() - t0
+        if hasattr(comm, 'max_over_ranks'):
+            dt = comm.max_over_ranks(dt)
+        acc['dt'] = dt
+        acc['redo'] = redo[0]
+        return acc
+
+    def summary(acc):
+        ka = float(np.mean(acc['kernel_ms'])) if acc['kernel_ms'] else float('nan')
+        ach = 8.0 * n / (ka * 1e-3) / 1e9
+        what = ('consecutive batches of one stream per rank, %d in flight: batch k + %d is submitted before batch k is waited for (%d of %d timed '
+                'steps ran ahead)%s' % (a.in_flight, a.in_flight - 1, acc['n_ahead'], steps,
+                                        '; the rank\'s time shard is that stream: one boundary exchange after its last batch' if sharded else '')
+                if acc['mode'] == 'ahead' else 'a fresh stream per step, pushed synchronously (nfc_push_device): nothing runs beside the threshold kernel')
+        return {'steps_are': what, 'ms_per_step': acc['dt'] / steps * 1e3, 'value': world * n * steps / acc['dt'] / 1e6, 'unit': 'Msamples/s',
+                'steps': steps, 'boundary_redos': acc['redo'],
+                'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                             'avg_launch_ms': ka, 'launches_timed': len(acc['kernel_ms']),
+                             'launches_per_step': float(np.mean(acc['n_pass'])) if acc['n_pass'] else None}}
+
+    ahead = a.primary == 'ahead' and not a.sync_steps
+    # (the region that lands beside the headline goes first: the headline's steps then run on a machine that is already at its clocks)
+    other = None if (a.no_extras or a.sync_steps) else region('sync' if ahead else 'ahead')
+    prim = region('ahead' if ahead else 'sync')
+    dt, kernel_ms, n_pass = prim['dt'], prim['kernel_ms'], prim['n_pass']
+    redo[0] = prim['redo']
     ctx.set_timing(2)   # one more, untimed, step for the per-stage split reported beside the headline (synchronous: stream markers)
     if ahead:
         ctx.push_device(res.buf, n)
@@ -334,9 +341,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                        'symbols_reader': int(cnt.n_symbols[1]), 'symbols_tag': int(cnt.n_symbols[0]),
                        'packets': int(cnt.n_packets[0] + cnt.n_packets[1]), 'boundary_redos': redo[0],
                        'shard_overlap_samples': capture_overlap(workload) if world > 1 else 0, 'exchange': backend if world > 1 else 'none',
-                       'steps_are': ('consecutive batches of one stream, %d in flight: batch k + %d is submitted before batch k is waited for (%d of %d timed steps ran ahead)' % (a.in_flight, a.in_flight - 1, n_ahead[0], steps))
-                                    + ('; the rank\'s time shard is that stream: one boundary exchange after its last batch' if sharded else '')
-                                    if ahead else 'a fresh stream per step, pushed synchronously'},
+                       'steps_are': summary(prim)['steps_are']},
             'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_lean / k_threshold (fused envelope + gated-mean threshold)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': tsrc, 'avg_launch_ms': k_avg, 'launches_timed': len(kernel_ms),
@@ -345,29 +350,32 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                          'streaming_read_ceiling': STREAM_CEILING_GBS, 'frac_of_streaming_ceiling': achieved / STREAM_CEILING_GBS,
                          'note': '8 B/sample only: the 16 B/edge of SURVEY 8(d) are written by the edge stage, listed under edge_stage'
                                  + ('; the launches of the timed region run BESIDE the previous batch\'s edge and decode stages (batches submitted ahead) and '
-                                    'share the SIMDs\' issue slots with them: one_batch_at_a_time.roofline is the same kernel with the machine to itself' if ahead else '')},
+                                    'share the SIMDs\' issue slots with them: one_batch_at_a_time.roofline is the same kernel with the machine to itself' if ahead else
+                                    '; submitted_ahead is the same stream with batches submitted ahead: more samples per second, and the kernel\'s launches '
+                                    'stretched by what runs beside them')},
             'edge_stage': {'algorithmic_bytes': edge_bytes, 'bytes_stored': stored_bytes, 'stage_ms': st.ms_edges,
                            'achieved_GBs': (edge_bytes / (st.ms_edges * 1e-3) / 1e9) if st.ms_edges > 0 else None,
                            'note': 'all kernels of the edge stage of the extra, marker-timed step (tile aggregates, writer); algorithmic_bytes '
                                    'is SURVEY 8(d)\'s 16 B per edge, the stage stores 6 B per entry and nfc_read_edges builds the 16-byte records'},
             'whole_path': {'algorithmic_bytes': thr_bytes + edge_bytes,
                            'achieved_GBs': (thr_bytes + edge_bytes) / (dt / steps) / 1e9, 'frac': (thr_bytes + edge_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS},
-            'one_batch_at_a_time': alone,
+            ('one_batch_at_a_time' if ahead else 'submitted_ahead'): (summary(other) if other else None),
             'stage_ms_extra_step': {'total_device': st.ms_total, 'threshold': st.ms_threshold, 'edges': st.ms_edges,
                                     'decode': st.ms_decode, 'used_sequential': int(st.used_sequential)},
         }
         if want_parity:
-            out['parity'] = parity_check(workload, own, flags, n, ahead)
+            out['parity'] = parity_check(workload, own, flags, n, True)
             # the context the timed loop ran in must have produced the same decode: a fresh stream per step / rank 0's shard
             # starts the stream; or, with consecutive batches of one stream, its steady state (when the rounds repeat)
+            want_counts = out['parity'] if ahead else out['parity']['first_round']
             if ahead and not out['parity'].get('stationary'):
                 out['parity']['timed_loop_counts_equal'] = None
             else:
-                same = bool(n_edges == out['parity']['n_edges'] and int(cnt.n_packets[0] + cnt.n_packets[1]) == out['parity']['n_packets'])
+                same = bool(n_edges == want_counts['n_edges'] and int(cnt.n_packets[0] + cnt.n_packets[1]) == want_counts['n_packets'])
                 out['parity']['timed_loop_counts_equal'] = same
                 if not same:
                     raise SystemExit('bench: the timed loop decoded %d edges / %d packets, the oracle %d / %d' % (
-                        n_edges, int(cnt.n_packets[0] + cnt.n_packets[1]), out['parity']['n_edges'], out['parity']['n_packets']))
+                        n_edges, int(cnt.n_packets[0] + cnt.n_packets[1]), want_counts['n_edges'], want_counts['n_packets']))
     ctx.set_stream(None)   # back on its own stream before the communicator's goes away
     ctx.close()
     return out, own, flags

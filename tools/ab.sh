@@ -4,7 +4,7 @@ w=$1; shift
 mkdir -p gpurun_out/ab
 for v in "$@"; do
   echo "== $v"
-  env $v python3 bench.py --workload $w --steps 40 --warmup 10 --no-cpu-baseline --no-parity 2>&1 | python3 -c "
+  env $v python3 bench.py --workload $w --steps 40 --warmup 10 --no-cpu-baseline --no-parity --no-extras ${AB_ARGS:---primary ahead} 2>&1 | python3 -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()

@@ -6,8 +6,8 @@ out=gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o $tag -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity --no-extras --sync-steps > $out/${tag}_bench_under_rocprof.json 2> $out/stats.log
-# the same with batches submitted ahead (the default): the threshold stage of batch k + 1 beside the later stages of batch k
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_ahead -o ${tag}a -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity --no-extras > $out/${tag}_bench_ahead_under_rocprof.json 2> $out/stats_ahead.log
+# the same with batches submitted ahead (--primary ahead): the threshold stage of batch k + 1 beside the later stages of batch k
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_ahead -o ${tag}a -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity --no-extras --primary ahead > $out/${tag}_bench_ahead_under_rocprof.json 2> $out/stats_ahead.log
 python3 tools/timeline2.py $out/stats_ahead/${tag}a_kernel_trace.csv 60 22 > $out/${tag}_timeline_ahead.txt 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/fetch.log
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/write.log
