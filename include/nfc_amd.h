@@ -146,7 +146,9 @@ void nfc_destroy(nfc_ctx *ctx);
 const char *nfc_last_error(const nfc_ctx *ctx); /* ctx may be NULL: message of the last failed nfc_create */
 
 /* transition_sink.work(): consume n samples (any n >= 0, any chunking gives the
- * same concatenated outputs).  Host buffer: staged to the device first. */
+ * same concatenated outputs).  Host buffer: staged to the device first.
+ * One call takes at most 2^30 samples (positions inside a batch are 32-bit: NFC_ERR_ARG beyond; push a longer capture in pieces,
+ * the stream index itself is 64-bit). */
 int nfc_push(nfc_ctx *ctx, const void *host_samples, size_t n);
 /* Same, input already in device memory (16-byte aligned). */
 int nfc_push_device(nfc_ctx *ctx, const void *dev_samples, size_t n);
@@ -287,7 +289,11 @@ int nfc_tx_encode(int encoding, const uint8_t *bits, size_t n_bits, nfc_tx_run *
 /* samples binary_src.work produces for the runs */
 int nfc_tx_sample_count(const nfc_tx_run *runs, size_t n_runs, double samp_rate, uint64_t *n_samples);
 /* renders the runs into dev_out (complex64, 32-byte aligned, cap_samples entries); carrier != 0 multiplies by the carrier,
- * sample k of this call having carrier index first_index + k.  kernel_ms (may be NULL): the kernel's duration by HIP events. */
+ * sample k of this call having carrier index first_index + k.  kernel_ms (may be NULL): the kernel's duration by HIP events.
+ * The carrier's phase is kept in 64-bit fixed point and its top 24 bits go into sincospif: a phase error of at most 3.7e-7 rad,
+ * 1.5e-7 of the amplitude.  The reference's carrier is GNU Radio's sig_source_c -- third party, not under the reference tree:
+ * parity at that boundary is unpinned (tx.hip.h states the arithmetic; tests/test_tx.py checks it against a float64
+ * restatement within that tolerance). */
 int nfc_tx_render_device(int device, const nfc_tx_run *runs, size_t n_runs, double samp_rate, int carrier, double freq,
                          float amp, uint64_t first_index, void *dev_out, size_t cap_samples, size_t *n_samples,
                          float *kernel_ms);
