@@ -33,8 +33,11 @@ struct DecCarry {
     uint32_t pending[2];  // bits of the open packet kept from earlier batches, per type
 };
 
-constexpr int DEC_ITEMS = 16;                       // edges (or symbols) per thread: one 16-byte load of bytes
-constexpr int DEC_TILE = SCAN_BLOCK * DEC_ITEMS;
+constexpr int DEC_ITEMS = 16;                       // edges per group: one 16-byte load of out-bytes, 32 symbol slots in a word
+constexpr int DEC_GROUPS = 2;                       // groups per thread in the multi-launch stage: a tile's block scans (the
+                                                    // larger part of k_dec_reduce's instructions) are paid per 32 edges, not 16
+constexpr int DEC_PER_THREAD = DEC_ITEMS * DEC_GROUPS;
+constexpr int DEC_TILE = SCAN_BLOCK * DEC_PER_THREAD;
 constexpr int DEC_LDS_ROWS = 512;                   // LUT rows staged in LDS: 4 (max_len + 1) <= 512 (cur = -1 .. 2)
 inline size_t dec_num_tiles(size_t n) { return (n + DEC_TILE - 1) / DEC_TILE; }
 
@@ -115,7 +118,7 @@ struct FrameAggOp {
         return r;
     }
 };
-// Inside a tile (<= 2 * DEC_TILE = 8192 symbols of a type) the counts fit 16 bits: the block scans run on this packed
+// Inside a tile (<= 2 * DEC_TILE = 16384 symbols of a type) the counts fit 16 bits: the block scans run on this packed
 // form, half the words to shuffle.  a = cnt | nb << 16, b = nc | fl << 16.
 struct FramePk {
     uint32_t a[2], b[2];
@@ -241,21 +244,25 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_reduce(const uint16_t *ecode
         __syncthreads();
     }
     const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    uint32_t c[8];
-    load_codes(ecode, tid * DEC_ITEMS, n, c);
+    uint32_t c[DEC_GROUPS][8];
+#pragma unroll
+    for (int g = 0; g < DEC_GROUPS; g++) load_codes(ecode, tid * DEC_PER_THREAD + DEC_ITEMS * g, n, c[g]);
     DecMaps agg = ComposeDec::identity();
 #pragma unroll
-    for (int k = 0; k < DEC_ITEMS; k++) {
-        const uint32_t code = (c[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-        const uint32_t li = code & 0x3FFFu, route = code >> 14;
-        if (route == 2u && T.reader) {
-            const uint4 v = LDS ? s_mil[li] : T.mil_map[li];
+    for (int g = 0; g < DEC_GROUPS; g++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) agg.mil[q] = lookup16x4(v.x, v.y, v.z, v.w, agg.mil[q]);
-        } else if (route == 1u && T.tag) {
-            const uint2 v = LDS ? s_man[li] : T.man_map[li];
-            agg.man[0] = __builtin_amdgcn_perm(v.y, v.x, agg.man[0]);
-            agg.man[1] = __builtin_amdgcn_perm(v.y, v.x, agg.man[1]);
+        for (int k = 0; k < DEC_ITEMS; k++) {
+            const uint32_t code = (c[g][k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            const uint32_t li = code & 0x3FFFu, route = code >> 14;
+            if (route == 2u && T.reader) {
+                const uint4 v = LDS ? s_mil[li] : T.mil_map[li];
+#pragma unroll
+                for (int q = 0; q < 4; q++) agg.mil[q] = lookup16x4(v.x, v.y, v.z, v.w, agg.mil[q]);
+            } else if (route == 1u && T.tag) {
+                const uint2 v = LDS ? s_man[li] : T.man_map[li];
+                agg.man[0] = __builtin_amdgcn_perm(v.y, v.x, agg.man[0]);
+                agg.man[1] = __builtin_amdgcn_perm(v.y, v.x, agg.man[1]);
+            }
         }
     }
     aggs[tid] = agg;
@@ -289,9 +296,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
             for (int i = threadIdx.x; i < rows; i += SCAN_BLOCK) ((uint4 *)s_man)[i] = ((const uint4 *)T.man_step)[i];
     }   // the block scan below synchronises before the tables are read
     const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    const size_t base = tid * DEC_ITEMS;
-    uint32_t c[8];
-    load_codes(ecode, base, n, c);
+    const size_t base = tid * DEC_PER_THREAD;
+    uint32_t c[DEC_GROUPS][8];
+#pragma unroll
+    for (int g = 0; g < DEC_GROUPS; g++) load_codes(ecode, base + DEC_ITEMS * g, n, c[g]);
     DecMaps total;
     const DecMaps excl = block_exclusive<ComposeDec>(aggs[tid], lds, total);
     // (own_prefix: the last tile publishes the total)
@@ -299,27 +307,32 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
     uint32_t st = ComposeDec::step(ComposeDec::op(pre, excl), state0);
     const uint16_t *mil = LDS ? s_mil : T.mil_step;
     const uint16_t *man = LDS ? s_man : T.man_step;
-    uint32_t ow[4] = {0u, 0u, 0u, 0u};
+    FramePk mine = FramePkOp::identity();
 #pragma unroll
-    for (int k = 0; k < DEC_ITEMS; k++) {
-        const uint32_t code = (c[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-        const uint32_t li = code & 0x3FFFu, route = code >> 14;
-        uint32_t w = 0;
-        if (route == 2u && T.reader) {
-            const uint32_t e = mil[li * 16u + (st & 15u)];
-            w = e >> 8;
-            st = (st & ~15u) | (e & 15u);
-        } else if (route == 1u && T.tag) {
-            const uint32_t e = man[li * 8u + ((st >> 4) & 7u)];
-            const uint32_t m = e >> 8;
-            w = (m & 3u) ? ((m & 0xFCu) | 3u) : 0u;
-            st = (st & 15u) | ((e & 15u) << 4);
+    for (int g = 0; g < DEC_GROUPS; g++) {
+        uint32_t ow[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < DEC_ITEMS; k++) {
+            const uint32_t code = (c[g][k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            const uint32_t li = code & 0x3FFFu, route = code >> 14;
+            uint32_t w = 0;
+            if (route == 2u && T.reader) {
+                const uint32_t e = mil[li * 16u + (st & 15u)];
+                w = e >> 8;
+                st = (st & ~15u) | (e & 15u);
+            } else if (route == 1u && T.tag) {
+                const uint32_t e = man[li * 8u + ((st >> 4) & 7u)];
+                const uint32_t m = e >> 8;
+                w = (m & 3u) ? ((m & 0xFCu) | 3u) : 0u;
+                st = (st & 15u) | ((e & 15u) << 4);
+            }
+            ow[k >> 2] |= w << (8 * (k & 3));
         }
-        ow[k >> 2] |= w << (8 * (k & 3));
+        const size_t gb = base + (size_t)DEC_ITEMS * g;
+        if (gb < n) *(uint4 *)(outw + gb) = make_uint4(ow[0], ow[1], ow[2], ow[3]);   // outw has 16 bytes of slack
+        mine = FramePkOp::op(mine, FramePkOp::pack(frame_agg_of(ow)));
     }
-    if (base < n) *(uint4 *)(outw + base) = make_uint4(ow[0], ow[1], ow[2], ow[3]);   // outw has 16 bytes of slack
     FramePk total_fa;
-    const FramePk mine = FramePkOp::pack(frame_agg_of(ow));
     *(uint4 *)(thread_aggs + tid) = make_uint4(mine.a[0], mine.a[1], mine.b[0], mine.b[1]);   // (k_frame_write scans them again)
     (void)block_exclusive<FramePkOp>(mine, lds2, total_fa);
     if (threadIdx.x == 0) frame_aggs[blockIdx.x] = FramePkOp::unpack(total_fa);
@@ -415,11 +428,16 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
     __shared__ FrameAgg lds_pre[SCAN_WAVES];
     // own_prefix: tile_pre still holds the tiles' aggregates (scan.hip.h: tile_prefix; first, while few registers are live)
     const FrameAgg pre = own_prefix ? tile_prefix<FrameAggOp, SCAN_BLOCK>(tile_pre, blockIdx.x, lds_pre) : tile_pre[blockIdx.x];
-    const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_ITEMS;
-    uint32_t ow[4] = {0u, 0u, 0u, 0u};
-    if (base < n) {   // k_dec_apply wrote whole 16-byte groups, zero past n
-        const uint4 a = *(const uint4 *)(outw + base);
-        ow[0] = a.x; ow[1] = a.y; ow[2] = a.z; ow[3] = a.w;
+    const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_PER_THREAD;
+    uint32_t ow[DEC_GROUPS][4];
+#pragma unroll
+    for (int g = 0; g < DEC_GROUPS; g++) {
+        ow[g][0] = ow[g][1] = ow[g][2] = ow[g][3] = 0u;
+        const size_t gb = base + (size_t)DEC_ITEMS * g;
+        if (gb < n) {   // k_dec_apply wrote whole 16-byte groups, zero past n
+            const uint4 a = *(const uint4 *)(outw + gb);
+            ow[g][0] = a.x; ow[g][1] = a.y; ow[g][2] = a.z; ow[g][3] = a.w;
+        }
     }
     const uint4 m4 = *(const uint4 *)(thread_aggs + (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x);
     FramePk total;
@@ -431,7 +449,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
         *total_out = all;
         epi(all);
     }
-    if (ow[0] | ow[1] | ow[2] | ow[3]) frame_write(P, FrameAggOp::op(pre, FramePkOp::unpack(in_tile)), ow, base);
+    // a thread's groups in order: each starts from everything before it
+    FrameAgg before = FrameAggOp::op(pre, FramePkOp::unpack(in_tile));
+#pragma unroll
+    for (int g = 0; g < DEC_GROUPS; g++) {
+        if (ow[g][0] | ow[g][1] | ow[g][2] | ow[g][3]) {
+            frame_write(P, before, ow[g], base + (size_t)DEC_ITEMS * g);
+            if (g + 1 < DEC_GROUPS) before = FrameAggOp::op(before, frame_agg_of(ow[g]));
+        }
+    }
 }
 
 // After framing: keep the open packets' bits for the next batch and publish the carry.  Reads nothing that it (or a
