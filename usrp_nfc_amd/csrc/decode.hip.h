@@ -34,7 +34,10 @@ struct DecCarry {
 };
 
 constexpr int DEC_ITEMS = 16;                       // edges per group: one 16-byte load of out-bytes, 32 symbol slots in a word
-constexpr int DEC_GROUPS = 2;                       // groups per thread in the multi-launch stage: a tile's block scans (the
+#ifndef NFC_DEC_GROUPS
+#define NFC_DEC_GROUPS 2
+#endif
+constexpr int DEC_GROUPS = NFC_DEC_GROUPS;          // groups per thread in the multi-launch stage: a tile's block scans (the
                                                     // larger part of k_dec_reduce's instructions) are paid per 32 edges, not 16
 constexpr int DEC_PER_THREAD = DEC_ITEMS * DEC_GROUPS;
 constexpr int DEC_TILE = SCAN_BLOCK * DEC_PER_THREAD;
