@@ -3,7 +3,7 @@
 w=${1:-miller}; tag=${2:-k}
 out=gpurun_out/kstats_$tag
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o $tag -- python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-extras ${KSTATS_ARGS:-} > $out/bench.json 2> $out/log.txt
 python3 - <<PY
 import csv

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/prof.sh <outdir> bench args...   -> per-kernel per-step table
 out=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$out -o p -- python3 bench.py "$@" > gpurun_out/$out.log 2>&1
 python3 - <<PY
 import csv,sys

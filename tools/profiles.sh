@@ -4,7 +4,7 @@
 tag=${1:-r02}
 out=gpurun_out/prof
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o $tag -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity --no-extras --sync-steps > $out/${tag}_bench_under_rocprof.json 2> $out/stats.log
 # the same with batches submitted ahead (--primary ahead): the threshold stage of batch k + 1 beside the later stages of batch k
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_ahead -o ${tag}a -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity --no-extras --primary ahead > $out/${tag}_bench_ahead_under_rocprof.json 2> $out/stats_ahead.log

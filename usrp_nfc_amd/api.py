@@ -115,7 +115,8 @@ class NfcContext(object):
         got = C.c_size_t(0)
         if total:
             self._chk(fn(self.h, *lead, out.ctypes.data, out.size, C.byref(got)), fn.__name__)
-            assert got.value == out.size
+            if got.value != out.size:
+                raise NfcError('%s returned %d of %d items' % (fn.__name__, got.value, out.size))
         return out
 
     def edges(self):
@@ -129,7 +130,8 @@ class NfcContext(object):
         got = C.c_size_t(0)
         if n:
             self._chk(self.L.nfc_read_edges_compact(self.h, 0, pos.ctypes.data, code.ctypes.data, n, C.byref(got)), 'nfc_read_edges_compact')
-            assert got.value == n
+            if got.value != n:
+                raise NfcError('nfc_read_edges_compact returned %d of %d items' % (got.value, n))
         return pos, code
 
     def transitions(self):
