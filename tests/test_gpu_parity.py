@@ -562,9 +562,11 @@ def test_rejected_launch_is_reported(monkeypatch):
     with api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
         ctx.push(iq)
         n_good = len(ctx.edges())
-        monkeypatch.setenv('NFC_DEBUG_BAD_LAUNCH', '1')
+    # (the switch is read once, when a context is created: an environment variable set later changes nothing)
+    monkeypatch.setenv('NFC_DEBUG_BAD_LAUNCH', '1')
+    with api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        monkeypatch.delenv('NFC_DEBUG_BAD_LAUNCH')
         with pytest.raises(api.NfcError) as e:
             ctx.push(iq)
         assert 'kernel launch failed' in str(e.value)
-        monkeypatch.delenv('NFC_DEBUG_BAD_LAUNCH')
     assert n_good > 1000

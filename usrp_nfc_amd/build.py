@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(HERE, 'libnfc_amd.so')
 SOURCES = ['nfc_amd.hip']
-DEPS = ['nfc_amd.hip', 'host_context.h', 'host_threshold.h', 'host_stages.h', 'host_submit.h', 'launch_check.h', 'threshold.hip.h', 'threshold_lean.hip.h', 'edges.hip.h', 'decode.hip.h', 'scan.hip.h', 'small.hip.h', 'tx.hip.h', 'decoder_tables.h', 'protocol.h',
+DEPS = ['nfc_amd.hip', 'host_context.h', 'host_threshold.h', 'host_stages.h', 'host_submit.h', 'launch_check.h', 'threshold.hip.h', 'threshold_lean.hip.h', 'threshold_wg.hip.h', 'edges.hip.h', 'decode.hip.h', 'scan.hip.h', 'small.hip.h', 'tx.hip.h', 'decoder_tables.h', 'protocol.h',
         os.path.join('..', '..', 'include', 'nfc_amd.h')]
 
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
@@ -26,7 +26,7 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return SO
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', SO]
+    cmd = [hipcc] + FLAGS + os.environ.get('NFC_HIPCC_EXTRA', '').split() + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', SO]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

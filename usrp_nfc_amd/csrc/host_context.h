@@ -91,6 +91,9 @@ struct nfc_ctx {
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
     int lean = 1, lean_k = 0, lean_rounds = 0, lean_slots = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
+    int wg = 1, wg_ok = 0, wg_d = 1, wg_slots = 0, wg_now = 0, wg_rounds = 0;   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
+                                                                 // asked for ahead (NFC_WG_D), resident workgroups, this batch uses it
+    size_t wg_lds = 0;
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
     int gring_ok = 0, gring_force = 0, wave_slots_g = 0;   // long windows qualify (NFC_RING=lds|global overrides the choice)
@@ -111,6 +114,9 @@ struct nfc_ctx {
     DecCarry dirty_dcarry;
     bool cert_pending = false;   // the first certification waits to share a launch with the edge stage (k_certify_and_count)
     CertLaunch cert;
+    // debugging switches, read ONCE in nfc_create (an inherited environment must not reach the per-launch path)
+    bool dbg_bad_launch = false, dbg_redo_submitted = false, dbg_no_submit_ahead = false, dbg_any = false, dbg_clk = false, dbg_trace = false;
+    std::string dbg_clk_path;
     uint32_t batch_seq = 0;   // stamped into the state block by every batch's first kernel, checked in the mirror
     int timing = 0;   // 0: no events, 1: the threshold kernels' own start / stop events, 2: + batch total and stages as stream markers (nfc_set_timing)
     hipEvent_t kev[2 * 6] = {};  // start/stop pairs around the first k_threshold launches of a batch
@@ -316,12 +322,25 @@ void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e
     else NFC_LAUNCH((k_threshold<KIND, 4, false>), dim3(blocks), dim3(64 * wpb), lds, c->st, A);
 }
 // Pass 0 with the LDS ring: the lean optimistic kernel (threshold_lean.hip.h); chunks it gives up on are re-run by k_threshold.
+// ... or, where it applies, with a chunk per workgroup (threshold_wg.hip.h)
+template <int KIND>
+void launch_wg(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipEvent_t e1) {
+    const size_t lds = c->wg_lds + (c->dbg_bad_launch ? (size_t)1 << 20 : 0);
+    auto go = [&](auto kern) {
+        if (e0) NFC_LAUNCH_EXT(kern, dim3(nwork), dim3(256), lds, c->st, e0, e1, 0, A);
+        else NFC_LAUNCH(kern, dim3(nwork), dim3(256), lds, c->st, A);
+    };
+    const bool b16 = (1 << c->nfold) == 16;
+    if (c->wg_d == 2) { if (b16) go(k_threshold_wg<KIND, 2, true>); else go(k_threshold_wg<KIND, 2, false>); }
+    else { if (b16) go(k_threshold_wg<KIND, 1, true>); else go(k_threshold_wg<KIND, 1, false>); }
+}
 template <int KIND>
 void launch_lean(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipEvent_t e1) {
+    if (c->wg_now) return launch_wg<KIND>(c, A, nwork, e0, e1);
     const uint32_t wpb = (uint32_t)c->wpb;
     const uint32_t blocks = (nwork + wpb - 1) / wpb;
     // (NFC_DEBUG_BAD_LAUNCH: a dynamic-LDS request the runtime must reject -- the test of the launch checks)
-    const size_t lds = (size_t)wpb * c->Lpad * c->lds_per_slot + (getenv("NFC_DEBUG_BAD_LAUNCH") ? (size_t)1 << 20 : 0);
+    const size_t lds = (size_t)wpb * c->Lpad * c->lds_per_slot + (c->dbg_bad_launch ? (size_t)1 << 20 : 0);
     auto go = [&](auto kern) {
         if (e0) NFC_LAUNCH_EXT(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, e0, e1, 0, A);
         else NFC_LAUNCH(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, A);

@@ -21,7 +21,7 @@ namespace {
 // batch submitted ahead against 2.7 ms one after the other) -- such batches take the synchronous path inside nfc_wait.
 bool submit_fast_ok(const nfc_ctx *c, uint32_t n) {
     return c->h_carry.stable && !(c->P.flags & (NFC_FLAG_NO_EDGES | NFC_FLAG_FORCE_SEQUENTIAL)) && c->L >= STEP && c->timing < 2 &&
-           !(c->use_small && n <= SM_MAX_SAMPLES) && n > 0 && c->lean_lds_per_cu <= 96 * 1024 && !getenv("NFC_DEBUG") && !getenv("NFC_DEBUG_CLK") && !getenv("NFC_NO_SUBMIT_AHEAD");
+           !(c->use_small && n <= SM_MAX_SAMPLES) && n > 0 && c->lean_lds_per_cu <= 96 * 1024 && !c->dbg_any && !c->dbg_clk && !c->dbg_no_submit_ahead;
 }
 
 // the threshold stage of a submitted batch, on st_a, into a free set of planes; b.fast is cleared when the batch turns out
@@ -56,7 +56,7 @@ int enqueue_threshold_ahead(nfc_ctx *c, nfc_ctx::Submitted &b) {
     A.mode = 0;
     A.cert = P.d_cert;
     A.sum = (CertSummary *)(dT(c) + TOT_CERT);
-    A.ksteps = c->lean_rounds;
+    A.ksteps = c->wg_now ? c->wg_rounds : c->lean_rounds;
     A.gfac = c->lean_gfac;
     A.gfloor = c->lean_gmin;
     A.blk = 1 << c->nfold;
@@ -240,7 +240,7 @@ int wait_batch(nfc_ctx *c) {
     if (summary.n_fail != 0) regular = false, why = "a chunk was not certified";
     else if (summary.flagged || !sums_exact(after, (int)summary.emin, (int)summary.emax, summary.vtop)) regular = false, why = "sums not provably exact";
     else if (!(ne <= c->cap_edges && ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1])) regular = false, why = "a capacity estimate was too small";
-    if (getenv("NFC_DEBUG_REDO_SUBMITTED") && (c->dbg_fast_waits++ % 3u) == 2u) regular = false, why = "test hook";   // every third batch that ran ahead
+    if (c->dbg_redo_submitted && (c->dbg_fast_waits++ % 3u) == 2u) regular = false, why = "test hook";   // every third batch that ran ahead
     if (regular) {
         c->h_carry = after;
         c->h_ecarry = c->hs->ecarry;
@@ -272,7 +272,7 @@ int wait_batch(nfc_ctx *c) {
     // The optimistic result does not stand: everything in flight is drained, the batch goes through the synchronous path
     // from the state before it (the host mirrors were last adopted there; its window buffer was not written since), and
     // the batches behind it start again from what that leaves.
-    if (getenv("NFC_TRACE")) fprintf(stderr, "[nfc] submitted batch %u processed again: %s\n", b.seq, why);
+    if (c->dbg_trace) fprintf(stderr, "[nfc] submitted batch %u processed again: %s\n", b.seq, why);
     HIPCHK(c, hipStreamSynchronize(c->st_a));
     HIPCHK(c, hipStreamSynchronize(c->st));
     c->stats_redo_submitted++;

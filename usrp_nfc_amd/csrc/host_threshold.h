@@ -51,14 +51,18 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     // shortened).  So the global ring is only taken on request (NFC_RING=global) or where the lean kernel does not apply.
     const bool lean_applies = c->lean && c->P.input_kind != NFC_IN_ENV_F32 && c->mx <= 500;
     c->gring = c->gring_ok && (c->gring_force || (!lean_applies && (uint64_t)n >= (uint64_t)c->wave_slots_g * 8u * (uint64_t)c->L));
+    // ... with a chunk per WORKGROUP where that kernel applies (threshold_wg.hip.h: max_len within one step, a ring that holds a round)
+    c->wg_now = lean_applies && c->wg && c->wg_ok && !c->gring;
     if (!c->P.chunk_samples) {
-        const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : (lean_applies ? c->lean_slots : c->wave_slots));
-        // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps)
-        const int stp = 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
+        const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : (c->wg_now ? c->wg_slots : (lean_applies ? c->lean_slots : c->wave_slots)));
+        // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps;
+        // the workgroup kernel whole rounds of four)
+        const int stp = c->wg_now ? WG_ROUND : 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
         uint64_t want = ((uint64_t)n + slots - 1) / slots;
         want = (want + stp - 1) / stp * stp;
         c->C = (int)std::max<uint64_t>(want, (uint64_t)c->C_min);
     }
+    if (c->wg_now && c->C % WG_ROUND != 0) c->wg_now = 0;   // (a configured chunk length that is not whole rounds: the one-wave kernel)
     const uint32_t off = 0u;   // (chunk c covers samples [c*C - off, (c+1)*C - off): the kernels here use off = 0)
     const uint32_t nch = (uint32_t)(((uint64_t)n + off + c->C - 1) / c->C);
     c->stats.n_chunks = nch;
@@ -200,13 +204,13 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                                                                     // max_len beyond 500 samples: not exercised, left to k_threshold)
         A.cert = d_cert;
         A.sum = (CertSummary *)(dT(c) + TOT_CERT);
-        A.ksteps = c->lean_rounds;
+        A.ksteps = c->wg_now ? c->wg_rounds : c->lean_rounds;
         A.gfac = c->lean_gfac;
         A.gfloor = c->lean_gmin;
         A.blk = 1 << c->nfold;
-        const bool dbg_clk = lean && getenv("NFC_DEBUG_CLK") != nullptr;
+        const bool dbg_clk = lean && c->dbg_clk;
         if (dbg_clk) {
-            HIPCHK(c, c->d_certinfo.ensure((size_t)nch * 32));
+            HIPCHK(c, c->d_certinfo.ensure((size_t)nch * 32 * 5));   // (+ 4 waves x 4 counters per chunk in a profiling build)
             A.dbg_clk = c->d_certinfo.as<unsigned long long>();
         }
         launch_threshold_kind(c, A, nch, lean);
@@ -227,10 +231,26 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 maxtot = std::max(maxtot, (double)(h[4 * k + 3] - h[4 * k]));
                 maxstart = std::max(maxstart, (double)(h[4 * k] - t0));
             }
+#ifdef NFC_WG_PROF
+            if (c->wg_now) {
+                std::vector<unsigned long long> pf((size_t)nch * 16);
+                HIPCHK(c, hipMemcpy(pf.data(), (char *)c->d_certinfo.p + (size_t)nch * 32, (size_t)nch * 128, hipMemcpyDeviceToHost));
+                double tk = 0, b1 = 0, b2 = 0, rr = 0;
+                for (size_t k = 0; k < (size_t)nch * 4; k++) {
+                    tk += (double)pf[4 * k];
+                    b1 += (double)pf[4 * k + 1];
+                    b2 += (double)pf[4 * k + 2];
+                    rr += (double)pf[4 * k + 3];
+                }
+                const double nw = (double)nch * 4;
+                fprintf(stderr, "[nfc] wg kernel, per wave: %.0f rounds; ticks waiting for samples %.0f, at the first barrier %.0f, at the closing barrier %.0f\n",
+                        rr / nw, tk / nw, b1 / nw, b2 / nw);
+            }
+#endif
             fprintf(stderr, "[nfc] lean kernel, %u chunks, s_memtime ticks: first start .. last end %llu; per wave: incoming state %.0f, loop %.0f, "
                     "summary %.0f, longest wave %.0f, latest start %.0f\n", nch, t1 - t0, pro / nch, loop / nch, epi / nch, maxtot, maxstart);
-            if (const char *path = getenv("NFC_DEBUG_CLK")) {
-                if (path[0] == '/' || path[0] == '.' || path[0] == 'g') {   // a file name: the raw stamps, for tools/clk_hist.py
+            if (const char *path = c->dbg_clk_path.c_str()) {
+                if (path[0] == '/' || path[0] == '.' || path[0] == 'g') {   // a file name: the raw stamps
                     if (FILE *f = fopen(path, "wb")) {
                         fwrite(h.data(), 8, h.size(), f);
                         fclose(f);
@@ -244,7 +264,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
 
         // certify; re-run what cannot be proven from the exact (look-back) state; certify again what can
         // see a re-run chunk.  Every round makes at least the first pending chunk final.
-        const bool dbg = getenv("NFC_DEBUG") != nullptr;
+        const bool dbg = c->dbg_any;
         bool first_round = true;
         c->h_list.clear();
         for (uint32_t k = 1; k < nch; k++) c->h_list.push_back(k);
@@ -306,7 +326,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             if (first_round && lean && !h_cert[0]) failing.push_back(0);   // chunk 0 gave up: re-run from the carried state
             for (uint32_t k : c->h_list)
                 if (!h_cert[k]) failing.push_back(k);
-            if (getenv("NFC_TRACE")) {
+            if (c->dbg_trace) {
                 fprintf(stderr, "[nfc] round %d: n_fail %u, %zu failing of %u pending (cert[0] %d):", rounds, summary.n_fail, failing.size(), np, (int)h_cert[0]);
                 for (size_t i = 0; i < failing.size() && i < 12; i++) fprintf(stderr, " %u", failing[i]);
                 fprintf(stderr, "\n");

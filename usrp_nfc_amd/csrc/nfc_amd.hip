@@ -43,6 +43,7 @@
 #include "small.hip.h"
 #include "threshold.hip.h"
 #include "threshold_lean.hip.h"
+#include "threshold_wg.hip.h"
 #include "tx.hip.h"
 
 using namespace nfc;
@@ -55,6 +56,20 @@ using namespace nfc;
 // ===========================================================================
 // C-ABI
 // ===========================================================================
+namespace {
+// the instantiation of k_threshold_wg a context launches (for the occupancy query and the LDS attribute)
+const void *wg_kernel_of(int kind, int d, bool b16) {
+#define WGK(K) (d == 2 ? (b16 ? (const void *)k_threshold_wg<K, 2, true> : (const void *)k_threshold_wg<K, 2, false>) \
+                       : (b16 ? (const void *)k_threshold_wg<K, 1, true> : (const void *)k_threshold_wg<K, 1, false>))
+    switch (kind) {
+    case NFC_IN_IQ_F32: return WGK(IN_IQ_F32);
+    case NFC_IN_REAL_F32_SQ: return WGK(IN_REAL_F32_SQ);
+    default: return WGK(IN_I16_SQ);
+    }
+#undef WGK
+}
+}  // namespace
+
 extern "C" {
 
 int nfc_abi_version(void) { return NFC_AMD_ABI_VERSION; }
@@ -92,6 +107,19 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     C = std::max(C, c->mx + 2);
     c->rows_per_step = 4;
     c->use_small = getenv("NFC_NO_SMALL") ? 0 : 1;
+    // every debugging switch is read here, once: nothing on the per-launch path looks at the environment
+    c->dbg_bad_launch = getenv("NFC_DEBUG_BAD_LAUNCH") != nullptr;
+    c->dbg_redo_submitted = getenv("NFC_DEBUG_REDO_SUBMITTED") != nullptr;
+    c->dbg_no_submit_ahead = getenv("NFC_NO_SUBMIT_AHEAD") != nullptr;
+    c->dbg_any = getenv("NFC_DEBUG") != nullptr;
+    c->dbg_trace = getenv("NFC_TRACE") != nullptr;
+    if (const char *e = getenv("NFC_DEBUG_CLK")) {
+        c->dbg_clk = true;
+        c->dbg_clk_path = e;
+    }
+    if (const char *e = getenv("NFC_WG")) c->wg = atoi(e) != 0;
+    if (const char *e = getenv("NFC_WG_D")) c->wg_d = atoi(e) >= 2 ? 2 : 1;
+    if (const char *e = getenv("NFC_WG_ROUNDS")) c->wg_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("NFC_LEAN")) c->lean = atoi(e) != 0;
     c->lean_k = 0;        // chosen below from the occupancy the LDS ring allows, unless set here
     c->lean_rounds = 0;
@@ -177,6 +205,22 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         // LDS the lean kernel's resident waves hold per CU: a batch is only run ahead of its predecessor's edge / decode stages
         // (nfc_submit_device) while those stages' workgroups (25 KB each) still fit beside it
         c->lean_lds_per_cu = (size_t)((c->lean_slots + prop.multiProcessorCount - 1) / prop.multiProcessorCount) * lds_wave;
+        // the workgroup kernel: one chunk per 256-thread workgroup, as many resident per CU as LDS and registers admit
+        c->wg_lds = (size_t)c->Lpad * 4 + WG_SHARED_BYTES;
+        c->wg_ok = p->input_kind != NFC_IN_ENV_F32 && c->mx <= 254 && c->L >= WG_ROUND && c->wg_lds <= 160 * 1024;
+        if (c->wg_ok) {
+            const void *kern = wg_kernel_of(p->input_kind, c->wg_d, (1 << c->nfold) == 16);
+            if (c->wg_lds > 64 * 1024) CRT(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->wg_lds));
+            int per_cu_wg = 0;
+            CRT(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wg, kern, 256, c->wg_lds));
+            per_cu_wg = std::max(1, std::min(4, per_cu_wg));   // (measured: four resident workgroups per CU -- four waves per SIMD -- beat five and three)
+            if (const char *e = getenv("NFC_WG_PER_CU")) per_cu_wg = std::max(1, std::min(per_cu_wg, atoi(e)));
+            c->wg_slots = prop.multiProcessorCount * per_cu_wg;
+            // rounds per superstep: its drift allowance grows with its length relative to the window (0.8 windows: beyond, the
+            // widened HIGH band reaches the loaded half bits of tag frames -- 1 % of the chunks gave up at twice that)
+            if (!c->wg_rounds) c->wg_rounds = std::max(1, (int)(0.8 * c->L / (double)WG_ROUND + 0.5));
+            if (c->wg) c->lean_lds_per_cu = (size_t)per_cu_wg * c->wg_lds;
+        }
     }
     CRT(hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking));
     c->st = c->own_st;

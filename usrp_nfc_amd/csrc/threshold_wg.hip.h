@@ -1,0 +1,879 @@
+// threshold_wg.hip.h -- pass 0 of the threshold stage (transition_sink.py:55-82) with a time chunk per WORKGROUP.
+//
+// k_threshold_lean (threshold_lean.hip.h) walks a chunk with ONE wave, so the number of waves on the machine equals the number
+// of chunks, and every chunk pays a window of speculation before it and a summary after it: occupancy could only be bought
+// with more of those.  Here the four waves of a workgroup share one chunk and one LDS ring:
+//
+//   * a ROUND is four steps of 256 samples; wave w takes step w of every round.  Given the thresholds of the round the four
+//     steps are independent (the proof of threshold_lean.hip.h: classifications against bands widened by the drift allowance
+//     G are the reference's while the accepted |x - prev| of the round sum to <= G), and their ring slots are disjoint while
+//     1024 <= L;
+//   * what a step needs of the samples before it is one thing only: where the last LOW sample lies, if within max_len + 1
+//     ("HIGH is ignored", transition_sink.py:71) -- with max_len <= 254 that is inside the step before, whose LOW masks its
+//     wave publishes in LDS before the round's first barrier (phase A: envelopes, pre-tests, LOW masks; phase B: ring update);
+//   * the round closes with one exchange of (B, D, failure) per wave and a second barrier; every wave then moves the tracked
+//     sum and opens the next round with the same arithmetic, so nothing is broadcast;
+//   * LOW runs longer than max_len are found by the aligned-block test alone (a run longer than max_len covers an aligned block
+//     of A.blk samples wherever step seams fall); only the run a chunk STARTS in is measured against the carried length;
+//   * rounds that are not four whole steps of stable samples (the stream's first stable sample, a batch's ragged end) take the
+//     masked general form in every wave, on synchronously loaded samples;
+//   * speculation, the saved incoming ring and the summary are spread over the 256 threads.
+//
+// Everything else is as in k_threshold_lean: nothing is repaired in place -- a failed check makes the whole workgroup give up
+// its chunk, which the host re-runs with k_threshold from the exact state.  Same summaries (ChunkInfo, RunMeta, ring_in,
+// ring_out, touched), so certification and re-runs do not know which kernel ran.
+#pragma once
+#include "threshold_lean.hip.h"
+
+namespace nfc {
+
+constexpr int WG_WAVES = 4;
+constexpr int WG_ROUND = 256 * WG_WAVES;
+// LDS behind the ring: LOW masks of the rounds' steps, the close exchange, scratch for workgroup reductions
+struct WgShared {
+    uint32_t msk[3][WG_WAVES][20];     // per round (modulo three) and wave: the four LOW masks of its step (dwords 0 .. 7), dword 16: any LOW sample
+    float red[4][WG_WAVES];            // close of a superstep: B, D, failure code (as bits) of every wave
+    uint32_t scr[2][WG_WAVES][8];      // workgroup reductions (alternating halves: one barrier per reduction)
+    int32_t fin[WG_WAVES][4];          // chunk end: last LOW index, last non-LOW index, latest step with LOW samples
+    float2 acc[WG_WAVES][64];          // close of a superstep: every lane's (sum |x - prev|, sum (x - prev)) over what it accepted
+    uint32_t flag[WG_WAVES];           // ... and every wave's failure code
+    float bc[8];                       // ... and what wave 0 makes of them: the next thresholds, the sum, the allowance, the verdict
+};
+constexpr size_t WG_SHARED_BYTES = (sizeof(WgShared) + 15) & ~(size_t)15;
+
+// The workgroup's barrier without the fence __syncthreads() brings: that fence waits for EVERY vector memory operation of the
+// wave (s_waitcnt vmcnt(0)) -- the samples asked for ahead included.  LDS traffic of this wave is complete (lgkmcnt) before it
+// arrives; the asm statement is a compiler barrier for memory accesses as well.
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The 256 samples at base (uniform) + voff (this lane's byte offset) into a[0 .. 7], as lean_load_step<KIND, 0> -- with the
+// address split into a scalar base and a 32-bit lane offset, so that walking the chunk costs scalar additions only.
+#define WG_LOAD4(OP, R0, R1, R2, R3, STRIDE, ...)                                                                                            \
+    asm volatile(OP " " R0 ", %0, %1\n\t" OP " " R1 ", %0, %1 offset:%2\n\t" OP " " R2 ", %0, %1 offset:%3\n\t" OP " " R3 ", %0, %1 offset:%4" \
+                 :                                                                                                                          \
+                 : "v"(voff), "s"(base), "n"(STRIDE), "n"(2 * STRIDE), "n"(3 * STRIDE)                                                      \
+                 : "memory", __VA_ARGS__)
+template <int KIND, int K>
+__device__ __forceinline__ void wg_load_step(uint32_t voff, const char *base) {
+    static_assert(K == 0 || K == 1, "two rounds of registers");
+    if constexpr (KIND == IN_IQ_F32) {
+        if constexpr (K == 0) WG_LOAD4("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", 512, LEAN_CLOB0);
+        else WG_LOAD4("global_load_dwordx2", "a[8:9]", "a[10:11]", "a[12:13]", "a[14:15]", 512, LEAN_CLOB1);
+    } else if constexpr (KIND == IN_I16_SQ) {
+        if constexpr (K == 0) WG_LOAD4("global_load_sshort", "a0", "a1", "a2", "a3", 128, LEAN_CLOB0);
+        else WG_LOAD4("global_load_sshort", "a8", "a9", "a10", "a11", 128, LEAN_CLOB1);
+    } else {
+        if constexpr (K == 0) WG_LOAD4("global_load_dword", "a0", "a1", "a2", "a3", 256, LEAN_CLOB0);
+        else WG_LOAD4("global_load_dword", "a8", "a9", "a10", "a11", 256, LEAN_CLOB1);
+    }
+}
+
+template <int KIND, int D, bool BLK16>
+__global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
+    static_assert(KIND != IN_ENV_F32, "raw envelopes may be negative: no sign bit to spare (they take k_threshold)");
+    static_assert(D == 1 || D == 2, "rounds of samples asked for ahead");
+    constexpr int NR = 4;
+    constexpr uint32_t STEPN = 64u * NR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = rfl(tid >> 6);
+    const uint32_t c = blockIdx.x;
+    float *ring = (float *)smem;
+    lean_lds_f *const rl = (lean_lds_f *)ring;
+    WgShared *const sh = (WgShared *)(smem + (size_t)A.Lpad * 4);
+    const int L = A.L;
+    const int mx = A.mx;
+    const uint32_t m_chunk = c * (uint32_t)A.C;
+    const uint32_t n1 = min(A.n, m_chunk + (uint32_t)A.C);
+    const uint32_t m_start = max(m_chunk, A.skip);
+    const Carry cr = *A.carry;
+    uint64_t *const neg_p = A.neg, *const pos_p = A.pos;
+    // lanes 0 .. 7 hold the neg plane's dwords of a step, 8 .. 15 the pos plane's
+    const uintptr_t plane_of_lane = (lane & 8) ? (uintptr_t)pos_p : (uintptr_t)neg_p;
+    const float i16s = A.i16_scale;
+    const float gfac = A.gfac, gfloor = A.gfloor;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    int scr_par = 0;
+    // sum / max / min of K values over the workgroup (every thread gets the result; uniform)
+    auto wg_gather = [&](const uint32_t (&v)[8], int k, uint32_t (&out)[WG_WAVES][8]) __attribute__((always_inline)) {
+        if (lane == 0)
+            for (int i = 0; i < k; i++) sh->scr[scr_par][wave][i] = v[i];
+        wg_barrier();
+        for (int w = 0; w < WG_WAVES; w++)
+            for (int i = 0; i < k; i++) out[w][i] = rfl(sh->scr[scr_par][w][i]);
+        scr_par ^= 1;
+    };
+
+    unsigned long long clk0 = 0, clk1 = 0, clk2 = 0;
+#ifdef NFC_WG_PROF
+    unsigned long long pf_take = 0, pf_b1 = 0, pf_b2 = 0, pf_rounds = 0, pf_t = 0;   // (a profiling build: where a wave waits)
+#define WG_PF_BEGIN() pf_t = clock64()
+#define WG_PF_END(acc) acc += clock64() - pf_t
+#else
+#define WG_PF_BEGIN() ((void)0)
+#define WG_PF_END(acc) ((void)0)
+#endif
+    if (A.dbg_clk) clk0 = clock64();
+
+    // ---------------- the state the chunk starts from (chunk_incoming / chunk_save_in of threshold.hip.h, 256 threads wide) ----------------
+    uint32_t emin = 255u, emax = 0u, vtop0 = 0u;
+    int nl_in, kl_in;
+    float ssf, eps = 0.f;
+    {
+        double ss0;
+        if (c == 0) {
+            for (int s = tid; s < L; s += 256) ring[s] = A.ring_carry[s];
+            ss0 = cr.ss;
+            nl_in = carried_nl(A);
+            kl_in = carried_kl(A);
+            wg_barrier();
+        } else {
+            // speculate: the L samples before the chunk, rejected-looking ones replaced by a level estimate
+            eps = A.eps;
+            const uint32_t w0 = m_chunk - (uint32_t)L;
+            const uint32_t slot0 = (A.g0modL + w0) % (uint32_t)L;
+            float mxv = 0.f;
+            for (int i0 = 0; i0 < L; i0 += 2048) {   // eight independent loads in flight per thread
+                typename RawOf<KIND>::T rw[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = i0 + 256 * k + tid;
+                    rw[k] = (i < L) ? load_raw<KIND>(A.in, (size_t)w0 + i) : raw_zero<KIND>();
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = i0 + 256 * k + tid;
+                    if (i < L) {
+                        const float x = env_of<KIND>(rw[k], A.i16_scale);
+                        uint32_t slot = slot0 + (uint32_t)i;
+                        slot = (slot >= (uint32_t)L) ? slot - (uint32_t)L : slot;
+                        ring[slot] = x;
+                        mxv = fmaxf(mxv, x);
+                    }
+                }
+            }
+            uint32_t v[8], g[WG_WAVES][8];
+            v[0] = __float_as_uint(wave_max_f32(mxv));   // (envelopes are >= 0: raw bits order like values)
+            wg_gather(v, 1, g);                          // (its barrier also completes the ring)
+            mxv = __uint_as_float(max(max(g[0][0], g[1][0]), max(g[2][0], g[3][0])));
+            const float half = 0.5f * mxv;
+            float sa = 0.f, na = 0.f;
+            for (int s = tid; s < L; s += 256) {
+                const float x = ring[s];
+                if (x >= half) { sa += x; na += 1.f; }
+            }
+            v[0] = __float_as_uint(wave_sum_f32(sa));
+            v[1] = __float_as_uint(wave_sum_f32(na));
+            wg_gather(v, 2, g);
+            sa = ((__uint_as_float(g[0][0]) + __uint_as_float(g[1][0])) + __uint_as_float(g[2][0])) + __uint_as_float(g[3][0]);
+            na = ((__uint_as_float(g[0][1]) + __uint_as_float(g[1][1])) + __uint_as_float(g[2][1])) + __uint_as_float(g[3][1]);
+            const float ca = (na > 0.f) ? sa / na : mxv;
+            float sb = 0.f, nb = 0.f;
+            for (int s = tid; s < L; s += 256) {
+                const float x = ring[s];
+                if (x >= half && x <= ca) { sb += x; nb += 1.f; }
+            }
+            v[0] = __float_as_uint(wave_sum_f32(sb));
+            v[1] = __float_as_uint(wave_sum_f32(nb));
+            wg_gather(v, 2, g);
+            sb = ((__uint_as_float(g[0][0]) + __uint_as_float(g[1][0])) + __uint_as_float(g[2][0])) + __uint_as_float(g[3][0]);
+            nb = ((__uint_as_float(g[0][1]) + __uint_as_float(g[1][1])) + __uint_as_float(g[2][1])) + __uint_as_float(g[3][1]);
+            const float c0 = (nb > 0.f) ? sb / nb : ca;
+            const float tlo = (float)A.lo * c0, thi = (float)A.hi * c0;
+            // ring slot s last saw sample m = w0 + ((s - slot0) mod L)
+            int ll = LL_NONE, nl = LL_NONE;
+            double part = 0;
+            for (int s = tid; s < L; s += 256) {
+                const int rel = (s >= (int)slot0) ? s - (int)slot0 : s - (int)slot0 + L;
+                const int m = (int)w0 + rel;
+                float x = ring[s];
+                if (x < tlo) ll = max(ll, m);
+                else nl = max(nl, m);
+                if (!(x >= tlo && x <= thi)) {
+                    x = c0;
+                    ring[s] = c0;
+                }
+                part += (double)x;
+            }
+            const double ps = wave_sum_f64(part);
+            v[0] = (uint32_t)wave_max_i32(ll);
+            v[1] = (uint32_t)wave_max_i32(nl);
+            v[2] = (uint32_t)__double2loint(ps);
+            v[3] = (uint32_t)__double2hiint(ps);
+            wg_gather(v, 4, g);
+            ll = max(max((int)g[0][0], (int)g[1][0]), max((int)g[2][0], (int)g[3][0]));
+            nl_in = max(max((int)g[0][1], (int)g[1][1]), max((int)g[2][1], (int)g[3][1]));
+            kl_in = (ll == LL_NONE) ? KEY_NONE : 2 * ll + 1;
+            double tot = 0;
+            for (int w = 0; w < WG_WAVES; w++) tot += __hiloint2double((int)g[w][3], (int)g[w][2]);
+            ss0 = tot + cr.delta;
+        }
+        ssf = rfl((float)ss0);
+        // keep the ring the evaluation starts from (for k_certify), mark every slot untouched, fold the exponent guard
+        float *rin = A.ring_in + (size_t)c * L;
+        for (int s = tid; s < L; s += 256) {
+            const float v = ring[s];
+            rin[s] = v;
+            vtop0 = max(vtop0, __float_as_uint(v));
+            ring[s] = __uint_as_float(__float_as_uint(v) | 0x80000000u);
+            if (v != 0.f) {
+                const uint32_t e = max(f32_expfield(v), 1u);
+                emin = min(emin, e);
+                emax = max(emax, e);
+            }
+        }
+        uint32_t v[8], g[WG_WAVES][8];
+        v[0] = wave_max_u32(vtop0);
+        v[1] = wave_min_u32(emin);
+        v[2] = wave_max_u32(emax);
+        wg_gather(v, 3, g);   // (its barrier: every slot carries its sign bit before the first round reads the ring)
+        vtop0 = max(max(g[0][0], g[1][0]), max(g[2][0], g[3][0]));
+        emin = min(min(g[0][1], g[1][1]), min(g[2][1], g[3][1]));
+        emax = max(max(g[0][2], g[1][2]), max(g[2][2], g[3][2]));
+    }
+    nl_in = rfl(nl_in);
+    kl_in = rfl(kl_in);
+
+    if (A.dbg_clk) clk1 = clock64();
+    bool good_run = A.fast_ok != 0;
+    uint32_t why = good_run ? 0u : 1u;   // 1 parameters / sums out of range, 2 a sample inside a band, 3 LOW run, 4 allowance, 5 first stable sample
+    float min_ss = 3.0e38f;
+    uint32_t vmin = 0xFFFFFFFFu, vmax = vtop0;
+    const float etaD = 1.0f - 9.5367431640625e-07f;  // 1 - 2^-20
+    const float slD = 1.0f - 3.814697265625e-06f, slU = 1.0f + 3.814697265625e-06f;
+    const float loLf = (float)A.lo_L, hiLf = (float)A.hi_L;
+    constexpr int RB = LeanRaw<KIND>::BYTES;
+    const uint32_t wbase0 = m_chunk + STEPN * (uint32_t)wave;   // this wave's step of round 0
+    uint32_t slot_step = (A.g0modL + wbase0) % (uint32_t)L;
+    const uint32_t slot_adv = (uint32_t)WG_ROUND % (uint32_t)L;
+    float G = ssf * 0.00390625f;
+    float Bneed = 0.f;
+    float b_acc = 0.f, dl_acc = 0.f;
+    float tlo_dn = 0.f, tlo_up = 0.f, thi_dn = 0.f, thi_up = 0.f;
+    uint32_t amb_lo = 0xFFFFFFFFu, amb_hi = 0xFFFFFFFFu;
+    uint32_t lrun = 0x7F7FFFFFu;
+    int my_ll = LL_NONE, my_nl = LL_NONE;   // last LOW / non-LOW sample of this wave's steps (kept exactly over the chunk's last rounds)
+    int lz_base = LL_NONE;                  // base of this wave's latest step with LOW samples
+    int rounds_since_sync = 0;
+
+    auto open_round = [&]() __attribute__((always_inline)) -> bool {
+        const float M = rfl(G + (eps + RND_SUM) * ssf);
+        const float dn = (ssf - M) * slD, up = (ssf + M) * slU;
+        tlo_dn = rfl(dn * loLf);
+        tlo_up = rfl(up * loLf);
+        thi_dn = rfl(dn * hiLf);
+        thi_up = rfl(up * hiLf);
+        if (!(ssf > 1e-30f && ssf < 1e30f && M < 0.25f * ssf && tlo_dn > 1e-30f && thi_up < 1e30f)) return false;
+        min_ss = fminf(min_ss, ssf * (etaD - RND_SUM));
+        vmax = max(vmax, __float_as_uint(up));
+        vmin = min(vmin, __float_as_uint(tlo_dn));
+        return true;
+    };
+    auto fetch_env = [&](uint32_t b, float (&x)[NR]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const uint32_t m = b + 64u * j + lane;
+            x[j] = (m < A.n) ? envelope_at<KIND>(A.in, (size_t)m, A.i16_scale) : 0.f;
+        }
+    };
+
+    // ---------------- the general step on wave masks (phase B) ----------------
+    // masked: lanes outside [m_start, n1) are not samples.  before: the last LOW sample before the step (LL_NONE: none in reach);
+    // carry_run: length of the LOW run the CHUNK starts in (its first step only).
+    auto general_step = [&](float (&x)[NR], const uint32_t base, const bool masked, int before, const int carry_run, int &pk) __attribute__((always_inline)) -> uint32_t {
+        float prev[NR];
+        uint32_t slot[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            uint32_t s = slot_step + 64u * j + lane;
+            s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
+            slot[j] = s;
+            prev[j] = fabsf(ring[s]);
+        }
+        unsigned long long unt[NR] = {0, 0, 0, 0}, am[NR] = {~0ull, ~0ull, ~0ull, ~0ull};
+        if (masked) {
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const uint32_t m = base + 64u * j + lane;
+                const bool inact = (m < m_start) || (m >= n1);
+                const bool untouched = (__float_as_uint(ring[slot[j]]) >> 31) != 0u;
+                unt[j] = __ballot(inact && untouched);
+                am[j] = __ballot(!inact);
+                if (inact) x[j] = prev[j];
+            }
+        }
+        unsigned long long lowm[NR], posm[NR], good = ~0ull, anylow = 0;
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const unsigned long long lo1 = __ballot(x[j] < tlo_dn), lo0 = __ballot(x[j] > tlo_up);
+            const unsigned long long hi1 = __ballot(x[j] > thi_up), hi0 = __ballot(x[j] < thi_dn);
+            unsigned long long g = (lo1 | lo0) & (hi1 | hi0);
+            lowm[j] = lo1;
+            posm[j] = hi1;
+            g |= ~am[j];
+            lowm[j] &= am[j];
+            posm[j] &= am[j];
+            good &= g;
+            anylow |= lowm[j];
+        }
+        if (good != ~0ull) return 2u;
+        if (anylow) {
+            const int lead = (lowm[0] == ~0ull) ? 64 : (__ffsll((long long)~lowm[0]) - 1);
+            unsigned long long pre = 0;
+#pragma unroll
+            for (int j = 0; j < NR; j++) pre |= lowm[j] & (lowm[j] >> A.probe_mid) & (lowm[j] >> A.probe_end);
+            unsigned long long hit = 0;
+            if (pre & A.selmask) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    unsigned long long t = lowm[j];
+#pragma unroll
+                    for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
+                    hit |= t & A.selmask;
+                }
+            }
+            if (hit || ((carry_run > 0) && (carry_run + lead > mx))) return 3u;
+            if (masked && base < m_start) return 5u;   // (a LOW run across the first stable sample: leave it to the exact kernel)
+        }
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            // HIGH is ignored within max_len + 1 samples after a LOW sample
+            const int rb = (int)(base + 64u * j);
+            const unsigned long long below = lowm[j] & lane_lt;
+            const int lastlow = below ? rb + last_set(below) : before;
+            const bool ps = (x[j] > thi_up) && ((rb + lane - lastlow) > mx + 1);
+            const bool a = !(x[j] < tlo_dn) && !ps;
+            const float t = x[j] - prev[j];
+            if (a) {
+                b_acc += fabsf(t);
+                dl_acc += t;
+                ring[slot[j]] = x[j];
+            }
+            const uint32_t xb = __float_as_uint(x[j]);
+            vmin = min(vmin, (a && xb != 0u) ? xb : 0xFFFFFFFFu);
+            vmax = max(vmax, a ? xb : 0u);
+            posm[j] = __ballot(ps);
+            posm[j] &= am[j];
+            before = lowm[j] ? rb + last_set(lowm[j]) : before;
+        }
+        int step_nl = LL_NONE, step_ll = LL_NONE;
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const int rb = (int)(base + 64u * j);
+            const unsigned long long nonlow = ~lowm[j] & am[j];
+            if ((unt[j] >> lane) & 1ull) ring[slot[j]] = __uint_as_float(__float_as_uint(x[j]) | 0x80000000u);
+            step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
+            step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
+        }
+        my_ll = (step_ll != LL_NONE) ? step_ll : my_ll;
+        my_nl = (step_nl != LL_NONE) ? step_nl : my_nl;
+        lz_base = anylow ? (int)base : lz_base;
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            PLANE_PUT(pk, lowm[k], 2 * k);
+            PLANE_PUT(pk, (lowm[k] >> 32), 2 * k + 1);
+            PLANE_PUT(pk, posm[k], 2 * NR + 2 * k);
+            PLANE_PUT(pk, (posm[k] >> 32), 2 * NR + 2 * k + 1);
+        }
+        return 0u;
+    };
+
+    // ---------------- the rounds ----------------
+    // A SUPERSTEP is `sup` regular rounds classified against one set of thresholds (A.ksteps), or ONE round that is not four whole
+    // steps of stable samples (the stream's first stable sample, a batch's ragged end): its
+    // rounds are separated by the first barrier only, the second one and the exchange behind it close the superstep.
+    const int sup = max(1, A.ksteps);
+    bool primed = false, need_open = true;
+    bool carry_pending = ((int)m_chunk - 1 - nl_in) > 0;   // the chunk starts inside a LOW run: its first step measures the carried length
+    int ks = 0;   // which registers hold this wave's samples of the round (D == 2: they alternate)
+    uint32_t rbase = m_chunk;   // base of the round
+    // which of the three mask buffers this round publishes in, and the round before it did (byte offsets of this wave's row)
+    uint32_t mo = 0u, mo_prev = 2u * (uint32_t)sizeof(sh->msk[0]);
+    uint32_t fail = good_run ? 0u : 1u;
+    // the plane words of a regular round leave one round later, beside the next request for samples (a store between a request
+    // and its use would be waited for with it)
+    int pk_prev = 0;
+    bool pk_pending = false;
+    uint32_t hot_last = 0u;   // base of this wave's step in the last regular round done
+    int hot_done = 0;         // regular rounds done
+    // this lane's dword of its wave's plane store (lanes 0 .. 7 the neg plane, 8 .. 15 the pos plane), advanced round by round
+    uintptr_t pl_addr = plane_of_lane + 4 * (2 * (uintptr_t)(wbase0 >> 6) + (uintptr_t)(lane & 7));
+    const char *const in_first = (const char *)A.in + (size_t)wbase0 * RB;   // this wave's step of the chunk's first round (uniform)
+    const char *in_wave = in_first;   // ... of the round in progress
+    uint32_t last_off = 0u;           // sample offset of the chunk's last regular round from its first
+    const uint32_t voff = (uint32_t)lane * (uint32_t)RB;
+    {
+        // what the step before the chunk's first one "published": the last LOW sample before the chunk, if it is in reach
+        if (tid < 17) {
+            uint32_t wv = 0u;
+            const int p = kl_in >> 1, q = p - ((int)m_chunk - (int)STEPN);
+            const bool live = (kl_in & 1) && q >= 0 && q < (int)STEPN;
+            if (live && tid == (q >> 5)) wv = 1u << (q & 31);
+            if (tid == 16) wv = live ? 1u : 0u;
+            sh->msk[2][WG_WAVES - 1][tid] = wv;
+        }
+        // (the first round's first barrier orders this before any read)
+    }
+    // the wave's samples of a round out of the registers `ks` names; N: vector memory operations that may stay in flight
+    auto take_ks = [&](float (&xx)[NR], auto n_tag) __attribute__((always_inline)) {
+        constexpr int N = decltype(n_tag)::value;
+        if constexpr (D == 1) {
+            lean_take<KIND, 0, N>(xx, i16s);
+        } else {
+            if (ks) lean_take<KIND, 1, N>(xx, i16s);
+            else lean_take<KIND, 0, N>(xx, i16s);
+        }
+    };
+    auto load_ks = [&](const char *from, bool other) __attribute__((always_inline)) {
+        if constexpr (D == 1) {
+            wg_load_step<KIND, 0>(voff, from);
+        } else {
+            if ((ks != 0) != other) wg_load_step<KIND, 1>(voff, from);
+            else wg_load_step<KIND, 0>(voff, from);
+        }
+    };
+    auto flush_planes = [&]() __attribute__((always_inline)) {
+        if (pk_pending) {
+            if (lane < 4 * NR) *(lean_g_u32 *)(pl_addr - (uintptr_t)(WG_ROUND / 8)) = (uint32_t)pk_prev;
+            pk_pending = false;
+        }
+    };
+    while (good_run && rbase < n1) {
+        const bool regular = rbase >= m_start && rbase + (uint32_t)WG_ROUND <= n1;
+        int nr = 1;
+        if (regular) {
+            const uint32_t whole = (n1 - rbase) / (uint32_t)WG_ROUND;   // regular rounds from here on
+            nr = (int)min((uint32_t)sup, whole);
+            if (!primed) {
+                // this wave's step of the first regular round is asked for; the first allowance comes from the samples of that
+                // round that look acceptable (a guess like any other allowance: the superstep's own B decides)
+                last_off = rbase - m_chunk + (whole - 1u) * (uint32_t)WG_ROUND;   // the chunk's last regular round
+                load_ks(in_wave, false);
+                if constexpr (D == 2) load_ks(in_first + (size_t)min(rbase - m_chunk + (uint32_t)WG_ROUND, last_off) * RB, true);
+                const float wlo = ssf * loLf * 0.5f, whi = ssf * hiLf * 1.02f;
+                float b0 = 0.f, n0 = 0.f;
+                float xv[NR];
+                take_ks(xv, std::integral_constant<int, 0>{});   // (reading leaves the registers as they are: the round takes them again)
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    uint32_t q = slot_step + 64u * j + lane;
+                    q = (q >= (uint32_t)L) ? q - (uint32_t)L : q;
+                    const bool in = xv[j] > wlo && xv[j] < whi;
+                    b0 += in ? fabsf(xv[j] - fabsf(ring[q])) : 0.f;
+                    n0 += in ? 1.f : 0.f;
+                }
+                uint32_t v[8], g[WG_WAVES][8];
+                v[0] = __float_as_uint(wave_sum_f32(b0));
+                v[1] = __float_as_uint(wave_sum_f32(n0));
+                wg_gather(v, 2, g);
+                b0 = ((__uint_as_float(g[0][0]) + __uint_as_float(g[1][0])) + __uint_as_float(g[2][0])) + __uint_as_float(g[3][0]);
+                n0 = ((__uint_as_float(g[0][1]) + __uint_as_float(g[1][1])) + __uint_as_float(g[2][1])) + __uint_as_float(g[3][1]);
+                // (half of sum |x - prev|: what the positive or the negative differences alone come to, see the close)
+                Bneed = ((n0 >= 64.f) ? 0.5f * b0 / n0 * (float)WG_ROUND : ssf * 0.0009765625f * (float)WG_WAVES) * (float)sup;
+                G = rfl(fminf(fmaxf(gfac * Bneed, ssf * gfloor), ssf * 0.125f));
+                primed = true;
+                need_open = true;
+            }
+        } else {
+            flush_planes();
+            primed = false;
+            G = rfl(fminf(fmaxf(G, ssf * 0.015625f), ssf * 0.125f));   // (up to 1024 samples against a guess: 2^-6 of the sum)
+        }
+        if (need_open) {   // (otherwise wave 0 opened the superstep when it closed the one before)
+            if (!open_round() && !fail) fail = 1u;
+        }
+        need_open = !regular;
+        if (carry_pending) {
+            // the LOW run the chunk starts in must not reach max_len inside it (transition_sink.py:95-99 resets the state there):
+            // measured on the chunk's first step by the wave that has it (a round in the general form does it itself)
+            carry_pending = false;
+            if (regular && wave == 0) {
+                float xv[NR];
+                take_ks(xv, std::integral_constant<int, 0>{});
+                int lead = 0;
+                bool open = true;
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const unsigned long long m = __ballot(xv[j] < tlo_dn);
+                    const int l = (m == ~0ull) ? 64 : (__ffsll((long long)~m) - 1);
+                    lead += open ? l : 0;
+                    open = open && (m == ~0ull);
+                }
+                if (((int)m_chunk - 1 - nl_in) + lead > mx && !fail) fail = 3u;
+            }
+        }
+
+        for (int k = 0; k < nr; k++) {
+            const uint32_t base = rbase + STEPN * (uint32_t)wave;
+            float x[NR];
+            int pk = 0;
+            unsigned long long lowany, highany;
+            // ---- phase A: this step's envelopes, what can classify at all, its LOW masks for the step after it ----
+            if (__builtin_expect(regular, 1)) {
+                // (D == 2: the request for the round after this one and the store beside it may stay in flight -- whatever order
+                // stores and loads complete in, at most four operations left means that this round's four loads are in)
+                WG_PF_BEGIN();
+                take_ks(x, std::integral_constant<int, (D - 1) * NR>{});
+                WG_PF_END(pf_take);
+                // the plane words of the round before leave, and the registers take the next round (if the chunk has one: past
+                // its end may be past the caller's buffer)
+                if (pk_pending) {
+                    if (lane < 4 * NR) *(lean_g_u32 *)(pl_addr - (uintptr_t)(WG_ROUND / 8)) = (uint32_t)pk_prev;
+                }
+                // (asked for unconditionally -- the counted wait above relies on it; past the chunk's last regular round the address
+                // is clamped to that round and the values are never used)
+                load_ks(in_first + (size_t)min(rbase - m_chunk + (uint32_t)(D * WG_ROUND), last_off) * RB, false);
+                const float xmin = __uint_as_float(min(min(__float_as_uint(x[0]), __float_as_uint(x[1])), min(__float_as_uint(x[2]), __float_as_uint(x[3]))));
+                const float xmax = __uint_as_float(max(max(__float_as_uint(x[0]), __float_as_uint(x[1])), max(__float_as_uint(x[2]), __float_as_uint(x[3]))));
+                lowany = __ballot(!(xmin > tlo_up));
+                highany = __ballot(!(xmax < thi_dn));
+                if (lowany) {
+                    unsigned long long lw[NR];
+#pragma unroll
+                    for (int j = 0; j < NR; j++) lw[j] = __ballot(x[j] < tlo_dn);
+                    PLANE_PUT8(pk, lw, 0);
+                    PLANE_PUT(pk, 1u, 16);
+                }
+            } else {
+                fetch_env(base, x);
+                unsigned long long lw[NR];
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const uint32_t m = base + 64u * j + lane;
+                    lw[j] = __ballot(x[j] < tlo_dn && !((m < m_start) || (m >= n1)));
+                }
+                PLANE_PUT8(pk, lw, 0);
+                PLANE_PUT(pk, 1u, 16);
+                lowany = highany = ~0ull;
+            }
+            if (lane < 17) *(uint32_t *)((char *)&sh->msk[0][wave][0] + mo + 4u * (uint32_t)lane) = (uint32_t)pk;
+            WG_PF_BEGIN();
+            wg_barrier();
+            WG_PF_END(pf_b1);
+
+            // ---- phase B: the ring, the drift accumulators, the HIGH plane ----
+            int form = 0;   // 0 nothing classifies, 1 only LOW, 2 only HIGH with no LOW sample in reach, 3 the general step
+            int before = LL_NONE;   // the last LOW sample before this step, if it can matter
+            int carry_run = 0;
+            if (highany) {
+                form = lowany ? 3 : 2;
+                if (!regular && base == m_chunk) {   // a chunk's first step in the general form: what the speculation (chunk 0: the carried state) says
+                    before = (kl_in & 1) ? (kl_in >> 1) : LL_NONE;
+                    carry_run = (int)m_chunk - 1 - nl_in;
+                } else {
+                    const uint32_t *pm = (wave == 0) ? (const uint32_t *)((const char *)&sh->msk[0][WG_WAVES - 1][0] + mo_prev)
+                                                     : (const uint32_t *)((const char *)&sh->msk[0][wave - 1][0] + mo);
+                    if (rfl(pm[16])) {
+                        const int pb = (int)base - (int)STEPN;
+#pragma unroll
+                        for (int j = 0; j < NR; j++) {
+                            const unsigned long long m = (unsigned long long)rfl(pm[2 * j]) | ((unsigned long long)rfl(pm[2 * j + 1]) << 32);
+                            before = m ? pb + 64 * j + last_set(m) : before;
+                        }
+                        if (((int)base - before) <= mx + 1) form = 3;
+                    }
+                }
+            } else if (lowany) {
+                form = 1;
+            }
+            if (__builtin_expect(form == 3, 0)) {
+                if (base < n1 && !fail) {
+                    fail = general_step(x, base, !regular, before, carry_run, pk);
+                    if (!regular) {
+                        const uint32_t w = (base >> 6) + (uint32_t)((lane & 7) >> 1);
+                        if (!fail && lane < 4 * NR && (size_t)w * 64 < A.n) *(lean_g_u32 *)pl_addr = (uint32_t)pk;
+                    }
+                }
+            } else {
+                // straight-line forms: ring addresses (a step wraps the ring once in L / 256 steps)
+                lean_lds_f *pa[NR];
+                {
+                    const uint32_t s0 = slot_step + (uint32_t)lane;
+                    if (slot_step + STEPN <= (uint32_t)L) {
+#pragma unroll
+                        for (int j = 0; j < NR; j++) pa[j] = rl + s0 + 64u * j;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NR; j++) {
+                            const uint32_t s = s0 + 64u * j;
+                            pa[j] = rl + min(s, s - (uint32_t)L);
+                        }
+                    }
+                }
+                float praw[NR];
+#pragma unroll
+                for (int j = 0; j < NR; j++) praw[j] = *pa[j];
+                if (form == 0) {
+                    // nothing classifies: every sample is accepted
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
+                        const float t = x[j] - fabsf(praw[j]);
+                        b_acc += fabsf(t);
+                        dl_acc += t;
+                        *pa[j] = x[j];
+                    }
+                } else if (form == 1) {
+                    // LOW samples only: rejected ones keep their slot (value and sign bit)
+                    unsigned long long lw[NR];
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
+                        const bool lo = x[j] < tlo_dn;
+                        lw[j] = __ballot(lo);
+                        const float val = lo ? praw[j] : x[j];
+                        const float ts = fabsf(val) - fabsf(praw[j]);   // 0 for a rejected sample
+                        b_acc += fabsf(ts);
+                        dl_acc += ts;
+                        *pa[j] = val;
+                    }
+                    amb_lo = min(min(amb_lo, __float_as_uint(x[0]) - __float_as_uint(tlo_dn)),
+                                 min(__float_as_uint(x[1]) - __float_as_uint(tlo_dn), __float_as_uint(x[2]) - __float_as_uint(tlo_dn)));
+                    amb_lo = min(amb_lo, __float_as_uint(x[3]) - __float_as_uint(tlo_dn));
+                    // a LOW run longer than max_len covers an aligned block of A.blk samples
+                    if constexpr (BLK16) {
+#pragma unroll
+                        for (int j = 0; j < NR; j++) lrun = min(lrun, max(__float_as_uint(x[j]), lean_dpp_shl8(__float_as_uint(x[j]))));
+                    } else if (A.blk == 64) {
+                        if ((lw[0] == ~0ull) || (lw[1] == ~0ull) || (lw[2] == ~0ull) || (lw[3] == ~0ull)) fail = fail ? fail : 3u;
+                    } else {
+                        unsigned long long hit = 0;
+#pragma unroll
+                        for (int j = 0; j < NR; j++) {
+                            unsigned long long t = lw[j];
+#pragma unroll
+                            for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
+                            hit |= t & A.selmask;
+                        }
+                        if (hit) fail = fail ? fail : 3u;
+                    }
+                    lz_base = (int)base;
+                } else {
+                    // HIGH samples only, no LOW sample in reach: all of them are rejected (transition_sink.py:71-74)
+                    unsigned long long hw[NR];
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
+                        const bool hi = x[j] > thi_up;
+                        hw[j] = __ballot(hi);
+                        const float val = hi ? praw[j] : x[j];
+                        const float ts = fabsf(val) - fabsf(praw[j]);
+                        b_acc += fabsf(ts);
+                        dl_acc += ts;
+                        *pa[j] = val;
+                    }
+                    PLANE_PUT8(pk, hw, 8);
+                    amb_hi = min(min(amb_hi, __float_as_uint(x[0]) - __float_as_uint(thi_dn)),
+                                 min(__float_as_uint(x[1]) - __float_as_uint(thi_dn), __float_as_uint(x[2]) - __float_as_uint(thi_dn)));
+                    amb_hi = min(amb_hi, __float_as_uint(x[3]) - __float_as_uint(thi_dn));
+                }
+            }
+            if (regular) {
+                ks ^= 1;
+                pk_prev = pk;
+                pk_pending = true;
+                hot_last = base;
+                hot_done++;
+            }
+            pl_addr += (uintptr_t)(WG_ROUND / 8);
+            in_wave += (size_t)WG_ROUND * RB;
+            slot_step += slot_adv;
+            slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
+            rounds_since_sync++;
+#ifdef NFC_WG_PROF
+            pf_rounds++;
+#endif
+            rbase += (uint32_t)WG_ROUND;
+            mo_prev = mo;
+            mo = (mo == 2u * (uint32_t)sizeof(sh->msk[0])) ? 0u : mo + (uint32_t)sizeof(sh->msk[0]);
+        }
+
+        // ---- the superstep closes: was the allowance enough for what the lanes accumulated, did no sample sit inside a band,
+        // can no LOW run have reached max_len?  Every lane hands in its two sums and every wave its verdict; WAVE 0 adds them up,
+        // moves the tracked sum on, sets the next allowance and opens the next superstep (a round of whole steps is taken for
+        // granted: anything else opens again above) -- the others only read the thresholds it leaves behind.
+        {
+            const uint32_t wlo = __float_as_uint(tlo_up) - __float_as_uint(tlo_dn), whi = __float_as_uint(thi_up) - __float_as_uint(thi_dn);
+            const unsigned long long inband = __ballot(amb_lo <= wlo || amb_hi <= whi);
+            const unsigned long long longlow = __ballot(lrun <= __float_as_uint(tlo_up)) & 0x0001000100010001ull;
+            amb_lo = 0xFFFFFFFFu;
+            amb_hi = 0xFFFFFFFFu;
+            lrun = 0x7F7FFFFFu;
+            if (!fail && inband) fail = 2u;
+            if (!fail && longlow) fail = 3u;
+            sh->acc[wave][lane] = make_float2(b_acc, dl_acc);
+            b_acc = 0.f;
+            dl_acc = 0.f;
+            if (lane == 0) sh->flag[wave] = fail;
+            const bool resync = rounds_since_sync >= 64;   // bound the rounding the f32 sum accumulates: re-derive it from the ring
+            if (resync) rounds_since_sync = 0;
+            WG_PF_BEGIN();
+            wg_barrier();
+            WG_PF_END(pf_b2);
+            if (wave == 0) {
+                const float2 a0 = sh->acc[0][lane], a1 = sh->acc[1][lane], a2 = sh->acc[2][lane], a3 = sh->acc[3][lane];
+                const float Bs = wave_sum_f32((a0.x + a1.x) + (a2.x + a3.x)) * 1.001f;
+                const float Dt = wave_sum_f32((a0.y + a1.y) + (a2.y + a3.y));
+                const uint4 fl = *(const uint4 *)&sh->flag[0];
+                uint32_t f = rfl(fl.x | fl.y | fl.z | fl.w);
+                // Every partial sum of the accepted (x - prev), in stream order, lies in [-N, P]: N / P the sums of the negative /
+                // the positive ones -- (Bs -/+ Dt) / 2.  The allowance has to cover the larger of the two, not their sum.
+                const float B = 0.5f * (Bs + fabsf(Dt)) * 1.0001f;
+                if (!f && !(B <= G)) f = 4u;
+                if (!f) {
+                    ssf = rfl(ssf + Dt);
+                    if (resync) {   // (the ring is quiescent: the other waves wait for the verdict)
+                        double part = 0;
+#pragma unroll 8
+                        for (int s2 = lane; s2 < L; s2 += 64) part += (double)fabsf(ring[s2]);
+                        ssf = (float)rfl(wave_sum_f64(part) + cr.delta);
+                    }
+                    if (regular) {
+                        Bneed = fmaxf(Bneed, B);
+                        G = rfl(fminf(fmaxf(gfac * Bneed, ssf * gfloor), ssf * 0.125f));
+                    }
+                    if (!open_round()) f = 1u;
+                }
+                if (lane == 0) {
+                    *(float4 *)&sh->bc[0] = make_float4(tlo_dn, tlo_up, thi_dn, thi_up);
+                    *(float4 *)&sh->bc[4] = make_float4(ssf, G, Bneed, __uint_as_float(f));
+                }
+            }
+            wg_barrier();
+            const float4 t4 = *(const float4 *)&sh->bc[0], s4 = *(const float4 *)&sh->bc[4];
+            const uint32_t f = rfl(__float_as_uint(s4.w));
+            if (f) {
+                why = (f > 5u) ? 2u : f;   // (codes of several waves may be or-ed together: the aid names one at most)
+                good_run = false;
+            } else {
+                tlo_dn = rfl(t4.x);
+                tlo_up = rfl(t4.y);
+                thi_dn = rfl(t4.z);
+                thi_up = rfl(t4.w);
+                ssf = rfl(s4.x);
+                G = rfl(s4.y);
+                Bneed = rfl(s4.z);
+            }
+        }
+    }
+    flush_planes();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the rounds' loads and stores is left in flight)
+
+    // ---------------- the chunk's summary ----------------
+    // LOW bookkeeping at the chunk's end: the last non-LOW sample and the last LOW sample lie in its last steps (a LOW sample
+    // further back is out of every HIGH sample's reach: any key that is not live stands for it, certify_block).  Regular rounds
+    // keep no such bookkeeping: the neg-plane words this wave stored for its last two steps say it.
+    int chunk_nl = LL_NONE, chunk_kl = KEY_NONE;
+    {
+        if (good_run && hot_done > 0) {
+            const int which = (lane >> 2) & 1;   // lanes 0 .. 3 the last regular step's words, 4 .. 7 the one a round before
+            const uint32_t sb = hot_last - (uint32_t)which * (uint32_t)WG_ROUND;
+            unsigned long long wd = 0ull;
+            const bool have = lane < 8 && (which == 0 || hot_done > 1);
+            if (have) wd = neg_p[(sb >> 6) + (uint32_t)(lane & 3)];
+            const int rb = (int)sb + 64 * (lane & 3);
+            int ll = (have && wd) ? rb + last_set(wd) : LL_NONE;
+            int nl = (have && ~wd) ? rb + last_set(~wd) : LL_NONE;
+            my_ll = max(my_ll, wave_max_i32(ll));
+            my_nl = max(my_nl, wave_max_i32(nl));
+        }
+        if (lane == 0) {
+            sh->fin[wave][0] = my_ll;
+            sh->fin[wave][1] = my_nl;
+            sh->fin[wave][2] = lz_base;
+        }
+        wg_barrier();
+        int ll = LL_NONE, nl = LL_NONE, lz = LL_NONE;
+        for (int w = 0; w < WG_WAVES; w++) {
+            ll = max(ll, rfl(sh->fin[w][0]));
+            nl = max(nl, rfl(sh->fin[w][1]));
+            lz = max(lz, rfl(sh->fin[w][2]));
+        }
+        chunk_nl = nl;
+        if (ll != LL_NONE) chunk_kl = 2 * ll + 1;
+        else if (lz != LL_NONE) chunk_kl = 2 * (lz + (int)STEPN - 1) + 1;
+        if (good_run && nl == LL_NONE && n1 > m_start) {   // (no non-LOW sample in the last rounds: the block test will have seen it)
+            good_run = false;
+            why = 3u;
+        }
+    }
+
+    if (A.dbg_clk) clk2 = clock64();
+    const uint32_t all_robust = good_run ? 1u : 0u;
+    if (c == 0 && tid == 0) {   // chunk 0 has no certification of its own: its verdict travels here
+        A.cert[0] = good_run ? 1 : 0;
+        if (!good_run) atomicAdd(&A.sum->n_fail, 1u);
+    }
+    {
+        // fold the raw-bit extremes of the rounds into the exponent guard
+        uint32_t v[8], g[WG_WAVES][8];
+        v[0] = wave_min_u32(vmin);
+        v[1] = wave_max_u32(vmax);
+        float *ro = A.ring_out[0] + (size_t)c * L;
+        uint32_t *to = A.touched[0] + (size_t)c * A.twords;
+        uint32_t untouched = 0;
+        for (int sbase = 64 * wave; sbase < A.twords * 32; sbase += 256) {
+            const int s = sbase + lane;
+            const float rv = (s < L) ? ring[s] : 0.f;
+            const bool t = (s < L) && !(__float_as_uint(rv) >> 31);
+            const unsigned long long bal = __ballot(t);
+            if (s < L) {
+                ro[s] = fabsf(rv);
+                if (!t) untouched++;
+            }
+            const int w = sbase >> 5;
+            if (lane == 0) {
+                to[w] = (uint32_t)bal;
+                if (w + 1 < A.twords) to[w + 1] = (uint32_t)(bal >> 32);
+            }
+        }
+        v[2] = (uint32_t)wave_sum_f32((float)untouched);
+        wg_gather(v, 3, g);
+        vmin = min(min(g[0][0], g[1][0]), min(g[2][0], g[3][0]));
+        vmax = max(max(g[0][1], g[1][1]), max(g[2][1], g[3][1]));
+        untouched = g[0][2] + g[1][2] + g[2][2] + g[3][2];
+        if (vmax != 0u) {
+            emax = max(emax, (vmax >> 31) ? 255u : max((vmax >> 23) & 0xFFu, 1u));
+            if (vmin != 0xFFFFFFFFu) emin = min(emin, max((vmin >> 23) & 0xFFu, 1u));
+        }
+        const uint32_t vtop = __float_as_uint(fmaxf(__uint_as_float(vmax), ssf * (1.0f + eps + RND_SUM)) * 1.0009765625f);
+        const uint32_t flags = good_run ? 0u : (4u | (why << 4));
+        if (tid == 0) {
+            ChunkInfo ci;
+            ci.ss_out = (double)ssf;   // informational
+            ci.low_key = chunk_kl;
+            ci.last_nonlow = chunk_nl;
+            ci.emin = emin;
+            ci.emax = emax;
+            ci.flags = flags;
+            ci.n_untouched = untouched;
+            A.info[0][c] = ci;
+            A.gmin[c] = (uint8_t)emin;
+            A.gmax[c] = (uint8_t)emax;
+            A.gflags[c] = (uint8_t)(flags | (untouched ? 2u : 0u));
+            A.gvtop[c] = vtop;
+            RunMeta mt;
+            mt.min_ss = min_ss;
+            mt.eps = eps;
+            mt.nl_in = nl_in;
+            mt.kl_in = kl_in;
+            mt.all_robust = all_robust;
+            mt.pad = 0;
+            A.meta[c] = mt;
+        }
+    }
+    if (A.dbg_clk && tid == 0) {
+        A.dbg_clk[4 * (size_t)c + 0] = clk0;
+        A.dbg_clk[4 * (size_t)c + 1] = clk1;
+        A.dbg_clk[4 * (size_t)c + 2] = clk2;
+        A.dbg_clk[4 * (size_t)c + 3] = clock64();
+    }
+#ifdef NFC_WG_PROF
+    if (A.dbg_clk && lane == 0) {   // behind the stamps of all chunks: per wave, ticks spent waiting for samples / at the two barriers
+        unsigned long long *pf = A.dbg_clk + 4 * (size_t)A.nchunks + 4 * ((size_t)c * WG_WAVES + wave);
+        pf[0] = pf_take;
+        pf[1] = pf_b1;
+        pf[2] = pf_b2;
+        pf[3] = pf_rounds;
+    }
+#endif
+}
+
+}  // namespace nfc
