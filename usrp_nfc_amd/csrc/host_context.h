@@ -91,8 +91,8 @@ struct nfc_ctx {
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
     int lean = 1, lean_k = 0, lean_rounds = 0, lean_slots = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
-    int wg = 1, wg_ok = 0, wg_d = 1, wg_slots = 0, wg_now = 0, wg_rounds = 0;   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
-                                                                 // asked for ahead (NFC_WG_D), resident workgroups, this batch uses it
+    int wg = 1, wg_ok = 0, wg_nr = 4, wg_slots = 0, wg_now = 0, wg_rounds = 0;   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
+                                                                 // rows of 64 samples per step (NFC_WG_NR), resident workgroups, this batch uses it, rounds per superstep
     size_t wg_lds = 0;
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
@@ -331,8 +331,11 @@ void launch_wg(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipE
         else NFC_LAUNCH(kern, dim3(nwork), dim3(256), lds, c->st, A);
     };
     const bool b16 = (1 << c->nfold) == 16;
-    if (c->wg_d == 2) { if (b16) go(k_threshold_wg<KIND, 2, true>); else go(k_threshold_wg<KIND, 2, false>); }
-    else { if (b16) go(k_threshold_wg<KIND, 1, true>); else go(k_threshold_wg<KIND, 1, false>); }
+    switch (c->wg_nr) {
+    case 8: if (b16) go(k_threshold_wg<KIND, 8, true>); else go(k_threshold_wg<KIND, 8, false>); break;
+    case 6: if (b16) go(k_threshold_wg<KIND, 6, true>); else go(k_threshold_wg<KIND, 6, false>); break;
+    default: if (b16) go(k_threshold_wg<KIND, 4, true>); else go(k_threshold_wg<KIND, 4, false>); break;
+    }
 }
 template <int KIND>
 void launch_lean(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipEvent_t e1) {

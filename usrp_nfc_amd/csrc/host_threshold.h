@@ -57,12 +57,12 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
         const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : (c->wg_now ? c->wg_slots : (lean_applies ? c->lean_slots : c->wave_slots)));
         // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps;
         // the workgroup kernel whole rounds of four)
-        const int stp = c->wg_now ? WG_ROUND : 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
+        const int stp = c->wg_now ? wg_round_samples(c->wg_nr) : 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
         uint64_t want = ((uint64_t)n + slots - 1) / slots;
         want = (want + stp - 1) / stp * stp;
         c->C = (int)std::max<uint64_t>(want, (uint64_t)c->C_min);
     }
-    if (c->wg_now && c->C % WG_ROUND != 0) c->wg_now = 0;   // (a configured chunk length that is not whole rounds: the one-wave kernel)
+    if (c->wg_now && c->C % wg_round_samples(c->wg_nr) != 0) c->wg_now = 0;   // (a configured chunk length that is not whole rounds: the one-wave kernel)
     const uint32_t off = 0u;   // (chunk c covers samples [c*C - off, (c+1)*C - off): the kernels here use off = 0)
     const uint32_t nch = (uint32_t)(((uint64_t)n + off + c->C - 1) / c->C);
     c->stats.n_chunks = nch;

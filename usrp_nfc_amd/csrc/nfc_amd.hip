@@ -58,9 +58,10 @@ using namespace nfc;
 // ===========================================================================
 namespace {
 // the instantiation of k_threshold_wg a context launches (for the occupancy query and the LDS attribute)
-const void *wg_kernel_of(int kind, int d, bool b16) {
-#define WGK(K) (d == 2 ? (b16 ? (const void *)k_threshold_wg<K, 2, true> : (const void *)k_threshold_wg<K, 2, false>) \
-                       : (b16 ? (const void *)k_threshold_wg<K, 1, true> : (const void *)k_threshold_wg<K, 1, false>))
+const void *wg_kernel_of(int kind, int nr, bool b16) {
+#define WGK(K) (nr == 8 ? (b16 ? (const void *)k_threshold_wg<K, 8, true> : (const void *)k_threshold_wg<K, 8, false>) \
+              : nr == 6 ? (b16 ? (const void *)k_threshold_wg<K, 6, true> : (const void *)k_threshold_wg<K, 6, false>) \
+                        : (b16 ? (const void *)k_threshold_wg<K, 4, true> : (const void *)k_threshold_wg<K, 4, false>))
     switch (kind) {
     case NFC_IN_IQ_F32: return WGK(IN_IQ_F32);
     case NFC_IN_REAL_F32_SQ: return WGK(IN_REAL_F32_SQ);
@@ -118,7 +119,6 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         c->dbg_clk_path = e;
     }
     if (const char *e = getenv("NFC_WG")) c->wg = atoi(e) != 0;
-    if (const char *e = getenv("NFC_WG_D")) c->wg_d = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("NFC_WG_ROUNDS")) c->wg_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("NFC_LEAN")) c->lean = atoi(e) != 0;
     c->lean_k = 0;        // chosen below from the occupancy the LDS ring allows, unless set here
@@ -207,9 +207,19 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         c->lean_lds_per_cu = (size_t)((c->lean_slots + prop.multiProcessorCount - 1) / prop.multiProcessorCount) * lds_wave;
         // the workgroup kernel: one chunk per 256-thread workgroup, as many resident per CU as LDS and registers admit
         c->wg_lds = (size_t)c->Lpad * 4 + WG_SHARED_BYTES;
-        c->wg_ok = p->input_kind != NFC_IN_ENV_F32 && c->mx <= 254 && c->L >= WG_ROUND && c->wg_lds <= 160 * 1024;
+        // rows per step: the largest of 8 / 6 / 4 that leaves a superstep of at least two rounds within 0.8 windows (measured at
+        // av_window 2000: six rows with one-round supersteps lose to four rows with two; at 10000 eight rows gain 2 %); a round
+        // (four steps) must fit the window, max_len must lie within one step
+        c->wg_nr = 4;
+        for (int v : {6, 8})
+            if (0.8 * c->L / (double)wg_round_samples(v) >= 1.5) c->wg_nr = v;
+        if (const char *e = getenv("NFC_WG_NR")) {
+            const int v = atoi(e);
+            if ((v == 4 || v == 6 || v == 8) && c->L >= wg_round_samples(v)) c->wg_nr = v;
+        }
+        c->wg_ok = p->input_kind != NFC_IN_ENV_F32 && c->mx <= 64 * c->wg_nr - 2 && c->L >= wg_round_samples(c->wg_nr) && c->wg_lds <= 160 * 1024;
         if (c->wg_ok) {
-            const void *kern = wg_kernel_of(p->input_kind, c->wg_d, (1 << c->nfold) == 16);
+            const void *kern = wg_kernel_of(p->input_kind, c->wg_nr, (1 << c->nfold) == 16);
             if (c->wg_lds > 64 * 1024) CRT(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->wg_lds));
             int per_cu_wg = 0;
             CRT(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wg, kern, 256, c->wg_lds));
@@ -218,7 +228,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             c->wg_slots = prop.multiProcessorCount * per_cu_wg;
             // rounds per superstep: its drift allowance grows with its length relative to the window (0.8 windows: beyond, the
             // widened HIGH band reaches the loaded half bits of tag frames -- 1 % of the chunks gave up at twice that)
-            if (!c->wg_rounds) c->wg_rounds = std::max(1, (int)(0.8 * c->L / (double)WG_ROUND + 0.5));
+            if (!c->wg_rounds) c->wg_rounds = std::max(1, (int)(0.8 * c->L / (double)wg_round_samples(c->wg_nr) + 0.5));
             if (c->wg) c->lean_lds_per_cu = (size_t)per_cu_wg * c->wg_lds;
         }
     }

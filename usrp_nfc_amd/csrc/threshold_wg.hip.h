@@ -28,11 +28,14 @@
 namespace nfc {
 
 constexpr int WG_WAVES = 4;
-constexpr int WG_ROUND = 256 * WG_WAVES;
+// A step is NR rows of 64 samples (lane l holds samples l, 64 + l, ...), a round four steps: NR is chosen so that a round fits the
+// window (its steps' ring slots must be disjoint) -- 4, 6 or 8 rows: 1024, 1536 or 2048 samples per round.  Everything a round
+// costs once (barriers, bookkeeping, the form dispatch) is spread over that many samples.
+constexpr int wg_round_samples(int nr) { return 64 * nr * WG_WAVES; }
+constexpr int WG_NR_MAX = 8;
 // LDS behind the ring: LOW masks of the rounds' steps, the close exchange, scratch for workgroup reductions
 struct WgShared {
-    uint32_t msk[3][WG_WAVES][20];     // per round (modulo three) and wave: the four LOW masks of its step (dwords 0 .. 7), dword 16: any LOW sample
-    float red[4][WG_WAVES];            // close of a superstep: B, D, failure code (as bits) of every wave
+    uint32_t msk[3][WG_WAVES][4 * WG_NR_MAX + 4];   // per round (modulo three) and wave: the LOW masks of its step (dwords 0 .. 2 NR - 1), dword 4 NR: any LOW sample
     uint32_t scr[2][WG_WAVES][8];      // workgroup reductions (alternating halves: one barrier per reduction)
     int32_t fin[WG_WAVES][4];          // chunk end: last LOW index, last non-LOW index, latest step with LOW samples
     float2 acc[WG_WAVES][64];          // close of a superstep: every lane's (sum |x - prev|, sum (x - prev)) over what it accepted
@@ -46,34 +49,104 @@ constexpr size_t WG_SHARED_BYTES = (sizeof(WgShared) + 15) & ~(size_t)15;
 // arrives; the asm statement is a compiler barrier for memory accesses as well.
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The 256 samples at base (uniform) + voff (this lane's byte offset) into a[0 .. 7], as lean_load_step<KIND, 0> -- with the
-// address split into a scalar base and a 32-bit lane offset, so that walking the chunk costs scalar additions only.
-#define WG_LOAD4(OP, R0, R1, R2, R3, STRIDE, ...)                                                                                            \
-    asm volatile(OP " " R0 ", %0, %1\n\t" OP " " R1 ", %0, %1 offset:%2\n\t" OP " " R2 ", %0, %1 offset:%3\n\t" OP " " R3 ", %0, %1 offset:%4" \
-                 :                                                                                                                          \
-                 : "v"(voff), "s"(base), "n"(STRIDE), "n"(2 * STRIDE), "n"(3 * STRIDE)                                                      \
+// The 64 NR samples at base (uniform) + voff (this lane's byte offset) into accumulator registers named literally (row j of an
+// IQ step in a[2 j : 2 j + 1], of the one-dword kinds in a[j]; see threshold_lean.hip.h for why) -- with the address split into
+// a scalar base and a 32-bit lane offset, so that walking the chunk costs scalar additions only.
+#define WG_LD2(OP, RA, RB, OFFA, OFFB, ...)                                                                              \
+    asm volatile(OP " " RA ", %0, %1 offset:%2\n\t" OP " " RB ", %0, %1 offset:%3"                                       \
+                 :                                                                                                       \
+                 : "v"(voff), "s"(base), "n"(OFFA), "n"(OFFB)                                                            \
                  : "memory", __VA_ARGS__)
-template <int KIND, int K>
+template <int KIND, int NR>
 __device__ __forceinline__ void wg_load_step(uint32_t voff, const char *base) {
-    static_assert(K == 0 || K == 1, "two rounds of registers");
+    static_assert(NR == 4 || NR == 6 || NR == 8, "rows per step");
     if constexpr (KIND == IN_IQ_F32) {
-        if constexpr (K == 0) WG_LOAD4("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", 512, LEAN_CLOB0);
-        else WG_LOAD4("global_load_dwordx2", "a[8:9]", "a[10:11]", "a[12:13]", "a[14:15]", 512, LEAN_CLOB1);
+        WG_LD2("global_load_dwordx2", "a[0:1]", "a[2:3]", 0, 512, "a0", "a1", "a2", "a3");
+        WG_LD2("global_load_dwordx2", "a[4:5]", "a[6:7]", 1024, 1536, "a4", "a5", "a6", "a7");
+        if constexpr (NR >= 6) WG_LD2("global_load_dwordx2", "a[8:9]", "a[10:11]", 2048, 2560, "a8", "a9", "a10", "a11");
+        if constexpr (NR >= 8) WG_LD2("global_load_dwordx2", "a[12:13]", "a[14:15]", 3072, 3584, "a12", "a13", "a14", "a15");
     } else if constexpr (KIND == IN_I16_SQ) {
-        if constexpr (K == 0) WG_LOAD4("global_load_sshort", "a0", "a1", "a2", "a3", 128, LEAN_CLOB0);
-        else WG_LOAD4("global_load_sshort", "a8", "a9", "a10", "a11", 128, LEAN_CLOB1);
+        WG_LD2("global_load_sshort", "a0", "a1", 0, 128, "a0", "a1");
+        WG_LD2("global_load_sshort", "a2", "a3", 256, 384, "a2", "a3");
+        if constexpr (NR >= 6) WG_LD2("global_load_sshort", "a4", "a5", 512, 640, "a4", "a5");
+        if constexpr (NR >= 8) WG_LD2("global_load_sshort", "a6", "a7", 768, 896, "a6", "a7");
     } else {
-        if constexpr (K == 0) WG_LOAD4("global_load_dword", "a0", "a1", "a2", "a3", 256, LEAN_CLOB0);
-        else WG_LOAD4("global_load_dword", "a8", "a9", "a10", "a11", 256, LEAN_CLOB1);
+        WG_LD2("global_load_dword", "a0", "a1", 0, 256, "a0", "a1");
+        WG_LD2("global_load_dword", "a2", "a3", 512, 768, "a2", "a3");
+        if constexpr (NR >= 6) WG_LD2("global_load_dword", "a4", "a5", 1024, 1280, "a4", "a5");
+        if constexpr (NR >= 8) WG_LD2("global_load_dword", "a6", "a7", 1536, 1792, "a6", "a7");
+    }
+}
+// Waits for EVERY vector memory operation of the wave (the request went out a round ago), then hands the step's samples over as
+// envelopes.  (The reads that follow the wait are statements of their own: asm volatile statements keep their order.)
+#define WG_RD4(WAIT, R0, R1, R2, R3, O)                                                                                                       \
+    asm volatile(WAIT "v_accvgpr_read_b32 %0, " R0 "\n\tv_accvgpr_read_b32 %1, " R1 "\n\tv_accvgpr_read_b32 %2, " R2 "\n\tv_accvgpr_read_b32 %3, " R3 \
+                 : "=v"(w[O]), "=v"(w[O + 1]), "=v"(w[O + 2]), "=v"(w[O + 3])                                                                  \
+                 :                                                                                                                           \
+                 : "memory")
+#define WG_RD2(WAIT, R0, R1, O)                                                               \
+    asm volatile(WAIT "v_accvgpr_read_b32 %0, " R0 "\n\tv_accvgpr_read_b32 %1, " R1           \
+                 : "=v"(w[O]), "=v"(w[O + 1])                                                  \
+                 :                                                                            \
+                 : "memory")
+template <int KIND, int NR>
+__device__ __forceinline__ void wg_take(float (&x)[NR], float i16_scale) {
+    if constexpr (KIND == IN_IQ_F32) {
+        float w[2 * NR];
+        WG_RD4("s_waitcnt vmcnt(0)\n\t", "a0", "a1", "a2", "a3", 0);
+        WG_RD4("", "a4", "a5", "a6", "a7", 4);
+        if constexpr (NR >= 6) WG_RD4("", "a8", "a9", "a10", "a11", 8);
+        if constexpr (NR >= 8) WG_RD4("", "a12", "a13", "a14", "a15", 12);
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const float a = w[2 * j] * w[2 * j], b = w[2 * j + 1] * w[2 * j + 1];   // gnuradio complex_to_mag_squared: two products, one sum
+            x[j] = a + b;
+        }
+    } else {
+        float w[NR];
+        WG_RD4("s_waitcnt vmcnt(0)\n\t", "a0", "a1", "a2", "a3", 0);
+        if constexpr (NR == 6) WG_RD2("", "a4", "a5", 4);
+        if constexpr (NR == 8) WG_RD4("", "a4", "a5", "a6", "a7", 4);
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            if constexpr (KIND == IN_I16_SQ) {
+                const float sv = i16_to_float(__float_as_int(w[j]), i16_scale);   // (global_load_sshort sign-extends into the register)
+                x[j] = sv * sv;
+            } else {
+                x[j] = w[j] * w[j];   // IN_REAL_F32_SQ
+            }
+        }
+    }
+}
+// the dwords of NR masks into lanes LANE0 .. LANE0 + 2 NR - 1 of pk
+#define PLANE_PUT4(pk, m, I0, LANE0)                                                                                                       \
+    asm volatile("s_nop 2\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %5+1\n\tv_writelane_b32 %0, %3, %5+2\n\tv_writelane_b32 %0, %4, %5+3" \
+                 : "+v"(pk)                                                                                                                \
+                 : "s"((uint32_t)(m)[I0]), "s"((uint32_t)((m)[I0] >> 32)), "s"((uint32_t)(m)[(I0) + 1]), "s"((uint32_t)((m)[(I0) + 1] >> 32)), "n"(LANE0))
+template <int NR>
+__device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (&m)[NR], std::integral_constant<int, 0>) {
+    PLANE_PUT8(pk, m, 0);
+    if constexpr (NR == 6) PLANE_PUT4(pk, m, 4, 8);
+    if constexpr (NR == 8) {
+        const unsigned long long m2[4] = {m[4], m[5], m[6], m[7]};
+        PLANE_PUT8(pk, m2, 8);
+    }
+}
+template <int NR>
+__device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (&m)[NR], std::integral_constant<int, 1>) {   // ... from lane 2 NR on
+    PLANE_PUT8(pk, m, 2 * NR);
+    if constexpr (NR == 6) PLANE_PUT4(pk, m, 4, 2 * NR + 8);
+    if constexpr (NR == 8) {
+        const unsigned long long m2[4] = {m[4], m[5], m[6], m[7]};
+        PLANE_PUT8(pk, m2, 2 * NR + 8);
     }
 }
 
-template <int KIND, int D, bool BLK16>
+template <int KIND, int NR, bool BLK16>
 __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     static_assert(KIND != IN_ENV_F32, "raw envelopes may be negative: no sign bit to spare (they take k_threshold)");
-    static_assert(D == 1 || D == 2, "rounds of samples asked for ahead");
-    constexpr int NR = 4;
     constexpr uint32_t STEPN = 64u * NR;
+    constexpr int WG_ROUND = wg_round_samples(NR);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = rfl(tid >> 6);
@@ -88,8 +161,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     const uint32_t m_start = max(m_chunk, A.skip);
     const Carry cr = *A.carry;
     uint64_t *const neg_p = A.neg, *const pos_p = A.pos;
-    // lanes 0 .. 7 hold the neg plane's dwords of a step, 8 .. 15 the pos plane's
-    const uintptr_t plane_of_lane = (lane & 8) ? (uintptr_t)pos_p : (uintptr_t)neg_p;
+    // lanes 0 .. 2 NR - 1 hold the neg plane's dwords of a step, 2 NR .. 4 NR - 1 the pos plane's
+    const uintptr_t plane_of_lane = (lane >= 2 * NR) ? (uintptr_t)pos_p : (uintptr_t)neg_p;
+    const int plane_dword = (lane >= 2 * NR) ? lane - 2 * NR : lane;
     const float i16s = A.i16_scale;
     const float gfac = A.gfac, gfloor = A.gfloor;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -290,7 +364,12 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             slot[j] = s;
             prev[j] = fabsf(ring[s]);
         }
-        unsigned long long unt[NR] = {0, 0, 0, 0}, am[NR] = {~0ull, ~0ull, ~0ull, ~0ull};
+        unsigned long long unt[NR], am[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            unt[j] = 0ull;
+            am[j] = ~0ull;
+        }
         if (masked) {
 #pragma unroll
             for (int j = 0; j < NR; j++) {
@@ -385,7 +464,6 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     const int sup = max(1, A.ksteps);
     bool primed = false, need_open = true;
     bool carry_pending = ((int)m_chunk - 1 - nl_in) > 0;   // the chunk starts inside a LOW run: its first step measures the carried length
-    int ks = 0;   // which registers hold this wave's samples of the round (D == 2: they alternate)
     uint32_t rbase = m_chunk;   // base of the round
     // which of the three mask buffers this round publishes in, and the round before it did (byte offsets of this wave's row)
     uint32_t mo = 0u, mo_prev = 2u * (uint32_t)sizeof(sh->msk[0]);
@@ -396,42 +474,24 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     bool pk_pending = false;
     uint32_t hot_last = 0u;   // base of this wave's step in the last regular round done
     int hot_done = 0;         // regular rounds done
-    // this lane's dword of its wave's plane store (lanes 0 .. 7 the neg plane, 8 .. 15 the pos plane), advanced round by round
-    uintptr_t pl_addr = plane_of_lane + 4 * (2 * (uintptr_t)(wbase0 >> 6) + (uintptr_t)(lane & 7));
+    // this lane's dword of its wave's plane store, advanced round by round
+    uintptr_t pl_addr = plane_of_lane + 4 * (2 * (uintptr_t)(wbase0 >> 6) + (uintptr_t)plane_dword);
     const char *const in_first = (const char *)A.in + (size_t)wbase0 * RB;   // this wave's step of the chunk's first round (uniform)
     const char *in_wave = in_first;   // ... of the round in progress
     uint32_t last_off = 0u;           // sample offset of the chunk's last regular round from its first
     const uint32_t voff = (uint32_t)lane * (uint32_t)RB;
     {
         // what the step before the chunk's first one "published": the last LOW sample before the chunk, if it is in reach
-        if (tid < 17) {
+        if (tid <= 4 * NR) {
             uint32_t wv = 0u;
             const int p = kl_in >> 1, q = p - ((int)m_chunk - (int)STEPN);
             const bool live = (kl_in & 1) && q >= 0 && q < (int)STEPN;
             if (live && tid == (q >> 5)) wv = 1u << (q & 31);
-            if (tid == 16) wv = live ? 1u : 0u;
+            if (tid == 4 * NR) wv = live ? 1u : 0u;
             sh->msk[2][WG_WAVES - 1][tid] = wv;
         }
         // (the first round's first barrier orders this before any read)
     }
-    // the wave's samples of a round out of the registers `ks` names; N: vector memory operations that may stay in flight
-    auto take_ks = [&](float (&xx)[NR], auto n_tag) __attribute__((always_inline)) {
-        constexpr int N = decltype(n_tag)::value;
-        if constexpr (D == 1) {
-            lean_take<KIND, 0, N>(xx, i16s);
-        } else {
-            if (ks) lean_take<KIND, 1, N>(xx, i16s);
-            else lean_take<KIND, 0, N>(xx, i16s);
-        }
-    };
-    auto load_ks = [&](const char *from, bool other) __attribute__((always_inline)) {
-        if constexpr (D == 1) {
-            wg_load_step<KIND, 0>(voff, from);
-        } else {
-            if ((ks != 0) != other) wg_load_step<KIND, 1>(voff, from);
-            else wg_load_step<KIND, 0>(voff, from);
-        }
-    };
     auto flush_planes = [&]() __attribute__((always_inline)) {
         if (pk_pending) {
             if (lane < 4 * NR) *(lean_g_u32 *)(pl_addr - (uintptr_t)(WG_ROUND / 8)) = (uint32_t)pk_prev;
@@ -448,12 +508,11 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 // this wave's step of the first regular round is asked for; the first allowance comes from the samples of that
                 // round that look acceptable (a guess like any other allowance: the superstep's own B decides)
                 last_off = rbase - m_chunk + (whole - 1u) * (uint32_t)WG_ROUND;   // the chunk's last regular round
-                load_ks(in_wave, false);
-                if constexpr (D == 2) load_ks(in_first + (size_t)min(rbase - m_chunk + (uint32_t)WG_ROUND, last_off) * RB, true);
+                wg_load_step<KIND, NR>(voff, in_wave);
                 const float wlo = ssf * loLf * 0.5f, whi = ssf * hiLf * 1.02f;
                 float b0 = 0.f, n0 = 0.f;
                 float xv[NR];
-                take_ks(xv, std::integral_constant<int, 0>{});   // (reading leaves the registers as they are: the round takes them again)
+                wg_take<KIND, NR>(xv, i16s);   // (reading leaves the registers as they are: the round takes them again)
 #pragma unroll
                 for (int j = 0; j < NR; j++) {
                     uint32_t q = slot_step + 64u * j + lane;
@@ -489,7 +548,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             carry_pending = false;
             if (regular && wave == 0) {
                 float xv[NR];
-                take_ks(xv, std::integral_constant<int, 0>{});
+                wg_take<KIND, NR>(xv, i16s);
                 int lead = 0;
                 bool open = true;
 #pragma unroll
@@ -510,29 +569,32 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             unsigned long long lowany, highany;
             // ---- phase A: this step's envelopes, what can classify at all, its LOW masks for the step after it ----
             if (__builtin_expect(regular, 1)) {
-                // (D == 2: the request for the round after this one and the store beside it may stay in flight -- whatever order
-                // stores and loads complete in, at most four operations left means that this round's four loads are in)
                 WG_PF_BEGIN();
-                take_ks(x, std::integral_constant<int, (D - 1) * NR>{});
+                wg_take<KIND, NR>(x, i16s);
                 WG_PF_END(pf_take);
                 // the plane words of the round before leave, and the registers take the next round (if the chunk has one: past
                 // its end may be past the caller's buffer)
                 if (pk_pending) {
                     if (lane < 4 * NR) *(lean_g_u32 *)(pl_addr - (uintptr_t)(WG_ROUND / 8)) = (uint32_t)pk_prev;
                 }
-                // (asked for unconditionally -- the counted wait above relies on it; past the chunk's last regular round the address
-                // is clamped to that round and the values are never used)
-                load_ks(in_first + (size_t)min(rbase - m_chunk + (uint32_t)(D * WG_ROUND), last_off) * RB, false);
-                const float xmin = __uint_as_float(min(min(__float_as_uint(x[0]), __float_as_uint(x[1])), min(__float_as_uint(x[2]), __float_as_uint(x[3]))));
-                const float xmax = __uint_as_float(max(max(__float_as_uint(x[0]), __float_as_uint(x[1])), max(__float_as_uint(x[2]), __float_as_uint(x[3]))));
+                // (asked for unconditionally; past the chunk's last regular round the address is clamped to that round and the values
+                // are never used)
+                wg_load_step<KIND, NR>(voff, in_first + (size_t)min(rbase - m_chunk + (uint32_t)WG_ROUND, last_off) * RB);
+                uint32_t xlo = __float_as_uint(x[0]), xhi = __float_as_uint(x[0]);   // (envelopes are >= 0: their raw bits order like their values)
+#pragma unroll
+                for (int j = 1; j < NR; j++) {
+                    xlo = min(xlo, __float_as_uint(x[j]));
+                    xhi = max(xhi, __float_as_uint(x[j]));
+                }
+                const float xmin = __uint_as_float(xlo), xmax = __uint_as_float(xhi);
                 lowany = __ballot(!(xmin > tlo_up));
                 highany = __ballot(!(xmax < thi_dn));
                 if (lowany) {
                     unsigned long long lw[NR];
 #pragma unroll
                     for (int j = 0; j < NR; j++) lw[j] = __ballot(x[j] < tlo_dn);
-                    PLANE_PUT8(pk, lw, 0);
-                    PLANE_PUT(pk, 1u, 16);
+                    wg_put_masks<NR>(pk, lw, std::integral_constant<int, 0>{});
+                    PLANE_PUT(pk, 1u, 4 * NR);
                 }
             } else {
                 fetch_env(base, x);
@@ -542,11 +604,11 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                     const uint32_t m = base + 64u * j + lane;
                     lw[j] = __ballot(x[j] < tlo_dn && !((m < m_start) || (m >= n1)));
                 }
-                PLANE_PUT8(pk, lw, 0);
-                PLANE_PUT(pk, 1u, 16);
+                wg_put_masks<NR>(pk, lw, std::integral_constant<int, 0>{});
+                PLANE_PUT(pk, 1u, 4 * NR);
                 lowany = highany = ~0ull;
             }
-            if (lane < 17) *(uint32_t *)((char *)&sh->msk[0][wave][0] + mo + 4u * (uint32_t)lane) = (uint32_t)pk;
+            if (lane <= 4 * NR) *(uint32_t *)((char *)&sh->msk[0][wave][0] + mo + 4u * (uint32_t)lane) = (uint32_t)pk;
             WG_PF_BEGIN();
             wg_barrier();
             WG_PF_END(pf_b1);
@@ -563,7 +625,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 } else {
                     const uint32_t *pm = (wave == 0) ? (const uint32_t *)((const char *)&sh->msk[0][WG_WAVES - 1][0] + mo_prev)
                                                      : (const uint32_t *)((const char *)&sh->msk[0][wave - 1][0] + mo);
-                    if (rfl(pm[16])) {
+                    if (rfl(pm[4 * NR])) {
                         const int pb = (int)base - (int)STEPN;
 #pragma unroll
                         for (int j = 0; j < NR; j++) {
@@ -580,7 +642,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 if (base < n1 && !fail) {
                     fail = general_step(x, base, !regular, before, carry_run, pk);
                     if (!regular) {
-                        const uint32_t w = (base >> 6) + (uint32_t)((lane & 7) >> 1);
+                        const uint32_t w = (base >> 6) + (uint32_t)(plane_dword >> 1);
                         if (!fail && lane < 4 * NR && (size_t)w * 64 < A.n) *(lean_g_u32 *)pl_addr = (uint32_t)pk;
                     }
                 }
@@ -625,15 +687,17 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                         dl_acc += ts;
                         *pa[j] = val;
                     }
-                    amb_lo = min(min(amb_lo, __float_as_uint(x[0]) - __float_as_uint(tlo_dn)),
-                                 min(__float_as_uint(x[1]) - __float_as_uint(tlo_dn), __float_as_uint(x[2]) - __float_as_uint(tlo_dn)));
-                    amb_lo = min(amb_lo, __float_as_uint(x[3]) - __float_as_uint(tlo_dn));
+#pragma unroll
+                    for (int j = 0; j < NR; j++) amb_lo = min(amb_lo, __float_as_uint(x[j]) - __float_as_uint(tlo_dn));
                     // a LOW run longer than max_len covers an aligned block of A.blk samples
                     if constexpr (BLK16) {
 #pragma unroll
                         for (int j = 0; j < NR; j++) lrun = min(lrun, max(__float_as_uint(x[j]), lean_dpp_shl8(__float_as_uint(x[j]))));
                     } else if (A.blk == 64) {
-                        if ((lw[0] == ~0ull) || (lw[1] == ~0ull) || (lw[2] == ~0ull) || (lw[3] == ~0ull)) fail = fail ? fail : 3u;
+                        bool whole_row = false;
+#pragma unroll
+                        for (int j = 0; j < NR; j++) whole_row = whole_row || (lw[j] == ~0ull);
+                        if (whole_row) fail = fail ? fail : 3u;
                     } else {
                         unsigned long long hit = 0;
 #pragma unroll
@@ -659,14 +723,12 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                         dl_acc += ts;
                         *pa[j] = val;
                     }
-                    PLANE_PUT8(pk, hw, 8);
-                    amb_hi = min(min(amb_hi, __float_as_uint(x[0]) - __float_as_uint(thi_dn)),
-                                 min(__float_as_uint(x[1]) - __float_as_uint(thi_dn), __float_as_uint(x[2]) - __float_as_uint(thi_dn)));
-                    amb_hi = min(amb_hi, __float_as_uint(x[3]) - __float_as_uint(thi_dn));
+                    wg_put_masks<NR>(pk, hw, std::integral_constant<int, 1>{});
+#pragma unroll
+                    for (int j = 0; j < NR; j++) amb_hi = min(amb_hi, __float_as_uint(x[j]) - __float_as_uint(thi_dn));
                 }
             }
             if (regular) {
-                ks ^= 1;
                 pk_prev = pk;
                 pk_pending = true;
                 hot_last = base;
@@ -763,12 +825,13 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     int chunk_nl = LL_NONE, chunk_kl = KEY_NONE;
     {
         if (good_run && hot_done > 0) {
-            const int which = (lane >> 2) & 1;   // lanes 0 .. 3 the last regular step's words, 4 .. 7 the one a round before
+            const int which = (lane >= NR) ? 1 : 0;   // lanes 0 .. NR - 1 the last regular step's words, NR .. 2 NR - 1 the one a round before
+            const int wi = lane - which * NR;
             const uint32_t sb = hot_last - (uint32_t)which * (uint32_t)WG_ROUND;
             unsigned long long wd = 0ull;
-            const bool have = lane < 8 && (which == 0 || hot_done > 1);
-            if (have) wd = neg_p[(sb >> 6) + (uint32_t)(lane & 3)];
-            const int rb = (int)sb + 64 * (lane & 3);
+            const bool have = lane < 2 * NR && (which == 0 || hot_done > 1);
+            if (have) wd = neg_p[(sb >> 6) + (uint32_t)wi];
+            const int rb = (int)sb + 64 * wi;
             int ll = (have && wd) ? rb + last_set(wd) : LL_NONE;
             int nl = (have && ~wd) ? rb + last_set(~wd) : LL_NONE;
             my_ll = max(my_ll, wave_max_i32(ll));
