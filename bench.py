@@ -325,6 +325,11 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
     st = ctx.stats()
     cnt = ctx.counts()
     n_edges = int(cnt.n_edges)
+    gathered = None
+    if want_parity and world > 1 and not ahead:
+        # that step was the whole sharding protocol once more: every rank's context holds the decode of ITS shard -- digests of
+        # it travel to rank 0 (JSON over the communicator), which checks every one against the oracle (sharded_parity)
+        gathered = comm.gather_objects(result_digest(ctx.edges(), ctx.symbols(0), ctx.symbols(1), ctx.packets()))
     out = None
     if rank == 0:
         k_avg = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
@@ -341,6 +346,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                        'symbols_reader': int(cnt.n_symbols[1]), 'symbols_tag': int(cnt.n_symbols[0]),
                        'packets': int(cnt.n_packets[0] + cnt.n_packets[1]), 'boundary_redos': redo[0],
                        'shard_overlap_samples': capture_overlap(workload) if world > 1 else 0, 'exchange': backend if world > 1 else 'none',
+                       'rccl_ranks_seen': getattr(comm, 'ranks_seen', None),
                        'steps_are': summary(prim)['steps_are']},
             'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_lean / k_threshold (fused envelope + gated-mean threshold)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -365,6 +371,10 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
         }
         if want_parity:
             out['parity'] = parity_check(workload, own, flags, n, True)
+            if gathered is not None:
+                out['parity']['sharded'] = sharded_parity(workload, n, world, flags, gathered)
+                if out['parity']['sharded'].get('all_equal') is False:
+                    raise SystemExit('bench: a rank\'s shard differs from the oracle\'s cut of the whole capture: %s' % json.dumps(out['parity']['sharded']))
             # the context the timed loop ran in must have produced the same decode: a fresh stream per step / rank 0's shard
             # starts the stream; or, with consecutive batches of one stream, its steady state (when the rounds repeat)
             want_counts = out['parity'] if ahead else out['parity']['first_round']
@@ -442,6 +452,53 @@ def parity_check(workload, own, flags, n, ahead=False):
                     'first_round': {'n_edges': int(per_round[0][0]), 'n_packets': int(per_round[0][1])},
                     'stationary': bool(per_round[-1] == per_round[-2])})
     return out
+
+
+def result_digest(edges, sym0, sym1, packets):
+    """64-bit digests (and counts) of one rank's decode of its shard: the edge list with GLOBAL sample indices, the two symbol
+    streams, the packets.  Same function on the GPU side and on the oracle side of sharded_parity."""
+    import hashlib
+    import numpy as np
+
+    def h(*arrs):
+        m = hashlib.sha256()
+        for a_ in arrs:
+            m.update(np.ascontiguousarray(a_).tobytes())
+        return m.hexdigest()[:16]
+    return {'n_edges': int(len(edges)), 'n_packets': int(len(packets)),
+            'edges': h(np.asarray(edges['idx'], '<i8'), np.asarray(edges['d'], '<i4'), np.asarray(edges['v'], 'i1'), np.asarray(edges['t'], 'i1')),
+            'symbols': h(np.asarray(sym0, np.uint8)) + h(np.asarray(sym1, np.uint8)),
+            'packets': h(np.array([t for t, b in packets], 'i1'), np.array([len(b) for t, b in packets], '<i4'),
+                         np.array([bit for t, b in packets for bit in b], np.uint8))}
+
+
+SHARDED_PARITY_CAP = 800_000_000   # samples of the whole capture the stitched parity leg regenerates and decodes on rank 0's host
+
+
+def sharded_parity(workload, n, world, flags, gathered):
+    """EVERY rank against the oracle: rank 0 regenerates the whole world * n sample capture shard by shard, runs the pinned C
+    oracle ONCE over it (one stream, from sample 0), cuts its outputs at the shard boundaries and compares each cut with what
+    the rank that decoded that shard reported (gathered: every rank's result_digest of its last protocol step)."""
+    from oracle import c_oracle as co
+    total = world * n
+    cap = int(float(os.environ.get('NFC_BENCH_SHARDED_PARITY_CAP', SHARDED_PARITY_CAP)))
+    if total > cap:
+        return {'skipped': 'the capture has %d samples, the stitched leg regenerates at most %d (NFC_BENCH_SHARDED_PARITY_CAP raises it)' % (total, cap),
+                'ranks_reported': gathered}
+    o = co.COracle(**stream_params(workload), **flags)
+    equal, want = [], []
+    for r in range(world):
+        _, own_r = make_capture_slice(workload, n, r, world)
+        tile = len(own_r) // 2
+        o.clear_outputs()
+        for _ in range((n + tile - 1) // tile):   # (a tiled capture: the rank's chunk is the tile again and again)
+            o.push_iq(own_r)
+        d = result_digest(o.edges(), o.symbols(0), o.symbols(1), o.packets())
+        want.append(d)
+        equal.append(bool(d == gathered[r]))
+        del own_r
+    return {'vs': 'oracle/nfc_oracle.c, ONE stream over the whole %d-sample capture, cut at the shard boundaries' % total,
+            'ranks_equal': equal, 'all_equal': bool(all(equal)), 'n_edges': [d['n_edges'] for d in want], 'n_packets': [d['n_packets'] for d in want]}
 
 
 def cpu_baseline(own, flags, params):

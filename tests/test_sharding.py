@@ -347,6 +347,43 @@ def test_bench_spawns_two_ranks_on_one_gpu():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['config']['exchange'] == 'host' and line['config']['boundary_redos'] == 0
     assert line['parity']['edges_equal'] and line['parity']['packets_equal']
+    # EVERY rank's shard against the oracle's cut of the whole capture (rank 0 regenerates it), not only rank 0's
+    sh = line['parity']['sharded']
+    assert sh['ranks_equal'] == [True, True] and sh['all_equal'] and min(sh['n_edges']) > 1000
+    assert line['config']['rccl_ranks_seen'] is None   # (the TCP carrier: no RCCL communicator)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sabotage', [-1, 1])
+def test_two_processes_rccl(sabotage):
+    # BASELINE.json configs[4]'s exchange for real: two PROCESSES, one GPU each, the boundary states all-gathered by RCCL between
+    # the devices (comm.RcclComm over ncclAllGather); each rank's decode against the oracle's cut of the whole capture.  Needs two
+    # visible devices (RCCL refuses two ranks on one): skipped on a one-GPU box.  The ranks are fresh child processes.
+    import json
+    import subprocess
+    import sys
+    from usrp_nfc_amd import api
+    if api.device_count() < 2:
+        pytest.skip('two GPUs needed for two RCCL ranks (%d visible)' % api.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   NFC_TEST_SABOTAGE=str(sabotage), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'rccl_rank.py')], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-2000:] + err[-2000:]
+        outs.append(json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1]))
+    for r, o in enumerate(outs):
+        assert o['rank'] == r and o['ranks_seen'] == 2 and o['device'] == r
+        assert o['got'] == o['want'], 'rank %d differs from the oracle: %r' % (r, o)
+        assert o['got']['n_edges'] > 1000
+    assert outs[0]['redos'] == 0
+    assert outs[1]['redos'] == (1 if sabotage == 1 else 0)
 
 
 class ThreadComm(object):
