@@ -330,11 +330,10 @@ void launch_wg(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipE
         if (e0) NFC_LAUNCH_EXT(kern, dim3(nwork), dim3(256), lds, c->st, e0, e1, 0, A);
         else NFC_LAUNCH(kern, dim3(nwork), dim3(256), lds, c->st, A);
     };
-    const bool b16 = (1 << c->nfold) == 16;
     switch (c->wg_nr) {
-    case 8: if (b16) go(k_threshold_wg<KIND, 8, true>); else go(k_threshold_wg<KIND, 8, false>); break;
-    case 6: if (b16) go(k_threshold_wg<KIND, 6, true>); else go(k_threshold_wg<KIND, 6, false>); break;
-    default: if (b16) go(k_threshold_wg<KIND, 4, true>); else go(k_threshold_wg<KIND, 4, false>); break;
+    case 8: go(k_threshold_wg<KIND, 8>); break;
+    case 6: go(k_threshold_wg<KIND, 6>); break;
+    default: go(k_threshold_wg<KIND, 4>); break;
     }
 }
 template <int KIND>

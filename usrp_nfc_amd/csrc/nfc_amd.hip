@@ -58,10 +58,8 @@ using namespace nfc;
 // ===========================================================================
 namespace {
 // the instantiation of k_threshold_wg a context launches (for the occupancy query and the LDS attribute)
-const void *wg_kernel_of(int kind, int nr, bool b16) {
-#define WGK(K) (nr == 8 ? (b16 ? (const void *)k_threshold_wg<K, 8, true> : (const void *)k_threshold_wg<K, 8, false>) \
-              : nr == 6 ? (b16 ? (const void *)k_threshold_wg<K, 6, true> : (const void *)k_threshold_wg<K, 6, false>) \
-                        : (b16 ? (const void *)k_threshold_wg<K, 4, true> : (const void *)k_threshold_wg<K, 4, false>))
+const void *wg_kernel_of(int kind, int nr) {
+#define WGK(K) (nr == 8 ? (const void *)k_threshold_wg<K, 8> : nr == 6 ? (const void *)k_threshold_wg<K, 6> : (const void *)k_threshold_wg<K, 4>)
     switch (kind) {
     case NFC_IN_IQ_F32: return WGK(IN_IQ_F32);
     case NFC_IN_REAL_F32_SQ: return WGK(IN_REAL_F32_SQ);
@@ -219,7 +217,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         }
         c->wg_ok = p->input_kind != NFC_IN_ENV_F32 && c->mx <= 64 * c->wg_nr - 2 && c->L >= wg_round_samples(c->wg_nr) && c->wg_lds <= 160 * 1024;
         if (c->wg_ok) {
-            const void *kern = wg_kernel_of(p->input_kind, c->wg_nr, (1 << c->nfold) == 16);
+            const void *kern = wg_kernel_of(p->input_kind, c->wg_nr);
             if (c->wg_lds > 64 * 1024) CRT(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->wg_lds));
             int per_cu_wg = 0;
             CRT(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wg, kern, 256, c->wg_lds));

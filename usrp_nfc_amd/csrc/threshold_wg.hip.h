@@ -13,8 +13,11 @@
 //     wave publishes in LDS before the round's first barrier (phase A: envelopes, pre-tests, LOW masks; phase B: ring update);
 //   * the round closes with one exchange of (B, D, failure) per wave and a second barrier; every wave then moves the tracked
 //     sum and opens the next round with the same arithmetic, so nothing is broadcast;
-//   * LOW runs longer than max_len are found by the aligned-block test alone (a run longer than max_len covers an aligned block
-//     of A.blk samples wherever step seams fall); only the run a chunk STARTS in is measured against the carried length;
+//   * a LOW run longer than max_len (a loss of signal) classifies like any other LOW sample; what it changes is whether a HIGH
+//     sample within max_len + 1 of its END is ignored (its last sample may have ended on a time-out, transition_sink.py:95-99).
+//     Only the general form ever asks: it gives up when a run in reach MAY be that long -- an aligned block of A.blk LOW samples
+//     in its step or the two before it (a run longer than max_len covers one wherever step seams fall) --, the run a chunk
+//     STARTS in is measured against the carried length, and a chunk that ends in reach of such a run gives up too;
 //   * rounds that are not four whole steps of stable samples (the stream's first stable sample, a batch's ragged end) take the
 //     masked general form in every wave, on synchronously loaded samples;
 //   * speculation, the saved incoming ring and the summary are spread over the 256 threads.
@@ -58,8 +61,11 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
                  : "v"(voff), "s"(base), "n"(OFFA), "n"(OFFB)                                                            \
                  : "memory", __VA_ARGS__)
 template <int KIND, int NR>
-__device__ __forceinline__ void wg_load_step(uint32_t voff, const char *base) {
+__device__ __forceinline__ void wg_load_step(uint32_t voff, const char *base_in) {
     static_assert(NR == 4 || NR == 6 || NR == 8, "rows per step");
+    // (the base is uniform by construction; said so explicitly, the asm statement's scalar operand is never handed a vector pair)
+    const uintptr_t bi = (uintptr_t)base_in;
+    const char *base = (const char *)(((uintptr_t)rfl((uint32_t)(bi >> 32)) << 32) | (uintptr_t)rfl((uint32_t)bi));
     if constexpr (KIND == IN_IQ_F32) {
         WG_LD2("global_load_dwordx2", "a[0:1]", "a[2:3]", 0, 512, "a0", "a1", "a2", "a3");
         WG_LD2("global_load_dwordx2", "a[4:5]", "a[6:7]", 1024, 1536, "a4", "a5", "a6", "a7");
@@ -142,7 +148,7 @@ __device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (
     }
 }
 
-template <int KIND, int NR, bool BLK16>
+template <int KIND, int NR>
 __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     static_assert(KIND != IN_ENV_F32, "raw envelopes may be negative: no sign bit to spare (they take k_threshold)");
     constexpr uint32_t STEPN = 64u * NR;
@@ -178,6 +184,22 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         scr_par ^= 1;
     };
 
+    // (steps before the chunk's first one have published nothing: their masks read as "no LOW sample"; the barriers of the
+    // prologue order this before the first round)
+    for (int i = tid; i < (int)(sizeof(sh->msk) / 4); i += 256) ((uint32_t *)sh->msk)[i] = 0u;
+    // does a step's LOW mask hold an aligned block of A.blk LOW samples?  (A LOW run longer than max_len covers one, wherever
+    // step seams fall: the last max_len + 1 samples of such a run do.)
+    auto blk_hit = [&](const unsigned long long (&m)[NR]) __attribute__((always_inline)) -> bool {
+        unsigned long long hit = 0;
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            unsigned long long t = m[j];
+#pragma unroll
+            for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
+            hit |= t & A.selmask;
+        }
+        return hit != 0ull;
+    };
     unsigned long long clk0 = 0, clk1 = 0, clk2 = 0;
 #ifdef NFC_WG_PROF
     unsigned long long pf_take = 0, pf_b1 = 0, pf_b2 = 0, pf_rounds = 0, pf_t = 0;   // (a profiling build: where a wave waits)
@@ -325,7 +347,6 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     float b_acc = 0.f, dl_acc = 0.f;
     float tlo_dn = 0.f, tlo_up = 0.f, thi_dn = 0.f, thi_up = 0.f;
     uint32_t amb_lo = 0xFFFFFFFFu, amb_hi = 0xFFFFFFFFu;
-    uint32_t lrun = 0x7F7FFFFFu;
     int my_ll = LL_NONE, my_nl = LL_NONE;   // last LOW / non-LOW sample of this wave's steps (kept exactly over the chunk's last rounds)
     int lz_base = LL_NONE;                  // base of this wave's latest step with LOW samples
     int rounds_since_sync = 0;
@@ -353,8 +374,10 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
 
     // ---------------- the general step on wave masks (phase B) ----------------
     // masked: lanes outside [m_start, n1) are not samples.  before: the last LOW sample before the step (LL_NONE: none in reach);
-    // carry_run: length of the LOW run the CHUNK starts in (its first step only).
-    auto general_step = [&](float (&x)[NR], const uint32_t base, const bool masked, int before, const int carry_run, int &pk) __attribute__((always_inline)) -> uint32_t {
+    // ext_hit: one of the two steps before this one holds an aligned block of LOW samples; own_off / pred_off / ppred_off: where
+    // the LOW masks of this step and of those two lie in LDS (byte offsets into sh->msk).
+    auto general_step = [&](float (&x)[NR], const uint32_t base, const bool masked, int before, const bool ext_hit, const uint32_t own_off,
+                            const uint32_t pred_off, const uint32_t ppred_off, int &pk) __attribute__((always_inline)) -> uint32_t {
         float prev[NR];
         uint32_t slot[NR];
 #pragma unroll
@@ -396,31 +419,79 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             anylow |= lowm[j];
         }
         if (good != ~0ull) return 2u;
-        if (anylow) {
-            const int lead = (lowm[0] == ~0ull) ? 64 : (__ffsll((long long)~lowm[0]) - 1);
-            unsigned long long pre = 0;
+        if (anylow && masked && base < m_start) return 5u;   // (a LOW run across the first stable sample: leave it to the exact kernel)
+        // A HIGH sample within max_len + 1 of a LOW sample is ignored UNLESS that LOW sample ended its run on a time-out
+        // (transition_sink.py:95-99: the sample at which dur exceeds max_len resets the state): sample s + k max_len of a run that
+        // starts at s, k >= 1.  Only a run longer than max_len has one: while no LOW run in reach can be that long -- no aligned
+        // block of LOW samples in this step or the two before it, and the chunk does not start inside a run -- every key is good.
+        // Otherwise the run's start is looked up, per HIGH sample that depends on it, in the LOW masks of those three steps
+        // (before the chunk: the last sample that was not LOW according to the state the chunk starts from).
+        const int carry_in = (int)m_chunk - 1 - nl_in;
+        bool unknown_key = false;
+        const bool exact_keys = blk_hit(lowm) || ext_hit || (carry_in > 0 && (int)base - 2 * (int)STEPN < (int)m_chunk);
+        // The LOW masks of the three steps as uniform words (row k covers samples R0 + 64 k ...), and per row the last sample before
+        // it that is not LOW: nl_in before the chunk's first sample, LL_NONE when nobody knows.
+        const int R0 = (int)base - 2 * (int)STEPN;
+        unsigned long long Mx[3 * NR];
+        int Px[3 * NR];
+        if (exact_keys) {
+            int run = LL_NONE;
+            bool known = false;   // a row inside the chunk has been seen: `run` is exact from here on
 #pragma unroll
-            for (int j = 0; j < NR; j++) pre |= lowm[j] & (lowm[j] >> A.probe_mid) & (lowm[j] >> A.probe_end);
-            unsigned long long hit = 0;
-            if (pre & A.selmask) {
-#pragma unroll
-                for (int j = 0; j < NR; j++) {
-                    unsigned long long t = lowm[j];
-#pragma unroll
-                    for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
-                    hit |= t & A.selmask;
+            for (int k = 0; k < 3 * NR; k++) {
+                const uint32_t so = k < NR ? ppred_off : (k < 2 * NR ? pred_off : own_off);
+                const uint32_t *wp = (const uint32_t *)((const char *)&sh->msk[0][0][0] + so) + 2 * (k % NR);
+                const bool inside = R0 + 64 * k >= (int)m_chunk;
+                if (inside && !known) {
+                    run = (R0 <= (int)m_chunk) ? nl_in : LL_NONE;   // (the window reaches back to the chunk's first sample, or nobody knows)
+                    known = true;
                 }
+                Mx[k] = inside ? ((unsigned long long)rfl(wp[0]) | ((unsigned long long)rfl(wp[1]) << 32)) : ~0ull;   // (before the chunk: nothing to find)
+                Px[k] = run;
+                const unsigned long long nonlow = ~Mx[k];
+                run = nonlow ? R0 + 64 * k + last_set(nonlow) : run;
             }
-            if (hit || ((carry_run > 0) && (carry_run + lead > mx))) return 3u;
-            if (masked && base < m_start) return 5u;   // (a LOW run across the first stable sample: leave it to the exact kernel)
         }
+        // (m is uniform: the lanes that depend on the same LOW sample are served together, see below)
+        auto key_state = [&](const int m) __attribute__((always_inline)) -> int {   // 0 good, 1 ended on a time-out, 2 cannot tell
+            if (m < (int)m_chunk) return 0;   // (a run that ended before the chunk: the incoming key says it, and it is certified)
+            const int q = (m - R0) >> 6, bit = (m - R0) & 63;
+            unsigned long long row = ~0ull;
+            int pq = LL_NONE;
+#pragma unroll
+            for (int k = 0; k < 3 * NR; k++) {
+                row = (q == k) ? Mx[k] : row;
+                pq = (q == k) ? Px[k] : pq;
+            }
+            const unsigned long long nonlow = ~row & ((1ull << bit) - 1ull);   // below m in its row
+            const int s1 = nonlow ? m - bit + last_set(nonlow) : pq;           // the last sample before m that is not LOW
+            if (s1 == LL_NONE) return 2;   // (three steps of LOW samples, or a chunk that starts from an unknown run)
+            const int koff = m - (s1 + 1);
+            return (koff > 0 && (koff % mx) == 0) ? 1 : 0;
+        };
 #pragma unroll
         for (int j = 0; j < NR; j++) {
-            // HIGH is ignored within max_len + 1 samples after a LOW sample
+            // HIGH is ignored within max_len + 1 samples after a LOW sample (whose key is good)
             const int rb = (int)(base + 64u * j);
             const unsigned long long below = lowm[j] & lane_lt;
             const int lastlow = below ? rb + last_set(below) : before;
-            const bool ps = (x[j] > thi_up) && ((rb + lane - lastlow) > mx + 1);
+            bool ign = (rb + lane - lastlow) <= mx + 1;
+            if (exact_keys) {
+                // the lanes whose outcome depends on a key, served one LOW sample at a time (uniform control flow)
+                const bool want = (x[j] > thi_up) && ign;
+                int ks = 0;
+                unsigned long long pend = __ballot(want);
+                while (pend) {
+                    const int m = __builtin_amdgcn_readlane(lastlow, __ffsll((long long)pend) - 1);
+                    const int st = key_state(m);
+                    const bool mine = want && lastlow == m;
+                    ks = mine ? st : ks;
+                    pend &= ~__ballot(mine);
+                }
+                unknown_key = unknown_key || ks == 2;
+                ign = ign && ks == 0;
+            }
+            const bool ps = (x[j] > thi_up) && !ign;
             const bool a = !(x[j] < tlo_dn) && !ps;
             const float t = x[j] - prev[j];
             if (a) {
@@ -435,6 +506,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             posm[j] &= am[j];
             before = lowm[j] ? rb + last_set(lowm[j]) : before;
         }
+        if (__ballot(unknown_key)) return 3u;   // (the ring has been written: nothing of this chunk stands anyway)
         int step_nl = LL_NONE, step_ll = LL_NONE;
 #pragma unroll
         for (int j = 0; j < NR; j++) {
@@ -463,7 +535,6 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // rounds are separated by the first barrier only, the second one and the exchange behind it close the superstep.
     const int sup = max(1, A.ksteps);
     bool primed = false, need_open = true;
-    bool carry_pending = ((int)m_chunk - 1 - nl_in) > 0;   // the chunk starts inside a LOW run: its first step measures the carried length
     uint32_t rbase = m_chunk;   // base of the round
     // which of the three mask buffers this round publishes in, and the round before it did (byte offsets of this wave's row)
     uint32_t mo = 0u, mo_prev = 2u * (uint32_t)sizeof(sh->msk[0]);
@@ -542,25 +613,6 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             if (!open_round() && !fail) fail = 1u;
         }
         need_open = !regular;
-        if (carry_pending) {
-            // the LOW run the chunk starts in must not reach max_len inside it (transition_sink.py:95-99 resets the state there):
-            // measured on the chunk's first step by the wave that has it (a round in the general form does it itself)
-            carry_pending = false;
-            if (regular && wave == 0) {
-                float xv[NR];
-                wg_take<KIND, NR>(xv, i16s);
-                int lead = 0;
-                bool open = true;
-#pragma unroll
-                for (int j = 0; j < NR; j++) {
-                    const unsigned long long m = __ballot(xv[j] < tlo_dn);
-                    const int l = (m == ~0ull) ? 64 : (__ffsll((long long)~m) - 1);
-                    lead += open ? l : 0;
-                    open = open && (m == ~0ull);
-                }
-                if (((int)m_chunk - 1 - nl_in) + lead > mx && !fail) fail = 3u;
-            }
-        }
 
         for (int k = 0; k < nr; k++) {
             const uint32_t base = rbase + STEPN * (uint32_t)wave;
@@ -616,23 +668,32 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             // ---- phase B: the ring, the drift accumulators, the HIGH plane ----
             int form = 0;   // 0 nothing classifies, 1 only LOW, 2 only HIGH with no LOW sample in reach, 3 the general step
             int before = LL_NONE;   // the last LOW sample before this step, if it can matter
-            int carry_run = 0;
+            bool ext_hit = false;   // the two steps before this one may hold a LOW run longer than max_len
+            // where the LOW masks of the step before this one and of the one before that lie: the waves before this one in the
+            // round, or the last waves of the round before
+            const uint32_t wrow = (uint32_t)sizeof(sh->msk[0][0]);
+            const uint32_t own_off = mo + (uint32_t)wave * wrow;
+            const uint32_t pred_off = (wave == 0) ? mo_prev + (uint32_t)(WG_WAVES - 1) * wrow : mo + (uint32_t)(wave - 1) * wrow;
+            const uint32_t ppred_off = (wave >= 2) ? mo + (uint32_t)(wave - 2) * wrow : mo_prev + (uint32_t)(wave + 2) * wrow;
             if (highany) {
                 form = lowany ? 3 : 2;
                 if (!regular && base == m_chunk) {   // a chunk's first step in the general form: what the speculation (chunk 0: the carried state) says
                     before = (kl_in & 1) ? (kl_in >> 1) : LL_NONE;
-                    carry_run = (int)m_chunk - 1 - nl_in;
                 } else {
-                    const uint32_t *pm = (wave == 0) ? (const uint32_t *)((const char *)&sh->msk[0][WG_WAVES - 1][0] + mo_prev)
-                                                     : (const uint32_t *)((const char *)&sh->msk[0][wave - 1][0] + mo);
-                    if (rfl(pm[4 * NR])) {
+                    const uint32_t *pm = (const uint32_t *)((const char *)&sh->msk[0][0][0] + pred_off);
+                    if (rfl(pm[4 * NR]) || lowany) {
+                        unsigned long long pmk[NR], ppk[NR];
+                        const uint32_t *pp = (const uint32_t *)((const char *)&sh->msk[0][0][0] + ppred_off);
                         const int pb = (int)base - (int)STEPN;
 #pragma unroll
                         for (int j = 0; j < NR; j++) {
-                            const unsigned long long m = (unsigned long long)rfl(pm[2 * j]) | ((unsigned long long)rfl(pm[2 * j + 1]) << 32);
-                            before = m ? pb + 64 * j + last_set(m) : before;
+                            pmk[j] = (unsigned long long)rfl(pm[2 * j]) | ((unsigned long long)rfl(pm[2 * j + 1]) << 32);
+                            ppk[j] = (unsigned long long)rfl(pp[2 * j]) | ((unsigned long long)rfl(pp[2 * j + 1]) << 32);
+                            before = pmk[j] ? pb + 64 * j + last_set(pmk[j]) : before;
                         }
-                        if (((int)base - before) <= mx + 1) form = 3;
+                        if (before != LL_NONE && ((int)base - before) <= mx + 1) form = 3;
+                        else before = LL_NONE;
+                        if (form == 3) ext_hit = blk_hit(pmk) || blk_hit(ppk);
                     }
                 }
             } else if (lowany) {
@@ -640,7 +701,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             }
             if (__builtin_expect(form == 3, 0)) {
                 if (base < n1 && !fail) {
-                    fail = general_step(x, base, !regular, before, carry_run, pk);
+                    fail = general_step(x, base, !regular, before, ext_hit, own_off, pred_off, ppred_off, pk);
                     if (!regular) {
                         const uint32_t w = (base >> 6) + (uint32_t)(plane_dword >> 1);
                         if (!fail && lane < 4 * NR && (size_t)w * 64 < A.n) *(lean_g_u32 *)pl_addr = (uint32_t)pk;
@@ -676,11 +737,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                     }
                 } else if (form == 1) {
                     // LOW samples only: rejected ones keep their slot (value and sign bit)
-                    unsigned long long lw[NR];
 #pragma unroll
                     for (int j = 0; j < NR; j++) {
                         const bool lo = x[j] < tlo_dn;
-                        lw[j] = __ballot(lo);
                         const float val = lo ? praw[j] : x[j];
                         const float ts = fabsf(val) - fabsf(praw[j]);   // 0 for a rejected sample
                         b_acc += fabsf(ts);
@@ -689,26 +748,6 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                     }
 #pragma unroll
                     for (int j = 0; j < NR; j++) amb_lo = min(amb_lo, __float_as_uint(x[j]) - __float_as_uint(tlo_dn));
-                    // a LOW run longer than max_len covers an aligned block of A.blk samples
-                    if constexpr (BLK16) {
-#pragma unroll
-                        for (int j = 0; j < NR; j++) lrun = min(lrun, max(__float_as_uint(x[j]), lean_dpp_shl8(__float_as_uint(x[j]))));
-                    } else if (A.blk == 64) {
-                        bool whole_row = false;
-#pragma unroll
-                        for (int j = 0; j < NR; j++) whole_row = whole_row || (lw[j] == ~0ull);
-                        if (whole_row) fail = fail ? fail : 3u;
-                    } else {
-                        unsigned long long hit = 0;
-#pragma unroll
-                        for (int j = 0; j < NR; j++) {
-                            unsigned long long t = lw[j];
-#pragma unroll
-                            for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
-                            hit |= t & A.selmask;
-                        }
-                        if (hit) fail = fail ? fail : 3u;
-                    }
                     lz_base = (int)base;
                 } else {
                     // HIGH samples only, no LOW sample in reach: all of them are rejected (transition_sink.py:71-74)
@@ -754,12 +793,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         {
             const uint32_t wlo = __float_as_uint(tlo_up) - __float_as_uint(tlo_dn), whi = __float_as_uint(thi_up) - __float_as_uint(thi_dn);
             const unsigned long long inband = __ballot(amb_lo <= wlo || amb_hi <= whi);
-            const unsigned long long longlow = __ballot(lrun <= __float_as_uint(tlo_up)) & 0x0001000100010001ull;
             amb_lo = 0xFFFFFFFFu;
             amb_hi = 0xFFFFFFFFu;
-            lrun = 0x7F7FFFFFu;
             if (!fail && inband) fail = 2u;
-            if (!fail && longlow) fail = 3u;
             sh->acc[wave][lane] = make_float2(b_acc, dl_acc);
             b_acc = 0.f;
             dl_acc = 0.f;
@@ -824,6 +860,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // keep no such bookkeeping: the neg-plane words this wave stored for its last two steps say it.
     int chunk_nl = LL_NONE, chunk_kl = KEY_NONE;
     {
+        bool tail_hit = false;   // an aligned block of LOW samples in this wave's last two regular steps
         if (good_run && hot_done > 0) {
             const int which = (lane >= NR) ? 1 : 0;   // lanes 0 .. NR - 1 the last regular step's words, NR .. 2 NR - 1 the one a round before
             const int wi = lane - which * NR;
@@ -834,25 +871,44 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             const int rb = (int)sb + 64 * wi;
             int ll = (have && wd) ? rb + last_set(wd) : LL_NONE;
             int nl = (have && ~wd) ? rb + last_set(~wd) : LL_NONE;
+            unsigned long long t = wd;
+#pragma unroll
+            for (int f = 0; f < 6; f++) t &= t >> A.fold_sh[f];
+            tail_hit = __ballot((t & A.selmask) != 0ull) != 0ull;
             my_ll = max(my_ll, wave_max_i32(ll));
-            my_nl = max(my_nl, wave_max_i32(nl));
+            nl = wave_max_i32(nl);
+            if (nl == LL_NONE && my_nl == LL_NONE) {
+                // (rare: both of them are LOW throughout -- a loss of signal.  The wave looks further back through the words it
+                // stored, four at a time, for its last sample that is not LOW.)
+                for (int k = 2; k < hot_done && nl == LL_NONE; k++) {
+                    const uint32_t sb2 = hot_last - (uint32_t)k * (uint32_t)WG_ROUND;
+                    unsigned long long w2 = ~0ull;
+                    if (lane < NR) w2 = neg_p[(sb2 >> 6) + (uint32_t)lane];
+                    nl = wave_max_i32((lane < NR && ~w2) ? (int)sb2 + 64 * lane + last_set(~w2) : LL_NONE);
+                }
+            }
+            my_nl = max(my_nl, nl);
         }
         if (lane == 0) {
             sh->fin[wave][0] = my_ll;
             sh->fin[wave][1] = my_nl;
             sh->fin[wave][2] = lz_base;
+            sh->fin[wave][3] = tail_hit ? 1 : 0;
         }
         wg_barrier();
-        int ll = LL_NONE, nl = LL_NONE, lz = LL_NONE;
+        int ll = LL_NONE, nl = LL_NONE, lz = LL_NONE, th = 0;
         for (int w = 0; w < WG_WAVES; w++) {
             ll = max(ll, rfl(sh->fin[w][0]));
             nl = max(nl, rfl(sh->fin[w][1]));
             lz = max(lz, rfl(sh->fin[w][2]));
+            th |= rfl(sh->fin[w][3]);
         }
         chunk_nl = nl;
         if (ll != LL_NONE) chunk_kl = 2 * ll + 1;
         else if (lz != LL_NONE) chunk_kl = 2 * (lz + (int)STEPN - 1) + 1;
-        if (good_run && nl == LL_NONE && n1 > m_start) {   // (no non-LOW sample in the last rounds: the block test will have seen it)
+        // the key of the chunk's last LOW sample is good unless its run ended on a time-out -- which nobody has measured: if
+        // that sample is still in reach of the next chunk and its run may have been longer than max_len, the chunk gives up
+        if (good_run && ll != LL_NONE && ((int)n1 - ll) <= mx + 1 && th) {
             good_run = false;
             why = 3u;
         }

@@ -206,8 +206,12 @@ def workload(name, n, rate_msps=2.0, seed=SEED, sigma=0.002):
     'miller'      reader frames only (REQA, ANTI1R, SEL1R, READR), 150 us gaps
     'manchester'  tag frames only (ATQA, ANTI1U, SEL1U, READT), 150 us gaps
     'all'         the whole Ultralight transaction, both directions
+    'stress'      the unhappy path (stress_workload): load modulation hovering at the threshold, five times the noise, drop-outs
+                  and level steps
     Returns interleaved float32 IQ of n samples.
     """
+    if name == 'stress':
+        return stress_workload(n, rate_msps=rate_msps, seed=seed)
     if name == 'miller':
         picks = [ULTRALIGHT_TXN[i] for i in (0, 2, 4, 10)]
     elif name == 'manchester':
@@ -219,6 +223,23 @@ def workload(name, n, rate_msps=2.0, seed=SEED, sigma=0.002):
     frames = [(d, frame_bits(data, sb)) for d, _, data, sb in picks]
     period = modulation_profile(frames, rate_msps=rate_msps, lead_in=0, tail=0)
     m = tiled_profile(period, n)
+    return iq_from_profile(m, seed=seed, sigma=sigma)
+
+
+def stress_workload(n, rate_msps=2.0, seed=SEED, depth=0.0488, sigma=0.01, every=1_000_000, dropout=400, step=1.15):
+    """What a marginal antenna set-up looks like (the reference's README: hi_val 1.05 .. 1.1 "depending on antenna setup"): the
+    whole Ultralight transaction with the tag's load modulation at mag^2 x 1.10 -- exactly hi_val 1.1, so loaded half bits
+    hover at the HIGH threshold --, five times the noise of the other workloads, and every `every` samples a `dropout`-sample
+    loss of signal followed by a level step (the carrier alternates between 1 and `step`)."""
+    frames = [(d, frame_bits(data, sb)) for d, _, data, sb in ULTRALIGHT_TXN]
+    period = modulation_profile(frames, rate_msps=rate_msps, lead_in=0, tail=0, depth=depth)
+    m = tiled_profile(period, n)
+    k = 0
+    for lo in range(every, n, every):
+        k += 1
+        if k & 1:
+            m[lo:min(n, lo + every)] *= np.float32(step)
+        m[lo:min(n, lo + dropout)] = 0.0
     return iq_from_profile(m, seed=seed, sigma=sigma)
 
 
