@@ -224,10 +224,9 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             per_cu_wg = std::max(1, std::min(4, per_cu_wg));   // (measured: four resident workgroups per CU -- four waves per SIMD -- beat five and three)
             if (const char *e = getenv("NFC_WG_PER_CU")) per_cu_wg = std::max(1, std::min(per_cu_wg, atoi(e)));
             c->wg_slots = prop.multiProcessorCount * per_cu_wg;
-            // rounds per superstep: its drift allowance grows with its length relative to the window (0.8 windows: beyond, the
-            // widened HIGH band reaches the loaded half bits of tag frames -- 1 % of the chunks gave up at twice that)
-            if (!c->wg_rounds) c->wg_rounds = std::max(1, (int)(0.8 * c->L / (double)wg_round_samples(c->wg_nr) + 0.5));
-            if (c->wg) c->lean_lds_per_cu = (size_t)per_cu_wg * c->wg_lds;
+            // the longest superstep (rounds): the kernel lengthens and shortens its supersteps by the head-room it sees between the
+            // samples and the thresholds; this caps them
+            if (!c->wg_rounds) c->wg_rounds = 8;
         }
     }
     CRT(hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking));

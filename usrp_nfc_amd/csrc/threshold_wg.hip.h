@@ -4,10 +4,13 @@
 // of chunks, and every chunk pays a window of speculation before it and a summary after it: occupancy could only be bought
 // with more of those.  Here the four waves of a workgroup share one chunk and one LDS ring:
 //
-//   * a ROUND is four steps of 256 samples; wave w takes step w of every round.  Given the thresholds of the round the four
-//     steps are independent (the proof of threshold_lean.hip.h: classifications against bands widened by the drift allowance
-//     G are the reference's while the accepted |x - prev| of the round sum to <= G), and their ring slots are disjoint while
-//     1024 <= L;
+//   * a ROUND is four steps of 64 NR samples; wave w takes step w of every round.  A SUPERSTEP of a few rounds is classified
+//     against the thresholds of the sum tracked at its start, so its steps are independent, and their ring slots are disjoint
+//     while a round fits the window.  No allowance is guessed: when the superstep closes, the drift the window sum turned out
+//     to have (the larger of the sums of the positive and of the negative accepted x - prev, plus what the speculated incoming
+//     ring may be off by) is compared with how close any sample came to a threshold -- farther than the drift, and the
+//     classifications are the reference's (by induction over the samples); the next superstep is made longer or shorter by the
+//     head-room seen;
 //   * what a step needs of the samples before it is one thing only: where the last LOW sample lies, if within max_len + 1
 //     ("HIGH is ignored", transition_sink.py:71) -- with max_len <= 254 that is inside the step before, whose LOW masks its
 //     wave publishes in LDS before the round's first barrier (phase A: envelopes, pre-tests, LOW masks; phase B: ring update);
@@ -41,7 +44,7 @@ struct WgShared {
     uint32_t msk[3][WG_WAVES][4 * WG_NR_MAX + 4];   // per round (modulo three) and wave: the LOW masks of its step (dwords 0 .. 2 NR - 1), dword 4 NR: any LOW sample
     uint32_t scr[2][WG_WAVES][8];      // workgroup reductions (alternating halves: one barrier per reduction)
     int32_t fin[WG_WAVES][4];          // chunk end: last LOW index, last non-LOW index, latest step with LOW samples
-    float2 acc[WG_WAVES][64];          // close of a superstep: every lane's (sum |x - prev|, sum (x - prev)) over what it accepted
+    float4 acc[WG_WAVES][64];          // close of a superstep: every lane's (sum |x - prev|, sum (x - prev)) over what it accepted, its smallest distances to the thresholds
     uint32_t flag[WG_WAVES];           // ... and every wave's failure code
     float bc[8];                       // ... and what wave 0 makes of them: the next thresholds, the sum, the allowance, the verdict
 };
@@ -50,37 +53,50 @@ constexpr size_t WG_SHARED_BYTES = (sizeof(WgShared) + 15) & ~(size_t)15;
 // The workgroup's barrier without the fence __syncthreads() brings: that fence waits for EVERY vector memory operation of the
 // wave (s_waitcnt vmcnt(0)) -- the samples asked for ahead included.  LDS traffic of this wave is complete (lgkmcnt) before it
 // arrives; the asm statement is a compiler barrier for memory accesses as well.
+// smallest value of a wave (finite, non-negative inputs), on DPP moves like wave_sum_f32
+__device__ __forceinline__ float wg_wave_min_f32(float v) {
+    constexpr int BIG = 0x7F7FFFFF;   // lanes without a source take this
+    v = fminf(v, __int_as_float(dpp_i32<0x111, 0xF>(BIG, __float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x112, 0xF>(BIG, __float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x114, 0xF>(BIG, __float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x118, 0xF>(BIG, __float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x142, 0xA>(BIG, __float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_i32<0x143, 0xC>(BIG, __float_as_int(v))));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The 64 NR samples at base (uniform) + voff (this lane's byte offset) into accumulator registers named literally (row j of an
 // IQ step in a[2 j : 2 j + 1], of the one-dword kinds in a[j]; see threshold_lean.hip.h for why) -- with the address split into
 // a scalar base and a 32-bit lane offset, so that walking the chunk costs scalar additions only.
-#define WG_LD2(OP, RA, RB, OFFA, OFFB, ...)                                                                              \
-    asm volatile(OP " " RA ", %0, %1 offset:%2\n\t" OP " " RB ", %0, %1 offset:%3"                                       \
+// (The scalar base may have been written by a VECTOR instruction just before -- v_readlane of a spilled register,
+// v_readfirstlane --, and a vector memory instruction that reads such a register within the next five issue slots gets the OLD
+// value: the hardware does not interlock and the compiler pads only between instructions it emitted itself.  Measured: a
+// memory access fault on whichever build happened to reload the base right in front of the statement.  Hence PRE, "s_nop 4"
+// in front of a step's first loads.)
+#define WG_LD2(PRE, OP, RA, RB, OFFA, OFFB, ...)                                                                         \
+    asm volatile(PRE OP " " RA ", %0, %1 offset:%2\n\t" OP " " RB ", %0, %1 offset:%3"                                   \
                  :                                                                                                       \
                  : "v"(voff), "s"(base), "n"(OFFA), "n"(OFFB)                                                            \
                  : "memory", __VA_ARGS__)
 template <int KIND, int NR>
-__device__ __forceinline__ void wg_load_step(uint32_t voff, const char *base_in) {
+__device__ __forceinline__ void wg_load_step(uint32_t voff, const char *base) {
     static_assert(NR == 4 || NR == 6 || NR == 8, "rows per step");
-    // (the base is uniform by construction; said so explicitly, the asm statement's scalar operand is never handed a vector pair)
-    const uintptr_t bi = (uintptr_t)base_in;
-    const char *base = (const char *)(((uintptr_t)rfl((uint32_t)(bi >> 32)) << 32) | (uintptr_t)rfl((uint32_t)bi));
     if constexpr (KIND == IN_IQ_F32) {
-        WG_LD2("global_load_dwordx2", "a[0:1]", "a[2:3]", 0, 512, "a0", "a1", "a2", "a3");
-        WG_LD2("global_load_dwordx2", "a[4:5]", "a[6:7]", 1024, 1536, "a4", "a5", "a6", "a7");
-        if constexpr (NR >= 6) WG_LD2("global_load_dwordx2", "a[8:9]", "a[10:11]", 2048, 2560, "a8", "a9", "a10", "a11");
-        if constexpr (NR >= 8) WG_LD2("global_load_dwordx2", "a[12:13]", "a[14:15]", 3072, 3584, "a12", "a13", "a14", "a15");
+        WG_LD2("s_nop 4\n\t", "global_load_dwordx2", "a[0:1]", "a[2:3]", 0, 512, "a0", "a1", "a2", "a3");
+        WG_LD2("", "global_load_dwordx2", "a[4:5]", "a[6:7]", 1024, 1536, "a4", "a5", "a6", "a7");
+        if constexpr (NR >= 6) WG_LD2("", "global_load_dwordx2", "a[8:9]", "a[10:11]", 2048, 2560, "a8", "a9", "a10", "a11");
+        if constexpr (NR >= 8) WG_LD2("", "global_load_dwordx2", "a[12:13]", "a[14:15]", 3072, 3584, "a12", "a13", "a14", "a15");
     } else if constexpr (KIND == IN_I16_SQ) {
-        WG_LD2("global_load_sshort", "a0", "a1", 0, 128, "a0", "a1");
-        WG_LD2("global_load_sshort", "a2", "a3", 256, 384, "a2", "a3");
-        if constexpr (NR >= 6) WG_LD2("global_load_sshort", "a4", "a5", 512, 640, "a4", "a5");
-        if constexpr (NR >= 8) WG_LD2("global_load_sshort", "a6", "a7", 768, 896, "a6", "a7");
+        WG_LD2("s_nop 4\n\t", "global_load_sshort", "a0", "a1", 0, 128, "a0", "a1");
+        WG_LD2("", "global_load_sshort", "a2", "a3", 256, 384, "a2", "a3");
+        if constexpr (NR >= 6) WG_LD2("", "global_load_sshort", "a4", "a5", 512, 640, "a4", "a5");
+        if constexpr (NR >= 8) WG_LD2("", "global_load_sshort", "a6", "a7", 768, 896, "a6", "a7");
     } else {
-        WG_LD2("global_load_dword", "a0", "a1", 0, 256, "a0", "a1");
-        WG_LD2("global_load_dword", "a2", "a3", 512, 768, "a2", "a3");
-        if constexpr (NR >= 6) WG_LD2("global_load_dword", "a4", "a5", 1024, 1280, "a4", "a5");
-        if constexpr (NR >= 8) WG_LD2("global_load_dword", "a6", "a7", 1536, 1792, "a6", "a7");
+        WG_LD2("s_nop 4\n\t", "global_load_dword", "a0", "a1", 0, 256, "a0", "a1");
+        WG_LD2("", "global_load_dword", "a2", "a3", 512, 768, "a2", "a3");
+        if constexpr (NR >= 6) WG_LD2("", "global_load_dword", "a4", "a5", 1024, 1280, "a4", "a5");
+        if constexpr (NR >= 8) WG_LD2("", "global_load_dword", "a6", "a7", 1536, 1792, "a6", "a7");
     }
 }
 // Waits for EVERY vector memory operation of the wave (the request went out a round ago), then hands the step's samples over as
@@ -171,7 +187,6 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     const uintptr_t plane_of_lane = (lane >= 2 * NR) ? (uintptr_t)pos_p : (uintptr_t)neg_p;
     const int plane_dword = (lane >= 2 * NR) ? lane - 2 * NR : lane;
     const float i16s = A.i16_scale;
-    const float gfac = A.gfac, gfloor = A.gfloor;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     int scr_par = 0;
     // sum / max / min of K values over the workgroup (every thread gets the result; uniform)
@@ -342,26 +357,21 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     const uint32_t wbase0 = m_chunk + STEPN * (uint32_t)wave;   // this wave's step of round 0
     uint32_t slot_step = (A.g0modL + wbase0) % (uint32_t)L;
     const uint32_t slot_adv = (uint32_t)WG_ROUND % (uint32_t)L;
-    float G = ssf * 0.00390625f;
-    float Bneed = 0.f;
     float b_acc = 0.f, dl_acc = 0.f;
-    float tlo_dn = 0.f, tlo_up = 0.f, thi_dn = 0.f, thi_up = 0.f;
-    uint32_t amb_lo = 0xFFFFFFFFu, amb_hi = 0xFFFFFFFFu;
+    float tlo = 0.f, thi = 0.f;   // the thresholds of the superstep in progress, from the sum tracked at its start
+    // how close a sample of the superstep came to a threshold -- looked at when it closes, against the drift the window sum
+    // turned out to have.  Per-sample distances where a step holds classified samples, the step's extremes otherwise.
+    float dlo = 3.0e38f, dhi = 3.0e38f;
+    uint32_t xlo_acc = 0x7F7FFFFFu, xhi_acc = 0u;   // (raw bits: envelopes are >= 0)
     int my_ll = LL_NONE, my_nl = LL_NONE;   // last LOW / non-LOW sample of this wave's steps (kept exactly over the chunk's last rounds)
     int lz_base = LL_NONE;                  // base of this wave's latest step with LOW samples
     int rounds_since_sync = 0;
 
     auto open_round = [&]() __attribute__((always_inline)) -> bool {
-        const float M = rfl(G + (eps + RND_SUM) * ssf);
-        const float dn = (ssf - M) * slD, up = (ssf + M) * slU;
-        tlo_dn = rfl(dn * loLf);
-        tlo_up = rfl(up * loLf);
-        thi_dn = rfl(dn * hiLf);
-        thi_up = rfl(up * hiLf);
-        if (!(ssf > 1e-30f && ssf < 1e30f && M < 0.25f * ssf && tlo_dn > 1e-30f && thi_up < 1e30f)) return false;
+        tlo = rfl(ssf * loLf);
+        thi = rfl(ssf * hiLf);
+        if (!(ssf > 1e-30f && ssf < 1e30f && tlo > 1e-30f && thi < 1e30f)) return false;
         min_ss = fminf(min_ss, ssf * (etaD - RND_SUM));
-        vmax = max(vmax, __float_as_uint(up));
-        vmin = min(vmin, __float_as_uint(tlo_dn));
         return true;
     };
     auto fetch_env = [&](uint32_t b, float (&x)[NR]) __attribute__((always_inline)) {
@@ -404,21 +414,16 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 if (inact) x[j] = prev[j];
             }
         }
-        unsigned long long lowm[NR], posm[NR], good = ~0ull, anylow = 0;
+        unsigned long long lowm[NR], posm[NR], anylow = 0;
 #pragma unroll
         for (int j = 0; j < NR; j++) {
-            const unsigned long long lo1 = __ballot(x[j] < tlo_dn), lo0 = __ballot(x[j] > tlo_up);
-            const unsigned long long hi1 = __ballot(x[j] > thi_up), hi0 = __ballot(x[j] < thi_dn);
-            unsigned long long g = (lo1 | lo0) & (hi1 | hi0);
-            lowm[j] = lo1;
-            posm[j] = hi1;
-            g |= ~am[j];
-            lowm[j] &= am[j];
-            posm[j] &= am[j];
-            good &= g;
+            const bool act = (am[j] >> lane) & 1ull;
+            lowm[j] = __ballot(x[j] < tlo) & am[j];
+            posm[j] = __ballot(x[j] > thi) & am[j];
+            dlo = fminf(dlo, act ? fabsf(x[j] - tlo) : 3.0e38f);
+            dhi = fminf(dhi, act ? fabsf(x[j] - thi) : 3.0e38f);
             anylow |= lowm[j];
         }
-        if (good != ~0ull) return 2u;
         if (anylow && masked && base < m_start) return 5u;   // (a LOW run across the first stable sample: leave it to the exact kernel)
         // A HIGH sample within max_len + 1 of a LOW sample is ignored UNLESS that LOW sample ended its run on a time-out
         // (transition_sink.py:95-99: the sample at which dur exceeds max_len resets the state): sample s + k max_len of a run that
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             bool ign = (rb + lane - lastlow) <= mx + 1;
             if (exact_keys) {
                 // the lanes whose outcome depends on a key, served one LOW sample at a time (uniform control flow)
-                const bool want = (x[j] > thi_up) && ign;
+                const bool want = (x[j] > thi) && ign;
                 int ks = 0;
                 unsigned long long pend = __ballot(want);
                 while (pend) {
@@ -491,8 +496,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 unknown_key = unknown_key || ks == 2;
                 ign = ign && ks == 0;
             }
-            const bool ps = (x[j] > thi_up) && !ign;
-            const bool a = !(x[j] < tlo_dn) && !ps;
+            const bool ps = (x[j] > thi) && !ign;
+            const bool a = !(x[j] < tlo) && !ps;
             const float t = x[j] - prev[j];
             if (a) {
                 b_acc += fabsf(t);
@@ -533,7 +538,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // A SUPERSTEP is `sup` regular rounds classified against one set of thresholds (A.ksteps), or ONE round that is not four whole
     // steps of stable samples (the stream's first stable sample, a batch's ragged end): its
     // rounds are separated by the first barrier only, the second one and the exchange behind it close the superstep.
-    const int sup = max(1, A.ksteps);
+    const int sup = max(1, A.ksteps);   // the longest superstep
+    int cur_sup = 1;                    // rounds of the next one (it adapts: see the close)
     bool primed = false, need_open = true;
     uint32_t rbase = m_chunk;   // base of the round
     // which of the three mask buffers this round publishes in, and the round before it did (byte offsets of this wave's row)
@@ -549,7 +555,6 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     uintptr_t pl_addr = plane_of_lane + 4 * (2 * (uintptr_t)(wbase0 >> 6) + (uintptr_t)plane_dword);
     const char *const in_first = (const char *)A.in + (size_t)wbase0 * RB;   // this wave's step of the chunk's first round (uniform)
     const char *in_wave = in_first;   // ... of the round in progress
-    uint32_t last_off = 0u;           // sample offset of the chunk's last regular round from its first
     const uint32_t voff = (uint32_t)lane * (uint32_t)RB;
     {
         // what the step before the chunk's first one "published": the last LOW sample before the chunk, if it is in reach
@@ -572,42 +577,19 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     while (good_run && rbase < n1) {
         const bool regular = rbase >= m_start && rbase + (uint32_t)WG_ROUND <= n1;
         int nr = 1;
+        uint32_t whole = 0u;   // regular rounds from here on
         if (regular) {
-            const uint32_t whole = (n1 - rbase) / (uint32_t)WG_ROUND;   // regular rounds from here on
-            nr = (int)min((uint32_t)sup, whole);
+            whole = (n1 - rbase) / (uint32_t)WG_ROUND;
+            nr = (int)min((uint32_t)cur_sup, whole);
             if (!primed) {
-                // this wave's step of the first regular round is asked for; the first allowance comes from the samples of that
-                // round that look acceptable (a guess like any other allowance: the superstep's own B decides)
-                last_off = rbase - m_chunk + (whole - 1u) * (uint32_t)WG_ROUND;   // the chunk's last regular round
+                // this wave's step of the first regular round is asked for
                 wg_load_step<KIND, NR>(voff, in_wave);
-                const float wlo = ssf * loLf * 0.5f, whi = ssf * hiLf * 1.02f;
-                float b0 = 0.f, n0 = 0.f;
-                float xv[NR];
-                wg_take<KIND, NR>(xv, i16s);   // (reading leaves the registers as they are: the round takes them again)
-#pragma unroll
-                for (int j = 0; j < NR; j++) {
-                    uint32_t q = slot_step + 64u * j + lane;
-                    q = (q >= (uint32_t)L) ? q - (uint32_t)L : q;
-                    const bool in = xv[j] > wlo && xv[j] < whi;
-                    b0 += in ? fabsf(xv[j] - fabsf(ring[q])) : 0.f;
-                    n0 += in ? 1.f : 0.f;
-                }
-                uint32_t v[8], g[WG_WAVES][8];
-                v[0] = __float_as_uint(wave_sum_f32(b0));
-                v[1] = __float_as_uint(wave_sum_f32(n0));
-                wg_gather(v, 2, g);
-                b0 = ((__uint_as_float(g[0][0]) + __uint_as_float(g[1][0])) + __uint_as_float(g[2][0])) + __uint_as_float(g[3][0]);
-                n0 = ((__uint_as_float(g[0][1]) + __uint_as_float(g[1][1])) + __uint_as_float(g[2][1])) + __uint_as_float(g[3][1]);
-                // (half of sum |x - prev|: what the positive or the negative differences alone come to, see the close)
-                Bneed = ((n0 >= 64.f) ? 0.5f * b0 / n0 * (float)WG_ROUND : ssf * 0.0009765625f * (float)WG_WAVES) * (float)sup;
-                G = rfl(fminf(fmaxf(gfac * Bneed, ssf * gfloor), ssf * 0.125f));
                 primed = true;
                 need_open = true;
             }
         } else {
             flush_planes();
             primed = false;
-            G = rfl(fminf(fmaxf(G, ssf * 0.015625f), ssf * 0.125f));   // (up to 1024 samples against a guess: 2^-6 of the sum)
         }
         if (need_open) {   // (otherwise wave 0 opened the superstep when it closed the one before)
             if (!open_round() && !fail) fail = 1u;
@@ -629,9 +611,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 if (pk_pending) {
                     if (lane < 4 * NR) *(lean_g_u32 *)(pl_addr - (uintptr_t)(WG_ROUND / 8)) = (uint32_t)pk_prev;
                 }
-                // (asked for unconditionally; past the chunk's last regular round the address is clamped to that round and the values
-                // are never used)
-                wg_load_step<KIND, NR>(voff, in_first + (size_t)min(rbase - m_chunk + (uint32_t)WG_ROUND, last_off) * RB);
+                // (asked for unconditionally; in the chunk's last regular round this round's samples are asked for again and the
+                // values are never used)
+                wg_load_step<KIND, NR>(voff, (uint32_t)(k + 1) < whole ? in_wave + (size_t)WG_ROUND * RB : in_wave);
                 uint32_t xlo = __float_as_uint(x[0]), xhi = __float_as_uint(x[0]);   // (envelopes are >= 0: their raw bits order like their values)
 #pragma unroll
                 for (int j = 1; j < NR; j++) {
@@ -639,12 +621,16 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                     xhi = max(xhi, __float_as_uint(x[j]));
                 }
                 const float xmin = __uint_as_float(xlo), xmax = __uint_as_float(xhi);
-                lowany = __ballot(!(xmin > tlo_up));
-                highany = __ballot(!(xmax < thi_dn));
+                lowany = __ballot(xmin < tlo);
+                highany = __ballot(xmax > thi);
+                // (a step without LOW samples is as far from the LOW threshold as its smallest sample, one without HIGH samples as
+                // far from the HIGH threshold as its largest: the steps that have them measure every sample, below)
+                xlo_acc = lowany ? xlo_acc : min(xlo_acc, xlo);
+                xhi_acc = highany ? xhi_acc : max(xhi_acc, xhi);
                 if (lowany) {
                     unsigned long long lw[NR];
 #pragma unroll
-                    for (int j = 0; j < NR; j++) lw[j] = __ballot(x[j] < tlo_dn);
+                    for (int j = 0; j < NR; j++) lw[j] = __ballot(x[j] < tlo);
                     wg_put_masks<NR>(pk, lw, std::integral_constant<int, 0>{});
                     PLANE_PUT(pk, 1u, 4 * NR);
                 }
@@ -654,7 +640,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
 #pragma unroll
                 for (int j = 0; j < NR; j++) {
                     const uint32_t m = base + 64u * j + lane;
-                    lw[j] = __ballot(x[j] < tlo_dn && !((m < m_start) || (m >= n1)));
+                    lw[j] = __ballot(x[j] < tlo && !((m < m_start) || (m >= n1)));
                 }
                 wg_put_masks<NR>(pk, lw, std::integral_constant<int, 0>{});
                 PLANE_PUT(pk, 1u, 4 * NR);
@@ -739,32 +725,32 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                     // LOW samples only: rejected ones keep their slot (value and sign bit)
 #pragma unroll
                     for (int j = 0; j < NR; j++) {
-                        const bool lo = x[j] < tlo_dn;
+                        const float dx = x[j] - tlo;
+                        const bool lo = dx < 0.f;
                         const float val = lo ? praw[j] : x[j];
                         const float ts = fabsf(val) - fabsf(praw[j]);   // 0 for a rejected sample
                         b_acc += fabsf(ts);
                         dl_acc += ts;
+                        dlo = fminf(dlo, fabsf(dx));
                         *pa[j] = val;
                     }
-#pragma unroll
-                    for (int j = 0; j < NR; j++) amb_lo = min(amb_lo, __float_as_uint(x[j]) - __float_as_uint(tlo_dn));
                     lz_base = (int)base;
                 } else {
                     // HIGH samples only, no LOW sample in reach: all of them are rejected (transition_sink.py:71-74)
                     unsigned long long hw[NR];
 #pragma unroll
                     for (int j = 0; j < NR; j++) {
-                        const bool hi = x[j] > thi_up;
+                        const float dx = x[j] - thi;
+                        const bool hi = dx > 0.f;
                         hw[j] = __ballot(hi);
                         const float val = hi ? praw[j] : x[j];
                         const float ts = fabsf(val) - fabsf(praw[j]);
                         b_acc += fabsf(ts);
                         dl_acc += ts;
+                        dhi = fminf(dhi, fabsf(dx));
                         *pa[j] = val;
                     }
                     wg_put_masks<NR>(pk, hw, std::integral_constant<int, 1>{});
-#pragma unroll
-                    for (int j = 0; j < NR; j++) amb_hi = min(amb_hi, __float_as_uint(x[j]) - __float_as_uint(thi_dn));
                 }
             }
             if (regular) {
@@ -786,19 +772,20 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             mo = (mo == 2u * (uint32_t)sizeof(sh->msk[0])) ? 0u : mo + (uint32_t)sizeof(sh->msk[0]);
         }
 
-        // ---- the superstep closes: was the allowance enough for what the lanes accumulated, did no sample sit inside a band,
-        // can no LOW run have reached max_len?  Every lane hands in its two sums and every wave its verdict; WAVE 0 adds them up,
-        // moves the tracked sum on, sets the next allowance and opens the next superstep (a round of whole steps is taken for
-        // granted: anything else opens again above) -- the others only read the thresholds it leaves behind.
+        // ---- the superstep closes: did every sample keep clear of the thresholds by more than the window sum drifted?  Every lane
+        // hands in its sums and distances and every wave its verdict; WAVE 0 adds them up, moves the tracked sum on, chooses the
+        // next superstep's length and opens it (a round of whole steps is taken for granted: anything else opens again above) --
+        // the others only read the thresholds it leaves behind.
         {
-            const uint32_t wlo = __float_as_uint(tlo_up) - __float_as_uint(tlo_dn), whi = __float_as_uint(thi_up) - __float_as_uint(thi_dn);
-            const unsigned long long inband = __ballot(amb_lo <= wlo || amb_hi <= whi);
-            amb_lo = 0xFFFFFFFFu;
-            amb_hi = 0xFFFFFFFFu;
-            if (!fail && inband) fail = 2u;
-            sh->acc[wave][lane] = make_float2(b_acc, dl_acc);
+            // every lane hands in (sum |x - prev|, sum (x - prev), its smallest distance to the LOW threshold, to the HIGH threshold)
+            const float dl2 = fminf(dlo, __uint_as_float(xlo_acc) - tlo), dh2 = fminf(dhi, thi - __uint_as_float(xhi_acc));
+            sh->acc[wave][lane] = make_float4(b_acc, dl_acc, dl2, dh2);
             b_acc = 0.f;
             dl_acc = 0.f;
+            dlo = 3.0e38f;
+            dhi = 3.0e38f;
+            xlo_acc = 0x7F7FFFFFu;
+            xhi_acc = 0u;
             if (lane == 0) sh->flag[wave] = fail;
             const bool resync = rounds_since_sync >= 64;   // bound the rounding the f32 sum accumulates: re-derive it from the ring
             if (resync) rounds_since_sync = 0;
@@ -806,16 +793,34 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             wg_barrier();
             WG_PF_END(pf_b2);
             if (wave == 0) {
-                const float2 a0 = sh->acc[0][lane], a1 = sh->acc[1][lane], a2 = sh->acc[2][lane], a3 = sh->acc[3][lane];
+                const float4 a0 = sh->acc[0][lane], a1 = sh->acc[1][lane], a2 = sh->acc[2][lane], a3 = sh->acc[3][lane];
                 const float Bs = wave_sum_f32((a0.x + a1.x) + (a2.x + a3.x)) * 1.001f;
                 const float Dt = wave_sum_f32((a0.y + a1.y) + (a2.y + a3.y));
+                const float dlmin = wg_wave_min_f32(fminf(fminf(a0.z, a1.z), fminf(a2.z, a3.z)));
+                const float dhmin = wg_wave_min_f32(fminf(fminf(a0.w, a1.w), fminf(a2.w, a3.w)));
                 const uint4 fl = *(const uint4 *)&sh->flag[0];
                 uint32_t f = rfl(fl.x | fl.y | fl.z | fl.w);
                 // Every partial sum of the accepted (x - prev), in stream order, lies in [-N, P]: N / P the sums of the negative /
-                // the positive ones -- (Bs -/+ Dt) / 2.  The allowance has to cover the larger of the two, not their sum.
+                // the positive ones -- (Bs -/+ Dt) / 2.  So every window sum of the superstep lay within M of the tracked one
+                // (eps: what the speculated incoming ring may be off by; RND: the rounding of the f32 tracking), every true
+                // threshold within that share of the one used -- and the classifications are the reference's if no sample came
+                // closer to it (by induction over the samples: while those so far are right, so is the drift bound).
                 const float B = 0.5f * (Bs + fabsf(Dt)) * 1.0001f;
-                if (!f && !(B <= G)) f = 4u;
+                const float M = (B + (eps + RND_SUM) * ssf) * slU + ssf * 7.62939453125e-06f;   // (+ 2^-17 of the sum: the f32 thresholds)
+                const float need_lo = M * loLf, need_hi = M * hiLf;
+                if (!f && !(dlmin > need_lo && dhmin > need_hi && M < 0.25f * ssf)) f = (dlmin > need_lo && dhmin > need_hi) ? 4u : 2u;
+                int next_sup = cur_sup;
                 if (!f) {
+                    // every window sum of the superstep lay below ssf + M, and what it accepted between the thresholds
+                    vmax = max(vmax, __float_as_uint((ssf + M) * slU));
+                    vmin = min(vmin, __float_as_uint(tlo));
+                    // the next superstep: longer while the samples keep well clear of what the drift needs, shorter when they come close
+                    // (twice as long drifts twice as far: doubled when the distances seen would still be twice what that needs,
+                    // halved when they are within half again of what this one needed)
+                    const float M2 = (2.f * B + (eps + RND_SUM) * ssf) * slU + ssf * 7.62939453125e-06f;
+                    const float head = fminf(dlmin / fmaxf(need_lo, 1e-30f), dhmin / fmaxf(need_hi, 1e-30f));
+                    const float head2 = fminf(dlmin / fmaxf(M2 * loLf, 1e-30f), dhmin / fmaxf(M2 * hiLf, 1e-30f));
+                    if (regular) next_sup = head2 > 2.f ? min(2 * cur_sup, sup) : (head < 1.5f ? max(1, cur_sup / 2) : cur_sup);
                     ssf = rfl(ssf + Dt);
                     if (resync) {   // (the ring is quiescent: the other waves wait for the verdict)
                         double part = 0;
@@ -823,31 +828,22 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                         for (int s2 = lane; s2 < L; s2 += 64) part += (double)fabsf(ring[s2]);
                         ssf = (float)rfl(wave_sum_f64(part) + cr.delta);
                     }
-                    if (regular) {
-                        Bneed = fmaxf(Bneed, B);
-                        G = rfl(fminf(fmaxf(gfac * Bneed, ssf * gfloor), ssf * 0.125f));
-                    }
                     if (!open_round()) f = 1u;
                 }
-                if (lane == 0) {
-                    *(float4 *)&sh->bc[0] = make_float4(tlo_dn, tlo_up, thi_dn, thi_up);
-                    *(float4 *)&sh->bc[4] = make_float4(ssf, G, Bneed, __uint_as_float(f));
-                }
+                if (lane == 0) *(float4 *)&sh->bc[0] = make_float4(tlo, thi, ssf, __uint_as_float(f | ((uint32_t)next_sup << 8)));
             }
             wg_barrier();
-            const float4 t4 = *(const float4 *)&sh->bc[0], s4 = *(const float4 *)&sh->bc[4];
-            const uint32_t f = rfl(__float_as_uint(s4.w));
+            const float4 t4 = *(const float4 *)&sh->bc[0];
+            const uint32_t fw = rfl(__float_as_uint(t4.w));
+            const uint32_t f = fw & 0xFFu;
             if (f) {
                 why = (f > 5u) ? 2u : f;   // (codes of several waves may be or-ed together: the aid names one at most)
                 good_run = false;
             } else {
-                tlo_dn = rfl(t4.x);
-                tlo_up = rfl(t4.y);
-                thi_dn = rfl(t4.z);
-                thi_up = rfl(t4.w);
-                ssf = rfl(s4.x);
-                G = rfl(s4.y);
-                Bneed = rfl(s4.z);
+                tlo = rfl(t4.x);
+                thi = rfl(t4.y);
+                ssf = rfl(t4.z);
+                cur_sup = (int)(fw >> 8);
             }
         }
     }
