@@ -17,3 +17,5 @@ def test_lean_kernel_isa_audit(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if 'k_threshold_lean' in l]
     assert len(lines) >= 6 and all(l.endswith('0 findings') for l in lines), r.stdout   # every instantiation was looked at
+    wg = [l for l in r.stdout.splitlines() if 'k_threshold_wg' in l]
+    assert len(wg) >= 9 and all(l.endswith('0 findings') for l in wg), r.stdout        # 3 input kinds x 3 step heights (+ the two-rounds-ahead form)

@@ -91,7 +91,7 @@ struct nfc_ctx {
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
     int lean = 1, lean_k = 0, lean_rounds = 0, lean_slots = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
-    int wg = 1, wg_ok = 0, wg_nr = 4, wg_slots = 0, wg_now = 0, wg_rounds = 0;   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
+    int wg = 1, wg_ok = 0, wg_nr = 4, wg_d = 1, wg_slots = 0, wg_now = 0, wg_rounds = 0;   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
                                                                  // rows of 64 samples per step (NFC_WG_NR), resident workgroups, this batch uses it, rounds per superstep
     size_t wg_lds = 0;
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
@@ -333,7 +333,12 @@ void launch_wg(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipE
     switch (c->wg_nr) {
     case 8: go(k_threshold_wg<KIND, 8>); break;
     case 6: go(k_threshold_wg<KIND, 6>); break;
-    default: go(k_threshold_wg<KIND, 4>); break;
+    default:
+        if constexpr (KIND == IN_IQ_F32) {
+            if (c->wg_d == 2) { go(k_threshold_wg<KIND, 4, 2>); break; }
+        }
+        go(k_threshold_wg<KIND, 4>);
+        break;
     }
 }
 template <int KIND>

@@ -58,7 +58,8 @@ using namespace nfc;
 // ===========================================================================
 namespace {
 // the instantiation of k_threshold_wg a context launches (for the occupancy query and the LDS attribute)
-const void *wg_kernel_of(int kind, int nr) {
+const void *wg_kernel_of(int kind, int nr, int d) {
+    if (kind == NFC_IN_IQ_F32 && nr == 4 && d == 2) return (const void *)k_threshold_wg<IN_IQ_F32, 4, 2>;
 #define WGK(K) (nr == 8 ? (const void *)k_threshold_wg<K, 8> : nr == 6 ? (const void *)k_threshold_wg<K, 6> : (const void *)k_threshold_wg<K, 4>)
     switch (kind) {
     case NFC_IN_IQ_F32: return WGK(IN_IQ_F32);
@@ -118,6 +119,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     }
     if (const char *e = getenv("NFC_WG")) c->wg = atoi(e) != 0;
     if (const char *e = getenv("NFC_WG_ROUNDS")) c->wg_rounds = std::max(1, atoi(e));
+    if (const char *e = getenv("NFC_WG_D")) c->wg_d = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("NFC_LEAN")) c->lean = atoi(e) != 0;
     c->lean_k = 0;        // chosen below from the occupancy the LDS ring allows, unless set here
     c->lean_rounds = 0;
@@ -163,6 +165,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         for (int k = 0; k < 64; k += b) c->selmask |= 1ull << k;
     }
     c->eps = 0.01f;  // certification margin of the speculative pass, relative to the window sum
+    if (const char *e = getenv("NFC_EPS")) c->eps = (float)atof(e);
     c->i16_scale = p->i16_scale > 0.f ? p->i16_scale : -1.0f;   // (0: GNU Radio's wavfile_source normalisation, sample / 32767; threshold.hip.h: i16_to_float)
     static const size_t bps[4] = {8, 4, 4, 2};
     c->in_bytes_per_sample = bps[p->input_kind];
@@ -217,12 +220,13 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         }
         c->wg_ok = p->input_kind != NFC_IN_ENV_F32 && c->mx <= 64 * c->wg_nr - 2 && c->L >= wg_round_samples(c->wg_nr) && c->wg_lds <= 160 * 1024;
         if (c->wg_ok) {
-            const void *kern = wg_kernel_of(p->input_kind, c->wg_nr);
+            const void *kern = wg_kernel_of(p->input_kind, c->wg_nr, c->wg_d);
             if (c->wg_lds > 64 * 1024) CRT(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->wg_lds));
             int per_cu_wg = 0;
             CRT(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wg, kern, 256, c->wg_lds));
+            const int per_cu_max = per_cu_wg;
             per_cu_wg = std::max(1, std::min(4, per_cu_wg));   // (measured: four resident workgroups per CU -- four waves per SIMD -- beat five and three)
-            if (const char *e = getenv("NFC_WG_PER_CU")) per_cu_wg = std::max(1, std::min(per_cu_wg, atoi(e)));
+            if (const char *e = getenv("NFC_WG_PER_CU")) per_cu_wg = std::max(1, std::min(per_cu_max, atoi(e)));
             c->wg_slots = prop.multiProcessorCount * per_cu_wg;
             // the longest superstep (rounds): the kernel lengthens and shortens its supersteps by the head-room it sees between the
             // samples and the thresholds; this caps them

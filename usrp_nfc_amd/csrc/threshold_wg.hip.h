@@ -72,31 +72,47 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // (The scalar base may have been written by a VECTOR instruction just before -- v_readlane of a spilled register,
 // v_readfirstlane --, and a vector memory instruction that reads such a register within the next five issue slots gets the OLD
 // value: the hardware does not interlock and the compiler pads only between instructions it emitted itself.  Measured: a
-// memory access fault on whichever build happened to reload the base right in front of the statement.  Hence PRE, "s_nop 4"
-// in front of a step's first loads.)
-#define WG_LD2(PRE, OP, RA, RB, OFFA, OFFB, ...)                                                                         \
-    asm volatile(PRE OP " " RA ", %0, %1 offset:%2\n\t" OP " " RB ", %0, %1 offset:%3"                                   \
-                 :                                                                                                       \
-                 : "v"(voff), "s"(base), "n"(OFFA), "n"(OFFB)                                                            \
+// memory access fault on whichever build happened to reload the base right in front of the statement.  Hence the "s_nop 4" at
+// the head, and ONE statement for all loads of a step: nothing of the compiler's comes between the pad and the last load.)
+#define WG_LDS_(OP, R, K) OP " " R ", %0, %1 offset:%" #K "\n\t"
+#define WG_LD4(OP, R0, R1, R2, R3, ST, ...)                                                                                  \
+    asm volatile("s_nop 4\n\t" WG_LDS_(OP, R0, 2) WG_LDS_(OP, R1, 3) WG_LDS_(OP, R2, 4) OP " " R3 ", %0, %1 offset:%5"         \
+                 :                                                                                                           \
+                 : "v"(voff), "s"(base), "n"(0), "n"(ST), "n"(2 * (ST)), "n"(3 * (ST))                                       \
                  : "memory", __VA_ARGS__)
+#define WG_LD6(OP, R0, R1, R2, R3, R4, R5, ST, ...)                                                                          \
+    asm volatile("s_nop 4\n\t" WG_LDS_(OP, R0, 2) WG_LDS_(OP, R1, 3) WG_LDS_(OP, R2, 4) WG_LDS_(OP, R3, 5) WG_LDS_(OP, R4, 6)  \
+                 OP " " R5 ", %0, %1 offset:%7"                                                                              \
+                 :                                                                                                           \
+                 : "v"(voff), "s"(base), "n"(0), "n"(ST), "n"(2 * (ST)), "n"(3 * (ST)), "n"(4 * (ST)), "n"(5 * (ST))         \
+                 : "memory", __VA_ARGS__)
+#define WG_LD8(OP, R0, R1, R2, R3, R4, R5, R6, R7, ST, ...)                                                                  \
+    asm volatile("s_nop 4\n\t" WG_LDS_(OP, R0, 2) WG_LDS_(OP, R1, 3) WG_LDS_(OP, R2, 4) WG_LDS_(OP, R3, 5) WG_LDS_(OP, R4, 6)  \
+                 WG_LDS_(OP, R5, 7) WG_LDS_(OP, R6, 8) OP " " R7 ", %0, %1 offset:%9"                                        \
+                 :                                                                                                           \
+                 : "v"(voff), "s"(base), "n"(0), "n"(ST), "n"(2 * (ST)), "n"(3 * (ST)), "n"(4 * (ST)), "n"(5 * (ST)),        \
+                   "n"(6 * (ST)), "n"(7 * (ST))                                                                              \
+                 : "memory", __VA_ARGS__)
+#define WG_A03 "a0", "a1", "a2", "a3"
+#define WG_A47 "a4", "a5", "a6", "a7"
+#define WG_A8B "a8", "a9", "a10", "a11"
+#define WG_ACF "a12", "a13", "a14", "a15"
 template <int KIND, int NR>
 __device__ __forceinline__ void wg_load_step(uint32_t voff, const char *base) {
     static_assert(NR == 4 || NR == 6 || NR == 8, "rows per step");
     if constexpr (KIND == IN_IQ_F32) {
-        WG_LD2("s_nop 4\n\t", "global_load_dwordx2", "a[0:1]", "a[2:3]", 0, 512, "a0", "a1", "a2", "a3");
-        WG_LD2("", "global_load_dwordx2", "a[4:5]", "a[6:7]", 1024, 1536, "a4", "a5", "a6", "a7");
-        if constexpr (NR >= 6) WG_LD2("", "global_load_dwordx2", "a[8:9]", "a[10:11]", 2048, 2560, "a8", "a9", "a10", "a11");
-        if constexpr (NR >= 8) WG_LD2("", "global_load_dwordx2", "a[12:13]", "a[14:15]", 3072, 3584, "a12", "a13", "a14", "a15");
+        if constexpr (NR == 4) WG_LD4("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", 512, WG_A03, WG_A47);
+        if constexpr (NR == 6) WG_LD6("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", "a[8:9]", "a[10:11]", 512, WG_A03, WG_A47, WG_A8B);
+        if constexpr (NR == 8)
+            WG_LD8("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", "a[8:9]", "a[10:11]", "a[12:13]", "a[14:15]", 512, WG_A03, WG_A47, WG_A8B, WG_ACF);
     } else if constexpr (KIND == IN_I16_SQ) {
-        WG_LD2("s_nop 4\n\t", "global_load_sshort", "a0", "a1", 0, 128, "a0", "a1");
-        WG_LD2("", "global_load_sshort", "a2", "a3", 256, 384, "a2", "a3");
-        if constexpr (NR >= 6) WG_LD2("", "global_load_sshort", "a4", "a5", 512, 640, "a4", "a5");
-        if constexpr (NR >= 8) WG_LD2("", "global_load_sshort", "a6", "a7", 768, 896, "a6", "a7");
+        if constexpr (NR == 4) WG_LD4("global_load_sshort", "a0", "a1", "a2", "a3", 128, WG_A03);
+        if constexpr (NR == 6) WG_LD6("global_load_sshort", "a0", "a1", "a2", "a3", "a4", "a5", 128, WG_A03, "a4", "a5");
+        if constexpr (NR == 8) WG_LD8("global_load_sshort", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", 128, WG_A03, WG_A47);
     } else {
-        WG_LD2("s_nop 4\n\t", "global_load_dword", "a0", "a1", 0, 256, "a0", "a1");
-        WG_LD2("", "global_load_dword", "a2", "a3", 512, 768, "a2", "a3");
-        if constexpr (NR >= 6) WG_LD2("", "global_load_dword", "a4", "a5", 1024, 1280, "a4", "a5");
-        if constexpr (NR >= 8) WG_LD2("", "global_load_dword", "a6", "a7", 1536, 1792, "a6", "a7");
+        if constexpr (NR == 4) WG_LD4("global_load_dword", "a0", "a1", "a2", "a3", 256, WG_A03);
+        if constexpr (NR == 6) WG_LD6("global_load_dword", "a0", "a1", "a2", "a3", "a4", "a5", 256, WG_A03, "a4", "a5");
+        if constexpr (NR == 8) WG_LD8("global_load_dword", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", 256, WG_A03, WG_A47);
     }
 }
 // Waits for EVERY vector memory operation of the wave (the request went out a round ago), then hands the step's samples over as
@@ -140,6 +156,34 @@ __device__ __forceinline__ void wg_take(float (&x)[NR], float i16_scale) {
         }
     }
 }
+// Two rounds of samples asked for ahead (IQ input, four rows per step): a second set of registers, a[8 .. 15], and a wait that
+// lets the younger request stay in flight.  A round issues exactly four loads and one store, in that order after its take: at
+// the take of round r the operations still in flight are -- oldest first -- the loads of round r, the store of round r - 2, the
+// loads of round r + 1 and the store of round r - 1; loads complete in order among themselves, so "at most four left" means
+// the loads of round r are in, whatever the stores do.
+template <int SET>
+__device__ __forceinline__ void wg_load_step_iq4(uint32_t voff, const char *base) {
+    if constexpr (SET == 0) WG_LD4("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", 512, WG_A03, WG_A47);
+    else WG_LD4("global_load_dwordx2", "a[8:9]", "a[10:11]", "a[12:13]", "a[14:15]", 512, WG_A8B, WG_ACF);
+}
+template <int SET, bool ALL>
+__device__ __forceinline__ void wg_take_iq4(float (&x)[4], float) {
+    float w[8];
+    if constexpr (SET == 0) {
+        if constexpr (ALL) WG_RD4("s_waitcnt vmcnt(0)\n\t", "a0", "a1", "a2", "a3", 0);
+        else WG_RD4("s_waitcnt vmcnt(4)\n\t", "a0", "a1", "a2", "a3", 0);
+        WG_RD4("", "a4", "a5", "a6", "a7", 4);
+    } else {
+        if constexpr (ALL) WG_RD4("s_waitcnt vmcnt(0)\n\t", "a8", "a9", "a10", "a11", 0);
+        else WG_RD4("s_waitcnt vmcnt(4)\n\t", "a8", "a9", "a10", "a11", 0);
+        WG_RD4("", "a12", "a13", "a14", "a15", 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float a = w[2 * j] * w[2 * j], b = w[2 * j + 1] * w[2 * j + 1];
+        x[j] = a + b;
+    }
+}
 // the dwords of NR masks into lanes LANE0 .. LANE0 + 2 NR - 1 of pk
 #define PLANE_PUT4(pk, m, I0, LANE0)                                                                                                       \
     asm volatile("s_nop 2\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %5+1\n\tv_writelane_b32 %0, %3, %5+2\n\tv_writelane_b32 %0, %4, %5+3" \
@@ -164,8 +208,9 @@ __device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (
     }
 }
 
-template <int KIND, int NR>
+template <int KIND, int NR, int D = 1>
 __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
+    static_assert(D == 1 || (D == 2 && NR == 4 && KIND == IN_IQ_F32), "two rounds ahead: IQ input, four rows per step");
     static_assert(KIND != IN_ENV_F32, "raw envelopes may be negative: no sign bit to spare (they take k_threshold)");
     constexpr uint32_t STEPN = 64u * NR;
     constexpr int WG_ROUND = wg_round_samples(NR);
@@ -540,7 +585,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // rounds are separated by the first barrier only, the second one and the exchange behind it close the superstep.
     const int sup = max(1, A.ksteps);   // the longest superstep
     int cur_sup = 1;                    // rounds of the next one (it adapts: see the close)
-    bool primed = false, need_open = true;
+    bool primed = false, need_open = true, just_primed = false;
+    int ks = 0;   // (D == 2) which registers hold this round's samples
     uint32_t rbase = m_chunk;   // base of the round
     // which of the three mask buffers this round publishes in, and the round before it did (byte offsets of this wave's row)
     uint32_t mo = 0u, mo_prev = 2u * (uint32_t)sizeof(sh->msk[0]);
@@ -583,7 +629,20 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             nr = (int)min((uint32_t)cur_sup, whole);
             if (!primed) {
                 // this wave's step of the first regular round is asked for
-                wg_load_step<KIND, NR>(voff, in_wave);
+                if constexpr (D == 1) {
+                    wg_load_step<KIND, NR>(voff, in_wave);
+                } else {
+                    // (this round into the set `ks` names, the next one into the other: asked for again if the chunk has none)
+                    const char *nx = whole > 1u ? in_wave + (size_t)WG_ROUND * RB : in_wave;
+                    if (ks) {
+                        wg_load_step_iq4<1>(voff, in_wave);
+                        wg_load_step_iq4<0>(voff, nx);
+                    } else {
+                        wg_load_step_iq4<0>(voff, in_wave);
+                        wg_load_step_iq4<1>(voff, nx);
+                    }
+                    just_primed = true;
+                }
                 primed = true;
                 need_open = true;
             }
@@ -604,7 +663,19 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             // ---- phase A: this step's envelopes, what can classify at all, its LOW masks for the step after it ----
             if (__builtin_expect(regular, 1)) {
                 WG_PF_BEGIN();
-                wg_take<KIND, NR>(x, i16s);
+                if constexpr (D == 1) {
+                    wg_take<KIND, NR>(x, i16s);
+                } else {
+                    // (right after the requests of a chunk's first rounds nothing has been stored in between: everything is waited for)
+                    if (just_primed) {
+                        if (ks) wg_take_iq4<1, true>(x, i16s);
+                        else wg_take_iq4<0, true>(x, i16s);
+                        just_primed = false;
+                    } else {
+                        if (ks) wg_take_iq4<1, false>(x, i16s);
+                        else wg_take_iq4<0, false>(x, i16s);
+                    }
+                }
                 WG_PF_END(pf_take);
                 // the plane words of the round before leave, and the registers take the next round (if the chunk has one: past
                 // its end may be past the caller's buffer)
@@ -613,7 +684,15 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 }
                 // (asked for unconditionally; in the chunk's last regular round this round's samples are asked for again and the
                 // values are never used)
-                wg_load_step<KIND, NR>(voff, (uint32_t)(k + 1) < whole ? in_wave + (size_t)WG_ROUND * RB : in_wave);
+                if constexpr (D == 1) {
+                    wg_load_step<KIND, NR>(voff, (uint32_t)(k + 1) < whole ? in_wave + (size_t)WG_ROUND * RB : in_wave);
+                } else {
+                    // (the registers just read take the round after next)
+                    const char *nx = (uint32_t)(k + 2) < whole ? in_wave + (size_t)(2 * WG_ROUND) * RB : in_wave;
+                    if (ks) wg_load_step_iq4<1>(voff, nx);
+                    else wg_load_step_iq4<0>(voff, nx);
+                    ks ^= 1;
+                }
                 uint32_t xlo = __float_as_uint(x[0]), xhi = __float_as_uint(x[0]);   // (envelopes are >= 0: their raw bits order like their values)
 #pragma unroll
                 for (int j = 1; j < NR; j++) {
