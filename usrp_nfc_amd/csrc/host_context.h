@@ -94,6 +94,7 @@ struct nfc_ctx {
     int wg = 1, wg_ok = 0, wg_nr = 4, wg_d = 1, wg_slots = 0, wg_now = 0, wg_rounds = 0;   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
                                                                  // rows of 64 samples per step (NFC_WG_NR), resident workgroups, this batch uses it, rounds per superstep
     size_t wg_lds = 0;
+    int wg_rerun = 0;   // certification-only failures re-run by k_threshold_wg in mode 1 (NFC_WG_RERUN=1; see host_threshold.h)
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
     int gring_ok = 0, gring_force = 0, wave_slots_g = 0;   // long windows qualify (NFC_RING=lds|global overrides the choice)

@@ -120,6 +120,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     if (const char *e = getenv("NFC_WG")) c->wg = atoi(e) != 0;
     if (const char *e = getenv("NFC_WG_ROUNDS")) c->wg_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("NFC_WG_D")) c->wg_d = atoi(e) >= 2 ? 2 : 1;
+    if (const char *e = getenv("NFC_WG_RERUN")) c->wg_rerun = atoi(e) != 0;
     if (const char *e = getenv("NFC_LEAN")) c->lean = atoi(e) != 0;
     c->lean_k = 0;        // chosen below from the occupancy the LDS ring allows, unless set here
     c->lean_rounds = 0;

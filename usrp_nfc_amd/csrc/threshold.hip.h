@@ -1101,8 +1101,12 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     const uint32_t slotid = bid * (blockDim.x >> 6) + wave;
     if (slotid >= A.nlist) return;
     const uint32_t c = A.list ? A.list[slotid] : slotid + 1;
-    if (c == 0) {   // (chunk 0 re-run from the carried state: nothing it could disagree with)
-        if (lane == 0) cert[0] = 1;
+    if (c == 0) {   // (chunk 0 re-run from the carried state: nothing it could disagree with -- unless the re-run itself gave up)
+        if (lane == 0) {
+            const bool ok0 = !(A.gflags[0] & 4u);
+            cert[0] = ok0 ? 1 : 0;
+            if (!ok0 && sum) atomicAdd(&sum->n_fail, 1u);
+        }
         return;
     }
     const int L = A.L;
@@ -1144,7 +1148,7 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     const bool low_ok = (nl == mt.nl_in) && ((kl == mt.kl_in) || (!live(kl) && !live(mt.kl_in)));
     bool ok;
     if (mt.eps > 0.f) ok = mt.all_robust && (d <= mt.eps * mt.min_ss * 0.999f) && low_ok;
-    else ok = !__any(differ) && (nl == mt.nl_in) && (kl == mt.kl_in);
+    else ok = !__any(differ) && (nl == mt.nl_in) && (kl == mt.kl_in) && !(A.gflags[c] & 4u);   // (flag 4: a re-run by k_threshold_wg that gave up)
     if (lane == 0) {
         cert[c] = ok ? 1 : 0;
         if (!ok && sum) atomicAdd(&sum->n_fail, 1u);

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = rfl(tid >> 6);
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = A.list ? rfl(A.list[blockIdx.x]) : blockIdx.x;   // (a re-run from the exact state, mode 1: the chunks of a list)
     float *ring = (float *)smem;
     lean_lds_f *const rl = (lean_lds_f *)ring;
     WgShared *const sh = (WgShared *)(smem + (size_t)A.Lpad * 4);
@@ -283,6 +283,23 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             nl_in = carried_nl(A);
             kl_in = carried_kl(A);
             wg_barrier();
+        } else if (A.mode == 1) {
+            // the exact state, resolved from the predecessors' summaries by look-back (chunk_incoming of threshold.hip.h)
+            double part = 0;
+            for (int s = tid; s < L; s += 256) {
+                const float v = resolve_slot(A, (int)c, s);
+                ring[s] = v;
+                part += (double)v;
+            }
+            const double ps = wave_sum_f64(part);
+            uint32_t v[8], g[WG_WAVES][8];
+            v[0] = (uint32_t)__double2loint(ps);
+            v[1] = (uint32_t)__double2hiint(ps);
+            wg_gather(v, 2, g);   // (its barrier also completes the ring)
+            double tot = 0;
+            for (int w = 0; w < WG_WAVES; w++) tot += __hiloint2double((int)g[w][1], (int)g[w][0]);
+            ss0 = tot + cr.delta;
+            resolve_low_state(A, (int)c, nl_in, kl_in);
         } else {
             // speculate: the L samples before the chunk, rejected-looking ones replaced by a level estimate
             eps = A.eps;
@@ -991,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
 
     if (A.dbg_clk) clk2 = clock64();
     const uint32_t all_robust = good_run ? 1u : 0u;
-    if (c == 0 && tid == 0) {   // chunk 0 has no certification of its own: its verdict travels here
+    if (c == 0 && tid == 0 && A.mode == 0) {   // chunk 0 has no certification of its own: its verdict travels here
         A.cert[0] = good_run ? 1 : 0;
         if (!good_run) atomicAdd(&A.sum->n_fail, 1u);
     }
@@ -1000,8 +1017,10 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         uint32_t v[8], g[WG_WAVES][8];
         v[0] = wave_min_u32(vmin);
         v[1] = wave_max_u32(vmax);
-        float *ro = A.ring_out[0] + (size_t)c * L;
-        uint32_t *to = A.touched[0] + (size_t)c * A.twords;
+        // pass 0 fills the buffer the version byte names (0: prepare_batch zeroes them), a re-run the other one
+        const int vb_new = (A.mode == 1) ? 1 - (int)A.ver[c] : (int)A.ver[c];
+        float *ro = (vb_new ? A.ring_out[1] : A.ring_out[0]) + (size_t)c * L;
+        uint32_t *to = (vb_new ? A.touched[1] : A.touched[0]) + (size_t)c * A.twords;
         uint32_t untouched = 0;
         for (int sbase = 64 * wave; sbase < A.twords * 32; sbase += 256) {
             const int s = sbase + lane;
@@ -1038,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             ci.emax = emax;
             ci.flags = flags;
             ci.n_untouched = untouched;
-            A.info[0][c] = ci;
+            (vb_new ? A.info[1] : A.info[0])[c] = ci;
             A.gmin[c] = (uint8_t)emin;
             A.gmax[c] = (uint8_t)emax;
             A.gflags[c] = (uint8_t)(flags | (untouched ? 2u : 0u));
