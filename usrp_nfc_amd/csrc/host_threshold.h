@@ -355,6 +355,21 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             }
             if (failing.empty()) break;
             first_round = false;
+            // A chunk right behind one that is re-run now and that did not give up itself is NOT re-run in this round: its own
+            // evaluation may well be sound -- what failed is the comparison with a predecessor whose summary was worthless -- and
+            // from the state resolved now it would only be evaluated against that worthless summary again.  It stays pending
+            // (below: it can see a re-run chunk) and is certified against the predecessor's new summary in the next round.
+            {
+                std::vector<uint32_t> now;
+                uint32_t last = 0xFFFFFFFFu;
+                for (uint32_t k : failing) {   // (ascending)
+                    const bool gave_up = (h_gflags[k] & 4) != 0;
+                    if (!gave_up && last != 0xFFFFFFFFu && k == last + 1) continue;
+                    now.push_back(k);
+                    last = k;
+                }
+                failing.swap(now);
+            }
             // Re-runs from the exact state.  A chunk whose speculation could not be certified -- its own pass was sound, only its
             // incoming state was not what it assumed -- is re-run by the workgroup kernel where that kernel ran pass 0 (mode 1: four
             // waves on the chunk take a tenth of what one does); a chunk that gave up, in pass 0 or in such a re-run, takes the
