@@ -281,8 +281,9 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
             for k in range(steps):
                 # every 8th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
                 # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are)
-                timed = k % 8 == 3   # (not the region's very first launches)
-                if timed or k % 8 == 4:
+                stride = 8 if steps >= 32 else max(2, steps // 5)   # (a short region still times several launches: 10 steps -> 5)
+                timed = k % stride == 1 if stride < 8 else k % 8 == 3   # (not the region's very first launch)
+                if timed or (k and (k - 1) % stride == 1 if stride < 8 else k % 8 == 4):
                     ctx.set_timing(1 if timed else 0)
                 one_step()
                 if timed:
@@ -348,7 +349,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                        'shard_overlap_samples': capture_overlap(workload) if world > 1 else 0, 'exchange': backend if world > 1 else 'none',
                        'rccl_ranks_seen': getattr(comm, 'ranks_seen', None),
                        'steps_are': summary(prim)['steps_are']},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_lean / k_threshold (fused envelope + gated-mean threshold)',
+            'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_wg (fused envelope + gated-mean threshold, a time chunk per workgroup; k_threshold_lean / k_threshold where it does not apply)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': tsrc, 'avg_launch_ms': k_avg, 'launches_timed': len(kernel_ms),
                          'launches_per_step': float(np.mean(n_pass)) if n_pass else None,
@@ -394,14 +395,58 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
 def hbm_traffic(workload, n):
     """HBM bytes per threshold launch from the rocprofv3 PMC passes recorded under profiles/ (separate --pmc FETCH_SIZE /
     WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md): a record of an
-    earlier run, not a measurement of this one -- `traffic_source` says so.  None unless the record matches the workload."""
+    earlier run, not a measurement of this one -- `traffic_source` says so.  profiles/hbm_traffic.json is a list of records
+    keyed by workload and sample count (tools/profiles.sh writes it); None unless one matches."""
     try:
-        rec = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
-        if rec.get('workload') == workload and int(rec.get('samples', 0)) == n:
-            return rec['bytes_per_launch'], 'profiles/hbm_traffic.json (%s)' % rec.get('kernel', 'k_threshold')
+        recs = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
+        if isinstance(recs, dict):
+            recs = [recs]
+        for rec in recs:
+            if rec.get('workload') == workload and int(rec.get('samples', 0)) == n:
+                return rec['bytes_per_launch'], 'profiles/hbm_traffic.json (%s)' % rec.get('kernel', 'k_threshold')
     except Exception:
         pass
     return None, None
+
+
+def stress_config(a, name, n, steps=6):
+    """The unhappy path, one batch at a time on fresh streams (usrp_nfc_amd/synth.py: stress_workload): what a step costs when
+    chunks of the threshold stage give up or cannot be certified and are evaluated again -- threshold passes, chunks re-run,
+    parity against the C oracle on the whole capture."""
+    import numpy as np
+    from oracle import c_oracle as co
+    from usrp_nfc_amd import api, synth
+    kw = {'stress_dropouts': dict(depth=0.08, sigma=0.002, step=1.0),
+          'stress_dropouts_steps': dict(depth=0.08, sigma=0.002),
+          'stress_hover': dict()}[name]
+    iq = synth.stress_workload(n, **kw)
+    buf = api.DeviceBuffer(iq)
+    out = {'workload': name, 'samples': n, 'generator': 'synth.stress_workload(%s)' % ', '.join('%s=%s' % kv for kv in sorted(kw.items())),
+           'what': {'stress_dropouts': 'the -t all workload with a 400-sample loss of signal every 1e6 samples',
+                    'stress_dropouts_steps': 'the same with a +-15 % level step behind every loss of signal',
+                    'stress_hover': 'tag load modulation at mag^2 x 1.10 = hi_val exactly, five times the noise, drop-outs and level steps: '
+                                    'every loaded half bit hovers at the HIGH threshold, no chunk of the speculative pass can be certified'}[name]}
+    with api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **stream_params('all'), **decoder_flags('all')) as ctx:
+        ts = []
+        for k in range(steps):
+            ctx.reset()
+            ctx.sync()
+            t0 = time.perf_counter()
+            ctx.push_device(buf, n)
+            ctx.sync()
+            ts.append(time.perf_counter() - t0)
+        st = ctx.stats()
+        out.update({'ms_per_step': float(np.median(ts[1:])) * 1e3, 'steps': steps - 1, 'threshold_passes': int(st.threshold_passes),
+                    'chunks_rerun': int(st.chunks_rerun), 'n_chunks': int(st.n_chunks), 'used_sequential': int(st.used_sequential)})
+        if not a.no_parity:
+            o = co.COracle(**stream_params('all'), **decoder_flags('all'))
+            o.push_iq(iq)
+            ge, oe = ctx.edges(), o.edges()
+            out['parity'] = {'edges_equal': bool(len(ge) == len(oe) and np.array_equal(ge['idx'].astype(np.int64), oe['idx']) and np.array_equal(ge['d'], oe['d'])
+                                                 and np.array_equal(ge['v'], oe['v']) and np.array_equal(ge['t'], oe['t'])),
+                             'symbols_equal': bool(all(np.array_equal(ctx.symbols(t), o.symbols(t)) for t in (0, 1))),
+                             'packets_equal': bool(ctx.packets() == o.packets()), 'n_edges': int(len(oe))}
+    return out
 
 
 def parity_check(workload, own, flags, n, ahead=False):
@@ -620,6 +665,11 @@ def rank_main(a):
                                'unit': 'Msamples/s', 'roofline': o2['roofline'], 'time_chunks': o2['config']['time_chunks'],
                                'parity': o2.get('parity')})
             line['other_configs'] = others
+            # the unhappy path: chunks that give up / cannot be certified
+            line['stress'] = [stress_config(a, nm, 100_000_000) for nm in ('stress_dropouts', 'stress_dropouts_steps', 'stress_hover')]
+            clean = out['ms_per_step']
+            for e in line['stress']:
+                e['vs_clean_step'] = e['ms_per_step'] / clean
         print(json.dumps(line))
         sys.stdout.flush()
     if hasattr(comm, 'barrier'):

@@ -9,9 +9,14 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -
 # the same with batches submitted ahead (--primary ahead): the threshold stage of batch k + 1 beside the later stages of batch k
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_ahead -o ${tag}a -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-parity --no-extras --primary ahead > $out/${tag}_bench_ahead_under_rocprof.json 2> $out/stats_ahead.log
 python3 tools/timeline2.py $out/stats_ahead/${tag}a_kernel_trace.csv 60 22 > $out/${tag}_timeline_ahead.txt 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/fetch.log
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o p -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/write.log
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $out/sq -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/sq.log
+# counter passes, per workload (configs[1], [2], [3]): FETCH_SIZE, WRITE_SIZE and the SQ instruction counters each in a pass of its own
+for wl in miller manchester classic1k; do
+  extra=""; [ $wl = classic1k ] && extra="--samples 1e9"
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch_$wl -o p -- python3 bench.py --workload $wl $extra --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/fetch_$wl.log
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write_$wl -o p -- python3 bench.py --workload $wl $extra --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/write_$wl.log
+  timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $out/sq_$wl -o p -- python3 bench.py --workload $wl $extra --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-extras --sync-steps > /dev/null 2> $out/sq_$wl.log
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o ${tag}_$wl -- python3 bench.py --workload $wl $extra --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-extras --sync-steps > $out/${tag}_bench_${wl}_under_rocprof.json 2> $out/stats_$wl.log
+done
 timeout 400 python3 bench.py > $out/${tag}_bench.json 2> $out/bench.log
 python3 - <<PY
 import csv, json, collections
@@ -40,25 +45,49 @@ def pmc(d, name):
     byd = collections.defaultdict(float)
     for r in rs: byd[r["Dispatch_Id"]] += float(r["Counter_Value"])
     v = sorted(byd.values()); return v[len(v) // 2]
-f, w = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
-kname = sorted({r["Kernel_Name"] for r in csv.DictReader(open(f"{out}/fetch/p_counter_collection.csv")) if "k_threshold" in r["Kernel_Name"]})
-rec = {"workload": "miller", "samples": 100000000, "kernel": ", ".join(k.replace("void nfc::", "").split("(")[0] for k in kname), "FETCH_SIZE_kb": round(f), "WRITE_SIZE_kb": round(w),
-       "correction": "FETCH_SIZE x2 (gfx950: TCC_EA0_RDREQ counted at 64 B per 128-B request, MI355X_MICROARCH.md section HBM); WRITE_SIZE as reported",
-       "bytes_per_launch": int((2 * f + w) * 1024),
-       "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps   (and the same with --pmc WRITE_SIZE); median over the launches"}
-json.dump(rec, open(f"{out}/hbm_traffic.json", "w"), indent=1)
-# instruction counts per wave of every kernel of a step (one --pmc pass of SQ counters)
-rows = list(csv.DictReader(open(f"{out}/sq/p_counter_collection.csv")))
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); nd = collections.defaultdict(set)
-for r in rows:
-    k = r["Kernel_Name"].replace("void nfc::", "").replace("nfc::", "").split("(")[0][:60]
-    agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); nd[k].add(r["Dispatch_Id"])
+recs = []
+for wl, ns in (("miller", 100000000), ("manchester", 100000000), ("classic1k", 1000000000)):
+    try:
+        f, w = pmc("fetch_" + wl, "FETCH_SIZE"), pmc("write_" + wl, "WRITE_SIZE")
+        kname = sorted({r["Kernel_Name"] for r in csv.DictReader(open(f"{out}/fetch_{wl}/p_counter_collection.csv")) if "k_threshold" in r["Kernel_Name"]})
+        recs.append({"workload": wl, "samples": ns, "kernel": ", ".join(k.replace("void nfc::", "").split("(")[0] for k in kname), "FETCH_SIZE_kb": round(f), "WRITE_SIZE_kb": round(w),
+                     "correction": "FETCH_SIZE x2 (gfx950: TCC_EA0_RDREQ counted at 64 B per 128-B request, MI355X_MICROARCH.md section HBM); WRITE_SIZE as reported",
+                     "bytes_per_launch": int((2 * f + w) * 1024),
+                     "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --workload %s%s --steps 2 --warmup 0 --no-cpu-baseline --no-parity --no-extras --sync-steps   (and the same with --pmc WRITE_SIZE); median over the launches" % (wl, " --samples 1e9" if wl == "classic1k" else "")})
+    except Exception as e:
+        print("no traffic record for", wl, e)
+rec = recs
+json.dump(recs, open(f"{out}/hbm_traffic.json", "w"), indent=1)
+# instruction counts per wave of every kernel of a step (one --pmc pass of SQ counters), per workload
 with open(f"{out}/{tag}_sq_counters.txt", "w") as fh:
-    fh.write("per dispatch: waves, and VALU / SALU / LDS / VMEM-read / VMEM-write instructions per wave\n")
-    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"]):
-        n = len(nd[k]); wv = max(v["SQ_WAVES"] / n, 1)
-        fh.write("%-62s dispatches %3d waves %8d  valu %7.0f salu %7.0f lds %6.0f vmem_rd %6.1f vmem_wr %6.1f\n" % (
-            k, n, wv, v["SQ_INSTS_VALU"] / n / wv, v["SQ_INSTS_SALU"] / n / wv, v["SQ_INSTS_LDS"] / n / wv, v["SQ_INSTS_VMEM_RD"] / n / wv, v["SQ_INSTS_VMEM_WR"] / n / wv))
+    for wl in ("miller", "manchester", "classic1k"):
+        try:
+            rows = list(csv.DictReader(open(f"{out}/sq_{wl}/p_counter_collection.csv")))
+        except Exception as e:
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(float)); nd = collections.defaultdict(set)
+        for r in rows:
+            k = r["Kernel_Name"].replace("void nfc::", "").replace("nfc::", "").split("(")[0][:60]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); nd[k].add(r["Dispatch_Id"])
+        fh.write("== %s: per dispatch: waves, and VALU / SALU / LDS / VMEM-read / VMEM-write instructions per wave\n" % wl)
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"]):
+            n = len(nd[k]); wv = max(v["SQ_WAVES"] / n, 1)
+            fh.write("%-62s dispatches %3d waves %8d  valu %7.0f salu %7.0f lds %6.0f vmem_rd %6.1f vmem_wr %6.1f\n" % (
+                k, n, wv, v["SQ_INSTS_VALU"] / n / wv, v["SQ_INSTS_SALU"] / n / wv, v["SQ_INSTS_LDS"] / n / wv, v["SQ_INSTS_VMEM_RD"] / n / wv, v["SQ_INSTS_VMEM_WR"] / n / wv))
+# per-workload kernel tables (one batch at a time)
+for wl in ("manchester", "classic1k"):
+    try:
+        rows = list(csv.DictReader(open(f"{out}/stats_{wl}/{tag}_{wl}_kernel_stats.csv")))
+    except Exception as e:
+        continue
+    thr = [r for r in rows if "k_threshold" in r["Name"]]
+    nstep = sum(int(r["Calls"]) for r in thr) if thr else 1
+    lines = []; tot = 0
+    for r in rows:
+        per = float(r["TotalDurationNs"]) / nstep / 1e3; tot += per
+        lines.append("%-90s calls/step %5.2f  avg %8.1f us  per-step %8.1f us" % (r["Name"].replace("nfc::", "").replace("void ", "")[:88], int(r["Calls"]) / nstep, float(r["AverageNs"]) / 1e3, per))
+    lines.append("total per step %.1f us over %d steps; --sync-steps: one batch at a time" % (tot, nstep))
+    open(f"{out}/{tag}_kernel_stats_per_step_{wl}.txt", "w").write("\n".join(lines) + "\n")
 print(open(f"{out}/{tag}_sq_counters.txt").read())
 print(rec)
 print(open(f"{out}/{tag}_kernel_stats_per_step.txt").read())
