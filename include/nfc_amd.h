@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define NFC_AMD_ABI_VERSION 1
+/* 2: nfc_stats grew (ran_ahead, redone_total); i16_scale == 0 means sample / 32767 (GNU Radio's wavfile_source), not / 32768 */
+#define NFC_AMD_ABI_VERSION 2
 
 typedef enum {
     NFC_OK = 0,

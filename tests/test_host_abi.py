@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.nfc_abi_version() == 1
+    assert L.nfc_abi_version() == _lib.ABI_VERSION
 
 
 def test_struct_layouts_match_header():
@@ -101,3 +101,24 @@ def test_window_beyond_the_upper_bound_is_refused():
         with pytest.raises(api.NfcError) as e:
             api.NfcContext(**kw)
         assert 'av_window' in str(e.value) or 'max_len' in str(e.value) or 'samp_rate' in str(e.value)
+
+
+def test_ctypes_structures_match_the_header(tmp_path):
+    # the sizes the C compiler gives the header's structures against the ctypes mirrors in usrp_nfc_amd/_lib.py, and the ABI version
+    # both sides name: a field added on one side only is caught here (nfc_get_stats writes the whole structure into the caller's)
+    import ctypes
+    import os
+    import subprocess
+    from usrp_nfc_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / 'sz.c'
+    src.write_text('#include <stdio.h>\n#include "nfc_amd.h"\nint main(void) { printf("%d %zu %zu %zu %zu %zu %zu %zu\\n", NFC_AMD_ABI_VERSION, '
+                   'sizeof(nfc_params), sizeof(nfc_counts), sizeof(nfc_stats), sizeof(nfc_state_header), sizeof(nfc_edge), sizeof(nfc_packet), '
+                   'sizeof(nfc_frame)); return 0; }\n')
+    exe = tmp_path / 'sz'
+    subprocess.check_call(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [_lib.ABI_VERSION, ctypes.sizeof(_lib.Params), ctypes.sizeof(_lib.Counts), ctypes.sizeof(_lib.Stats), ctypes.sizeof(_lib.StateHeader),
+            _lib.EDGE_DTYPE.itemsize, _lib.PACKET_DTYPE.itemsize, ctypes.sizeof(_lib.Frame)]
+    assert got == want, (got, want)
+    assert _lib.load().nfc_abi_version() == _lib.ABI_VERSION == 2

@@ -147,3 +147,59 @@ def test_decoder_reads_raw_iq_file(tmp_path):
     o.push_iq(iq)
     assert f.got == o.packets() and len(f.got) > 50
 
+
+
+@pytest.mark.gpu
+def test_background_decodes_a_foreign_sinks_transitions():
+    # the mirror of INTEGRATION.md section B: the REFERENCE's transition_sink (here its line-for-line restatement) feeding THIS
+    # package's background through append(): lists it did not produce go through the device's decode and framing stages
+    # (nfc_push_edges) and come out as the packets the reference's own background.run would have made (background.py:27-52)
+    from oracle import py_oracle as po
+    from usrp_nfc_amd import background as bg
+    c = Case('fx_ultralight_txn')
+    got = []
+
+    class Fsm(object):
+        def process_bits(self, bits, ptype):
+            got.append((ptype, list(bits)))
+
+    back = bg.background(reader=True, tag=True, fsm=Fsm(), samp_rate=c.params['samp_rate'], max_len=c.params['max_len'])
+    ts = po.TransitionSink(c.params['samp_rate'], back.append, lo_val=c.params['lo_val'], hi_val=c.params['hi_val'],
+                           av_window=c.params['av_window'], max_len=c.params['max_len'])
+    po.drive_sink(ts, c.x, 8192)
+    back.close()
+    assert got == c.packets and len(got) == 19
+    assert list(back.packets) == c.packets
+
+
+@pytest.mark.gpu
+def test_integration_md_hybrid_block_runs():
+    # INTEGRATION.md section B's code block, executed as written (with a stand-in for gnuradio.gr and the library's real path):
+    # the reference's transition_sink class body replaced by the ctypes calls, fed the Ultralight transaction in scheduler-sized
+    # calls; the concatenated callback content must be the reference's transition list
+    import os
+    import re
+    import types
+    from usrp_nfc_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', md, re.S)
+    code = [b for b in blocks if 'class transition_sink(gr.sync_block)' in b]
+    assert len(code) == 1
+    src = code[0].replace("C.CDLL('libnfc_amd.so')", 'C.CDLL(%r)' % build.SO)
+    gr = types.SimpleNamespace()
+
+    class sync_block(object):
+        def __init__(self, name=None, in_sig=None, out_sig=None):
+            pass
+
+    gr.sync_block = sync_block
+    ns = {'gr': gr}
+    exec(compile(src, 'INTEGRATION.md', 'exec'), ns)
+    c = Case('fx_ultralight_txn')
+    out = []
+    sink = ns['transition_sink'](c.params['samp_rate'], out.extend, lo_val=c.params['lo_val'], hi_val=c.params['hi_val'],
+                                 av_window=c.params['av_window'], max_len=c.params['max_len'])
+    for i in range(0, len(c.x), 8192):
+        assert sink.work([c.x[i:i + 8192]], None) == len(c.x[i:i + 8192])
+    assert out == c.transitions

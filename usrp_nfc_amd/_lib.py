@@ -12,6 +12,7 @@ from . import build as _build
 
 NFC_IN_IQ_F32, NFC_IN_ENV_F32, NFC_IN_REAL_F32_SQ, NFC_IN_I16_SQ = 0, 1, 2, 3
 NFC_FLAG_FORCE_SEQUENTIAL, NFC_FLAG_NO_EDGES = 1, 2
+ABI_VERSION = 2   # NFC_AMD_ABI_VERSION of the header these structures mirror
 
 
 class Params(C.Structure):
@@ -84,6 +85,8 @@ def load():
     L = C.CDLL(path)
     vp, sz, psz = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)
     L.nfc_abi_version.restype = C.c_int
+    if L.nfc_abi_version() != ABI_VERSION:   # (the ctypes structures below are written for exactly this header)
+        raise RuntimeError('%s has ABI version %d, this package binds version %d of include/nfc_amd.h' % (path, L.nfc_abi_version(), ABI_VERSION))
     L.nfc_device_count.restype = C.c_int
     L.nfc_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     L.nfc_destroy.argtypes = [vp]

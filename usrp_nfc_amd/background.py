@@ -23,10 +23,16 @@ class _Recorder(object):
 
 
 class background(object):
-    def __init__(self, reader=False, tag=False, emulator=None, fsm=None, keep=None):
+    def __init__(self, reader=False, tag=False, emulator=None, fsm=None, keep=None, samp_rate=2e6, max_len=50, device=0):
         """keep: how many packets / symbols of the stream stay in ``self.packets`` / ``self.symbols`` -- None: everything (offline
-        decodes, tests), 0: nothing (the reference keeps nothing: a long live capture must not grow without bound), N: the last N."""
+        decodes, tests), 0: nothing (the reference keeps nothing: a long live capture must not grow without bound), N: the last N.
+        samp_rate, max_len: only for transition lists that did NOT come from this package's transition_sink (``append`` below):
+        their durations are microseconds, the device decoders count samples (the reference's defaults, transition_sink.py:12)."""
         import collections
+        self._attached = False       # this package's transition_sink feeds this object (it decodes on the device and delivers itself)
+        self._foreign = None         # the context that decodes lists handed to append() by anybody else
+        self._foreign_args = dict(samp_rate=float(samp_rate), max_len=int(max_len), device=int(device))
+        self._n_foreign = 0
         self.reader = bool(reader)   # Modified-Miller decoder present (background.py:20)
         self.tag = bool(tag)         # Manchester decoder present      (background.py:21)
         self._keep = keep
@@ -51,10 +57,35 @@ class background(object):
 
     # -- reference surface ---------------------------------------------------------
     def append(self, transitions):
-        """background.py:27-28.  With the GPU path the decoders have already consumed these
-        transitions on the device; the list is kept only when ``self.transitions`` is a list."""
+        """background.py:27-28.  Fed by this package's ``transition_sink`` the decoders have already consumed these transitions on
+        the device (the list is kept only when ``self.transitions`` is a list).  A list from ANY OTHER producer -- the reference's
+        own ``transition_sink``, INTEGRATION.md's hybrid -- is what the reference's ``background.run`` would work through
+        (background.py:37-52): it goes through the device's decode and framing stages alone (``nfc_push_edges``), synchronously,
+        and the packets are delivered as usual.  Entries are ``((v, d * factor), t)`` with ``factor = 1e6 / samp_rate``
+        (transition_sink.py:89-90): ``d = round(us / factor)`` is exact for every duration the sink can produce."""
         if self.transitions is not None:
             self.transitions.extend(transitions)
+        if self._attached or not transitions:
+            return
+        import numpy as np
+        from . import api
+        if self._foreign is None:
+            a = self._foreign_args
+            self._foreign = api.NfcContext(samp_rate=a['samp_rate'], max_len=a['max_len'], reader=self.reader, tag=self.tag, device=a['device'])
+        factor = 1e6 / self._foreign_args['samp_rate']
+        e = np.zeros(len(transitions), api.EDGE_DTYPE)
+        e['v'] = [v for (v, _), _ in transitions]
+        e['d'] = [int(round(us / factor)) for (_, us), _ in transitions]
+        e['t'] = [t for _, t in transitions]
+        e['idx'] = np.arange(self._n_foreign, self._n_foreign + len(transitions), dtype=np.uint64)   # (only labels the packets)
+        self._n_foreign += len(transitions)
+        self._foreign.push_edges(e)
+        self._deliver(self._foreign)
+
+    def close(self):
+        if self._foreign is not None:
+            self._foreign.close()
+            self._foreign = None
 
     # -- GPU delivery (called by transition_sink after each batch) ---------------------
     def _deliver(self, ctx):

@@ -123,6 +123,7 @@ struct nfc_ctx {
     hipEvent_t kev[2 * 6] = {};  // start/stop pairs around the first k_threshold launches of a batch
     int n_kev = 0;
     std::string err;
+    LaunchError launch_err;   // the first launch of the batch in work that the runtime rejected (launch_check.h)
 
     // tables
     DevBuf d_mil_map, d_man_map, d_mil_out, d_man_out;

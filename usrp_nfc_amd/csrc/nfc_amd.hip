@@ -351,6 +351,7 @@ void nfc_destroy(nfc_ctx *c) {
 }
 
 int nfc_push_device(nfc_ctx *c, const void *dev_samples, size_t n) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     if (n && !dev_samples) return fail(c, NFC_ERR_ARG, "null input");
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
@@ -358,6 +359,7 @@ int nfc_push_device(nfc_ctx *c, const void *dev_samples, size_t n) {
 }
 
 int nfc_submit_device(nfc_ctx *c, const void *dev_samples, size_t n) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     if (n && !dev_samples) return fail(c, NFC_ERR_ARG, "null input");
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
@@ -365,6 +367,7 @@ int nfc_submit_device(nfc_ctx *c, const void *dev_samples, size_t n) {
 }
 
 int nfc_wait(nfc_ctx *c) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
     return wait_batch(c);
@@ -378,6 +381,7 @@ int nfc_submitted(nfc_ctx *c) { return c ? c->sub_count : 0; }
     } while (0)
 
 int nfc_push(nfc_ctx *c, const void *host_samples, size_t n) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     NOSUB(c);
     if (n && !host_samples) return fail(c, NFC_ERR_ARG, "null input");
@@ -389,6 +393,7 @@ int nfc_push(nfc_ctx *c, const void *host_samples, size_t n) {
 }
 
 int nfc_push_edges(nfc_ctx *c, const nfc_edge *host_edges, size_t n64) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     NOSUB(c);
     if (n64 && !host_edges) return fail(c, NFC_ERR_ARG, "null input");
@@ -451,12 +456,14 @@ int nfc_push_edges(nfc_ctx *c, const nfc_edge *host_edges, size_t n64) {
 }
 
 int nfc_sync(nfc_ctx *c) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->st));
     return NFC_OK;
 }
 
 int nfc_set_stream(nfc_ctx *c, void *stream) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     NOSUB(c);
     HIPCHK(c, hipStreamSynchronize(c->st));   // nothing of this context is left on the stream it leaves
@@ -465,6 +472,7 @@ int nfc_set_stream(nfc_ctx *c, void *stream) {
 }
 
 int nfc_get_counts(nfc_ctx *c, nfc_counts *out) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || !out) return NFC_ERR_ARG;
     if (!c->have_outputs) return fail(c, NFC_ERR_STATE, "no completed batch");
     memset(out, 0, sizeof *out);
@@ -537,6 +545,7 @@ int edge_range(nfc_ctx *c, size_t first, const void *out, size_t cap, size_t *n_
 }  // extern "C++"
 
 int nfc_read_edges(nfc_ctx *c, size_t first, nfc_edge *out, size_t cap, size_t *n_out) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     size_t n;
     const int rc = edge_range(c, first, out, cap, n_out, n);
@@ -576,6 +585,7 @@ int nfc_read_edges(nfc_ctx *c, size_t first, nfc_edge *out, size_t cap, size_t *
 }
 
 int nfc_read_edges_compact(nfc_ctx *c, size_t first, uint32_t *pos_out, uint16_t *code_out, size_t cap, size_t *n_out) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     size_t n;
     int rc = edge_range(c, first, pos_out, cap, n_out, n);
@@ -589,11 +599,13 @@ int nfc_read_edges_compact(nfc_ctx *c, size_t first, uint32_t *pos_out, uint16_t
 }
 
 int nfc_read_symbols(nfc_ctx *c, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || type < 0 || type > 1) return NFC_ERR_ARG;
     return read_range(c, c->d_sym[type].p, c->n_sym[type], 1, first, out, cap, n_out);
 }
 
 int nfc_read_packets(nfc_ctx *c, int type, nfc_packet *out, size_t cap, size_t *n_out) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || type < 0 || type > 1) return NFC_ERR_ARG;
     if (!c->have_outputs) return fail(c, NFC_ERR_STATE, "no completed batch");
     int rc = build_packets(c, type);
@@ -606,11 +618,13 @@ int nfc_read_packets(nfc_ctx *c, int type, nfc_packet *out, size_t cap, size_t *
 }
 
 int nfc_read_packet_bits(nfc_ctx *c, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || type < 0 || type > 1) return NFC_ERR_ARG;
     return read_range(c, c->d_bits[type].p, c->n_bits[type], 1, first, out, cap, n_out);
 }
 
 int nfc_read_val(nfc_ctx *c, size_t first, int8_t *out, size_t cap, size_t *n_out) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     if (!c->have_outputs) return fail(c, NFC_ERR_STATE, "no completed batch");
     size_t n = 0;
@@ -649,12 +663,14 @@ static int upload_carried(nfc_ctx *c) {
 }
 
 int nfc_set_timing(nfc_ctx *c, int level) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || level < 0 || level > 2) return NFC_ERR_ARG;
     c->timing = level;
     return NFC_OK;
 }
 
 int nfc_reset(nfc_ctx *c) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c) return NFC_ERR_ARG;
     NOSUB(c);
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
@@ -665,6 +681,7 @@ int nfc_reset(nfc_ctx *c) {
 }
 
 int nfc_prime(nfc_ctx *c, uint64_t start_index, float level) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || !(level >= 0.f) || !std::isfinite(level)) return NFC_ERR_ARG;
     NOSUB(c);
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
@@ -714,6 +731,7 @@ __global__ void k_export_state(uint8_t *dst, uint32_t len, int fits, nfc_state_h
 }
 
 int nfc_export_state(nfc_ctx *c, void *device_dst, size_t cap, size_t *len_out) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || !device_dst || cap < 16 || ((uintptr_t)device_dst & 15u)) return NFC_ERR_ARG;
     NOSUB(c);
     if (hipSetDevice(c->P.device) != hipSuccess) return fail(c, NFC_ERR_DEVICE, "hipSetDevice failed");
@@ -731,6 +749,7 @@ int nfc_export_state(nfc_ctx *c, void *device_dst, size_t cap, size_t *len_out) 
 }
 
 int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap, uint8_t *pending, size_t pending_cap) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || !h) return NFC_ERR_ARG;
     NOSUB(c);
     flush_state(c);
@@ -764,6 +783,7 @@ int nfc_get_state(nfc_ctx *c, nfc_state_header *h, float *ring, size_t ring_cap,
 
 int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size_t ring_len, const uint8_t *pending,
                   size_t pending_len) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || !h || !ring) return NFC_ERR_ARG;
     NOSUB(c);
     if (h->av_window != c->L || ring_len != (size_t)c->L) return fail(c, NFC_ERR_ARG, "state was taken with another av_window");
@@ -798,6 +818,7 @@ int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size
 }
 
 int nfc_get_stats(nfc_ctx *c, nfc_stats *out) {
+    LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || !out) return NFC_ERR_ARG;
     *out = c->stats;
     out->redone_total = c->stats_redo_submitted;

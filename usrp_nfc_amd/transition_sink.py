@@ -54,6 +54,8 @@ class transition_sink(_Base):
         self._dtype = api.INPUT_DTYPES[input_kind][0] if hasattr(api, 'INPUT_DTYPES') else (numpy.int16 if input_kind == api.NFC_IN_I16_SQ else numpy.float32)
         back = getattr(callback, '__self__', None)
         self._back = back if hasattr(back, '_deliver') else None
+        if self._back is not None:
+            self._back._attached = True   # (its append() then only records: the packets come from this sink's own context)
         reader = bool(self._back.reader) if self._back else False
         tag = bool(self._back.tag) if self._back else False
         self._want_list = self._back is None or self._back.transitions is not None
