@@ -570,3 +570,68 @@ def test_rejected_launch_is_reported(monkeypatch):
             ctx.push(iq)
         assert 'kernel launch failed' in str(e.value)
     assert n_good > 1000
+
+
+def _wg_torture(seed, n=1_500_000):
+    """IQ stream for the workgroup threshold kernel: carrier with noise, LOW runs of every length around the multiples of
+    max_len (1 .. 700 samples), each followed -- at 0 .. 70 samples from its end -- by a burst of HIGH samples; now and then a
+    level step of a few percent, a tag-like stretch of alternating loaded half bits, and runs placed right on the multiples of
+    1024 / 4096 samples where rounds and chunks meet."""
+    rng = np.random.default_rng(seed)
+    m = np.ones(n, np.float32)
+    p = 6000
+    k = 0
+    while p < n - 5000:
+        k += 1
+        kind = int(rng.integers(0, 10))
+        if kind < 6:
+            ln = int(rng.choice([1, 2, 7, 49, 50, 51, 52, 99, 100, 101, 102, 150, 151, 152, 201, 255, 256, 257, 400, 511, 513, 700])) if rng.random() < 0.7 else int(rng.integers(1, 700))
+            if rng.random() < 0.3:   # put the run's end (or start) on a seam of rounds / chunks
+                seam = (p // 1024 + 1) * 1024 if rng.random() < 0.5 else (p // 4096 + 1) * 4096
+                p = seam - (ln if rng.random() < 0.5 else 0) + int(rng.integers(-2, 3))
+            m[p:p + ln] = 0.0
+            gap = int(rng.integers(0, 70))
+            hl = int(rng.integers(1, 40))
+            m[p + ln + gap:p + ln + gap + hl] = 1.09
+            p += ln + gap + hl + int(rng.integers(60, 2500))
+        elif kind < 8:   # a stretch of loaded half bits (mag^2 x 1.17)
+            for b in range(int(rng.integers(20, 200))):
+                if rng.random() < 0.5:
+                    m[p:p + 9] = 1.08
+                p += 19
+            p += int(rng.integers(100, 3000))
+        else:            # a level step (the window follows within one length)
+            m[p:] *= np.float32(1.0 + rng.uniform(-0.04, 0.04))
+            p += int(rng.integers(3000, 9000))
+    return synth.iq_from_profile(m, seed=seed, sigma=0.0015)
+
+
+@pytest.mark.parametrize('nr', ['4', '6', '8'])
+@pytest.mark.parametrize('chunk', [0, 4096 * 3])
+def test_workgroup_kernel_low_runs_time_outs_and_seams(monkeypatch, nr, chunk):
+    # k_threshold_wg against the C oracle where its reasoning is thinnest (threshold_wg.hip.h): LOW runs longer than max_len whose
+    # last sample may have ended on a time-out with HIGH samples in reach of it, runs and HIGH bursts across the seams of steps,
+    # rounds and chunks, level steps between supersteps; every step height, the library's chunk length and a short one (many
+    # chunk seams: speculation, certification, chunks that start inside a run).  Per-sample val, edges, symbols, packets.
+    monkeypatch.setenv('NFC_WG_NR', nr)
+    L = {'4': 2000, '6': 2000, '8': 2560}[nr]
+    iq = _wg_torture(int(nr) * 10 + (1 if chunk else 0))
+    params = dict(hi_val=1.1, av_window=L)
+    o = oracle_run(iq, params, api.NFC_IN_IQ_F32)
+    r = run_gpu(iq, params, kind=api.NFC_IN_IQ_F32, chunk_samples=(chunk // (256 * int(nr))) * 256 * int(nr))
+    d = first_diff(r['val'][L:], o.trace().tolist())
+    assert d is None, 'val %s' % (d,)
+    d = first_diff(r['transitions'], o.transitions())
+    assert d is None, 'transition %s' % (d,)
+    assert r['sym_tag'] == o.symbols(0).tolist() and r['sym_reader'] == o.symbols(1).tolist() and r['packets'] == o.packets()
+    assert r['stats'].used_sequential == 0 and len(o.transitions()) > 30000
+
+
+def test_workgroup_kernel_two_rounds_ahead(monkeypatch):
+    # the optional second round of samples in flight (NFC_WG_D=2: a second register set and a counted wait)
+    monkeypatch.setenv('NFC_WG_D', '2')
+    iq = _wg_torture(77, 1_200_000)
+    o = oracle_run(iq, dict(hi_val=1.1), api.NFC_IN_IQ_F32)
+    r = run_gpu(iq, dict(hi_val=1.1), kind=api.NFC_IN_IQ_F32, pushes=[0, 400_003, 800_001, 1_200_000])
+    assert first_diff(r['val'][2000:], o.trace().tolist()) is None
+    assert first_diff(r['transitions'], o.transitions()) is None and r['packets'] == o.packets()
