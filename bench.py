@@ -107,10 +107,21 @@ def default_samples(workload):
     return 1_000_000_000 if workload == 'classic1k' else 100_000_000
 
 
-def capture_overlap(workload):
+OVERLAP_WINDOWS = (16, 32, 64)   # warm-up lengths a rank > 0 tries, in averaging windows (sharding.overlap_schedule)
+
+
+def overlap_steps(workload, n_per_rank=None):
+    """The warm-up lengths (samples) a rank > 0 tries, shortest first; the slice of its predecessor it holds is the longest."""
     from usrp_nfc_amd import sharding
     sp = stream_params(workload)
-    return sharding.shard_overlap(sp['samp_rate'], sp.get('av_window', 2000))
+    steps = [sharding.shard_overlap(sp['samp_rate'], sp.get('av_window', 2000), windows=w) for w in OVERLAP_WINDOWS]
+    if n_per_rank is not None:
+        steps = [s for s in steps if s <= n_per_rank] or [n_per_rank // 256 * 256]
+    return steps
+
+
+def capture_overlap(workload, n_per_rank=None):
+    return overlap_steps(workload, n_per_rank)[-1]
 
 
 def make_capture_slice(workload, n_per_rank, rank, world):
@@ -133,7 +144,7 @@ def make_capture_slice(workload, n_per_rank, rank, world):
         period = synth.modulation_profile(frames, rate_msps=2.0, lead_in=0, tail=0)
         lead = 3000
         n_gen = n_per_rank
-    overlap = capture_overlap(workload)
+    overlap = capture_overlap(workload, min(n_per_rank, n_gen))
 
     def profile(g_lo, g_hi):
         g = np.arange(g_lo, g_hi, dtype=np.int64)
@@ -203,9 +214,16 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
     redo = [0]
     force_exchange = bool(os.environ.get('NFC_BENCH_FORCE_EXCHANGE'))   # 1-rank smoke of the collective path
 
+    ov_steps = [s for s in overlap_steps(workload, n) if s <= n_ov] if n_ov else None
+    if ov_steps:   # the carrier level where each try starts
+        level = [sharding.carrier_level(synth.envelope_f32(ov[2 * (n_ov - s):2 * (n_ov - s) + 2 * 4096])) for s in ov_steps]
+
+    def push_overlap(nov):   # the LAST nov samples before the shard (lengths are multiples of 256 samples: 16-byte aligned)
+        ctx.push_device(d_ov.ptr.value + 8 * (n_ov - nov), nov)
+
     def one_step():
-        redo[0] += sharding.decode_shard(ctx, comm, lambda: ctx.push_device(d_ov, n_ov), lambda: ctx.push_device(res.buf, n),
-                                         g_lo - n_ov, level, force_exchange=force_exchange)
+        redo[0] += sharding.decode_shard(ctx, comm, push_overlap, lambda: ctx.push_device(res.buf, n),
+                                         g_lo - n_ov, level, force_exchange=force_exchange, overlap_steps=ov_steps, shard_start=g_lo)
 
     def barrier():
         if hasattr(comm, 'barrier'):
@@ -258,8 +276,8 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
         redo[0] = 0
         if mode == 'ahead' and sharded:
             def shard(count, timed_every):
-                redo[0] += sharding.decode_shard(ctx, comm, lambda: ctx.push_device(d_ov, n_ov), lambda: stream_steps(count, timed_every, acc),
-                                                 g_lo - n_ov, level, force_exchange=force_exchange)
+                redo[0] += sharding.decode_shard(ctx, comm, push_overlap, lambda: stream_steps(count, timed_every, acc),
+                                                 g_lo - n_ov, level, force_exchange=force_exchange, overlap_steps=ov_steps, shard_start=g_lo)
             if warmup:
                 shard(warmup, 0)
             redo[0] = 0
@@ -331,6 +349,9 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
         # that step was the whole sharding protocol once more: every rank's context holds the decode of ITS shard -- digests of
         # it travel to rank 0 (JSON over the communicator), which checks every one against the oracle (sharded_parity)
         gathered = comm.gather_objects(result_digest(ctx.edges(), ctx.symbols(0), ctx.symbols(1), ctx.packets()))
+    ov_used = None
+    if world > 1:   # the warm-up length every rank ended on (rank 0 has none)
+        ov_used = comm.gather_objects(int(getattr(ctx, 'overlap_used', 0) or 0))
     out = None
     if rank == 0:
         k_avg = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
@@ -346,7 +367,8 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                        'time_chunks': int(st.n_chunks), 'parallelism': 'time-chunk x%d' % world, 'edges_per_gpu': n_edges,
                        'symbols_reader': int(cnt.n_symbols[1]), 'symbols_tag': int(cnt.n_symbols[0]),
                        'packets': int(cnt.n_packets[0] + cnt.n_packets[1]), 'boundary_redos': redo[0],
-                       'shard_overlap_samples': capture_overlap(workload) if world > 1 else 0, 'exchange': backend if world > 1 else 'none',
+                       'shard_overlap_samples': overlap_steps(workload, n) if world > 1 else [], 'overlap_used': ov_used,
+                       'exchange': backend if world > 1 else 'none',
                        'rccl_ranks_seen': getattr(comm, 'ranks_seen', None),
                        'steps_are': summary(prim)['steps_are']},
             'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_wg (fused envelope + gated-mean threshold, a time chunk per workgroup; k_threshold_lean / k_threshold where it does not apply)',

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-/* 2: nfc_stats grew (ran_ahead, redone_total); i16_scale == 0 means sample / 32767 (GNU Radio's wavfile_source), not / 32768 */
+/* 2: nfc_stats grew (ran_ahead, redone_total, ring_slots_carried); i16_scale == 0 means sample / 32767 (GNU Radio's wavfile_source), not / 32768 */
 #define NFC_AMD_ABI_VERSION 2
 
 typedef enum {
@@ -116,6 +116,10 @@ typedef struct {
     uint32_t chunk_samples;   /* time-chunk length the threshold kernel used for the last batch */
     uint32_t ran_ahead;       /* 1: the last batch's threshold stage ran ahead of the batch before it (nfc_submit_device) */
     uint32_t redone_total;    /* submitted batches of this context that had to be processed again synchronously */
+    uint32_t ring_slots_carried; /* window slots whose value at the end of the last batch is still the one the batch started from
+                                  * (no sample landing on them was accepted): 0 after a warm-up (nfc_prime + overlap) means the
+                                  * window no longer depends on the level it was primed with */
+    uint32_t reserved0;
 } nfc_stats;
 
 /* Everything a successor time chunk needs from its predecessor:

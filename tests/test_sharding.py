@@ -474,3 +474,102 @@ def test_classic1k_10msps_four_shards_on_gpu(sabotage):
         assert redos == [0, 0, 0, 0]
     else:
         assert redos[sabotage] == 1 and redos[0] == 0
+
+
+def test_overlap_schedule_stops_at_the_first_converged_try():
+    """decode_shard's measured warm-up: tries the schedule shortest first, primes each try at its own start with its own level,
+    stops when the engine says every window slot has been rewritten, and leaves the length it ended on in engine.overlap_used."""
+    assert sharding.overlap_schedule(2e6, 2000, 10**6) == [38400, 70400, 134400, 262400, 518400]
+    assert sharding.overlap_schedule(2e6, 2000, 80000) == [38400, 70400]
+    assert sharding.overlap_schedule(2e6, 2000, 1000) == [1000]
+    assert sharding.overlap_schedule(2e6, 2000, 0) == []
+
+    class Engine(object):
+        def __init__(self, converges_at):
+            self.calls, self.at = [], converges_at
+
+        def prime(self, start, level):
+            self.calls.append(('prime', start, level))
+
+        def window_converged(self):
+            return self.calls[-1][1] >= self.at
+
+    class Rank1(object):
+        rank, world, device_slots = 1, 1, False   # (world 1: no exchange -- only the warm-up is under test)
+
+    for at, want in ((0, 100), (200, 200), (10**9, 400)):
+        e = Engine(at)
+        sharding.decode_shard(e, Rank1(), lambda nov: e.calls.append(('ov', nov)), lambda: e.calls.append(('own',)), None,
+                              [1.0, 2.0, 3.0], overlap_steps=[100, 200, 400], shard_start=5000)
+        tries = [100, 200, 400][:[100, 200, 400].index(want) + 1]
+        assert e.calls == [c for k, nov in enumerate(tries) for c in (('prime', 5000 - nov, float(k + 1)), ('ov', nov))] + [('own',)]
+        assert e.overlap_used == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('measured,kind', [(True, 'train'), (False, 'train'), (True, 'dense')])
+def test_overlap_is_measured_not_assumed(measured, kind):
+    # A capture on which NO fixed number of warm-up windows is enough: for 40 windows before the shard boundary the reader sends a
+    # pause every 100 samples -- a period that divides the 2000-sample window, so the same 20 x ~30 window slots are rejected on
+    # every pass and keep the values they had before the train.  A warm-up that starts inside the train leaves the primed level in
+    # those slots (nfc_stats.ring_slots_carried says how many); decode_shard's measured schedule (16, 32, 64 windows) goes on until
+    # the count is zero and gets the boundary state exactly -- no re-decode; the fixed 16 windows are caught by the exchange and
+    # pay the re-decode.  Either way the outputs equal the oracle's over the whole capture.
+    # 'dense': frames back to back with 50 us gaps (a third of the usual) and no train -- the first try converges, no re-decode.
+    import threading
+    from oracle import c_oracle as co
+    from usrp_nfc_amd import api
+    world, n_per, L = 2, 400_000, 2000
+    m = synth.tiled_profile(synth.modulation_profile(synth.txn_frames(), gap_us=50.0 if kind == 'dense' else 150.0, lead_in=0, tail=0),
+                            world * n_per)
+    if kind == 'train':
+        train = np.ones(40 * L + 1000, np.float32)
+        train.reshape(-1, 100)[:, 10:40] = 0.0
+        m[n_per - 40 * L:n_per + 1000] = train
+    iq = synth.iq_from_profile(m, seed=5)
+    o = co.COracle()
+    o.push_iq(iq)
+    steps = sharding.overlap_schedule(2e6, L, n_per)[:3] if measured else None
+    fixed = sharding.shard_overlap(2e6, L)
+    shared = ThreadComm.Shared(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            lo = rank * n_per
+            own = iq[2 * lo:2 * (lo + n_per)]
+            ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32)
+            comm = ThreadComm(shared, rank)
+            level_at = lambda nov: sharding.carrier_level(synth.envelope_f32(iq[2 * (lo - nov):2 * (lo - nov + 4096)]))
+            carried = []
+
+            def push_overlap(nov=fixed):
+                ctx.push(iq[2 * (lo - nov):2 * lo])
+                carried.append(int(ctx.stats().ring_slots_carried))
+            if rank and measured:
+                redos = sharding.decode_shard(ctx, comm, push_overlap, lambda: ctx.push(own), None, [level_at(s) for s in steps],
+                                              overlap_steps=steps, shard_start=lo)
+            else:
+                redos = sharding.decode_shard(ctx, comm, push_overlap, lambda: ctx.push(own), lo - fixed, level_at(fixed) if rank else 0.0)
+            results[rank] = (redos, ctx.transitions(), ctx.packets(), carried, getattr(ctx, 'overlap_used', None))
+            ctx.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append((rank, repr(e)))
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert [t for r in results for t in r[1]] == o.transitions()
+    assert [p for r in results for p in r[2]] == o.packets()
+    redos, carried, used = [r[0] for r in results], results[1][3], results[1][4]
+    if kind == 'dense':
+        assert carried == [0] and used == steps[0] and redos == [0, 0]
+    elif measured:
+        assert len(carried) == 3 and carried[0] > 300 and carried[1] > 300 and carried[2] == 0, carried
+        assert used == steps[2] and redos == [0, 0]
+    else:
+        assert carried[0] > 300 and redos == [0, 1]

@@ -106,6 +106,12 @@ class NfcContext(object):
         self._chk(self.L.nfc_get_stats(self.h, C.byref(s)), 'nfc_get_stats')
         return s
 
+    def window_converged(self):
+        """After a warm-up (prime + overlap): has every window slot taken an accepted sample since the prime?  (nfc_stats'
+        ring_slots_carried of the last batch: slots whose value is still the one the batch started from.)"""
+        st = self.stats()   # (a batch that needed the sequential prefix is not vouched for: its parallel rest counts from the prefix's end)
+        return int(st.ring_slots_carried) == 0 and not int(st.used_sequential)
+
     def set_timing(self, level):
         """0: no HIP events (default), 1: threshold kernel durations (events attached to the launches), 2: + batch total and per-stage split (stream markers, a few us each)."""
         self._chk(self.L.nfc_set_timing(self.h, int(level)), 'nfc_set_timing')

@@ -66,12 +66,13 @@ enum : int {
     TOT_PKT1 = 80,
     TOT_LAST2 = 88,     // Last2 (8 bytes)
     TOT_NSYM = 96,      // u32[2]: symbols per packet type
-    TOT_CERT = 104,     // CertSummary (16 bytes)
+    TOT_CERT = 104,     // CertSummary (24 bytes)
     TOT_FRAME = 128,    // FrameAgg (32 bytes): symbol counts, framing maps, bit / close counts of the batch
     TOT_BYTES = 160
 };
 
 // Everything the host mirrors after a batch, in one block so that one copy fetches it.
+static_assert(sizeof(CertSummary) <= TOT_FRAME - TOT_CERT, "the verdict summary fits its slot of the totals");
 struct DevState {
     Carry carry;
     EdgeCarry ecarry;

@@ -822,6 +822,12 @@ int nfc_get_stats(nfc_ctx *c, nfc_stats *out) {
     if (!c || !out) return NFC_ERR_ARG;
     *out = c->stats;
     out->redone_total = c->stats_redo_submitted;
+    {
+        CertSummary cs;
+        memcpy(&cs, c->hs->totals + TOT_CERT, sizeof cs);   // (the mirror of the last batch's state block)
+        out->ring_slots_carried = cs.n_carried;
+        out->reserved0 = 0;
+    }
     return NFC_OK;
 }
 

@@ -328,6 +328,13 @@ __device__ __forceinline__ void resolve_low_state(const ThrArgs &A, int c, int &
 }
 
 // exact incoming ring value of slot s for chunk c: latest predecessor that accepted a sample into it
+__device__ __forceinline__ bool slot_untouched_by_all(const ThrArgs &A, int c, int s) {   // no chunk < c accepted a sample into slot s
+    for (int cc = c - 1; cc >= 0; cc--) {
+        const uint32_t w = A.touched[A.ver[cc]][(size_t)cc * A.twords + (s >> 5)];
+        if ((w >> (s & 31)) & 1u) return false;
+    }
+    return true;
+}
 __device__ __forceinline__ float resolve_slot(const ThrArgs &A, int c, int s) {
     if (c >= 1) {   // common case: the predecessor accepted a sample into the slot; both loads issue at once
         const int vb = A.ver[c - 1];
@@ -1002,15 +1009,17 @@ struct CertSummary {
     uint32_t emin, emax;        // exponent fields over every chunk's accepted values
     uint32_t flagged;           // some chunk met a value it cannot vouch for
     uint32_t vtop;              // raw bits of an upper bound of every ring value of the batch
+    uint32_t n_carried;         // window slots that no chunk of the batch accepted a sample into (their value is the incoming ring's)
 };
 constexpr int FIN_BLOCK = 256;
 // The ring at the end of the batch (look-back over all chunks) and its sum become the carried state; with
 // `sum` the guard summary of the batch is folded too.  One workgroup of FIN_BLOCK threads.
 __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_next, Carry *carry, CertSummary *sum) {
     __shared__ double s_part[FIN_BLOCK / 64];
-    __shared__ uint32_t s_mn[FIN_BLOCK / 64], s_mx[FIN_BLOCK / 64], s_fl[FIN_BLOCK / 64], s_vt[FIN_BLOCK / 64];
+    __shared__ uint32_t s_mn[FIN_BLOCK / 64], s_mx[FIN_BLOCK / 64], s_fl[FIN_BLOCK / 64], s_vt[FIN_BLOCK / 64], s_cr[FIN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double part = 0;
+    uint32_t carried = 0;
     // a thread's slots in rounds of eight: the common case (the last chunk accepted a sample into the slot) is two
     // loads per slot, all sixteen in flight at once; only slots it left untouched walk further back
     const int last = A.nchunks - 1;
@@ -1031,13 +1040,17 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
         for (int k = 0; k < 8; k++) {
             const int s = s0 + k * FIN_BLOCK;
             if (s < A.L) {
-                if (!((w[k] >> (s & 31)) & 1u)) v[k] = resolve_slot(A, last, s);   // look further back
+                if (!((w[k] >> (s & 31)) & 1u)) {   // look further back
+                    v[k] = resolve_slot(A, last, s);
+                    if (slot_untouched_by_all(A, last, s)) carried++;
+                }
                 ring_next[s] = v[k];
                 part += (double)v[k];
             }
         }
     }
     uint32_t mn = 255u, mx = 0u, fl = 0u, vt = 0u;
+    carried = (uint32_t)wave_sum_f32((float)carried);
     if (sum)
         for (int k = tid; k < A.nchunks; k += FIN_BLOCK) {
             mn = min(mn, (uint32_t)A.gmin[k]);
@@ -1056,9 +1069,12 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
         s_mn[wave] = mn;
         s_mx[wave] = mx;
         s_fl[wave] = fl;
+        s_cr[wave] = carried;
     }
     __syncthreads();
     if (tid == 0) {
+        uint32_t cr_all = 0;
+        for (int w = 0; w < FIN_BLOCK / 64; w++) cr_all += s_cr[w];
         double S = 0;
         for (int w = 0; w < FIN_BLOCK / 64; w++) {
             S += s_part[w];
@@ -1085,6 +1101,7 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
             sum->flagged = fl;
             sum->vtop = vt;
         }
+        if (A.sum) A.sum->n_carried = cr_all;   // (whichever launch resolves the end-of-batch window says it)
     }
 }
 

@@ -68,14 +68,32 @@ def shard_overlap(samp_rate, av_window, longest_frame_bits=164, windows=16):
     return (n + 255) // 256 * 256
 
 
-def decode_shard(engine, comm, push_overlap, push_own, start_index, level, force_exchange=False):
+def overlap_schedule(samp_rate, av_window, available, longest_frame_bits=164):
+    """Warm-up lengths to try, shortest first: 16, 32, 64 ... averaging windows (+ two frames), as far as `available` samples
+    before the shard exist.  decode_shard stops at the first one after which the engine says its window has converged."""
+    out, w = [], 16
+    while True:
+        n = shard_overlap(samp_rate, av_window, longest_frame_bits, w)
+        if n > available:
+            break
+        out.append(n)
+        w *= 2
+    return out or ([available] if available > 0 else [])
+
+
+def decode_shard(engine, comm, push_overlap, push_own, start_index, level, force_exchange=False, overlap_steps=None, shard_start=None):
     """Run the protocol for this rank.
 
     engine: reset(), prime(start_index, level), state_blob(), set_state_blob(blob)
     push_overlap(): feeds the overlap samples (rank > 0) -- outputs are discarded
     push_own():     feeds the rank's own chunk; the engine then holds that chunk's outputs
     force_exchange: run the exchange even with a single rank (exercises the collective path on one GPU).
-    Returns the number of re-decodes this rank had to do.
+    overlap_steps:  (optional) warm-up lengths to try, shortest first (overlap_schedule); push_overlap is then called with the
+                    length -- it feeds the LAST that-many samples before the shard -- and shard_start is the shard's first sample
+                    index.  The warm-up stops at the first length after which ``engine.window_converged()`` holds: every window
+                    slot has taken an accepted sample since the prime, i.e. the window no longer depends on the level it was
+                    primed with (the fixed 16 windows are the first try, not a constant to tune per capture).
+    Returns the number of re-decodes this rank had to do; ``engine.overlap_used`` is the warm-up length that was used.
     """
     rank, world = comm.rank, comm.world
     exchanging = world > 1 or (force_exchange and hasattr(comm, 'exchange'))
@@ -100,6 +118,19 @@ def decode_shard(engine, comm, push_overlap, push_own, start_index, level, force
         engine.reset()
         if exchanging and not on_device:
             comm.put(0, _EMPTY)   # (a device send buffer starts zeroed and rank 0 never writes its slot 0)
+    elif overlap_steps:
+        used = 0
+        for k, nov in enumerate(overlap_steps):
+            engine.prime(shard_start - nov, level[k] if hasattr(level, '__len__') else level)   # (a level per try: estimated where it starts)
+            push_overlap(nov)
+            used = nov
+            if not hasattr(engine, 'window_converged') or engine.window_converged():
+                break
+        try:
+            engine.overlap_used = used
+        except AttributeError:
+            pass
+        capture(0)
     else:
         engine.prime(start_index, level)
         push_overlap()
