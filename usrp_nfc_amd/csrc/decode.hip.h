@@ -235,6 +235,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_reduce(const uint16_t *ecode
                                                           DecMaps *partials, DecMaps *aggs) {
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
+    TP_DECL();
     __shared__ uint4 s_mil[LDS ? DEC_LDS_ROWS : 1];
     __shared__ uint2 s_man[LDS ? DEC_LDS_ROWS : 1];
     __shared__ DecMaps lds[SCAN_WAVES];
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_reduce(const uint16_t *ecode
     uint32_t c[DEC_GROUPS][8];
 #pragma unroll
     for (int g = 0; g < DEC_GROUPS; g++) load_codes(ecode, tid * DEC_PER_THREAD + DEC_ITEMS * g, n, c[g]);
+    TP_MARK();   // 1: tables to LDS, codes asked for
     DecMaps agg = ComposeDec::identity();
 #pragma unroll
     for (int g = 0; g < DEC_GROUPS; g++) {
@@ -268,10 +270,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_reduce(const uint16_t *ecode
             }
         }
     }
+    TP_MARK();   // 2: the compositions
     aggs[tid] = agg;
     DecMaps total;
     (void)block_exclusive<ComposeDec>(agg, lds, total);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
+    TP_DONE(1);   // 3: block scan
 }
 
 // ---- pass 2: a thread walks its edges from its incoming states, one LUT look-up per edge ----
@@ -285,12 +289,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
     if (n_dev) n = min(n, (size_t)*n_dev);
     if (own_prefix && n == 0 && blockIdx.x == 0 && threadIdx.x == 0) *total_out = ComposeDec::identity();
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
+    TP_DECL();
     __shared__ __attribute__((aligned(16))) uint16_t s_mil[LDS ? DEC_LDS_ROWS * 16 : 8];
     __shared__ __attribute__((aligned(16))) uint16_t s_man[LDS ? DEC_LDS_ROWS * 8 : 8];
     __shared__ DecMaps lds[SCAN_WAVES];
     __shared__ FramePk lds2[SCAN_WAVES];
     // own_prefix: `partials` still holds the tiles' maps (scan.hip.h: tile_prefix; first, while few registers are live)
     const DecMaps pre = own_prefix ? tile_prefix<ComposeDec, SCAN_BLOCK>(partials, blockIdx.x, lds) : partials[blockIdx.x];
+    TP_MARK();   // 1: tile prefix
     if (LDS) {
         const int rows = 4 * T.nd;
         if (T.reader)
@@ -308,6 +314,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
     // (own_prefix: the last tile publishes the total)
     if (own_prefix && threadIdx.x == 0 && ((size_t)blockIdx.x + 1) * DEC_TILE >= n) *total_out = ComposeDec::op(pre, total);
     uint32_t st = ComposeDec::step(ComposeDec::op(pre, excl), state0);
+    TP_MARK();   // 2: tables, codes, block scan
     const uint16_t *mil = LDS ? s_mil : T.mil_step;
     const uint16_t *man = LDS ? s_man : T.man_step;
     FramePk mine = FramePkOp::identity();
@@ -335,10 +342,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
         if (gb < n) *(uint4 *)(outw + gb) = make_uint4(ow[0], ow[1], ow[2], ow[3]);   // outw has 16 bytes of slack
         mine = FramePkOp::op(mine, FramePkOp::pack(frame_agg_of(ow)));
     }
+    TP_MARK();   // 3: the walk
     FramePk total_fa;
     *(uint4 *)(thread_aggs + tid) = make_uint4(mine.a[0], mine.a[1], mine.b[0], mine.b[1]);   // (k_frame_write scans them again)
     (void)block_exclusive<FramePkOp>(mine, lds2, total_fa);
     if (threadIdx.x == 0) frame_aggs[blockIdx.x] = FramePkOp::unpack(total_fa);
+    TP_DONE(2);   // 4: block scan
 }
 
 // ---- pass 3: symbols, packet bits and packet ends to their places ------------------------------------------------
@@ -427,11 +436,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
         epi(FrameAggOp::identity());
     }
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
+    TP_DECL();
     __shared__ FramePk lds[SCAN_WAVES];
     __shared__ FrameAgg lds_pre[SCAN_WAVES];
     // own_prefix: tile_pre still holds the tiles' aggregates (scan.hip.h: tile_prefix; first, while few registers are live)
     const FrameAgg pre = own_prefix ? tile_prefix<FrameAggOp, SCAN_BLOCK>(tile_pre, blockIdx.x, lds_pre) : tile_pre[blockIdx.x];
     const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_PER_THREAD;
+    TP_MARK();   // 1: tile prefix
     uint32_t ow[DEC_GROUPS][4];
 #pragma unroll
     for (int g = 0; g < DEC_GROUPS; g++) {
@@ -453,6 +464,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
         epi(all);
     }
     // a thread's groups in order: each starts from everything before it
+    TP_MARK();   // 2: loads + block scan
     FrameAgg before = FrameAggOp::op(pre, FramePkOp::unpack(in_tile));
 #pragma unroll
     for (int g = 0; g < DEC_GROUPS; g++) {
@@ -461,6 +473,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
             if (g + 1 < DEC_GROUPS) before = FrameAggOp::op(before, frame_agg_of(ow[g]));
         }
     }
+    TP_DONE(3);   // 3: the scatter
 }
 
 // After framing: keep the open packets' bits for the next batch and publish the carry.  Reads nothing that it (or a

@@ -410,6 +410,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
     __shared__ uint16_t s_pos[EW_CAP];   // (tile-local sample position: a tile is EW_WORDS * 64 <= 65536 samples)
     __shared__ uint16_t s_code[EW_CAP];
     __shared__ EdgeAgg s_agg[SCAN_WAVES];
+    TP_DECL();
     const size_t wt = (size_t)blockIdx.x * EW_WORDS;   // first word of the tile
     const size_t w_first = wt + (size_t)threadIdx.x * EW_ITEMS;
     // own_prefix: partials still holds the tiles' aggregates and the workgroup folds its predecessors' itself
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
     const int val_before = load_words<EW_ITEMS>(A, w_first, nwords, ng, ps, m);
     const EdgeAgg pre = own_prefix ? tile_prefix_with<SCAN_BLOCK>(op, partials, blockIdx.x, s_agg) : partials[blockIdx.x];
     const uint32_t gbase = entries_before(A, pre, (int32_t)(wt * 64));
+    TP_MARK();   // 1: words + tile prefix
     EdgeAgg agg = op.identity();
 #pragma unroll
     for (int i = 0; i < EW_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w_first + i) * 64), m[i]));
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
         }
     }
     const int32_t tile_p0 = (int32_t)(wt * 64);
+    TP_MARK();   // 2: block scan + where the walk stands
     for (uint32_t rbase = 0; rbase < total; rbase += EW_CAP) {   // (a second round walks again: only tiles denser than EW_CAP)
         EdgeWalk W = W0;
         uint32_t k = off - rbase;   // wraps below the round: the unsigned compare drops those
@@ -496,7 +499,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
                 if (!is_to) mm &= mm - 1;
             }
         }
+        TP_MARK();   // 3: the walk
         __syncthreads();
+        TP_MARK();   // 4: waiting for the slowest wave
         const uint32_t cnt = min((uint32_t)EW_CAP, total - rbase);
         for (uint32_t j = threadIdx.x; j < cnt; j += SCAN_BLOCK) {
             const uint32_t g = gbase + rbase + j;
@@ -507,6 +512,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
         }
         __syncthreads();
     }
+    TP_DONE(0);   // 5: the stores
 }
 
 }  // namespace nfc

@@ -54,7 +54,7 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     // ... with a chunk per WORKGROUP where that kernel applies (threshold_wg.hip.h: max_len within one step, a ring that holds a round)
     c->wg_now = lean_applies && c->wg && c->wg_ok && !c->gring;
     if (!c->P.chunk_samples) {
-        const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : (c->wg_now ? c->wg_slots : (lean_applies ? c->lean_slots : c->wave_slots)));
+        const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : (c->wg_now ? (low_on_device ? c->wg_slots_ahead : c->wg_slots) : (lean_applies ? c->lean_slots : c->wave_slots)));
         // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps;
         // the workgroup kernel whole rounds of four)
         const int stp = c->wg_now ? wg_round_samples(c->wg_nr) : 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);

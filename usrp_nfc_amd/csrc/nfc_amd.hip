@@ -229,6 +229,13 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             per_cu_wg = std::max(1, std::min(4, per_cu_wg));   // (measured: four resident workgroups per CU -- four waves per SIMD -- beat five and three)
             if (const char *e = getenv("NFC_WG_PER_CU")) per_cu_wg = std::max(1, std::min(per_cu_max, atoi(e)));
             c->wg_slots = prop.multiProcessorCount * per_cu_wg;
+            // Batches submitted ahead run beside the edge and decode stages of the batch before them, and those need registers to
+            // be resident at all: four workgroups of this kernel per CU hold 4 x 96 of a SIMD's 512 registers and leave the stages
+            // ONE wave per SIMD (measured: k_dec_apply 19 -> 102 us beside it, the stages' chain -- not this kernel -- then sets the
+            // period).  Three per CU leave them two or three: 0.263 -> 0.241 ms per batch (two: 0.254).
+            int per_cu_ahead = std::min(per_cu_wg, 3);
+            if (const char *e = getenv("NFC_WG_PER_CU_AHEAD")) per_cu_ahead = std::max(1, std::min(per_cu_max, atoi(e)));
+            c->wg_slots_ahead = prop.multiProcessorCount * per_cu_ahead;
             // the longest superstep (rounds): the kernel lengthens and shortens its supersteps by the head-room it sees between the
             // samples and the thresholds; this caps them
             if (!c->wg_rounds) c->wg_rounds = 8;
@@ -1137,3 +1144,15 @@ int nfc_host_decode_lut(const nfc_params *p, int type, const int8_t *cur, const 
 }
 
 }  // extern "C"
+
+#ifdef NFC_TAIL_PROF
+extern "C" int nfc_debug_tail_prof(unsigned long long *out, int reset) {
+    const size_t bytes = sizeof(unsigned long long) * 4 * nfc::TP_WGS * 8;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nfc::g_tail_prof), bytes) != hipSuccess) return -1;
+    if (reset) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(nfc::g_tail_prof)) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

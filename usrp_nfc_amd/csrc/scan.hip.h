@@ -19,6 +19,26 @@
 
 namespace nfc {
 
+#ifdef NFC_TAIL_PROF
+// (a profiling build: s_memtime stamps of every workgroup's thread 0, [kernel][workgroup][stamp]; read by nfc_debug_tail_prof)
+constexpr int TP_WGS = 4096;
+__device__ unsigned long long g_tail_prof[4 * TP_WGS * 8];
+#define TP_DECL() unsigned long long tp_t[8]; int tp_n = 0; tp_t[tp_n++] = clock64()
+#define TP_MARK() tp_t[tp_n++] = clock64()
+#define TP_DONE(slot)                                                                                             \
+    do {                                                                                                          \
+        tp_t[tp_n++] = clock64();                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < TP_WGS) {                                                            \
+            unsigned long long *o_ = g_tail_prof + ((size_t)(slot) * TP_WGS + blockIdx.x) * 8;                    \
+            for (int i_ = 0; i_ < 8; i_++) o_[i_] = i_ < tp_n ? tp_t[i_] : 0ull;                                  \
+        }                                                                                                         \
+    } while (0)
+#else
+#define TP_DECL() ((void)0)
+#define TP_MARK() ((void)0)
+#define TP_DONE(slot) ((void)0)
+#endif
+
 constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_WAVES = SCAN_BLOCK / 64;
 
