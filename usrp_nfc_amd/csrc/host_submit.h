@@ -266,6 +266,7 @@ int wait_batch(nfc_ctx *c) {
         c->last_in = b.d_in;
         c->have_outputs = true;
         c->low_valid = true;
+        if (c->fine_adapt && c->fine_left > 0) c->fine_left--;   // (a batch without a re-run: run_threshold's bookkeeping, for this path)
         pop();
         return NFC_OK;
     }

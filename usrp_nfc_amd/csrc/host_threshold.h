@@ -54,7 +54,12 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     // ... with a chunk per WORKGROUP where that kernel applies (threshold_wg.hip.h: max_len within one step, a ring that holds a round)
     c->wg_now = lean_applies && c->wg && c->wg_ok && !c->gring;
     if (!c->P.chunk_samples) {
-        const uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : (c->wg_now ? (low_on_device ? c->wg_slots_ahead : c->wg_slots) : (lean_applies ? c->lean_slots : c->wave_slots)));
+        uint64_t slots = (uint64_t)(c->gring ? c->wave_slots_g : (c->wg_now ? (low_on_device ? c->wg_slots_ahead : c->wg_slots) : (lean_applies ? c->lean_slots : c->wave_slots)));
+        // A stream whose last batches needed re-runs (a level that steps, load modulation at the threshold) is cut finer: a re-run
+        // pass is ONE wave walking a chunk, so it costs what a chunk is long -- measured on the stress captures, 1e8 samples:
+        // 4 x as many chunks take 2.14 -> 1.34 ms (level steps) and 7.3 -> 4.0 ms (hovering), 8 x is worse again (the rounds' fixed
+        // costs); a clean stream pays 0.353 -> 0.406 ms for it, so the cut goes back after eight batches without a re-run.
+        if (c->fine_left > 0 && c->wg_now) slots *= (uint64_t)c->fine_mult;
         // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps;
         // the workgroup kernel whole rounds of four)
         const int stp = c->wg_now ? wg_round_samples(c->wg_nr) : 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
@@ -530,6 +535,10 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
         if (rc) return rc;
         if (!need_seq) {
             *clean = span_clean && base == 0;
+            if (c->fine_adapt) {   // (a hint about the stream, not part of its state: it survives nfc_reset)
+                if ((uint64_t)c->stats.chunks_rerun * 64u > (uint64_t)c->stats.n_chunks) c->fine_left = 8;
+                else if (c->fine_left > 0) c->fine_left--;
+            }
             return NFC_OK;
         }
         const bool forced = (c->P.flags & NFC_FLAG_FORCE_SEQUENTIAL) != 0 || c->L < STEP;

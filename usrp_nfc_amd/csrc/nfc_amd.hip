@@ -239,6 +239,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             // the longest superstep (rounds): the kernel lengthens and shortens its supersteps by the head-room it sees between the
             // samples and the thresholds; this caps them
             if (!c->wg_rounds) c->wg_rounds = 8;
+            if (const char *e = getenv("NFC_CHUNK_ADAPT")) c->fine_adapt = atoi(e) != 0;
+            if (const char *e = getenv("NFC_CHUNK_MULT")) c->fine_mult = std::max(1, std::min(16, atoi(e)));
         }
     }
     CRT(hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking));

@@ -185,26 +185,52 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+// max / min across the wave on the same DPP moves (a __shfl_xor is an LDS permute: ~60 cycles a step, six steps in a row).  All 64
+// lanes must be active, as for the sums above.
+template <class F>
+__device__ __forceinline__ int wave_reduce_i32(int v, int ident, F f) {
+    v = f(v, dpp_i32<0x111, 0xF>(ident, v));
+    v = f(v, dpp_i32<0x112, 0xF>(ident, v));
+    v = f(v, dpp_i32<0x114, 0xF>(ident, v));
+    v = f(v, dpp_i32<0x118, 0xF>(ident, v));
+    v = f(v, dpp_i32<0x142, 0xA>(ident, v));
+    v = f(v, dpp_i32<0x143, 0xC>(ident, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {   // (v >= 0 or any finite value: the identity is -inf)
+    return __int_as_float(wave_reduce_i32(__float_as_int(v), (int)0xFF800000u,
+                                          [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); }));
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-    return __builtin_amdgcn_readfirstlane(v);
+    return wave_reduce_i32(v, INT32_MIN, [](int a, int b) { return max(a, b); });
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    return (uint32_t)wave_reduce_i32((int)v, -1, [](int a, int b) { return (int)min((uint32_t)a, (uint32_t)b); });
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    return (uint32_t)wave_reduce_i32((int)v, 0, [](int a, int b) { return (int)max((uint32_t)a, (uint32_t)b); });
 }
+// ordered inclusive scans on the same moves, and the value of the lane below (`ident` in lane 0)
+__device__ __forceinline__ int wave_scan_max_i32(int v, int ident) {
+    v = max(v, dpp_i32<0x111, 0xF>(ident, v));
+    v = max(v, dpp_i32<0x112, 0xF>(ident, v));
+    v = max(v, dpp_i32<0x114, 0xF>(ident, v));
+    v = max(v, dpp_i32<0x118, 0xF>(ident, v));
+    v = max(v, dpp_i32<0x142, 0xA>(ident, v));
+    v = max(v, dpp_i32<0x143, 0xC>(ident, v));
+    return v;
+}
+__device__ __forceinline__ int wave_below_i32(int v, int ident) { return dpp_i32<0x138, 0xF>(ident, v); }   // wave_shr:1
+__device__ __forceinline__ double wave_scan_sum_f64(double v) {
+    v += dpp_f64<0x111, 0xF>(v);
+    v += dpp_f64<0x112, 0xF>(v);
+    v += dpp_f64<0x114, 0xF>(v);
+    v += dpp_f64<0x118, 0xF>(v);
+    v += dpp_f64<0x142, 0xA>(v);
+    v += dpp_f64<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ double wave_below_f64(double v) { return dpp_f64<0x138, 0xF>(v); }   // (0 in lane 0)
 // One dword of a wave mask into lane LANE of pk.  An asm statement because there is no builtin for it in this toolchain -- and
 // therefore with its own wait states: on gfx950 a scalar register written by a vector instruction (the v_cmp behind a ballot)
 // must not be read by a vector instruction within the next two issue slots, and inside an asm statement nobody pads that
@@ -365,30 +391,16 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
         if (act) classify_one(A, x64, ss, lw, hg);
         low = lw;
         // last non-LOW index before this lane
-        int inc = (act && !lw) ? m : LL_NONE;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(inc, d, 64);
-            if (lane >= d) inc = max(inc, up);
-        }
-        int nl = __shfl_up(inc, 1, 64);
-        if (lane == 0) nl = LL_NONE;
-        nl = max(nl, w_nl);
+        const int inc = wave_scan_max_i32((act && !lw) ? m : LL_NONE, LL_NONE);
+        const int nl = max(wave_below_i32(inc, LL_NONE), w_nl);
         key = KEY_NONE;
         if (lw) {
             const int p = m - nl;  // 1-based position in the LOW run
             const bool bad = (p > mx) && ((p - 1) % mx == 0);
             key = 2 * m + (bad ? 0 : 1);
         }
-        int kinc = key;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(kinc, d, 64);
-            if (lane >= d) kinc = max(kinc, up);
-        }
-        int kl = __shfl_up(kinc, 1, 64);
-        if (lane == 0) kl = KEY_NONE;
-        kl = max(kl, w_kl);
+        const int kinc = wave_scan_max_i32(key, KEY_NONE);
+        const int kl = max(wave_below_i32(kinc, KEY_NONE), w_kl);
         const bool st2 = (kl & 1) && (m - (kl >> 1)) <= mx + 1;
         int v = 0;
         if (lw) v = -1;
@@ -399,15 +411,8 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
         val = v;
         if (iter > 0 && __all(same)) break;
         if (iter >= MAX_FIX_ITERS) { flags |= 1u; break; }   // (iter is uniform: a scalar branch)
-        double incs = acc ? (x64 - (double)prev) : 0.0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double up = shfl_up_f64(incs, d);
-            if (lane >= d) incs += up;
-        }
-        double ex = shfl_up_f64(incs, 1);
-        if (lane == 0) ex = 0;
-        ss = ss0 + ex;
+        const double incs = wave_scan_sum_f64(acc ? (x64 - (double)prev) : 0.0);
+        ss = ss0 + wave_below_f64(incs);
     }
     double dl = 0;
     if (acc) {
@@ -441,7 +446,27 @@ __device__ __forceinline__ void chunk_incoming(const ThrArgs &A, uint32_t c, int
         w_nl = carried_nl(A);
         w_kl = carried_kl(A);
     } else if (!PASS0 && A.mode == 1) {
-        for (int s = lane; s < L; s += 64) ring[s] = resolve_slot(A, (int)c, s);
+        // (four slots per round, their loads in flight together: the predecessor's touched word and value decide almost every slot)
+        {
+            const int vb = A.ver[c - 1];
+            const uint32_t *tw = A.touched[vb] + (size_t)(c - 1) * A.twords;
+            const float *rv = A.ring_out[vb] + (size_t)(c - 1) * L;
+            for (int s0 = 0; s0 < L; s0 += 256) {
+                uint32_t w[4];
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int s = s0 + 64 * k + lane;
+                    w[k] = (s < L) ? tw[s >> 5] : 0u;
+                    v[k] = (s < L) ? rv[s] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int s = s0 + 64 * k + lane;
+                    if (s < L) ring[s] = ((w[k] >> (s & 31)) & 1u) ? v[k] : resolve_slot(A, (int)c, s);
+                }
+            }
+        }
         double part = 0;
         #pragma unroll 8
         for (int s = lane; s < L; s += 64) part += (double)ring[s];
