@@ -458,8 +458,11 @@ def stress_config(a, name, n, steps=6):
             ctx.sync()
             ts.append(time.perf_counter() - t0)
         st = ctx.stats()
-        out.update({'ms_per_step': float(np.median(ts[1:])) * 1e3, 'steps': steps - 1, 'threshold_passes': int(st.threshold_passes),
-                    'chunks_rerun': int(st.chunks_rerun), 'n_chunks': int(st.n_chunks), 'used_sequential': int(st.used_sequential)})
+        # (the first step is the stream's first batch in this regime, on the chunking of a clean stream; the context then cuts its
+        # batches four times finer for as long as they need re-runs -- host_threshold.h: fine_left -- which is what the median shows)
+        out.update({'ms_per_step': float(np.median(ts[1:])) * 1e3, 'steps': steps - 1, 'first_step_ms': ts[0] * 1e3,
+                    'threshold_passes': int(st.threshold_passes), 'chunks_rerun': int(st.chunks_rerun), 'n_chunks': int(st.n_chunks),
+                    'chunk_samples': int(st.chunk_samples), 'used_sequential': int(st.used_sequential)})
         if not a.no_parity:
             o = co.COracle(**stream_params('all'), **decoder_flags('all'))
             o.push_iq(iq)

@@ -1158,3 +1158,14 @@ extern "C" int nfc_debug_tail_prof(unsigned long long *out, int reset) {
     return 0;
 }
 #endif
+#ifdef NFC_GEN_PROF
+extern "C" int nfc_debug_gen_prof(unsigned long long *out, int reset) {
+    const size_t bytes = sizeof(unsigned long long) * 8192 * 8;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nfc::g_gen_prof), bytes) != hipSuccess) return -1;
+    if (reset) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(nfc::g_gen_prof)) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

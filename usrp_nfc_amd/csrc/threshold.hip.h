@@ -634,6 +634,12 @@ __device__ __forceinline__ void chunk_publish(const ThrArgs &A, uint32_t c, int 
 
 // GRING: the ring lives in global memory (one row of A.gring per chunk) instead of LDS -- for windows whose LDS ring would
 // leave a SIMD with one or two waves; its old values are then asked for one step ahead, like the input.
+#ifdef NFC_GEN_PROF
+__device__ unsigned long long g_gen_prof[8192 * 8];
+#define GP_T() clock64()
+#else
+#define GP_T() 0ull
+#endif
 template <int KIND, int NR, bool GRING>
 __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     constexpr uint32_t STEPN = 64u * NR;   // samples per step: NR rows of 64
@@ -671,12 +677,16 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     float eps = 0.f;  // margin of this evaluation
 
     // ---------------- incoming state ----------------
+    unsigned long long gp0 = GP_T(), gp_fast = 0, gp_exact = 0, gp_exsum = 0, gp_nex = 0, gp_t = 0;
+    (void)gp0; (void)gp_fast; (void)gp_exact; (void)gp_exsum; (void)gp_nex; (void)gp_t;
     chunk_incoming<KIND>(A, c, lane, ring, cr, m_chunk, ss0, w_nl, w_kl, eps);
     ss0 = rfl(ss0);
     w_nl = rfl(w_nl);
     w_kl = rfl(w_kl);
     const int nl_in = w_nl, kl_in = w_kl;
     const uint32_t vtop0 = chunk_save_in<SIGN_T>(A, c, lane, ring, tch, emin, emax);
+    const unsigned long long gp1 = GP_T();
+    (void)gp1;
 
     // ---------------- the chunk, NR rows of 64 samples per step ----------------
     uint32_t flags = 0;
@@ -948,12 +958,15 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         }
         if (__builtin_expect(!fast, 0)) {   // (the hint keeps the cold path out of the loop's layout: measured 4 % on the kernel)
             // ---- exact path, one 64-sample row at a time ----
+            gp_t = GP_T();
+            gp_nex++;
             if (eps > 0.f) all_robust = 0;
             if (!ss0_valid) {
                 ss0 = exact_sum();
                 ss0_valid = true;
                 steps_since_sync = 0;
             }
+            gp_exsum += GP_T() - gp_t;
             float xs[NR], pv[NR];
             float bx = 0.f;
 #pragma unroll
@@ -991,6 +1004,7 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
                 if (w_kl != kl_b) chunk_kl = w_kl;
             }
             ssf = (float)ss0;
+            gp_exact += GP_T() - gp_t;
         }
         {   // the step's NR words per plane: the masks are scalar pairs, v_writelane puts their halves into lanes 0 .. 2 NR - 1
             // (neg) and 2 NR .. 4 NR - 1 (pos) of ONE register, and those lanes store a dword each (the builtin, not an asm
@@ -1011,8 +1025,23 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
         slot_step += STEPN;
         slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
     }
+    const unsigned long long gp2 = GP_T();
+    (void)gp2;
     chunk_publish<SIGN_T>(A, c, lane, ring, tch, emin, emax, vmin, vmax, ssf, eps, flags, chunk_kl, chunk_nl,
                           ss0_valid ? ss0 : (double)ssf, min_ss, nl_in, kl_in, all_robust);
+#ifdef NFC_GEN_PROF
+    if (lane == 0 && c < 8192u) {
+        unsigned long long *o = g_gen_prof + (size_t)c * 8;
+        o[0] = gp1 - gp0;          // incoming state
+        o[1] = gp2 - gp1;          // the loop
+        o[2] = gp_exact;           // ... of which in exact steps
+        o[3] = gp_exsum;           // ... of which re-deriving the sum
+        o[4] = gp_nex;             // exact steps
+        o[5] = GP_T() - gp2;       // summary
+        o[6] = (n1 - m_chunk) / STEPN;
+        o[7] = (unsigned long long)A.mode + 1;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
