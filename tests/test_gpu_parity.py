@@ -635,3 +635,46 @@ def test_workgroup_kernel_two_rounds_ahead(monkeypatch):
     r = run_gpu(iq, dict(hi_val=1.1), kind=api.NFC_IN_IQ_F32, pushes=[0, 400_003, 800_001, 1_200_000])
     assert first_diff(r['val'][2000:], o.trace().tolist()) is None
     assert first_diff(r['transitions'], o.transitions()) is None and r['packets'] == o.packets()
+
+
+def test_chunking_adapts_to_a_stream_that_needs_reruns(monkeypatch):
+    # A stream whose batches need re-runs (level steps behind losses of signal: the chunk with the step gives up, the one behind it
+    # cannot be certified) is cut four times finer from the next batch on -- a re-run pass is one wave walking a chunk -- and goes back
+    # to the clean stream's chunking after eight batches without a re-run.  Same stream, synchronous pushes and batches submitted
+    # ahead mixed: the outputs are the single stream's whatever the chunking.
+    monkeypatch.setenv('NFC_WG_PER_CU', '1')   # (a chunk per CU: batches of a test's size are then cut well above the smallest chunk)
+    n_b = 2_400_000
+    dirty = synth.stress_workload(3 * n_b, depth=0.08, sigma=0.002, every=250_000)
+    clean = synth.workload('all', 10 * n_b)
+    iq = np.concatenate([dirty, clean])
+    n = len(iq) // 2
+    o = oracle_run(iq, dict(hi_val=1.1), api.NFC_IN_IQ_F32)
+    tr, s0, s1, pk, chunks, reruns = [], [], [], [], [], []
+    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        def take():
+            nonlocal tr, s0, s1, pk
+            tr += ctx.transitions()
+            s0 += ctx.symbols(0).tolist()
+            s1 += ctx.symbols(1).tolist()
+            pk += ctx.packets()
+            st = ctx.stats()
+            chunks.append(int(st.chunk_samples))
+            reruns.append(int(st.chunks_rerun))
+        bufs = [api.DeviceBuffer(iq[2 * k * n_b:2 * (k + 1) * n_b]) for k in range(13)]
+        for k in range(5):                       # synchronous: three dirty batches, two clean ones
+            ctx.push_device(bufs[k], n_b)
+            take()
+        nxt = 5
+        for k in range(5, 13):                   # the rest submitted ahead, two in flight
+            while nxt < 13 and nxt < k + 2:
+                ctx.submit_device(bufs[nxt], n_b)
+                nxt += 1
+            ctx.wait()
+            take()
+    d = first_diff(tr, o.transitions())
+    assert d is None, 'transition %s' % (d,)
+    assert s0 == o.symbols(0).tolist() and s1 == o.symbols(1).tolist() and pk == o.packets()
+    assert reruns[0] > 0 and reruns[1] > 0 and reruns[2] > 0 and sum(reruns[4:]) == 0, reruns
+    assert chunks[1] * 2 <= chunks[0] and chunks[2] == chunks[1], chunks   # cut finer after the first dirty batch
+    assert chunks[4] == chunks[1], chunks                                  # ... and still, two clean batches later
+    assert chunks[-1] == chunks[0], chunks                                 # back after eight without a re-run
