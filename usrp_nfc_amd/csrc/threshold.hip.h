@@ -150,10 +150,6 @@ __device__ __forceinline__ double rfl(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 __device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
-__device__ __forceinline__ double shfl_up_f64(double v, int d) {
-    int lo = __shfl_up(__double2loint(v), d, 64), hi = __shfl_up(__double2hiint(v), d, 64);
-    return __hiloint2double(hi, lo);
-}
 // DPP row_shr / row_bcast reductions (gfx9 family): result valid in lane 63, broadcast by readlane.
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp_i32(int ident, int v) {
