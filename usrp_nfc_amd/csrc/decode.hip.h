@@ -383,6 +383,33 @@ __device__ __forceinline__ void frame_write(const FrameOut &P, const FrameAgg &p
         const uint32_t closes = m.ST[t] & before;
         uint32_t off = pre.cnt[t];
         const uint32_t bo = P.pend[t] + fa_bits(pre, t, P.started_in[t]), co = fa_closes(pre, t, P.started_in[t]);
+        if (__all(off + 33u < P.cap_sym[t] && bo + 32u < P.cap_bits[t])) {
+            // every lane's symbols and bits fit their buffers (the usual case): the same walk without the per-symbol capacity
+            // checks, the appended bits' places counted along instead of recounted, the (rare) packet ends in a loop of their own
+            uint8_t *const sp = P.sym[t], *const bp = P.bits[t];
+            uint32_t bi = bo;
+            while (v) {
+                const uint32_t low = v & (0u - v);
+                const int slot = __ffs((int)v) - 1, k = slot >> 1;
+                v ^= low;
+                const uint32_t byte = (uint32_t)((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFFu;
+                const uint32_t s = (byte >> ((slot & 1) ? 5 : 2)) & 7u;
+                sp[off++] = (uint8_t)s;
+                if (appended & low) bp[bi++] = (uint8_t)s;
+            }
+            uint32_t cl = closes;
+            while (cl) {
+                const uint32_t low = cl & (0u - cl);
+                const int k = (__ffs((int)cl) - 1) >> 1;
+                cl ^= low;
+                const uint32_t j = co + (uint32_t)__popc(closes & (low - 1u));
+                if (j < P.cap_close[t]) {
+                    P.close_end[t][j] = bo + (uint32_t)__popc(appended & (low - 1u));
+                    P.close_idx[t][j] = P.idx64 ? P.idx64[base + k] : P.g0 + (uint64_t)P.epos[base + k];
+                }
+            }
+            continue;
+        }
         while (v) {
             const uint32_t low = v & (0u - v);
             const int slot = __ffs((int)v) - 1, k = slot >> 1;
