@@ -573,3 +573,21 @@ def test_overlap_is_measured_not_assumed(measured, kind):
         assert used == steps[2] and redos == [0, 0]
     else:
         assert carried[0] > 300 and redos == [0, 1]
+
+
+def test_bench_capture_slices_agree_on_the_samples_they_share():
+    # bench.py: a rank's warm-up samples are the END of its predecessor's chunk, bit for bit, whatever length of the schedule is
+    # used (the longest is generated, the shorter ones are its tail); the schedule follows the workload's rate and window.
+    import bench
+    assert bench.overlap_steps('miller', 100_000_000) == [38400, 70400, 134400]
+    assert bench.overlap_steps('classic1k', 1_000_000_000) == [190976, 350976, 670976]
+    assert bench.overlap_steps('miller', 50_000) == [38400]
+    assert bench.overlap_steps('miller', 10_000) == [9984]
+    n = 300_000
+    ov1, own1 = bench.make_capture_slice('miller', n, 1, 3)
+    ov0, own0 = bench.make_capture_slice('miller', n, 0, 3)
+    assert len(ov0) == 0 and len(own0) == 2 * n and len(own1) == 2 * n
+    assert len(ov1) == 2 * bench.overlap_steps('miller', n)[-1]
+    assert np.array_equal(ov1, own0[-len(ov1):])
+    ov2, _ = bench.make_capture_slice('miller', n, 2, 3)
+    assert np.array_equal(ov2, own1[-len(ov2):])
