@@ -190,8 +190,9 @@ def test_batches_submitted_ahead(monkeypatch, hook, depth):
     cuts = [0, 300_000, 700_000, 1_000_003, 1_400_000, 1_800_001, 2_100_000, 2_400_000, 2_700_000, n]
     with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
         tr, s0, s1, pk, ahead = _run_submitted(ctx, iq, cuts, depth)
+        extra = api.DeviceBuffer(iq[:600_000])   # (kept alive: a batch that does not run ahead reads it inside nfc_wait)
         with pytest.raises(api.NfcError):   # nothing else touches the stream while batches are in flight
-            ctx.submit_device(api.DeviceBuffer(iq[:600_000]), 300_000)
+            ctx.submit_device(extra, 300_000)
             ctx.reset()
         ctx.wait()
         st = ctx.stats()
