@@ -330,22 +330,42 @@ constexpr int EW_WORDS = SCAN_BLOCK * EW_ITEMS;      // words per tile, in both 
 #endif
 inline size_t edge_num_tiles(size_t nwords) { return (nwords + EW_WORDS - 1) / EW_WORDS; }
 
-// ---- launch 1: one aggregate per tile ----
-__device__ __forceinline__ void edge_reduce_block(const EdgeArgs &A, size_t nwords, uint32_t tile, EdgeAgg *partials) {
+// ---- launch 1: one aggregate per tile, and one per group of EW_SUPER tiles ----
+// The reduce pass as launched: a workgroup takes EW_SUPER consecutive tiles -- one per WAVE (a thread eight consecutive words, so
+// a wave's 512 words are exactly a writer tile) -- and leaves every tile's aggregate AND the aggregate of the four together.
+// Short batches only use the tiles' (the writer's workgroups fold their predecessors themselves); a long batch scans the
+// SUPER-aggregates in its single-workgroup prefix launch -- a quarter of the items: 7 630 instead of 30 517 at 1e9 samples, one round
+// of that workgroup instead of four -- and the writer adds at most three sibling tiles to its group's prefix.
+constexpr int EW_SUPER = SCAN_WAVES;               // tiles per super-aggregate
+constexpr int ES_ITEMS = EW_WORDS / 64;            // words per thread here: a wave covers one tile
+static_assert(ES_ITEMS % 2 == 0 && ES_ITEMS * 64 == EW_WORDS, "a wave of the reduce pass covers one writer tile");
+inline size_t edge_num_supers(size_t nwords) { return (edge_num_tiles(nwords) + EW_SUPER - 1) / EW_SUPER; }
+__device__ __forceinline__ void edge_reduce_super(const EdgeArgs &A, size_t nwords, uint32_t super, EdgeAgg *partials, EdgeAgg *supers) {
     __shared__ EdgeAgg lds[SCAN_WAVES];
     const EdgeAggOp op{A.mx, A.mx_magic};
-    const size_t w = (size_t)tile * EW_WORDS + (size_t)threadIdx.x * EW_ITEMS;
-    uint64_t ng[EW_ITEMS], ps[EW_ITEMS], m[EW_ITEMS];
-    load_words<EW_ITEMS>(A, w, nwords, ng, ps, m);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t tile = (size_t)super * EW_SUPER + wave;
+    const size_t w = tile * EW_WORDS + (size_t)lane * ES_ITEMS;
+    uint64_t ng[ES_ITEMS], ps[ES_ITEMS], m[ES_ITEMS];
+    load_words<ES_ITEMS>(A, w, nwords, ng, ps, m);
     EdgeAgg agg = op.identity();
 #pragma unroll
-    for (int i = 0; i < EW_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w + i) * 64), m[i]));
-    EdgeAgg total;
-    (void)block_exclusive_with<SCAN_WAVES>(op, agg, lds, total);
-    if (threadIdx.x == 0) partials[tile] = total;
+    for (int i = 0; i < ES_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w + i) * 64), m[i]));
+    const EdgeAgg inc = wave_inclusive_with(op, agg);
+    if (lane == 63) {
+        lds[wave] = inc;
+        if (tile * EW_WORDS < nwords) partials[tile] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        EdgeAgg t = lds[0];
+#pragma unroll
+        for (int k = 1; k < SCAN_WAVES; k++) t = op(t, lds[k]);
+        supers[super] = t;
+    }
 }
-__global__ __launch_bounds__(SCAN_BLOCK) void k_edge_reduce(EdgeArgs A, size_t nwords, EdgeAgg *partials) {
-    edge_reduce_block(A, nwords, blockIdx.x, partials);
+__global__ __launch_bounds__(SCAN_BLOCK) void k_edge_reduce(EdgeArgs A, size_t nwords, EdgeAgg *partials, EdgeAgg *supers) {
+    edge_reduce_super(A, nwords, blockIdx.x, partials, supers);
 }
 
 // per edge, for the decoders: LUT row (v + 1) * nd + d in the low 14 bits, route in the top two
@@ -404,7 +424,7 @@ struct EdgeWalk {
     int32_t q;
     bool timed, carried;
 };
-__global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const EdgeAgg *partials, uint32_t *epos,
+__global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const EdgeAgg *partials, const EdgeAgg *supers, uint32_t *epos,
                                                            uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
                                                            Last2 *last2_total, EdgeCarry *carry_out) {
     __shared__ uint16_t s_pos[EW_CAP];   // (tile-local sample position: a tile is EW_WORDS * 64 <= 65536 samples)
@@ -419,7 +439,19 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
     const EdgeAggOp op{A.mx, A.mx_magic};
     uint64_t ng[EW_ITEMS], ps[EW_ITEMS], m[EW_ITEMS];
     const int val_before = load_words<EW_ITEMS>(A, w_first, nwords, ng, ps, m);
-    const EdgeAgg pre = own_prefix ? tile_prefix_with<SCAN_BLOCK>(op, partials, blockIdx.x, s_agg) : partials[blockIdx.x];
+    EdgeAgg pre;
+    if (own_prefix) {
+        pre = tile_prefix_with<SCAN_BLOCK>(op, partials, blockIdx.x, s_agg);
+    } else {
+        // (the prefix launch scanned the super-aggregates: the group's prefix, then the sibling tiles before this one)
+        const uint32_t g = blockIdx.x / EW_SUPER, q = blockIdx.x % EW_SUPER;
+        EdgeAgg sib[EW_SUPER - 1];
+#pragma unroll
+        for (int k = 0; k < EW_SUPER - 1; k++) sib[k] = (uint32_t)k < q ? partials[(size_t)g * EW_SUPER + k] : op.identity();
+        pre = supers[g];
+#pragma unroll
+        for (int k = 0; k < EW_SUPER - 1; k++) pre = op(pre, sib[k]);
+    }
     const uint32_t gbase = entries_before(A, pre, (int32_t)(wt * 64));
     TP_MARK();   // 1: words + tile prefix
     EdgeAgg agg = op.identity();

@@ -18,12 +18,12 @@ struct CertLaunch {
     CertSummary *sum;
     uint32_t blocks;
 };
-__global__ __launch_bounds__(256) void k_certify_and_reduce(CertLaunch C, EdgeArgs E, size_t nwords, EdgeAgg *partials) {
+__global__ __launch_bounds__(256) void k_certify_and_reduce(CertLaunch C, EdgeArgs E, size_t nwords, EdgeAgg *partials, EdgeAgg *supers) {
     if (blockIdx.x < C.blocks) {
         certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, blockIdx.x, C.blocks);
         return;
     }
-    edge_reduce_block(E, nwords, blockIdx.x - C.blocks, partials);
+    edge_reduce_super(E, nwords, blockIdx.x - C.blocks, partials, supers);
 }
 
 struct DevBuf {

@@ -29,8 +29,10 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     E.per_mask = 0;
     for (int b = 0; b < 64; b += c->mx) E.per_mask |= 1ull << b;
     const size_t tiles = edge_num_tiles(nwords);   // EW_WORDS words per tile in both launches of the stage
-    HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(EdgeAgg)));
+    const size_t supers = edge_num_supers(nwords);   // the reduce pass: a workgroup per EW_SUPER tiles, both levels of aggregates
+    HIPCHK(c, c->d_partials.ensure((tiles + supers + 2) * sizeof(EdgeAgg)));
     EdgeAgg *parts = c->d_partials.as<EdgeAgg>();
+    EdgeAgg *sups = parts + tiles + 1;
     // launch 1: one aggregate per tile (first change, last two changes, entries it is sure of).  While the tiles are few,
     // each tile's workgroup of the writer folds its predecessors' aggregates itself (scan.hip.h: tile_prefix) and the
     // single-workgroup prefix launch is not needed.
@@ -40,18 +42,18 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     const EdgeAggOp op{E.mx, E.mx_magic};
     if (c->cert_pending && tiles) {
         c->cert_pending = false;
-        NFC_LAUNCH(k_certify_and_reduce, dim3((unsigned)(c->cert.blocks + tiles)), dim3(256), 0, c->st, c->cert, E, nwords, parts);
+        NFC_LAUNCH(k_certify_and_reduce, dim3((unsigned)(c->cert.blocks + supers)), dim3(256), 0, c->st, c->cert, E, nwords, parts, sups);
     } else if (tiles) {
-        NFC_LAUNCH(k_edge_reduce, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, parts);
+        NFC_LAUNCH(k_edge_reduce, dim3((unsigned)supers), dim3(SCAN_BLOCK), 0, c->st, E, nwords, parts, sups);
     }
-    if (!own || !tiles)
-        scan_partials_with(c->st, op, tiles, nullptr, (uint32_t)EW_WORDS, parts, op.identity(), (EdgeAgg *)nullptr,
+    if (!own || !tiles)   // (long batches: the prefix launch over the SUPER-aggregates; the totals and the carry in its epilogue)
+        scan_partials_with(c->st, op, supers, nullptr, (uint32_t)(EW_WORDS * EW_SUPER), sups, op.identity(), (EdgeAgg *)nullptr,
                            EdgeTotalEpilogue{E, edges_total, last2_total, dE(c)});
     const uint32_t cap = c->cap_edges;
     HIPCHK(c, c->d_epos.ensure(((size_t)cap + 8) * 4));
     HIPCHK(c, c->d_ecode.ensure(((size_t)cap + 8) * 2));
     if (tiles)
-        NFC_LAUNCH(k_write_edges, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, parts, c->d_epos.as<uint32_t>(),
+        NFC_LAUNCH(k_write_edges, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, parts, sups, c->d_epos.as<uint32_t>(),
                    c->d_ecode.as<uint16_t>(), cap, own, edges_total, last2_total, dE(c));
     c->edges_from_host = false;
     return NFC_OK;
