@@ -1269,6 +1269,7 @@ __device__ __forceinline__ void fill_reduce(FillRed &r, double &part, uint32_t &
 
 // Per batch: S(ring), delta = ss - S(ring), and the guard span of the carried values; also resets the
 // summary version bytes and the certification summary.  Runs as the tail of k_fill (one launch per batch for both).
+__device__ __forceinline__ void prepare_batch_finish(Carry *carry, CertSummary *sum, double S, uint32_t emin, uint32_t emax);
 __device__ __forceinline__ void prepare_batch(const float *ring, int L, Carry *carry, uint8_t *ver, int nchunks, CertSummary *sum,
                                               FillRed &red) {
     const int tid = threadIdx.x;
@@ -1285,8 +1286,11 @@ __device__ __forceinline__ void prepare_batch(const float *ring, int L, Carry *c
         }
     }
     fill_reduce(red, part, emin, emax);
-    if (tid == 0) {
-        const double S = part;
+    prepare_batch_finish(carry, sum, part, emin, emax);
+}
+// (the tail of the above, for a caller that has just summed the same window itself)
+__device__ __forceinline__ void prepare_batch_finish(Carry *carry, CertSummary *sum, double S, uint32_t emin, uint32_t emax) {
+    if (threadIdx.x == 0) {
         carry_apply_fin(*carry);
         const double ss = carry->ss;
         const double delta = ss - S;
@@ -1389,8 +1393,9 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_fill(const void *in, uint32_t n,
         eci.dst[1] = 0;
         eci.dst[2] = eci.dur0;
     }
-    __syncthreads();   // thread 0's carry->ss is read by prepare_batch's thread 0 only; the ring by everyone
-    prepare_batch(ring, L, carry, ver, nchunks, sum, red);
+    // the per-batch preparation: the window was summed just now (S, emin, emax are every thread's), only the resets are left
+    for (int i = tid; i < nchunks; i += FILL_BLOCK) ver[i] = 0;
+    prepare_batch_finish(carry, sum, S, emin, emax);
 }
 
 // After the passes converged: the ring at the end of the batch (look-back over all
