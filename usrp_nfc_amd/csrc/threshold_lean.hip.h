@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
                 if (inact) x[j] = prev[j];
             }
         }
-        unsigned long long lowm[NR], posm[NR], good = ~0ull, anylow = 0, anyhi = 0;
+        unsigned long long lowm[NR], posm[NR], good = ~0ull, anylow = 0;
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             const unsigned long long lo1 = __ballot(x[j] < tlo_dn), lo0 = __ballot(x[j] > tlo_up);
@@ -378,7 +378,6 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
             posm[j] &= am[j];
             good &= g;
             anylow |= lowm[j];
-            anyhi |= posm[j];
         }
         bool ok = (good == ~0ull);
         if (!ok) why = 2u;

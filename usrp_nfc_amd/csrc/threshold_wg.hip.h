@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     float min_ss = 3.0e38f;
     uint32_t vmin = 0xFFFFFFFFu, vmax = vtop0;
     const float etaD = 1.0f - 9.5367431640625e-07f;  // 1 - 2^-20
-    const float slD = 1.0f - 3.814697265625e-06f, slU = 1.0f + 3.814697265625e-06f;
+    const float slU = 1.0f + 3.814697265625e-06f;
     const float loLf = (float)A.lo_L, hiLf = (float)A.hi_L;
     constexpr int RB = LeanRaw<KIND>::BYTES;
     const uint32_t wbase0 = m_chunk + STEPN * (uint32_t)wave;   // this wave's step of round 0
