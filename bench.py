@@ -39,9 +39,13 @@ def parse():
     ap.add_argument('--steps', type=int, default=100)   # 0.4 ms each: the device reaches its steady clocks within the first few dozen
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--samples', type=float, default=0, help='samples per GPU (default: 1e8; 1e9 for classic1k)')
-    ap.add_argument('--workload', default='miller', choices=['miller', 'manchester', 'all', 'classic1k'],
+    ap.add_argument('--workload', default=None, choices=['miller', 'manchester', 'all', 'classic1k'],
                     help="BASELINE.json configs[1] / [2] / both decoders at 2 Msps, or configs[3] / [4]: the MIFARE Classic 1K "
-                         "transaction of outputs/1k_with_enc.out at 10 Msps, 1e9 samples per GPU (a 1e8-sample capture tiled)")
+                         "transaction of outputs/1k_with_enc.out at 10 Msps, 1e9 samples per GPU (a 1e8-sample capture tiled).  Default: miller; "
+                         "with --gpus N > 1 and no --workload the line also carries configs[4] (classic1k, 1e9 samples per GPU) under other_configs")
+    ap.add_argument('--input-kind', default='iq', choices=['iq', 'env', 'i16'],
+                    help="what the caller hands over: fc32 IQ (8 B/sample, BASELINE's metric), the float32 envelope that the reference's own "
+                         "transition_sink.work receives (4 B/sample, transition_sink.py:13-18), or 16-bit PCM as the WAV branch reads it (2 B/sample)")
     ap.add_argument('--chunk', type=int, default=0, help='time-chunk samples of the threshold kernel (0: library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
@@ -51,7 +55,10 @@ def parse():
                     '(the threshold kernel with the machine to itself); ahead: consecutive batches of one stream, submitted ahead (nfc_submit_device / nfc_wait). '
                     'The other one is measured beside it unless --no-extras')
     ap.add_argument('--sync-steps', action='store_true', help='(same as --primary sync --no-extras for the stepping: kept for the profiling scripts)')
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.workload_given = a.workload is not None
+    a.workload = a.workload or 'miller'
+    return a
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -105,6 +112,40 @@ TILE = 100_000_000   # classic1k: samples of the synthetic capture that is tiled
 
 def default_samples(workload):
     return 1_000_000_000 if workload == 'classic1k' else 100_000_000
+
+
+# input kinds: (bytes per sample, elements per sample, what it is)
+INPUT_KINDS = {'iq': (8, 2, 'fc32 IQ, 8 B/sample (envelope computed in the kernel)'),
+               'env': (4, 1, 'float32 envelope, 4 B/sample: what transition_sink.work receives (transition_sink.py:13-18, decoder.py:27-33)'),
+               'i16': (2, 1, '16-bit PCM, 2 B/sample: scaled by 1/32767 and squared in the kernel (the WAV branch, decoder.py:25-27)')}
+PCM_SCALE = 40000.0   # i16: PCM value of a unit amplitude (the synthetic carrier, amplitude 0.5, sits at 20 000)
+
+
+def api_kind(kind):
+    from usrp_nfc_amd import api
+    return {'iq': api.NFC_IN_IQ_F32, 'env': api.NFC_IN_ENV_F32, 'i16': api.NFC_IN_I16_SQ}[kind]
+
+
+def convert_input(iq, kind):
+    """The capture as the caller of that input kind would hold it (from the synthetic IQ)."""
+    import numpy as np
+    from usrp_nfc_amd import synth
+    if kind == 'iq' or not len(iq):
+        return iq if kind == 'iq' else np.zeros(0, np.float32 if kind == 'env' else np.int16)
+    env = synth.envelope_f32(iq)
+    if kind == 'env':
+        return env
+    return np.clip(np.rint(np.sqrt(env) * np.float32(PCM_SCALE)), -32768, 32767).astype(np.int16)
+
+
+def oracle_push(o, x, kind):
+    import numpy as np
+    if kind == 'iq':
+        o.push_iq(x)
+    elif kind == 'env':
+        o.push_env(x)
+    else:   # (fl(pcm / 32767) as GNU Radio's wavfile_source scales it -- tests/test_host_abi.py pins the kernel's form of it --, then squared)
+        o.push_real_sq((x.astype(np.float32) / np.float32(32767.0)).astype(np.float32))
 
 
 OVERLAP_WINDOWS = (16, 32, 64)   # warm-up lengths a rank > 0 tries, in averaging windows (sharding.overlap_schedule)
@@ -181,33 +222,38 @@ def make_capture_slice(workload, n_per_rank, rank, world):
 class Resident(object):
     """A rank's input in HBM: the host capture uploaded once -- a tile repeated `reps` times for classic1k."""
 
-    def __init__(self, api, own, n, dev):
+    def __init__(self, api, own, n, dev, kind='iq'):
         import numpy as np
         self.n = n
-        tile = len(own) // 2
+        bps, per, _ = INPUT_KINDS[kind]
+        tile = len(own) // per
         self.reps = (n + tile - 1) // tile
         if self.reps == 1:
             self.buf = api.DeviceBuffer(own, dev)
         else:
-            self.buf = api.DeviceBuffer(np.zeros(0, np.float32), dev, nbytes=8 * tile * self.reps)
+            self.buf = api.DeviceBuffer(np.zeros(0, np.float32), dev, nbytes=bps * tile * self.reps)
             L = self.buf.L
             for k in range(self.reps):
-                assert L.nfc_device_upload(dev, self.buf.ptr.value + 8 * tile * k, own.ctypes.data, own.nbytes) == 0
+                assert L.nfc_device_upload(dev, self.buf.ptr.value + bps * tile * k, own.ctypes.data, own.nbytes) == 0
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # one configuration on this rank
 # ---------------------------------------------------------------------------------------------------------------------
-def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend, want_parity, chunk=0):
+def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend, want_parity, chunk=0, kind='iq'):
     import numpy as np
     from usrp_nfc_amd import api, sharding, synth
     ndev = max(1, api.device_count())
     dev = (local % ndev) if world > 1 else 0
-    ov, own = make_capture_slice(workload, n, rank, world)
+    bps = INPUT_KINDS[kind][0]
+    ov, own_iq = make_capture_slice(workload, n, rank, world)
+    own = convert_input(own_iq, kind)      # (what is resident in HBM and what the oracle is given: the caller's form of the capture)
+    if kind != 'iq':
+        del own_iq
     flags = decoder_flags(workload)
-    res = Resident(api, own, n, dev)
-    d_ov = api.DeviceBuffer(ov, dev) if len(ov) else None
-    ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, device=dev, chunk_samples=chunk, **stream_params(workload), **flags)
+    res = Resident(api, own, n, dev, kind)
+    d_ov = api.DeviceBuffer(convert_input(ov, kind), dev) if len(ov) else None
+    ctx = api.NfcContext(input_kind=api_kind(kind), device=dev, chunk_samples=chunk, **stream_params(workload), **flags)
     level = sharding.carrier_level(synth.envelope_f32(ov[:2 * 4096])) if len(ov) else 0.0
     g_lo = rank * n
     n_ov = len(ov) // 2
@@ -219,7 +265,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
         level = [sharding.carrier_level(synth.envelope_f32(ov[2 * (n_ov - s):2 * (n_ov - s) + 2 * 4096])) for s in ov_steps]
 
     def push_overlap(nov):   # the LAST nov samples before the shard (lengths are multiples of 256 samples: 16-byte aligned)
-        ctx.push_device(d_ov.ptr.value + 8 * (n_ov - nov), nov)
+        ctx.push_device(d_ov.ptr.value + bps * (n_ov - nov), nov)
 
     def one_step():
         redo[0] += sharding.decode_shard(ctx, comm, push_overlap, lambda: ctx.push_device(res.buf, n),
@@ -319,7 +365,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
 
     def summary(acc):
         ka = float(np.mean(acc['kernel_ms'])) if acc['kernel_ms'] else float('nan')
-        ach = 8.0 * n / (ka * 1e-3) / 1e9
+        ach = float(bps) * n / (ka * 1e-3) / 1e9
         what = ('consecutive batches of one stream per rank, %d in flight: batch k + %d is submitted before batch k is waited for (%d of %d timed '
                 'steps ran ahead)%s' % (a.in_flight, a.in_flight - 1, acc['n_ahead'], steps,
                                         '; the rank\'s time shard is that stream: one boundary exchange after its last batch' if sharded else '')
@@ -355,15 +401,15 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
     out = None
     if rank == 0:
         k_avg = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
-        thr_bytes = 8.0 * n                              # 8 B per sample read by the envelope + threshold kernel ...
+        thr_bytes = float(bps) * n                       # 8 B per sample (fc32 IQ; 4 / 2 for the other input kinds) read by the envelope + threshold kernel ...
         edge_bytes = 16.0 * n_edges                      # ... 16 B per emitted edge (the nfc_edge record) in SURVEY's count; the edge
         stored_bytes = 6.0 * n_edges                     # stage now keeps 6 B per entry (u32 position + u16 code), records built on read
         achieved = thr_bytes / (k_avg * 1e-3) / 1e9
-        traffic, tsrc = hbm_traffic(workload, n)
+        traffic, tsrc = hbm_traffic(workload, n, kind)
         out = {
             'ms_per_step': dt / steps * 1e3,
             'value': world * n * steps / dt / 1e6,
-            'config': {'workload': WORKLOAD_NAMES[workload], 'samples_per_gpu': n, 'time_chunk_samples': int(st.chunk_samples),
+            'config': {'workload': WORKLOAD_NAMES[workload], 'input_kind': INPUT_KINDS[kind][2], 'samples_per_gpu': n, 'time_chunk_samples': int(st.chunk_samples),
                        'time_chunks': int(st.n_chunks), 'parallelism': 'time-chunk x%d' % world, 'edges_per_gpu': n_edges,
                        'symbols_reader': int(cnt.n_symbols[1]), 'symbols_tag': int(cnt.n_symbols[0]),
                        'packets': int(cnt.n_packets[0] + cnt.n_packets[1]), 'boundary_redos': redo[0],
@@ -377,7 +423,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                          'launches_per_step': float(np.mean(n_pass)) if n_pass else None,
                          'algorithmic_bytes_per_launch': thr_bytes,
                          'streaming_read_ceiling': STREAM_CEILING_GBS, 'frac_of_streaming_ceiling': achieved / STREAM_CEILING_GBS,
-                         'note': '8 B/sample only: the 16 B/edge of SURVEY 8(d) are written by the edge stage, listed under edge_stage'
+                         'note': '%d B/sample only: the 16 B/edge of SURVEY 8(d) are written by the edge stage, listed under edge_stage' % bps
                                  + ('; the launches of the timed region run BESIDE the previous batch\'s edge and decode stages (batches submitted ahead) and '
                                     'share the SIMDs\' issue slots with them: one_batch_at_a_time.roofline is the same kernel with the machine to itself' if ahead else
                                     '; submitted_ahead is the same stream with batches submitted ahead: more samples per second, and the kernel\'s launches '
@@ -393,7 +439,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                                     'decode': st.ms_decode, 'used_sequential': int(st.used_sequential)},
         }
         if want_parity:
-            out['parity'] = parity_check(workload, own, flags, n, True)
+            out['parity'] = parity_check(workload, own, flags, n, True, kind)
             if gathered is not None:
                 out['parity']['sharded'] = sharded_parity(workload, n, world, flags, gathered)
                 if out['parity']['sharded'].get('all_equal') is False:
@@ -414,7 +460,7 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
     return out, own, flags
 
 
-def hbm_traffic(workload, n):
+def hbm_traffic(workload, n, kind='iq'):
     """HBM bytes per threshold launch from the rocprofv3 PMC passes recorded under profiles/ (separate --pmc FETCH_SIZE /
     WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md): a record of an
     earlier run, not a measurement of this one -- `traffic_source` says so.  profiles/hbm_traffic.json is a list of records
@@ -424,7 +470,7 @@ def hbm_traffic(workload, n):
         if isinstance(recs, dict):
             recs = [recs]
         for rec in recs:
-            if rec.get('workload') == workload and int(rec.get('samples', 0)) == n:
+            if rec.get('workload') == workload and int(rec.get('samples', 0)) == n and rec.get('input_kind', 'iq') == kind:
                 return rec['bytes_per_launch'], 'profiles/hbm_traffic.json (%s)' % rec.get('kernel', 'k_threshold')
     except Exception:
         pass
@@ -474,7 +520,7 @@ def stress_config(a, name, n, steps=6):
     return out
 
 
-def parity_check(workload, own, flags, n, ahead=False):
+def parity_check(workload, own, flags, n, ahead=False, kind='iq'):
     """Rank 0's chunk, GPU vs the pinned C oracle, full size, every pass compared in full (edges, symbols, packets).
     A tiled capture goes tile by tile.  ahead: as the timed loop does it -- ONE stream, the capture again and again, batch
     k + 2 submitted before batch k is waited for; four rounds (two for a tiled capture), so that a batch that follows a
@@ -482,10 +528,10 @@ def parity_check(workload, own, flags, n, ahead=False):
     import numpy as np
     from oracle import c_oracle as co
     from usrp_nfc_amd import api
-    tile = len(own) // 2
+    tile = len(own) // INPUT_KINDS[kind][1]
     reps = (n + tile - 1) // tile
     rounds = (4 if reps == 1 else 2) if ahead else 1
-    ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **stream_params(workload), **flags)
+    ctx = api.NfcContext(input_kind=api_kind(kind), **stream_params(workload), **flags)
     o = co.COracle(**stream_params(workload), **flags)
     ok_edges = ok_sym = ok_pk = True
     per_round = []
@@ -503,7 +549,7 @@ def parity_check(workload, own, flags, n, ahead=False):
         else:
             ctx.push(own)
         o.clear_outputs()
-        o.push_iq(own)
+        oracle_push(o, own, kind)
         ge, oe = ctx.edges(), o.edges()
         ok_edges &= bool(len(ge) == len(oe) and np.array_equal(ge['idx'].astype(np.int64), oe['idx']) and np.array_equal(ge['d'], oe['d'])
                          and np.array_equal(ge['v'], oe['v']) and np.array_equal(ge['t'], oe['t']))
@@ -548,17 +594,24 @@ SHARDED_PARITY_CAP = 800_000_000   # samples of the whole capture the stitched p
 def sharded_parity(workload, n, world, flags, gathered):
     """EVERY rank against the oracle: rank 0 regenerates the whole world * n sample capture shard by shard, runs the pinned C
     oracle ONCE over it (one stream, from sample 0), cuts its outputs at the shard boundaries and compares each cut with what
-    the rank that decoded that shard reported (gathered: every rank's result_digest of its last protocol step)."""
+    the rank that decoded that shard reported (gathered: every rank's result_digest of its last protocol step).
+    A TILED capture (classic1k beyond one tile: BASELINE.json configs[3] / [4]) needs no regeneration -- every rank's chunk is the
+    same tile again and again -- so it is checked at full size whatever that is (8 x 1e9 samples: half a minute of the C oracle);
+    a generated capture is regenerated shard by shard up to NFC_BENCH_SHARDED_PARITY_CAP samples."""
     from oracle import c_oracle as co
     total = world * n
+    tiled = workload == 'classic1k' and n > TILE
     cap = int(float(os.environ.get('NFC_BENCH_SHARDED_PARITY_CAP', SHARDED_PARITY_CAP)))
-    if total > cap:
+    if total > cap and not tiled:
         return {'skipped': 'the capture has %d samples, the stitched leg regenerates at most %d (NFC_BENCH_SHARDED_PARITY_CAP raises it)' % (total, cap),
                 'ranks_reported': gathered}
     o = co.COracle(**stream_params(workload), **flags)
     equal, want = [], []
+    own_r = None
+    t0 = time.perf_counter()
     for r in range(world):
-        _, own_r = make_capture_slice(workload, n, r, world)
+        if own_r is None or not tiled:
+            _, own_r = make_capture_slice(workload, n, r, world)
         tile = len(own_r) // 2
         o.clear_outputs()
         for _ in range((n + tile - 1) // tile):   # (a tiled capture: the rank's chunk is the tile again and again)
@@ -566,23 +619,31 @@ def sharded_parity(workload, n, world, flags, gathered):
         d = result_digest(o.edges(), o.symbols(0), o.symbols(1), o.packets())
         want.append(d)
         equal.append(bool(d == gathered[r]))
-        del own_r
+    del own_r
     return {'vs': 'oracle/nfc_oracle.c, ONE stream over the whole %d-sample capture, cut at the shard boundaries' % total,
-            'ranks_equal': equal, 'all_equal': bool(all(equal)), 'n_edges': [d['n_edges'] for d in want], 'n_packets': [d['n_packets'] for d in want]}
+            'ranks_equal': equal, 'all_equal': bool(all(equal)), 'n_edges': [d['n_edges'] for d in want], 'n_packets': [d['n_packets'] for d in want],
+            'oracle_seconds': time.perf_counter() - t0}
 
 
-def cpu_baseline(own, flags, params):
+def cpu_baseline(own, flags, params, kind='iq'):
     """The reference's CPU path timed on this host: the pinned C port of the per-sample loop (1 core),
     and -- for the reference's own language -- the line-for-line Python restatement on a prefix."""
     from oracle import c_oracle as co, py_oracle as po
     from usrp_nfc_amd import synth
+    import numpy as np
     o = co.COracle(**params, **flags)
-    n = len(own) // 2
+    n = len(own) // INPUT_KINDS[kind][1]
     t0 = time.perf_counter()
-    o.push_iq(own)
+    oracle_push(o, own, kind)
     tc = time.perf_counter() - t0
     npy = min(n, 4_000_000)
-    x = synth.envelope_f32(own[:2 * npy])
+    if kind == 'iq':
+        x = synth.envelope_f32(own[:2 * npy])
+    elif kind == 'env':
+        x = own[:npy]
+    else:
+        x = (own[:npy].astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+        x = x * x
     t0 = time.perf_counter()
     po.run_path(x, chunk=8192, **params, **flags)
     tp = time.perf_counter() - t0
@@ -670,7 +731,10 @@ def rank_main(a):
         comm = sharding.LocalComm()
     assert comm.world == world
     n = int(a.samples) if a.samples else default_samples(a.workload)
-    out, own, flags = run_config(a, a.workload, n, a.steps, a.warmup, rank, world, local, comm, backend, not a.no_parity, a.chunk)
+    kind = a.input_kind
+    if kind != 'iq' and world > 1:
+        raise SystemExit('bench: --input-kind %s is a one-GPU figure (the sharded runs take fc32 IQ, BASELINE.json\'s metric)' % kind)
+    out, own, flags = run_config(a, a.workload, n, a.steps, a.warmup, rank, world, local, comm, backend, not a.no_parity, a.chunk, kind)
     if rank == 0:
         line = {'metric': 'IQ Msamples/s -> decoded bits (2 Msps stream)' if a.workload != 'classic1k' else 'IQ Msamples/s -> decoded bits (10 Msps stream)',
                 'value': out['value'], 'unit': 'Msamples/s', 'n_gpus': comm.world, 'steps': a.steps, 'warmup': a.warmup,
@@ -678,8 +742,8 @@ def rank_main(a):
                 'dtype': 'f32 envelope / f64 window sums / u8 symbols', 'data': 'synthetic'}
         line.update({k: v for k, v in out.items() if k not in ('value', 'ms_per_step')})
         if not a.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
-            line['cpu_baseline'] = cpu_baseline(own, flags, stream_params(a.workload))
-        if world == 1 and not a.no_extras and a.workload == 'miller' and n == 100_000_000:
+            line['cpu_baseline'] = cpu_baseline(own, flags, stream_params(a.workload), kind)
+        if world == 1 and not a.no_extras and a.workload == 'miller' and n == 100_000_000 and kind == 'iq':
             # the figures SURVEY.md 8(d) asks for beside the headline, measured in this same invocation
             line['end_to_end'] = end_to_end(a.workload, own, flags)
             del own
@@ -689,12 +753,32 @@ def rank_main(a):
                 others.append({'workload': WORKLOAD_NAMES[wl], 'samples': nn, 'steps': st, 'ms_per_step': o2['ms_per_step'], 'value': o2['value'],
                                'unit': 'Msamples/s', 'roofline': o2['roofline'], 'time_chunks': o2['config']['time_chunks'],
                                'parity': o2.get('parity')})
+            # the other input kinds of the boundary on configs[1]'s capture: the float32 envelope the reference's own sink is handed
+            # (4 B/sample) and 16-bit PCM (2 B/sample).  Same kernel, same ~0.19 ms launch -- it is bound by instruction issue,
+            # not by bytes -- so the fraction of the HBM roofline falls with the bytes per sample; each entry says its own.
+            for kd in ('env', 'i16'):
+                o2, _, _ = run_config(a, 'miller', 100_000_000, 20, 3, 0, 1, 0, sharding.LocalComm(), 'none', not a.no_parity, 0, kd)
+                others.append({'workload': WORKLOAD_NAMES['miller'], 'input_kind': INPUT_KINDS[kd][2], 'samples': 100_000_000, 'steps': 20,
+                               'ms_per_step': o2['ms_per_step'], 'value': o2['value'], 'unit': 'Msamples/s', 'roofline': o2['roofline'],
+                               'time_chunks': o2['config']['time_chunks'], 'parity': o2.get('parity')})
             line['other_configs'] = others
             # the unhappy path: chunks that give up / cannot be certified
             line['stress'] = [stress_config(a, nm, 100_000_000) for nm in ('stress_dropouts', 'stress_dropouts_steps', 'stress_hover')]
             clean = out['ms_per_step']
             for e in line['stress']:
                 e['vs_clean_step'] = e['ms_per_step'] / clean
+    own = None   # (the capture's host copy is not needed any more)
+    if world > 1 and not a.workload_given and not a.samples and not a.no_extras:
+        # BASELINE.json configs[4]: the -t all decode of the MIFARE Classic 1K capture at 10 Msps, 1e9 samples per GPU, time-sharded
+        # over the same ranks (every rank in step: the protocol's collectives run inside)
+        st4 = min(a.steps, 10)
+        o4, _, _ = run_config(a, 'classic1k', default_samples('classic1k'), st4, min(a.warmup, 3), rank, world, local, comm, backend, not a.no_parity)
+        if rank == 0:
+            line['other_configs'] = [{'workload': WORKLOAD_NAMES['classic1k'], 'baseline_config': 'configs[4]', 'samples_per_gpu': default_samples('classic1k'),
+                                      'n_gpus': world, 'steps': st4, 'ms_per_step': o4['ms_per_step'], 'value': o4['value'], 'unit': 'Msamples/s',
+                                      'scaling': 'weak', 'roofline': o4['roofline'], 'config': o4['config'], 'submitted_ahead': o4.get('submitted_ahead'),
+                                      'parity': o4.get('parity')}]
+    if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()
     if hasattr(comm, 'barrier'):

@@ -5,7 +5,7 @@ import pytest
 
 from oracle import c_oracle as co
 from tests.golden_util import PATH_CASES, Case, load_npz
-from usrp_nfc_amd import api, synth
+from usrp_nfc_amd import _lib, api, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -71,6 +71,43 @@ def test_golden_streamed(name, step):
 def test_golden_sequential_kernel(name):
     c = Case(name)
     check_case(c, run_gpu(c.x, c.params, flags=api.NFC_FLAG_FORCE_SEQUENTIAL))
+
+
+@pytest.mark.parametrize('name', PATH_CASES)
+def test_golden_general_kernel(monkeypatch, name):
+    # The fixtures are float32 ENVELOPES (what transition_sink.work receives, transition_sink.py:13-18): since round 4 that input
+    # kind takes the workgroup / lean kernels like the others (tests above); NFC_LEAN=0 keeps round 1's general kernel reachable
+    # as the A/B -- and it is still what re-runs a chunk the fast kernels give up on.
+    monkeypatch.setenv('NFC_LEAN', '0')
+    c = Case(name)
+    r = run_gpu(c.x, c.params)
+    check_case(c, r)
+    check_case(c, run_gpu(c.x, c.params, chunk_samples=256))
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_envelope_input_with_negative_samples(seed):
+    # A raw envelope is the caller's: nothing says it is >= 0.  The fast kernels keep "slot not written by this chunk" in a ring
+    # value's sign bit and order samples by their raw bits, so a chunk that meets a negative sample -- in the window it starts
+    # from (the fill phase stores whatever comes) or among its own samples -- gives up and the general kernel takes it.  The
+    # reference classifies a negative sample LOW (lo > ratio, transition_sink.py:62-66).
+    rng = np.random.default_rng(900 + seed)
+    n = 300_000
+    x = (0.3 * (1 + 0.01 * rng.standard_normal(n))).astype(np.float32)
+    for _ in range(60):
+        s = int(rng.integers(2100, n - 300))
+        k = int(rng.integers(1, 120))
+        x[s:s + k] *= np.float32(rng.choice([0.0, 0.05, 1.12, 1.5]))
+    neg = rng.integers(0, n, 40)
+    x[neg] = -np.abs(x[neg]) * np.float32(rng.choice([1.0, 1e-3, 50.0]))
+    if seed % 2:
+        x[rng.integers(0, 2000, 5)] = np.float32(-0.25)   # ... in the fill phase too: the window then holds negative values
+    x[4096 * 7 - 1] = np.float32(-1.0)                    # ... and on a seam of time chunks
+    params = dict(hi_val=1.09)
+    r = check_vs_oracle(x, params)
+    assert r['stats'].n_chunks > 8
+    check_vs_oracle(x, params, chunk_samples=256)
+    check_vs_oracle(x, params, pushes=[0, 1500, 2000, 2001, 50_000, 123_457, n])
 
 
 def test_golden_iq_input():
@@ -188,7 +225,8 @@ def test_batches_submitted_ahead(monkeypatch, hook, depth):
     n = len(iq) // 2
     o = oracle_run(iq, dict(hi_val=1.1), api.NFC_IN_IQ_F32)
     cuts = [0, 300_000, 700_000, 1_000_003, 1_400_000, 1_800_001, 2_100_000, 2_400_000, 2_700_000, n]
-    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+    # (the hook only exists in the test build of the library, -DNFC_TEST_HOOKS)
+    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32, lib_path=_lib.hooks_path() if hook else None) as ctx:
         tr, s0, s1, pk, ahead = _run_submitted(ctx, iq, cuts, depth)
         extra = api.DeviceBuffer(iq[:600_000])   # (kept alive: a batch that does not run ahead reads it inside nfc_wait)
         with pytest.raises(api.NfcError):   # nothing else touches the stream while batches are in flight
@@ -327,6 +365,32 @@ def test_state_set_from_the_host_is_not_run_ahead_of():
             flags.append(int(ctx.stats().ran_ahead))
     assert first_diff(tr, o.transitions()) is None and pk == o.packets()
     assert flags == [0, 0, 0, 1], flags
+
+
+def test_stats_after_wait_belong_to_that_batch():
+    # nfc_stats.ring_slots_carried is documented as "of the last batch": for a batch submitted ahead it must come from that batch's
+    # own snapshot -- by the time nfc_wait returns, the device's summary has been rewritten by the batch submitted behind it
+    iq = synth.workload('miller', 900_000)
+    n = len(iq) // 2
+    iq = iq.copy()
+    iq[2 * 300_000:2 * 600_000] *= np.float32(1e-3)   # the second batch: a loss of signal throughout -- no sample accepted, every slot carried
+    cuts = [0, 300_000, 600_000, n]
+    want = []
+    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ctx.push(iq[2 * a:2 * b])
+            want.append(int(ctx.stats().ring_slots_carried))
+    assert want[0] == 0 and want[1] == 2000 and want[2] == 0, want
+    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        bufs = [api.DeviceBuffer(iq[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        ctx.push_device(bufs[0], cuts[1])          # (the window fills here: batches can be submitted ahead from the next one on)
+        got = [int(ctx.stats().ring_slots_carried)]
+        ctx.submit_device(bufs[1], cuts[2] - cuts[1])
+        ctx.submit_device(bufs[2], cuts[3] - cuts[2])
+        for _ in range(2):
+            ctx.wait()
+            got.append(int(ctx.stats().ring_slots_carried))
+    assert got == want, (got, want)
 
 
 def test_batches_submitted_ahead_int16_and_misuse():
@@ -564,8 +628,13 @@ def test_rejected_launch_is_reported(monkeypatch):
         ctx.push(iq)
         n_good = len(ctx.edges())
     # (the switch is read once, when a context is created: an environment variable set later changes nothing)
+    # ... and only by the test build of the library (-DNFC_TEST_HOOKS); the product library does not know the switch
     monkeypatch.setenv('NFC_DEBUG_BAD_LAUNCH', '1')
     with api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        ctx.push(iq)
+        assert len(ctx.edges()) == n_good
+    from usrp_nfc_amd import _lib
+    with api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32, lib_path=_lib.hooks_path()) as ctx:
         monkeypatch.delenv('NFC_DEBUG_BAD_LAUNCH')
         with pytest.raises(api.NfcError) as e:
             ctx.push(iq)

@@ -354,6 +354,40 @@ def test_bench_spawns_two_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_of_configs4_on_one_gpu():
+    # BASELINE.json configs[4] in miniature: `bench.py --gpus 8 --workload classic1k` (the -t all decode of the MIFARE Classic 1K
+    # capture at 10 Msps, av_window 10000), eight ranks sharing this box's one GPU, boundary states over TCP; EVERY rank's shard
+    # against the oracle's cut of the one stream over the whole capture
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NFC_BENCH_BACKEND='host')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--workload', 'classic1k', '--samples', '2e7', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline', '--no-extras'], capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 8 and line['config']['exchange'] == 'host'
+    assert 'configs[3]/[4]' in line['config']['workload'] and line['config']['samples_per_gpu'] == 20_000_000
+    sh = line['parity']['sharded']
+    assert sh['ranks_equal'] == [True] * 8 and sh['all_equal'] and min(sh['n_edges']) > 1000
+    assert line['parity']['edges_equal'] and line['parity']['packets_equal']
+
+
+def test_bench_checks_a_tiled_capture_at_full_size():
+    # configs[4] at its real size must not lose its all-rank parity to the regeneration cap: a tiled capture (every rank's chunk is
+    # the same tile again and again) is checked whatever its length; a generated one beyond the cap says it was skipped
+    import bench
+    assert bench.SHARDED_PARITY_CAP < 8 * bench.default_samples('classic1k')
+    skipped = bench.sharded_parity('miller', 10 ** 9, 8, bench.decoder_flags('miller'), [None] * 8)
+    assert 'skipped' in skipped
+    import inspect
+    src = inspect.getsource(bench.sharded_parity)
+    assert 'not tiled' in src and "workload == 'classic1k' and n > TILE" in src
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('sabotage', [-1, 1])
 def test_two_processes_rccl(sabotage):
     # BASELINE.json configs[4]'s exchange for real: two PROCESSES, one GPU each, the boundary states all-gathered by RCCL between

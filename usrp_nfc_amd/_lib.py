@@ -69,19 +69,24 @@ SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', '
            'nfc_fsm_create', 'nfc_fsm_destroy', 'nfc_fsm_reset', 'nfc_fsm_process', 'nfc_fsm_process_packets', 'nfc_fsm_set_keys',
            'nfc_command_count', 'nfc_command_get', 'nfc_crc_a', 'nfc_tx_encode', 'nfc_tx_sample_count', 'nfc_tx_render_device']
 
-_lib = None
+_libs = {}
 
 
 def lib_path():
     return _build.SO
 
 
-def load():
-    """Load (building if needed) the shared library and declare its prototypes."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = os.environ.get('NFC_AMD_LIB') or _build.build()   # NFC_AMD_LIB: a variant build (kernel experiments)
+def hooks_path():
+    """The test build (-DNFC_TEST_HOOKS), built on demand: the NFC_DEBUG_* / NFC_TRACE switches only exist there."""
+    return _build.build(hooks=True)
+
+
+def load(path=None):
+    """Load (building if needed) the shared library and declare its prototypes.  path: another build of the same ABI (the
+    test build, a kernel experiment); default: NFC_AMD_LIB, else the in-tree product library."""
+    path = path or os.environ.get('NFC_AMD_LIB') or _build.build()
+    if path in _libs:
+        return _libs[path]
     L = C.CDLL(path)
     vp, sz, psz = C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)
     L.nfc_abi_version.restype = C.c_int
@@ -147,5 +152,5 @@ def load():
                                        C.POINTER(C.c_float)]
     for name in SYMBOLS:
         getattr(L, name)
-    _lib = L
+    _libs[path] = L
     return L

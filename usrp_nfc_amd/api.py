@@ -29,8 +29,9 @@ class NfcContext(object):
     background.background (background.py:17) of the reference."""
 
     def __init__(self, samp_rate=2e6, lo_val=0.1, hi_val=1.1, av_window=2000, max_len=50, reader=True, tag=True,
-                 input_kind=NFC_IN_IQ_F32, device=0, i16_scale=0.0, flags=0, chunk_samples=0):
-        self.L = _lib.load()
+                 input_kind=NFC_IN_IQ_F32, device=0, i16_scale=0.0, flags=0, chunk_samples=0, lib_path=None):
+        """lib_path: another build of libnfc_amd.so for this context (tests: the build with the test hooks, _lib.hooks_path())."""
+        self.L = _lib.load(lib_path)
         self.h = C.c_void_p()
         self.input_kind = input_kind
         self.factor = 1e6 / samp_rate

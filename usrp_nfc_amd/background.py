@@ -69,13 +69,21 @@ class background(object):
             return
         import numpy as np
         from . import api
+        factor = 1e6 / self._foreign_args['samp_rate']
+        # A sink running at another rate or max_len than this object was constructed with would be decoded with the wrong
+        # durations and time-outs: its durations are whole samples of ITS rate and at most ITS max_len, so check both.
+        us = np.asarray([u for (_, u), _ in transitions], np.float64)
+        d = np.rint(us / factor)
+        if np.any(np.abs(us / factor - d) > 1e-6 * np.maximum(1.0, d)) or np.any(d < 0) or np.any(d > self._foreign_args['max_len']):
+            raise ValueError('transition durations are not whole samples within max_len=%d at samp_rate=%g: construct background(..., '
+                             'samp_rate=, max_len=) with the values of the transition_sink that produced them'
+                             % (self._foreign_args['max_len'], self._foreign_args['samp_rate']))
         if self._foreign is None:
             a = self._foreign_args
             self._foreign = api.NfcContext(samp_rate=a['samp_rate'], max_len=a['max_len'], reader=self.reader, tag=self.tag, device=a['device'])
-        factor = 1e6 / self._foreign_args['samp_rate']
         e = np.zeros(len(transitions), api.EDGE_DTYPE)
         e['v'] = [v for (v, _), _ in transitions]
-        e['d'] = [int(round(us / factor)) for (_, us), _ in transitions]
+        e['d'] = d.astype(np.int64)
         e['t'] = [t for _, t in transitions]
         e['idx'] = np.arange(self._n_foreign, self._n_foreign + len(transitions), dtype=np.uint64)   # (only labels the packets)
         self._n_foreign += len(transitions)
@@ -83,9 +91,21 @@ class background(object):
         self._deliver(self._foreign)
 
     def close(self):
-        if self._foreign is not None:
+        if getattr(self, '_foreign', None) is not None:
             self._foreign.close()
             self._foreign = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):   # (the device context of foreign lists must not outlive a caller who forgot close())
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # -- GPU delivery (called by transition_sink after each batch) ---------------------
     def _deliver(self, ctx):

@@ -6,6 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(HERE, 'libnfc_amd.so')
+SO_HOOKS = os.path.join(HERE, 'libnfc_amd_hooks.so')   # the same sources with -DNFC_TEST_HOOKS: test hooks and diagnostics (README.md)
 SOURCES = ['nfc_amd.hip']
 DEPS = ['nfc_amd.hip', 'host_context.h', 'host_threshold.h', 'host_stages.h', 'host_submit.h', 'launch_check.h', 'threshold.hip.h', 'threshold_lean.hip.h', 'threshold_wg.hip.h', 'edges.hip.h', 'decode.hip.h', 'scan.hip.h', 'small.hip.h', 'tx.hip.h', 'decoder_tables.h', 'protocol.h',
         os.path.join('..', '..', 'include', 'nfc_amd.h')]
@@ -15,22 +16,26 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
          '-Wall', '-Wno-unused-function']
 
 
-def stale():
-    if not os.path.exists(SO):
+def stale(so=SO):
+    if not os.path.exists(so):
         return True
-    t = os.path.getmtime(SO)
+    t = os.path.getmtime(so)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
-        return SO
+def build(force=False, verbose=False, hooks=False):
+    """The product library; hooks=True: the test build (NFC_DEBUG_* / NFC_TRACE switches compiled in), which only tests and
+    the profiling helpers under tools/ load (NFC_AMD_LIB or NfcContext(lib_path=...))."""
+    so = SO_HOOKS if hooks else SO
+    if not force and not stale(so):
+        return so
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + os.environ.get('NFC_HIPCC_EXTRA', '').split() + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', SO]
+    extra = ['-DNFC_TEST_HOOKS'] if hooks else []
+    cmd = [hipcc] + FLAGS + extra + os.environ.get('NFC_HIPCC_EXTRA', '').split() + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', so]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
-    return SO
+    return so
 
 
 def device_isa(out_path):
@@ -44,3 +49,5 @@ def device_isa(out_path):
 
 if __name__ == '__main__':
     build(force='-f' in sys.argv, verbose=True)
+    if '--hooks' in sys.argv:
+        build(force='-f' in sys.argv, verbose=True, hooks=True)

@@ -91,6 +91,7 @@ struct nfc_ctx {
     double factor;
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
+    uint32_t ring_carried = 0;   // nfc_stats.ring_slots_carried of the last batch adopted
     int lean = 1, lean_k = 0, lean_rounds = 0, lean_slots = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
     int wg = 1, wg_ok = 0, wg_nr = 4, wg_d = 1, wg_slots = 0, wg_slots_ahead = 0, wg_now = 0, wg_rounds = 0;
     int fine_left = 0, fine_adapt = 1, fine_mult = 4;   // batches still to be cut into fine_mult times as many chunks (after a batch that needed re-runs); NFC_CHUNK_ADAPT=0 turns it off   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
@@ -164,6 +165,7 @@ struct nfc_ctx {
     uint32_t slot_next = 0;
     bool low_valid = false;        // Carry.low_nl / low_kl on the device describe the end of the last completed batch
     size_t lean_lds_per_cu = 0;
+    size_t ahead_lds_per_cu = 0;   // LDS the threshold kernel of a batch submitted ahead holds per CU (the kernel that actually runs)
     uint32_t stamp_b = 0;          // the batch number the decode stage's last launch writes into the mirror (seq[1])
     bool in_wait = false;
     uint32_t dbg_fast_waits = 0;
@@ -373,6 +375,7 @@ void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, bool le
     if (lean) {
         switch (c->P.input_kind) {
         case NFC_IN_IQ_F32: launch_lean<IN_IQ_F32>(c, A, nwork, e0, e1); break;
+        case NFC_IN_ENV_F32: launch_lean<IN_ENV_F32>(c, A, nwork, e0, e1); break;
         case NFC_IN_REAL_F32_SQ: launch_lean<IN_REAL_F32_SQ>(c, A, nwork, e0, e1); break;
         default: launch_lean<IN_I16_SQ>(c, A, nwork, e0, e1); break;
         }

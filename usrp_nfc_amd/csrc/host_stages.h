@@ -242,6 +242,13 @@ void update_estimates(nfc_ctx *c, uint32_t n) {
         if (c->n_edges) c->sym_rate[t] = std::max((double)c->n_sym[t] / (double)c->n_edges, c->sym_rate[t] * 0.9);
 }
 
+// nfc_stats.ring_slots_carried of the batch just adopted: the host is synchronised with the stream and the mirror is this batch's
+void note_carried(nfc_ctx *c) {
+    CertSummary cs;
+    memcpy(&cs, c->hs->totals + TOT_CERT, sizeof cs);
+    c->ring_carried = cs.n_carried;
+}
+
 int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     if (c->sub_count && !c->in_wait) return fail(c, NFC_ERR_STATE, "batches submitted with nfc_submit_device are in flight: nfc_wait for them first");
     c->low_valid = false;
@@ -291,6 +298,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         HIPCHK(c, hipStreamSynchronize(c->st));
         BATCHCHK(c, fills);
         c->h_carry = c->hs->carry;
+        note_carried(c);
         c->nseen += n;
         c->have_outputs = true;
         return NFC_OK;
@@ -386,6 +394,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
         c->stats.ms_edges = elapsed_ms(c->ev[2], c->ev[3]);
         c->stats.ms_decode = elapsed_ms(c->ev[3], c->ev[4]);
     }
+    note_carried(c);
     for (int i = 0; i < c->n_kev; i++) c->stats.ms_threshold_kernel[i] = elapsed_ms(c->kev[2 * i], c->kev[2 * i + 1]);
     c->stats.n_threshold_timed = (uint32_t)c->n_kev;
     c->nseen += n;

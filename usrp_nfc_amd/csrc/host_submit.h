@@ -21,7 +21,7 @@ namespace {
 // batch submitted ahead against 2.7 ms one after the other) -- such batches take the synchronous path inside nfc_wait.
 bool submit_fast_ok(const nfc_ctx *c, uint32_t n) {
     return c->h_carry.stable && !(c->P.flags & (NFC_FLAG_NO_EDGES | NFC_FLAG_FORCE_SEQUENTIAL)) && c->L >= STEP && c->timing < 2 &&
-           !(c->use_small && n <= SM_MAX_SAMPLES) && n > 0 && c->lean_lds_per_cu <= 96 * 1024 && !c->dbg_any && !c->dbg_clk && !c->dbg_no_submit_ahead;
+           !(c->use_small && n <= SM_MAX_SAMPLES) && n > 0 && c->ahead_lds_per_cu <= 96 * 1024 && !c->dbg_any && !c->dbg_clk && !c->dbg_no_submit_ahead;
 }
 
 // the threshold stage of a submitted batch, on st_a, into a free set of planes; b.fast is cleared when the batch turns out
@@ -261,6 +261,7 @@ int wait_batch(nfc_ctx *c) {
             c->stats.ms_threshold_kernel[0] = elapsed_ms(c->kev_sub[b.slot][0], c->kev_sub[b.slot][1]);
             c->stats.n_threshold_timed = 1;
         }
+        c->ring_carried = summary.n_carried;   // (from this batch's own snapshot: the device's summary belongs to the next batch by now)
         c->ring_cur = (b.ring_in + 1) % NRING;
         c->nseen = b.g0 + b.n;
         c->last_in = b.d_in;

@@ -49,7 +49,7 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     // 1024 chunks -- takes 2.3 ms per pass, k_threshold with the ring in global memory at five waves per SIMD 4.7 ms (the delay
     // line adds a read and a write per sample; a lone wave is bound by its own instruction stream, which the lean kernel
     // shortened).  So the global ring is only taken on request (NFC_RING=global) or where the lean kernel does not apply.
-    const bool lean_applies = c->lean && c->P.input_kind != NFC_IN_ENV_F32 && c->mx <= 500;
+    const bool lean_applies = c->lean && c->mx <= 500;   // (every input kind: a raw envelope that turns out negative makes its chunk give up)
     c->gring = c->gring_ok && (c->gring_force || (!lean_applies && (uint64_t)n >= (uint64_t)c->wave_slots_g * 8u * (uint64_t)c->L));
     // ... with a chunk per WORKGROUP where that kernel applies (threshold_wg.hip.h: max_len within one step, a ring that holds a round)
     c->wg_now = lean_applies && c->wg && c->wg_ok && !c->gring;
@@ -60,6 +60,9 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
         // 4 x as many chunks take 2.14 -> 1.34 ms (level steps) and 7.3 -> 4.0 ms (hovering), 8 x is worse again (the rounds' fixed
         // costs); a clean stream pays 0.353 -> 0.406 ms for it, so the cut goes back after eight batches without a re-run.
         if (c->fine_left > 0 && c->wg_now) slots *= (uint64_t)c->fine_mult;
+        // (every chunk owns three windows of summaries -- ring_in, ring_out[2] -- in device memory: however fine the cut, they stay
+        // within 1 GiB, 4 x 1024 chunks of a 10 000-sample window take 0.5 GB)
+        slots = std::min<uint64_t>(slots, std::max<uint64_t>(256, ((uint64_t)1 << 30) / ((uint64_t)12 * (uint64_t)c->L)));
         // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps;
         // the workgroup kernel whole rounds of four)
         const int stp = c->wg_now ? wg_round_samples(c->wg_nr) : 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
@@ -205,8 +208,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
         A.nlist = 0;
         A.mode = 0;
         // the lean kernel wherever it applies (LDS ring, more than one chunk: chunk 0's verdict travels with the certification)
-        const bool lean = lean_applies && !c->gring && nch > 1;   // (raw envelopes may be negative: no sign bit to spare;
-                                                                    // max_len beyond 500 samples: not exercised, left to k_threshold)
+        const bool lean = lean_applies && !c->gring && nch > 1;   // (max_len beyond 500 samples: not exercised, left to k_threshold)
         A.cert = d_cert;
         A.sum = (CertSummary *)(dT(c) + TOT_CERT);
         A.ksteps = c->wg_now ? c->wg_rounds : c->lean_rounds;

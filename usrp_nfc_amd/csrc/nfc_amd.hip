@@ -63,6 +63,7 @@ const void *wg_kernel_of(int kind, int nr, int d) {
 #define WGK(K) (nr == 8 ? (const void *)k_threshold_wg<K, 8> : nr == 6 ? (const void *)k_threshold_wg<K, 6> : (const void *)k_threshold_wg<K, 4>)
     switch (kind) {
     case NFC_IN_IQ_F32: return WGK(IN_IQ_F32);
+    case NFC_IN_ENV_F32: return WGK(IN_ENV_F32);
     case NFC_IN_REAL_F32_SQ: return WGK(IN_REAL_F32_SQ);
     default: return WGK(IN_I16_SQ);
     }
@@ -107,16 +108,21 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     C = std::max(C, c->mx + 2);
     c->rows_per_step = 4;
     c->use_small = getenv("NFC_NO_SMALL") ? 0 : 1;
-    // every debugging switch is read here, once: nothing on the per-launch path looks at the environment
+    // Every switch is read here, once: nothing on the per-launch path looks at the environment.  README.md lists them all.
+    // The switches that make a context misbehave on purpose or talk (test hooks and diagnostics) only exist in the TEST build
+    // (-DNFC_TEST_HOOKS: usrp_nfc_amd/libnfc_amd_hooks.so, build.py) -- an environment inherited by a production process cannot
+    // reach them; what is left below are tuning switches, which select between paths that are all exact.
+#ifdef NFC_TEST_HOOKS
     c->dbg_bad_launch = getenv("NFC_DEBUG_BAD_LAUNCH") != nullptr;
     c->dbg_redo_submitted = getenv("NFC_DEBUG_REDO_SUBMITTED") != nullptr;
-    c->dbg_no_submit_ahead = getenv("NFC_NO_SUBMIT_AHEAD") != nullptr;
     c->dbg_any = getenv("NFC_DEBUG") != nullptr;
     c->dbg_trace = getenv("NFC_TRACE") != nullptr;
     if (const char *e = getenv("NFC_DEBUG_CLK")) {
         c->dbg_clk = true;
         c->dbg_clk_path = e;
     }
+#endif
+    c->dbg_no_submit_ahead = getenv("NFC_NO_SUBMIT_AHEAD") != nullptr;
     if (const char *e = getenv("NFC_WG")) c->wg = atoi(e) != 0;
     if (const char *e = getenv("NFC_WG_ROUNDS")) c->wg_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("NFC_WG_D")) c->wg_d = atoi(e) >= 2 ? 2 : 1;
@@ -207,6 +213,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         // LDS the lean kernel's resident waves hold per CU: a batch is only run ahead of its predecessor's edge / decode stages
         // (nfc_submit_device) while those stages' workgroups (25 KB each) still fit beside it
         c->lean_lds_per_cu = (size_t)((c->lean_slots + prop.multiProcessorCount - 1) / prop.multiProcessorCount) * lds_wave;
+        c->ahead_lds_per_cu = c->lean_lds_per_cu;
         // the workgroup kernel: one chunk per 256-thread workgroup, as many resident per CU as LDS and registers admit
         c->wg_lds = (size_t)c->Lpad * 4 + WG_SHARED_BYTES;
         // rows per step: the largest of 8 / 6 / 4 that leaves a superstep of at least two rounds within 0.8 windows (measured at
@@ -219,13 +226,14 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             const int v = atoi(e);
             if ((v == 4 || v == 6 || v == 8) && c->L >= wg_round_samples(v)) c->wg_nr = v;
         }
-        c->wg_ok = p->input_kind != NFC_IN_ENV_F32 && c->mx <= 64 * c->wg_nr - 2 && c->L >= wg_round_samples(c->wg_nr) && c->wg_lds <= 160 * 1024;
+        c->wg_ok = c->mx <= 64 * c->wg_nr - 2 && c->L >= wg_round_samples(c->wg_nr) && c->wg_lds <= 160 * 1024;
         if (c->wg_ok) {
             const void *kern = wg_kernel_of(p->input_kind, c->wg_nr, c->wg_d);
             if (c->wg_lds > 64 * 1024) CRT(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->wg_lds));
             int per_cu_wg = 0;
             CRT(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wg, kern, 256, c->wg_lds));
             const int per_cu_max = per_cu_wg;
+            if (per_cu_wg < 1) c->wg_ok = 0;   // (the kernel does not fit a CU with this ring: the one-wave kernels)
             per_cu_wg = std::max(1, std::min(4, per_cu_wg));   // (measured: four resident workgroups per CU -- four waves per SIMD -- beat five and three)
             if (const char *e = getenv("NFC_WG_PER_CU")) per_cu_wg = std::max(1, std::min(per_cu_max, atoi(e)));
             c->wg_slots = prop.multiProcessorCount * per_cu_wg;
@@ -236,6 +244,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             int per_cu_ahead = std::min(per_cu_wg, 3);
             if (const char *e = getenv("NFC_WG_PER_CU_AHEAD")) per_cu_ahead = std::max(1, std::min(per_cu_max, atoi(e)));
             c->wg_slots_ahead = prop.multiProcessorCount * per_cu_ahead;
+            // (what a batch submitted ahead holds of a CU's LDS is this kernel's, not the lean kernel's: host_submit.h, submit_fast_ok)
+            if (c->wg_ok && c->wg && c->lean) c->ahead_lds_per_cu = c->wg_lds * (size_t)per_cu_ahead;
             // the longest superstep (rounds): the kernel lengthens and shortens its supersteps by the head-room it sees between the
             // samples and the thresholds; this caps them
             if (!c->wg_rounds) c->wg_rounds = 8;
@@ -271,6 +281,10 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -831,12 +845,10 @@ int nfc_get_stats(nfc_ctx *c, nfc_stats *out) {
     if (!c || !out) return NFC_ERR_ARG;
     *out = c->stats;
     out->redone_total = c->stats_redo_submitted;
-    {
-        CertSummary cs;
-        memcpy(&cs, c->hs->totals + TOT_CERT, sizeof cs);   // (the mirror of the last batch's state block)
-        out->ring_slots_carried = cs.n_carried;
-        out->reserved0 = 0;
-    }
+    // (noted when the batch was adopted -- process_batch / wait_batch -- from the mirror that belongs to THAT batch: by now the
+    // device's summary may have been rewritten by a batch submitted behind it)
+    out->ring_slots_carried = c->ring_carried;
+    out->reserved0 = 0;
     return NFC_OK;
 }
 

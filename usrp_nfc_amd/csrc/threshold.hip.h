@@ -350,14 +350,9 @@ __device__ __forceinline__ void resolve_low_state(const ThrArgs &A, int c, int &
 }
 
 // exact incoming ring value of slot s for chunk c: latest predecessor that accepted a sample into it
-__device__ __forceinline__ bool slot_untouched_by_all(const ThrArgs &A, int c, int s) {   // no chunk < c accepted a sample into slot s
-    for (int cc = c - 1; cc >= 0; cc--) {
-        const uint32_t w = A.touched[A.ver[cc]][(size_t)cc * A.twords + (s >> 5)];
-        if ((w >> (s & 31)) & 1u) return false;
-    }
-    return true;
-}
-__device__ __forceinline__ float resolve_slot(const ThrArgs &A, int c, int s) {
+// (*from_carry, when asked for: no chunk before c accepted a sample into the slot -- the value is the incoming ring's)
+__device__ __forceinline__ float resolve_slot(const ThrArgs &A, int c, int s, bool *from_carry = nullptr) {
+    if (from_carry) *from_carry = false;
     if (c >= 1) {   // common case: the predecessor accepted a sample into the slot; both loads issue at once
         const int vb = A.ver[c - 1];
         const uint32_t w = A.touched[vb][(size_t)(c - 1) * A.twords + (s >> 5)];
@@ -369,6 +364,7 @@ __device__ __forceinline__ float resolve_slot(const ThrArgs &A, int c, int s) {
         const uint32_t w = A.touched[vb][(size_t)cc * A.twords + (s >> 5)];
         if ((w >> (s & 31)) & 1u) return A.ring_out[vb][(size_t)cc * A.L + s];
     }
+    if (from_carry) *from_carry = true;
     return A.ring_carry[s];
 }
 
@@ -1091,8 +1087,9 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
             const int s = s0 + k * FIN_BLOCK;
             if (s < A.L) {
                 if (!((w[k] >> (s & 31)) & 1u)) {   // look further back
-                    v[k] = resolve_slot(A, last, s);
-                    if (slot_untouched_by_all(A, last, s)) carried++;
+                    bool from_carry;   // (one look-back answers both questions)
+                    v[k] = resolve_slot(A, last, s, &from_carry);
+                    if (from_carry) carried++;
                 }
                 ring_next[s] = v[k];
                 part += (double)v[k];

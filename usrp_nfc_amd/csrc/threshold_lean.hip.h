@@ -112,6 +112,8 @@ __device__ __forceinline__ void lean_take(float (&x)[4], float i16_scale) {
             if constexpr (KIND == IN_I16_SQ) {
                 const float sv = i16_to_float(__float_as_int(w[j]), i16_scale);   // (global_load_sshort sign-extends into the register)
                 x[j] = sv * sv;
+            } else if constexpr (KIND == IN_ENV_F32) {
+                x[j] = w[j];          // the envelope itself (what transition_sink.work receives, transition_sink.py:13-18)
             } else {
                 x[j] = w[j] * w[j];   // IN_REAL_F32_SQ
             }
@@ -131,7 +133,6 @@ __device__ __forceinline__ uint32_t lean_dpp_shl8(uint32_t v) {   // lane l <- l
 // the LOW-only form is then two DPP instructions per row; otherwise it works on the row's mask (A.blk).
 template <int KIND, int PF, bool BLK16>
 __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
-    static_assert(KIND != IN_ENV_F32, "raw envelopes may be negative: no sign bit to spare (they take k_threshold)");
     static_assert(PF >= 2 && PF <= 4, "planes of a superstep leave in one store of 16 lanes per step");
     constexpr int NR = 4;
     constexpr uint32_t STEPN = 64u * NR;
@@ -175,6 +176,10 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
 
     if (A.dbg_clk) clk1 = clock64();
     bool good_run = A.fast_ok != 0;   // false: the wave gave up
+    // (raw envelopes, IN_ENV_F32: a negative sample, an infinity or a NaN -- raw bits 0x7F800000 and up -- in the state the chunk
+    // starts from or among its samples makes the wave give up: the sign bit of a ring value and the raw-bit ordering are taken;
+    // threshold_wg.hip.h says the same)
+    if constexpr (KIND == IN_ENV_F32) good_run = good_run && !__ballot(vtop0 >= 0x7F800000u);
     uint32_t why = good_run ? 0u : 1u;   // (debugging aid: 1 parameters / sums out of range, 2 a sample inside a band, 3 LOW run, 4 allowance, 5 first stable sample)
     float min_ss = 3.0e38f;
     int chunk_nl = LL_NONE, chunk_kl = KEY_NONE;
@@ -475,6 +480,9 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
         const unsigned long long lowany = __ballot(!(xmin > tlo_up)), highany = __ballot(!(xmax < thi_dn));
         const bool lowp = lowany != 0ull, highp = highany != 0ull;
         bool ok = true;
+        if constexpr (KIND == IN_ENV_F32) {
+            if (__ballot(__float_as_uint(xmax) >= 0x7F800000u)) { why = 1u; return 1; }
+        }
         // which form: 0 nothing classifies, 1 only LOW, 2 only HIGH with no LOW sample in reach, 3 the general step
         if (__builtin_expect((lowany && highany) || force_general || (highany && steps_since_low < ssl_min), 0)) {
             force_general = false;

@@ -150,6 +150,8 @@ __device__ __forceinline__ void wg_take(float (&x)[NR], float i16_scale) {
             if constexpr (KIND == IN_I16_SQ) {
                 const float sv = i16_to_float(__float_as_int(w[j]), i16_scale);   // (global_load_sshort sign-extends into the register)
                 x[j] = sv * sv;
+            } else if constexpr (KIND == IN_ENV_F32) {
+                x[j] = w[j];          // the envelope itself (what transition_sink.work receives, transition_sink.py:13-18)
             } else {
                 x[j] = w[j] * w[j];   // IN_REAL_F32_SQ
             }
@@ -211,7 +213,6 @@ __device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (
 template <int KIND, int NR, int D = 1>
 __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     static_assert(D == 1 || (D == 2 && NR == 4 && KIND == IN_IQ_F32), "two rounds ahead: IQ input, four rows per step");
-    static_assert(KIND != IN_ENV_F32, "raw envelopes may be negative: no sign bit to spare (they take k_threshold)");
     constexpr uint32_t STEPN = 64u * NR;
     constexpr int WG_ROUND = wg_round_samples(NR);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -409,6 +410,11 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
 
     if (A.dbg_clk) clk1 = clock64();
     bool good_run = A.fast_ok != 0;
+    // Raw envelopes (IN_ENV_F32) come from the caller as they are: a mag^2 envelope is never negative, but nothing says so.  This
+    // kernel keeps "no sample of this chunk accepted into the slot" in a ring value's SIGN bit and orders samples by their raw
+    // bits, so a negative sample, an infinity or a NaN -- raw bits 0x7F800000 and up -- makes the chunk give up (k_threshold takes
+    // it, as it took every chunk of this kind before): in the state it starts from (here), in a round's samples (below).
+    if constexpr (KIND == IN_ENV_F32) good_run = good_run && vtop0 < 0x7F800000u;
     uint32_t why = good_run ? 0u : 1u;   // 1 parameters / sums out of range, 2 a sample inside a band, 3 LOW run, 4 allowance, 5 first stable sample
     float min_ss = 3.0e38f;
     uint32_t vmin = 0xFFFFFFFFu, vmax = vtop0;
@@ -715,6 +721,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 for (int j = 1; j < NR; j++) {
                     xlo = min(xlo, __float_as_uint(x[j]));
                     xhi = max(xhi, __float_as_uint(x[j]));
+                }
+                if constexpr (KIND == IN_ENV_F32) {   // (raw envelopes: see good_run above)
+                    if (__ballot(xhi >= 0x7F800000u) && !fail) fail = 1u;
                 }
                 const float xmin = __uint_as_float(xlo), xmax = __uint_as_float(xhi);
                 lowany = __ballot(xmin < tlo);

@@ -21,7 +21,7 @@ from . import api
 from .background import background
 from .transition_sink import transition_sink
 
-try:  # pragma: no cover
+try:  # (GNU Radio is not in the build image: tests/test_gr_branch.py runs this branch against stand-ins)
     from gnuradio import blocks as _blocks
     from gnuradio import gr as _gr
 except Exception:
@@ -51,7 +51,7 @@ def _load_source(src, wav_scale):
     return numpy.fromfile(src, dtype=numpy.float32), api.NFC_IN_REAL_F32_SQ, 0.0
 
 
-if _gr is not None:  # pragma: no cover  (GNU Radio is not in the build image)
+if _gr is not None:
 
     class decoder(_gr.hier_block2):
         def __init__(self, src="uhd", dst=None, repeat=False, reader=True, tag=True, samp_rate=2e6, emulator=None):
