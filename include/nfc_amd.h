@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 /* 2: nfc_stats grew (ran_ahead, redone_total, ring_slots_carried); i16_scale == 0 means sample / 32767 (GNU Radio's wavfile_source), not / 32768 */
-#define NFC_AMD_ABI_VERSION 2
+/* 3: nfc_stats.reserved0 became decode_respeculated (same layout); the raw float32 envelope takes the fast threshold kernels */
+#define NFC_AMD_ABI_VERSION 3
 
 typedef enum {
     NFC_OK = 0,
@@ -119,7 +120,9 @@ typedef struct {
     uint32_t ring_slots_carried; /* window slots whose value at the end of the last batch is still the one the batch started from
                                   * (no sample landing on them was accepted): 0 after a warm-up (nfc_prime + overlap) means the
                                   * window no longer depends on the level it was primed with */
-    uint32_t reserved0;
+    uint32_t decode_respeculated; /* batches of this context whose decode stage was repeated in the three-launch form because a tile of the
+                                   * speculative form (a run-in of the predecessor tile's last edges instead of a scan over all tiles)
+                                   * had assumed a decoder state that the check found wrong: a frame longer than the run-in */
 } nfc_stats;
 
 /* Everything a successor time chunk needs from its predecessor:

@@ -367,6 +367,41 @@ def test_state_set_from_the_host_is_not_run_ahead_of():
     assert flags == [0, 0, 0, 1], flags
 
 
+@pytest.mark.parametrize('runin', ['512', '2048'])
+def test_frames_longer_than_the_run_in_take_the_fall_back(monkeypatch, runin):
+    # The speculative decode (decode.hip.h: k_dec_spec) derives a tile's incoming decoder states from a run-in of the edges before
+    # it: right wherever a frame gap lies within the run-in.  Frames of 250 bytes (4 500 edges, ISO 14443-4 allows 256-byte frames)
+    # back to back leave tile seams with no gap in reach: the check (dec_verify) must say so, the stage must be repeated in the
+    # three-launch form, and the result must be the reference's -- for that batch, the following ones (which take the three-launch
+    # form straight away), and again once the stream is back to short frames.
+    monkeypatch.setenv('NFC_NO_SMALL', '1')
+    monkeypatch.setenv('NFC_DEC_RUNIN', runin)
+    rng = np.random.default_rng(41)
+    long_frames = [(synth.READER, synth.frame_bits(rng.integers(0, 256, 250).tolist(), 0)) for _ in range(6)]
+    m_long = synth.modulation_profile(long_frames, rate_msps=2.0, gap_us=60.0, lead_in=3000, tail=400)
+    short = synth.workload('miller', 600_000)
+    iq_long = synth.iq_from_profile(m_long)
+    iq = np.concatenate([iq_long, short[2 * 3000:]])   # one stream: the long frames, then ordinary traffic
+    n_long = len(iq_long) // 2
+    n = len(iq) // 2
+    o = oracle_run(iq, dict(hi_val=1.1), api.NFC_IN_IQ_F32)
+    cuts = [0, n_long] + list(range(n_long + 50_000, n, 50_000)) + [n]
+    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        tr, s0, s1, pk, resp = [], [], [], [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ctx.push(iq[2 * a:2 * b])
+            tr += ctx.transitions()
+            s0 += ctx.symbols(0).tolist()
+            s1 += ctx.symbols(1).tolist()
+            pk += ctx.packets()
+            resp.append(int(ctx.stats().decode_respeculated))
+    assert resp[0] == 1, resp            # the fall-back was taken for the batch with the long frames ...
+    assert resp[-1] == 1, resp           # ... and only there: the batches behind it took the three-launch form, then speculated again
+    assert first_diff(tr, o.transitions()) is None
+    assert s0 == o.symbols(0).tolist() and s1 == o.symbols(1).tolist()
+    assert pk == o.packets() and sum(len(b) > 2000 for _, b in pk) == 6
+
+
 def test_stats_after_wait_belong_to_that_batch():
     # nfc_stats.ring_slots_carried is documented as "of the last batch": for a batch submitted ahead it must come from that batch's
     # own snapshot -- by the time nfc_wait returns, the device's summary has been rewritten by the batch submitted behind it
@@ -448,13 +483,15 @@ def test_compact_transitions_are_the_records():
                 assert (p7 == pos[5:12]).all() and (c7 == code[5:12]).all()
 
 
+@pytest.mark.parametrize('dec_spec', ['1', '0'])
 @pytest.mark.parametrize('max_len', [1, 7, 31, 32, 50, 62, 63, 64, 200])
-def test_edge_stage_dense_and_long_runs(monkeypatch, max_len):
+def test_edge_stage_dense_and_long_runs(monkeypatch, max_len, dec_spec):
     # The multi-launch edge stage (edges.hip.h) on a short batch: samples that flicker between LOW, accepted and HIGH from one
     # sample to the next (more entries per tile than the writer stages in one round), runs of every length around max_len
     # and its multiples (time-outs inside a word, across words, across tiles and across pushes), for max_len on both
     # sides of the 32 / 63 boundaries where the in-word time-out count changes form.
     monkeypatch.setenv('NFC_NO_SMALL', '1')
+    monkeypatch.setenv('NFC_DEC_SPEC', dec_spec)   # both forms of the decode stage behind it: speculative (k_dec_spec) / three launches
     rng = np.random.default_rng(7000 + max_len)
     n = 150_000
     x = (0.25 * (1 + 0.002 * rng.standard_normal(n))).astype(np.float32)
@@ -540,8 +577,9 @@ def test_random_parameters_many_chunks(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dec_spec', ['1', '0'])
 @pytest.mark.parametrize('tagname,rate', [('1', 1e6), ('0p5', 2e6), ('0p25', 4e6), ('0p1', 10e6), ('frames_0p5', 2e6), ('frames_0p25', 4e6)])
-def test_decode_kernels_on_decoder_vectors(tagname, rate):
+def test_decode_kernels_on_decoder_vectors(monkeypatch, tagname, rate, dec_spec):
     # the reference's decoder-only vectors (6 000 random (cur, d) pairs per rate with every error branch, and whole frames)
     # straight into k_dec_reduce / k_dec_apply / k_frame_write through nfc_push_edges -- interleaved runs of both routes, in
     # several calls (decoder and framing state carried on the device); symbols against the reference's, packets against its
@@ -549,6 +587,7 @@ def test_decode_kernels_on_decoder_vectors(tagname, rate):
     from oracle import py_oracle as po
     from usrp_nfc_amd import api
     from tests.golden_util import load_npz
+    monkeypatch.setenv('NFC_DEC_SPEC', dec_spec)   # k_dec_spec (every tile's states from a run-in, checked) / k_dec_reduce + k_dec_apply
     z = load_npz('fx_decoder_vectors.npz')
     dm = z['dm_' + tagname] if 'dm_' + tagname in z else z['d_' + tagname]
     dt = z['dt_' + tagname] if 'dt_' + tagname in z else z['d_' + tagname]

@@ -138,7 +138,7 @@ class _Fsm(object):
 def test_gr_branch_pumps_the_ultralight_transaction(gr_modules):
     m = gr_modules
     c = Case('fx_ultralight_txn')
-    d = m.decoder.decoder(src='x.wav', reader=True, tag=True, samp_rate=c.params['samp_rate'])
+    d = m.decoder.decoder(src='x.wav', repeat=True, reader=True, tag=True, samp_rate=c.params['samp_rate'])
     _check_wiring(m, d, 'wav', 1.09)
     # the fixture was generated with its own hi_val: a second sink with it, behind the same background, takes the stream
     f = _Fsm()

@@ -350,6 +350,203 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
     TP_DONE(2);   // 4: block scan
 }
 
+// ---- passes 1 + 2 in ONE launch: every tile derives its incoming decoder states by itself (round 4) ----------------------------
+// Both decoders re-synchronise at a frame gap: an edge whose duration is out of range resets them (miller.py:165-176,
+// manchester.py:40-43), so the composed map of a stretch of edges that spans a gap is CONSTANT -- whatever state the stretch is
+// entered in, it leaves in the same one.  A tile therefore composes a RUN-IN of `runin` edges right before its own (its
+// predecessor's last ones) and takes the run-in's map at the carried state of the batch: where that map is constant, the tile's
+// incoming state is known without any scan over the tiles before it, and k_dec_reduce, the tile-prefix fold over its maps and the
+// re-load of codes and maps between two launches all go away.  Where it is not (a frame longer than the run-in across the tile's
+// first edge; a decoder that has seen no edge for longer than that) the assumption may be wrong, so nothing is taken on trust:
+// the tile leaves its own composed map, the state it assumed, and -- per decoder -- whether any of its outputs depends on that
+// assumption (a thread whose map from the run-in's start to its first edge is constant does not); dec_verify (one extra workgroup
+// of k_frame_write) scans the tiles' maps, compares every assumption that matters with the true state, publishes the decoder
+// states after the batch from the true scan, and leaves a verdict in the state block.  The host repeats the decode stage with
+// the three-launch form (k_dec_reduce / k_dec_apply: exact whatever the edges look like) when a tile was wrong.
+struct DecSpec {
+    DecMaps map;      // composed map of the tile's own edges
+    uint32_t s_in;    // the incoming state the tile assumed (miller | manchester << 4)
+    uint32_t needs;   // bit 0 / 1: Miller / Manchester outputs of the tile depend on that assumption
+};
+static_assert(sizeof(DecSpec) == 32, "two 16-byte loads");
+__device__ __forceinline__ bool mil_map_constant(const DecMaps &m) {
+    return m.mil[0] == m.mil[1] && m.mil[1] == m.mil[2] && m.mil[2] == m.mil[3] && m.mil[0] == (m.mil[0] & 0xFFu) * 0x01010101u;
+}
+__device__ __forceinline__ bool man_map_constant(const DecMaps &m) {
+    return m.man[0] == m.man[1] && m.man[0] == (m.man[0] & 0xFFu) * 0x01010101u;
+}
+constexpr int DEC_RUNIN_MAX = 8;   // run-in edges per thread at most (runin = 2, 4 or 8 x SCAN_BLOCK: 512, 1024 or 2048 edges)
+template <bool LDS>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, size_t n, const uint32_t *n_dev, DecTables T, uint32_t state0, int runin_per_thread,
+                                                        uint8_t *outw, FrameAgg *frame_aggs, FramePk *thread_aggs, DecSpec *spec) {
+    if (n_dev) n = min(n, (size_t)*n_dev);
+    if ((size_t)blockIdx.x * DEC_TILE >= n) return;
+    TP_DECL();
+    __shared__ uint4 s_milmap[LDS ? DEC_LDS_ROWS : 1];
+    __shared__ uint2 s_manmap[LDS ? DEC_LDS_ROWS : 1];
+    __shared__ __attribute__((aligned(16))) uint16_t s_mil[LDS ? DEC_LDS_ROWS * 16 : 8];
+    __shared__ __attribute__((aligned(16))) uint16_t s_man[LDS ? DEC_LDS_ROWS * 8 : 8];
+    __shared__ DecMaps lds[SCAN_WAVES];
+    __shared__ FramePk lds2[SCAN_WAVES];
+    __shared__ uint32_t s_needs;
+    if (LDS) {
+        const int rows = 4 * T.nd;
+        for (int i = threadIdx.x; i < rows; i += SCAN_BLOCK) {
+            if (T.reader) s_milmap[i] = T.mil_map[i];
+            if (T.tag) s_manmap[i] = T.man_map[i];
+        }
+        if (T.reader)
+            for (int i = threadIdx.x; i < rows * 2; i += SCAN_BLOCK) ((uint4 *)s_mil)[i] = ((const uint4 *)T.mil_step)[i];
+        if (T.tag)
+            for (int i = threadIdx.x; i < rows; i += SCAN_BLOCK) ((uint4 *)s_man)[i] = ((const uint4 *)T.man_step)[i];
+    }
+    if (threadIdx.x == 0) s_needs = 0u;
+    const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const size_t base = tid * DEC_PER_THREAD;
+    uint32_t c[DEC_GROUPS][8];
+#pragma unroll
+    for (int g = 0; g < DEC_GROUPS; g++) load_codes(ecode, base + DEC_ITEMS * g, n, c[g]);
+    // the run-in: this thread's share of the `runin` edges before the tile (tile 0 has none: its incoming state is the carried one)
+    uint32_t rc[DEC_RUNIN_MAX / 2];
+    const bool have_runin = blockIdx.x > 0;
+    {
+        const size_t r0 = (size_t)blockIdx.x * DEC_TILE - (size_t)runin_per_thread * SCAN_BLOCK + (size_t)threadIdx.x * runin_per_thread;
+#pragma unroll
+        for (int k = 0; k < DEC_RUNIN_MAX / 2; k++) rc[k] = (have_runin && 2 * k < runin_per_thread) ? *(const uint32_t *)(ecode + r0 + 2 * k) : 0u;   // (code 0 is dropped)
+    }
+    __syncthreads();   // the tables are staged
+    TP_MARK();   // 1: tables, codes
+    auto compose = [&](DecMaps &agg, uint32_t code, uint32_t &seen) __attribute__((always_inline)) {
+        const uint32_t li = code & 0x3FFFu, route = code >> 14;
+        if (route == 2u && T.reader) {
+            const uint4 v = LDS ? s_milmap[li] : T.mil_map[li];
+#pragma unroll
+            for (int q = 0; q < 4; q++) agg.mil[q] = lookup16x4(v.x, v.y, v.z, v.w, agg.mil[q]);
+            seen |= 1u;
+        } else if (route == 1u && T.tag) {
+            const uint2 v = LDS ? s_manmap[li] : T.man_map[li];
+            agg.man[0] = __builtin_amdgcn_perm(v.y, v.x, agg.man[0]);
+            agg.man[1] = __builtin_amdgcn_perm(v.y, v.x, agg.man[1]);
+            seen |= 2u;
+        }
+    };
+    DecMaps runin = ComposeDec::identity();
+    if (have_runin) {   // (uniform)
+        uint32_t seen_r = 0u;
+        DecMaps ra = ComposeDec::identity();
+#pragma unroll
+        for (int k = 0; k < DEC_RUNIN_MAX; k++)
+            if (k < runin_per_thread) compose(ra, (rc[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, seen_r);
+        (void)block_exclusive<ComposeDec>(ra, lds, runin);
+    }
+    DecMaps agg = ComposeDec::identity();
+    uint32_t seen = 0u;
+#pragma unroll
+    for (int g = 0; g < DEC_GROUPS; g++) {
+#pragma unroll
+        for (int k = 0; k < DEC_ITEMS; k++) compose(agg, (c[g][k >> 1] >> (16 * (k & 1))) & 0xFFFFu, seen);
+    }
+    TP_MARK();   // 2: the compositions
+    DecMaps total;
+    const DecMaps excl = block_exclusive<ComposeDec>(agg, lds, total);
+    // the map from the run-in's first edge to this thread's first: constant for a decoder = its state here is known whatever came before
+    const DecMaps upto = ComposeDec::op(runin, excl);
+    uint32_t st = ComposeDec::step(upto, state0);
+    const uint32_t dep = ((seen & 1u) && !mil_map_constant(upto) ? 1u : 0u) | ((seen & 2u) && !man_map_constant(upto) ? 2u : 0u);
+    if (blockIdx.x > 0 && dep) atomicOr(&s_needs, dep);   // (rare; tile 0 starts from the carried state itself)
+    TP_MARK();   // 3: block scans, incoming states
+    const uint16_t *mil = LDS ? s_mil : T.mil_step;
+    const uint16_t *man = LDS ? s_man : T.man_step;
+    FramePk mine = FramePkOp::identity();
+#pragma unroll
+    for (int g = 0; g < DEC_GROUPS; g++) {
+        uint32_t ow[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < DEC_ITEMS; k++) {
+            const uint32_t code = (c[g][k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            const uint32_t li = code & 0x3FFFu, route = code >> 14;
+            uint32_t w = 0;
+            if (route == 2u && T.reader) {
+                const uint32_t e = mil[li * 16u + (st & 15u)];
+                w = e >> 8;
+                st = (st & ~15u) | (e & 15u);
+            } else if (route == 1u && T.tag) {
+                const uint32_t e = man[li * 8u + ((st >> 4) & 7u)];
+                const uint32_t m = e >> 8;
+                w = (m & 3u) ? ((m & 0xFCu) | 3u) : 0u;
+                st = (st & 15u) | ((e & 15u) << 4);
+            }
+            ow[k >> 2] |= w << (8 * (k & 3));
+        }
+        const size_t gb = base + (size_t)DEC_ITEMS * g;
+        if (gb < n) *(uint4 *)(outw + gb) = make_uint4(ow[0], ow[1], ow[2], ow[3]);   // outw has 16 bytes of slack
+        mine = FramePkOp::op(mine, FramePkOp::pack(frame_agg_of(ow)));
+    }
+    TP_MARK();   // 4: the walk
+    FramePk total_fa;
+    *(uint4 *)(thread_aggs + tid) = make_uint4(mine.a[0], mine.a[1], mine.b[0], mine.b[1]);   // (k_frame_write scans them again)
+    (void)block_exclusive<FramePkOp>(mine, lds2, total_fa);   // (its barriers: every thread's atomicOr has landed)
+    if (threadIdx.x == 0) {
+        frame_aggs[blockIdx.x] = FramePkOp::unpack(total_fa);
+        DecSpec sp;
+        sp.map = total;
+        sp.s_in = ComposeDec::step(runin, state0);
+        sp.needs = s_needs;
+        spec[blockIdx.x] = sp;
+    }
+    TP_DONE(1);   // 5: block scan
+}
+
+// The check of k_dec_spec's assumptions: ONE workgroup scans the tiles' maps from the carried state, compares the state every tile
+// assumed with the true one wherever the tile said its outputs depend on it, and publishes the decoder states after the batch.
+struct DecVerify {
+    const DecSpec *spec;   // NULL: the three-launch form ran (nothing to check)
+    uint32_t state0;
+    DecCarry *carry;
+    uint32_t *verdict;     // 0: every assumption that mattered was right
+};
+constexpr int DV_ITEMS = 4;
+__device__ __forceinline__ void dec_verify(const DecVerify &V, size_t ntiles, DecMaps *lds) {
+    DecMaps before = ComposeDec::identity();   // the map of all tiles before this round's
+    int bad = 0;
+    for (size_t b0 = 0; b0 < ntiles; b0 += (size_t)SCAN_BLOCK * DV_ITEMS) {
+        const size_t i0 = b0 + (size_t)threadIdx.x * DV_ITEMS;
+        DecSpec sp[DV_ITEMS];
+#pragma unroll
+        for (int k = 0; k < DV_ITEMS; k++) {
+            if (i0 + k < ntiles) {
+                const uint4 a = ((const uint4 *)(V.spec + i0 + k))[0], b = ((const uint4 *)(V.spec + i0 + k))[1];
+                sp[k].map = DecMaps{{a.x, a.y, a.z, a.w}, {b.x, b.y}};
+                sp[k].s_in = b.z;
+                sp[k].needs = b.w;
+            } else {
+                sp[k].map = ComposeDec::identity();
+                sp[k].s_in = 0u;
+                sp[k].needs = 0u;
+            }
+        }
+        DecMaps agg = sp[0].map;
+#pragma unroll
+        for (int k = 1; k < DV_ITEMS; k++) agg = ComposeDec::op(agg, sp[k].map);
+        DecMaps total;
+        DecMaps run = ComposeDec::op(before, block_exclusive<ComposeDec>(agg, lds, total));
+#pragma unroll
+        for (int k = 0; k < DV_ITEMS; k++) {
+            const uint32_t diff = ComposeDec::step(run, V.state0) ^ sp[k].s_in;
+            if (((sp[k].needs & 1u) && (diff & 15u)) || ((sp[k].needs & 2u) && (diff >> 4))) bad = 1;
+            run = ComposeDec::op(run, sp[k].map);
+        }
+        before = ComposeDec::op(before, total);
+    }
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) {
+        const uint32_t st = ComposeDec::step(before, V.state0);
+        V.carry->mil_state = (int32_t)(st & 15u);
+        V.carry->man_state = (int32_t)(st >> 4);
+        *V.verdict = bad ? 1u : 0u;
+    }
+}
+
 // ---- pass 3: symbols, packet bits and packet ends to their places ------------------------------------------------
 struct FrameOut {
     uint8_t *sym[2];        // [0] Manchester / tag, [1] Miller / reader
@@ -442,9 +639,11 @@ struct DecCarryEpilogue {
     PktCnt *pk_total;
     uint32_t pend[2], started_in[2];
     __device__ __forceinline__ void operator()(const FrameAgg &ft) const {
-        const uint32_t st = ComposeDec::step(*total, state_in);
-        carry->mil_state = (int32_t)(st & 15u);
-        carry->man_state = (int32_t)(st >> 4);
+        if (total) {   // (NULL: the speculative decode ran -- dec_verify publishes the decoder states from its own scan)
+            const uint32_t st = ComposeDec::step(*total, state_in);
+            carry->mil_state = (int32_t)(st & 15u);
+            carry->man_state = (int32_t)(st >> 4);
+        }
         nsym[1] = ft.cnt[1];   // Miller / reader
         nsym[0] = ft.cnt[0];   // Manchester / tag
 #pragma unroll
@@ -453,22 +652,31 @@ struct DecCarryEpilogue {
     }
 };
 
+// (V.spec set: the grid has ONE workgroup more, in front -- the check of the speculative decode, dec_verify, beside the tiles)
 __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw, size_t n, const uint32_t *n_dev, const FrameAgg *tile_pre,
                                                            const FramePk *thread_aggs, FrameOut P, bool own_prefix, FrameAgg *total_out,
-                                                           DecCarryEpilogue epi) {
-    if (blockIdx.x == 0) copy_pending(P, threadIdx.x, SCAN_BLOCK);
+                                                           DecCarryEpilogue epi, DecVerify V) {
     if (n_dev) n = min(n, (size_t)*n_dev);
-    if (own_prefix && n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (V.spec) {
+        if (blockIdx.x == 0) {
+            __shared__ DecMaps lds_v[SCAN_WAVES];
+            dec_verify(V, (n + DEC_TILE - 1) / DEC_TILE, lds_v);
+            return;
+        }
+    }
+    const uint32_t bid = blockIdx.x - (V.spec ? 1u : 0u);   // the tile
+    if (bid == 0) copy_pending(P, threadIdx.x, SCAN_BLOCK);
+    if (own_prefix && n == 0 && bid == 0 && threadIdx.x == 0) {
         *total_out = FrameAggOp::identity();
         epi(FrameAggOp::identity());
     }
-    if ((size_t)blockIdx.x * DEC_TILE >= n) return;
+    if ((size_t)bid * DEC_TILE >= n) return;
     TP_DECL();
     __shared__ FramePk lds[SCAN_WAVES];
     __shared__ FrameAgg lds_pre[SCAN_WAVES];
     // own_prefix: tile_pre still holds the tiles' aggregates (scan.hip.h: tile_prefix; first, while few registers are live)
-    const FrameAgg pre = own_prefix ? tile_prefix<FrameAggOp, SCAN_BLOCK>(tile_pre, blockIdx.x, lds_pre) : tile_pre[blockIdx.x];
-    const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_PER_THREAD;
+    const FrameAgg pre = own_prefix ? tile_prefix<FrameAggOp, SCAN_BLOCK>(tile_pre, bid, lds_pre) : tile_pre[bid];
+    const size_t base = ((size_t)bid * SCAN_BLOCK + threadIdx.x) * DEC_PER_THREAD;
     TP_MARK();   // 1: tile prefix
     uint32_t ow[DEC_GROUPS][4];
 #pragma unroll
@@ -480,12 +688,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
             ow[g][0] = a.x; ow[g][1] = a.y; ow[g][2] = a.z; ow[g][3] = a.w;
         }
     }
-    const uint4 m4 = *(const uint4 *)(thread_aggs + (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x);
+    const uint4 m4 = *(const uint4 *)(thread_aggs + (size_t)bid * SCAN_BLOCK + threadIdx.x);
     FramePk total;
     const FramePk in_tile = block_exclusive<FramePkOp>(FramePk{{m4.x, m4.y}, {m4.z, m4.w}}, lds, total);
     // (staging the tile's symbols and bits in LDS to store whole words measured slower: 32 vs 26 us)
     // (own_prefix: the last tile publishes the total and the carries)
-    if (own_prefix && threadIdx.x == 0 && ((size_t)blockIdx.x + 1) * DEC_TILE >= n) {
+    if (own_prefix && threadIdx.x == 0 && ((size_t)bid + 1) * DEC_TILE >= n) {
         const FrameAgg all = FrameAggOp::op(pre, FramePkOp::unpack(total));
         *total_out = all;
         epi(all);

@@ -62,6 +62,7 @@ enum : int {
     TOT_RUNS = 0,       // u32
     TOT_EDGES = 8,      // u32
     TOT_DECMAP = 16,    // DecMaps (24 bytes)
+    TOT_SPEC = 40,      // u32: verdict of the speculative decode's check (decode.hip.h: dec_verify), 0 = every assumption that mattered held
     TOT_PKT0 = 72,      // PktCnt: per type, bits | closes << 32
     TOT_PKT1 = 80,
     TOT_LAST2 = 88,     // Last2 (8 bytes)
@@ -92,6 +93,11 @@ struct nfc_ctx {
     double hi_plus, lo_a, lo_b, hi_a, hi_b;
     int bands_ok, fast_ok, nfold, rows_per_step, C_min, wave_slots, lds_per_slot;
     uint32_t ring_carried = 0;   // nfc_stats.ring_slots_carried of the last batch adopted
+    // the decode stage's speculative form (decode.hip.h: k_dec_spec): on unless NFC_DEC_SPEC=0; run-in edges per thread (2 / 4 / 8);
+    // after a batch whose check failed the next batches take the three-launch form (spec_off_left counts them down)
+    bool dec_spec = true, dec_spec_now = false;
+    int dec_runin = 2, spec_off_left = 0;
+    uint32_t decode_respeculated = 0;   // batches whose decode stage was repeated with the three-launch form (nfc_stats)
     int lean = 1, lean_k = 0, lean_rounds = 0, lean_slots = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
     int wg = 1, wg_ok = 0, wg_nr = 4, wg_d = 1, wg_slots = 0, wg_slots_ahead = 0, wg_now = 0, wg_rounds = 0;
     int fine_left = 0, fine_adapt = 1, fine_mult = 4;   // batches still to be cut into fine_mult times as many chunks (after a batch that needed re-runs); NFC_CHUNK_ADAPT=0 turns it off   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
@@ -159,7 +165,7 @@ struct nfc_ctx {
         uint32_t n = 0, seq = 0, nch = 0, chunk = 0;
         uint64_t g0 = 0;
         int slot = 0, planes = -1, ring_in = 0, timing = 0;   // (timing: nfc_set_timing's level when the batch was submitted)
-        bool fast = false, b_enqueued = false, timed = false;
+        bool fast = false, b_enqueued = false, timed = false, spec = false;   // (spec: its decode stage ran in the speculative form)
     } sub[NSUB];
     int sub_count = 0;             // batches submitted and not yet waited for (sub[0] the oldest)
     uint32_t slot_next = 0;
@@ -184,6 +190,7 @@ struct nfc_ctx {
     DevBuf d_states, d_sym[2], d_bits[2], d_pending[2][2], d_close_end[2],
         d_close_idx[2];
     DevBuf d_partials, d_partials2, d_aggs, d_faggs;  // scan scratch
+    DevBuf d_spec;                           // per decode tile: its map, the state it assumed (decode.hip.h: DecSpec)
     DevBuf d_pack;                           // nfc_get_state staging
     DevBuf d_gvtop;                          // per chunk: bound of the ring values (guard of the fp64 sums)
     DevBuf d_seqout;                         // sequential kernel: edge-timing state after its last sample

@@ -93,7 +93,7 @@ int frame_out(nfc_ctx *c, FrameOut &P, const bool (&enabled)[2]) {
     return NFC_OK;
 }
 
-int run_decode(nfc_ctx *c) {
+int run_decode(nfc_ctx *c, bool force_classic = false) {
     uint8_t *tot = dT(c);
     const uint32_t ce = c->cap_edges;                      // capacity; the count is on the device
     const uint32_t *ne_dev = (const uint32_t *)(tot + TOT_EDGES);
@@ -119,28 +119,46 @@ int run_decode(nfc_ctx *c) {
     FrameAgg *fparts = c->d_partials2.as<FrameAgg>();
     FrameAgg *frame_total = (FrameAgg *)(tot + TOT_FRAME);
     PktCnt *pk_total = (PktCnt *)(tot + TOT_PKT0);
-    if (tiles) {
-        if (lds_tables)
-            NFC_LAUNCH(k_dec_reduce<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
-        else
-            NFC_LAUNCH(k_dec_reduce<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
-    }
     const bool own = tiles <= c->own_prefix_max;   // (scan.hip.h: tile_prefix -- no prefix launches while the tiles are few)
     DecMaps *map_total = (DecMaps *)(tot + TOT_DECMAP);
-    const DecCarryEpilogue epi{map_total, dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM), pk_total,
+    // the speculative form (k_dec_spec: reduce + apply in one launch, every tile's incoming states from a run-in of its
+    // predecessor's last edges) unless it is switched off, or the stream's last batches needed the three-launch form
+    const bool spec = c->dec_spec && c->spec_off_left == 0 && !force_classic;
+    c->dec_spec_now = spec;
+    const DecCarryEpilogue epi{spec ? (DecMaps *)nullptr : map_total, dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM), pk_total,
                                {P.pend[0], P.pend[1]}, {P.started_in[0], P.started_in[1]}};
-    if (!own) scan_partials<ComposeDec>(c->st, tiles, ne_dev, DEC_TILE, dparts, ComposeDec::identity_host(), map_total);
-    if (tiles) {
-        if (lds_tables)
-            NFC_LAUNCH(k_dec_apply<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
-                               dec_state_in, outw, fparts, c->d_faggs.as<FramePk>(), own, map_total);
-        else
-            NFC_LAUNCH(k_dec_apply<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
-                               dec_state_in, outw, fparts, c->d_faggs.as<FramePk>(), own, map_total);
+    DecVerify V{nullptr, dec_state_in, dD(c), (uint32_t *)(tot + TOT_SPEC)};
+    if (spec) {
+        HIPCHK(c, c->d_spec.ensure((tiles + 1) * sizeof(DecSpec)));
+        V.spec = c->d_spec.as<DecSpec>();
+        if (tiles) {
+            if (lds_tables)
+                NFC_LAUNCH(k_dec_spec<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dec_state_in, c->dec_runin, outw,
+                           fparts, c->d_faggs.as<FramePk>(), c->d_spec.as<DecSpec>());
+            else
+                NFC_LAUNCH(k_dec_spec<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dec_state_in, c->dec_runin, outw,
+                           fparts, c->d_faggs.as<FramePk>(), c->d_spec.as<DecSpec>());
+        }
+    } else {
+        if (tiles) {
+            if (lds_tables)
+                NFC_LAUNCH(k_dec_reduce<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
+            else
+                NFC_LAUNCH(k_dec_reduce<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
+        }
+        if (!own) scan_partials<ComposeDec>(c->st, tiles, ne_dev, DEC_TILE, dparts, ComposeDec::identity_host(), map_total);
+        if (tiles) {
+            if (lds_tables)
+                NFC_LAUNCH(k_dec_apply<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
+                                   dec_state_in, outw, fparts, c->d_faggs.as<FramePk>(), own, map_total);
+            else
+                NFC_LAUNCH(k_dec_apply<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs,
+                                   dec_state_in, outw, fparts, c->d_faggs.as<FramePk>(), own, map_total);
+        }
     }
     if (!own) scan_partials<FrameAggOp>(c->st, tiles, ne_dev, DEC_TILE, fparts, FrameAggOp::identity(), frame_total, epi);
-    NFC_LAUNCH(k_frame_write, dim3((unsigned)std::max<size_t>(tiles, 1)), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts,
-                       c->d_faggs.as<FramePk>(), P, own, frame_total, epi);
+    NFC_LAUNCH(k_frame_write, dim3((unsigned)(std::max<size_t>(tiles, 1) + (spec ? 1 : 0))), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts,
+                       c->d_faggs.as<FramePk>(), P, own, frame_total, epi, V);
     const int pn = 1 - c->pend_cur;
     PktFinish F;
     memset(&F, 0, sizeof F);
@@ -165,6 +183,23 @@ int run_decode(nfc_ctx *c) {
     F.stamp = c->stamp_b;
     NFC_LAUNCH(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
     return NFC_OK;
+}
+
+// The speculative decode's verdict (host synchronised, mirror of this batch): true = a tile's assumed state was wrong where it mattered
+bool spec_failed(const nfc_ctx *c) {
+    if (!c->dec_spec_now) return false;
+    uint32_t v;
+    memcpy(&v, c->hs->totals + TOT_SPEC, 4);
+    return v != 0;
+}
+// ... then the stage is repeated in the three-launch form, and the next batches of the stream take that form straight away
+// (frames longer than the run-in come in bursts: a long read, a firmware download); speculation is tried again after eight
+void note_respeculation(nfc_ctx *c) {
+    c->decode_respeculated++;
+    c->spec_off_left = 8;
+}
+void spec_batch_done(nfc_ctx *c) {
+    if (!c->dec_spec_now && c->spec_off_left > 0) c->spec_off_left--;
 }
 
 // ---------------------------------------------------------------------------
@@ -218,6 +253,7 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     A.mirror_words = (uint32_t)(sizeof(DevState) / 4);
     A.stamp_word = (uint32_t)(offsetof(DevState, seq) / 4 + 1);
     A.stamp = c->stamp_b;
+    c->dec_spec_now = false;
     NFC_LAUNCH(k_small_stage, dim3(1), dim3(SM_BLOCK), 0, c->st, A);
     return NFC_OK;
 }
@@ -336,9 +372,10 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     int rc = run_threshold(c, d_in, n, skip, want_edges ? &ahead : nullptr, &clean);
     if (rc) return rc;
     if (want_edges) {
+        bool decode_only = false;   // the edges stand, the decode stage is repeated in the form that assumes nothing
         for (int attempt = 0;; attempt++) {
             if (attempt > 0 || !clean) {
-                rc = edges_and_decode();
+                rc = decode_only ? run_decode(c, true) : edges_and_decode();
                 if (rc) return rc;
                 HIPCHK(c, hipStreamSynchronize(c->st));
             }
@@ -347,12 +384,19 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
             memcpy(&ne, c->hs->totals + TOT_EDGES, 4);
             memcpy(ns, c->hs->totals + TOT_NSYM, 8);
             const bool fit = ne <= c->cap_edges && ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1];
+            if (fit && spec_failed(c)) {   // (decode.hip.h: dec_verify -- a decode tile's assumed incoming state was wrong)
+                if (attempt >= 3) return fail(c, NFC_ERR_INTERNAL, "edge / symbol capacity did not settle");
+                note_respeculation(c);
+                decode_only = true;
+                continue;
+            }
             if (fit) {
                 c->n_edges = ne;
                 c->n_sym[0] = ns[0];
                 c->n_sym[1] = ns[1];
                 break;
             }
+            decode_only = false;
             // a buffer was too small: the stages read carried values by value and wrote only write-only slots, so
             // they can simply run again with room for what was counted
             if (attempt >= 3) return fail(c, NFC_ERR_INTERNAL, "edge / symbol capacity did not settle");
@@ -361,6 +405,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
             c->cap_sym_floor[1] = (uint64_t)ns[1] * 5 / 4 + 65536;
         }
         update_estimates(c, n);
+        spec_batch_done(c);
         c->pend_cur = 1 - c->pend_cur;
     } else {
         if (c->timing >= 2) {

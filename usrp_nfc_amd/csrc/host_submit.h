@@ -105,6 +105,7 @@ int enqueue_stages_behind(nfc_ctx *c, nfc_ctx::Submitted &b) {
     int rc = run_edges(c, b.n, 0u, b.g0);
     if (!rc) rc = run_decode(c);   // (its last launch mirrors the state block and stamps it)
     if (rc) return rc;
+    b.spec = c->dec_spec_now;
     HIPCHK(c, hipEventRecord(c->ev_b[b.slot], c->st));
     b.b_enqueued = true;
     return NFC_OK;
@@ -240,6 +241,14 @@ int wait_batch(nfc_ctx *c) {
     if (summary.n_fail != 0) regular = false, why = "a chunk was not certified";
     else if (summary.flagged || !sums_exact(after, (int)summary.emin, (int)summary.emax, summary.vtop)) regular = false, why = "sums not provably exact";
     else if (!(ne <= c->cap_edges && ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1])) regular = false, why = "a capacity estimate was too small";
+    else if (b.spec) {   // (decode.hip.h: dec_verify's verdict on the speculative decode of THIS batch, in the mirror its last launch wrote)
+        uint32_t v;
+        memcpy(&v, c->hs->totals + TOT_SPEC, 4);
+        if (v) {
+            regular = false, why = "a decode tile's assumed state was wrong";
+            note_respeculation(c);   // (the synchronous path below takes the three-launch form straight away)
+        }
+    }
     if (c->dbg_redo_submitted && (c->dbg_fast_waits++ % 3u) == 2u) regular = false, why = "test hook";   // every third batch that ran ahead
     if (regular) {
         c->h_carry = after;
@@ -249,6 +258,8 @@ int wait_batch(nfc_ctx *c) {
         c->n_sym[0] = ns[0];
         c->n_sym[1] = ns[1];
         update_estimates(c, b.n);
+        c->dec_spec_now = b.spec;
+        spec_batch_done(c);
         c->pend_cur = 1 - c->pend_cur;
         uint64_t pk[2];
         memcpy(&pk[0], c->hs->totals + TOT_PKT0, 8);

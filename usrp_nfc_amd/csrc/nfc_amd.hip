@@ -135,6 +135,11 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     if (const char *e = getenv("NFC_LEAN_GFAC")) c->lean_gfac = (float)atof(e);
     if (const char *e = getenv("NFC_LEAN_GMIN")) c->lean_gmin = (float)atof(e);
     if (const char *e = getenv("NFC_OWN_PREFIX_MAX")) c->own_prefix_max = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char *e = getenv("NFC_DEC_SPEC")) c->dec_spec = atoi(e) != 0;
+    if (const char *e = getenv("NFC_DEC_RUNIN")) {   // run-in edges per decode tile: 512, 1024 or 2048
+        const int v = atoi(e);
+        c->dec_runin = v >= 2048 ? 8 : (v >= 1024 ? 4 : 2);
+    }
     {
         c->rows_per_step = 4;   // (8-row steps measured slower: 126 VGPRs, four waves per SIMD)
         const int stp = 64 * c->rows_per_step;
@@ -351,7 +356,7 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ecode, &c->d_epos, &c->d_eidx, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_gring, &c->d_pack, &c->d_gvtop, &c->d_seqout};
+                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_spec, &c->d_gring, &c->d_pack, &c->d_gvtop, &c->d_seqout};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -454,10 +459,18 @@ int nfc_push_edges(nfc_ctx *c, const nfc_edge *host_edges, size_t n64) {
         HIPCHK(c, hipMemcpyAsync(c->d_ecode.p, code.data(), (size_t)n * 2, hipMemcpyHostToDevice, c->st));
     }
     HIPCHK(c, hipMemcpyAsync(dT(c) + TOT_EDGES, &n, 4, hipMemcpyHostToDevice, c->st));
-    const int rc = run_decode(c);   // k_dec_reduce -> k_dec_apply -> k_frame_write -> k_pkt_finish (mirrors the state block)
+    const int rc = run_decode(c);   // k_dec_spec (or k_dec_reduce -> k_dec_apply) -> k_frame_write -> k_pkt_finish (mirrors the state block)
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->st));
     BATCHCHK(c, false);
+    if (spec_failed(c)) {   // a tile's assumed decoder state was wrong: the stage again, in the form that assumes nothing
+        note_respeculation(c);
+        const int rc2 = run_decode(c, true);
+        if (rc2) return rc2;
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        BATCHCHK(c, false);
+    }
+    spec_batch_done(c);
     uint32_t ns[2];
     memcpy(ns, c->hs->totals + TOT_NSYM, 8);
     c->n_edges = n;
@@ -845,10 +858,10 @@ int nfc_get_stats(nfc_ctx *c, nfc_stats *out) {
     if (!c || !out) return NFC_ERR_ARG;
     *out = c->stats;
     out->redone_total = c->stats_redo_submitted;
+    out->decode_respeculated = c->decode_respeculated;
     // (noted when the batch was adopted -- process_batch / wait_batch -- from the mirror that belongs to THAT batch: by now the
     // device's summary may have been rewritten by a batch submitted behind it)
     out->ring_slots_carried = c->ring_carried;
-    out->reserved0 = 0;
     return NFC_OK;
 }
 
