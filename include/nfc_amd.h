@@ -327,6 +327,14 @@ int nfc_host_free_pinned(void *p);
  * reference decoders' golden vectors.  type: 0 Manchester, 1 Miller. */
 int nfc_host_decode_lut(const nfc_params *params, int type, const int8_t *cur, const int32_t *d, size_t n,
                         uint8_t *sym_out, size_t cap, size_t *n_out);
+/* (type 2: Modified Miller through the decoder's QUOTIENT machine -- states that no sequence of transitions can tell apart are
+ * one class, csrc/decoder_tables.h: miller_quotient -- which is what the speculative decode kernel walks: its state maps are
+ * then 8 bytes.  Same symbols as type 1 by construction; the CPU suite checks it on the reference's decoder vectors.)
+ * nfc_host_miller_classes: the class (0 .. n_classes - 1; 0xFF: a state no transition sequence reaches from the initial one)
+ * and the canonical state of every one of the 16 Miller states (stage | has_started << 2 | prev << 3, miller.py:14-29).
+ * The carried Miller state -- nfc_state_header.miller_state, the exported boundary state -- is always the canonical one:
+ * `prev` reads 0 wherever the decoder cannot read it before writing it (miller.py:81 is its only read). */
+int nfc_host_miller_classes(const nfc_params *params, uint8_t class_of[16], uint8_t canonical[16], int *n_classes);
 
 /* The decoders themselves on the host, one transition at a time with any duration in microseconds (the walk the LUTs are
  * built from: csrc/decoder_tables.h), decoder state carried across calls in *state (0 before the first call; type 0

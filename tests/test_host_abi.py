@@ -59,6 +59,41 @@ def test_lut_frame_vectors(key, factor):
     assert got.tolist() == z['symt_' + key].tolist()
 
 
+@pytest.mark.parametrize('key,factor', [('1', 1.0), ('0p5', 0.5), ('0p25', 0.25), ('0p1', 0.1), ('frames_0p5', 0.5), ('frames_0p25', 0.25)])
+def test_miller_quotient_machine_on_the_reference_vectors(key, factor):
+    # The speculative decode kernel walks the Miller decoder's QUOTIENT machine (decoder_tables.h: miller_quotient -- states no
+    # transition sequence can tell apart are one class, so a state map is 8 bytes): driven sequentially on the host (type 2) it must
+    # emit exactly what the reference's decoder emitted on its own vectors, every error branch included.
+    z = load_npz('fx_decoder_vectors.npz')
+    rate = 1e6 / factor
+    d = z['dm_' + key] if 'dm_' + key in z else z['d_' + key]
+    got = api.host_decode_lut(2, z['curm_' + key], d, samp_rate=rate)
+    assert got.tolist() == z['symm_' + key].tolist()
+
+
+def test_miller_classes_are_what_the_reference_decoder_cannot_tell_apart():
+    import ctypes as C
+    from usrp_nfc_amd import _lib
+    L = _lib.load()
+    for rate, mx in ((2e6, 50), (1e7, 250), (1e6, 50), (4e6, 100)):
+        p = api._params(rate, 0.1, 1.1, 2000, mx, True, True, api.NFC_IN_IQ_F32, 0, 0.0, 0, 0)
+        q_of, canon, ncls = (C.c_uint8 * 16)(), (C.c_uint8 * 16)(), C.c_int(0)
+        assert L.nfc_host_miller_classes(C.byref(p), q_of, canon, C.byref(ncls)) == 0
+        q_of, canon = list(q_of), list(canon)
+        # state = stage | has_started << 2 | prev << 3 (miller.py:14-29).  Reachable: has_started False only in stage BEGINNING
+        # (reset() sets both, miller.py:65-67); `_prev` is read in ONE place, stage BEGINNING of a started frame (miller.py:81):
+        # everywhere else the two values of prev are one class
+        assert ncls.value == 6
+        reachable = [s for s in range(16) if (s & 4) or (s & 3) == 0]
+        assert all(q_of[s] != 0xFF for s in reachable) and all(q_of[s] == 0xFF for s in range(16) if s not in reachable)
+        for s in reachable:
+            stage, started, prev = s & 3, (s >> 2) & 1, s >> 3
+            if stage == 0 and started:
+                assert canon[s] == s and q_of[s] != q_of[s ^ 8]      # prev matters here, and only here
+            else:
+                assert canon[s] == (s & 7) and q_of[s] == q_of[s & 7]
+
+
 def test_no_gpu_means_loud_failure():
     L = _lib.load()
     if L.nfc_device_count() > 0:

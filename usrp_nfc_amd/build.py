@@ -47,7 +47,18 @@ def device_isa(out_path):
     return out_path
 
 
+def build_variant(out, extra):
+    """An experiment: the same sources with extra compiler flags into another file (loaded through NFC_AMD_LIB)."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    subprocess.check_call([hipcc] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out])
+    return out
+
+
 if __name__ == '__main__':
+    if '--variant' in sys.argv:   # python build.py --variant out.so -DNFC_X=1 ...
+        i = sys.argv.index('--variant')
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+        sys.exit(0)
     build(force='-f' in sys.argv, verbose=True)
     if '--hooks' in sys.argv:
         build(force='-f' in sys.argv, verbose=True, hooks=True)

@@ -20,12 +20,22 @@ namespace nfc {
 
 struct DecTables {
     const uint4 *mil_map;      // [(cur+1) * nd + d]  16 states, one byte each
-    const uint2 *man_map;      //                      8 states, one byte each
+    const uint2 *man_map;      //                      8 states, one byte each (+ one row more at 4 nd: the identity)
     const uint16_t *mil_step;  // [((cur+1) * nd + d) * 16 + state] = next state | out byte << 8
     const uint16_t *man_step;  // [((cur+1) * nd + d) * 8 + state]
     int32_t nd;                // max_len + 1
     int32_t reader, tag;
+    // The Miller decoder as its QUOTIENT machine (decoder_tables.h: miller_quotient): states that no sequence of edges can tell
+    // apart -- the 16 states fall into 9 classes, the ones reachable from the initial state into 6 -- are one class, so a state map
+    // is 8 bytes and composing two of them is two v_perm_b32 (a 16-byte map takes 28 instructions).  The speculative decode works
+    // on classes; the three-launch form keeps the 16 states.  Both publish the CANONICAL state of the class they end in.
+    const uint2 *qmil_map;     // [(cur+1) * nd + d] 8 classes, one byte each (unused class ids follow class 0; + the identity row at 4 nd)
+    const uint16_t *qmil_step; // [((cur+1) * nd + d) * 8 + class] = next class | out byte << 8
+    uint32_t q_rep[2];         // class -> its canonical state
+    uint32_t canon[4];         // state -> the canonical state of its class (itself where the quotient machine does not know it)
+    int32_t q_ok;              // the reachable classes fit 8
 };
+__device__ __forceinline__ uint32_t byte_of(const uint32_t *w, uint32_t i) { return (w[i >> 2] >> (8u * (i & 3u))) & 0xFFu; }
 
 struct DecCarry {
     int32_t mil_state, man_state;
@@ -363,18 +373,33 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
 // of k_frame_write) scans the tiles' maps, compares every assumption that matters with the true state, publishes the decoder
 // states after the batch from the true scan, and leaves a verdict in the state block.  The host repeats the decode stage with
 // the three-launch form (k_dec_reduce / k_dec_apply: exact whatever the edges look like) when a tile was wrong.
+// The Miller decoder runs as its quotient machine here (DecTables: classes, not states): maps of 8 bytes for both decoders.
+struct QMaps {
+    uint32_t mil[2];   // Miller: class -> class, one byte each
+    uint32_t man[2];   // Manchester: state -> state
+};
+struct ComposeQ {
+    using T = QMaps;
+    static __host__ __device__ __forceinline__ T identity() { return T{{0x03020100u, 0x07060504u}, {0x03020100u, 0x07060504u}}; }
+    static __device__ __forceinline__ T op(const T &a, const T &b) {   // a, then b
+        return T{{__builtin_amdgcn_perm(b.mil[1], b.mil[0], a.mil[0]), __builtin_amdgcn_perm(b.mil[1], b.mil[0], a.mil[1])},
+                 {__builtin_amdgcn_perm(b.man[1], b.man[0], a.man[0]), __builtin_amdgcn_perm(b.man[1], b.man[0], a.man[1])}};
+    }
+    // states packed as miller class | manchester state << 4
+    static __device__ __forceinline__ uint32_t step(const T &m, uint32_t st) {
+        const uint32_t a = __builtin_amdgcn_perm(m.mil[1], m.mil[0], st & 7u) & 15u;
+        const uint32_t b = __builtin_amdgcn_perm(m.man[1], m.man[0], (st >> 4) & 7u) & 15u;
+        return a | (b << 4);
+    }
+};
 struct DecSpec {
-    DecMaps map;      // composed map of the tile's own edges
-    uint32_t s_in;    // the incoming state the tile assumed (miller | manchester << 4)
+    QMaps map;        // composed map of the tile's own edges
+    uint32_t s_in;    // the incoming state the tile assumed (miller class | manchester state << 4)
     uint32_t needs;   // bit 0 / 1: Miller / Manchester outputs of the tile depend on that assumption
+    uint32_t pad[2];
 };
 static_assert(sizeof(DecSpec) == 32, "two 16-byte loads");
-__device__ __forceinline__ bool mil_map_constant(const DecMaps &m) {
-    return m.mil[0] == m.mil[1] && m.mil[1] == m.mil[2] && m.mil[2] == m.mil[3] && m.mil[0] == (m.mil[0] & 0xFFu) * 0x01010101u;
-}
-__device__ __forceinline__ bool man_map_constant(const DecMaps &m) {
-    return m.man[0] == m.man[1] && m.man[0] == (m.man[0] & 0xFFu) * 0x01010101u;
-}
+__device__ __forceinline__ bool map8_constant(const uint32_t (&m)[2]) { return m[0] == m[1] && m[0] == (m[0] & 0xFFu) * 0x01010101u; }
 constexpr int DEC_RUNIN_MAX = 8;   // run-in edges per thread at most (runin = 2, 4 or 8 x SCAN_BLOCK: 512, 1024 or 2048 edges)
 template <bool LDS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, size_t n, const uint32_t *n_dev, DecTables T, uint32_t state0, int runin_per_thread,
@@ -382,23 +407,24 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
     TP_DECL();
-    __shared__ uint4 s_milmap[LDS ? DEC_LDS_ROWS : 1];
-    __shared__ uint2 s_manmap[LDS ? DEC_LDS_ROWS : 1];
-    __shared__ __attribute__((aligned(16))) uint16_t s_mil[LDS ? DEC_LDS_ROWS * 16 : 8];
+    __shared__ uint2 s_milmap[LDS ? DEC_LDS_ROWS + 1 : 1];
+    __shared__ uint2 s_manmap[LDS ? DEC_LDS_ROWS + 1 : 1];
+    __shared__ __attribute__((aligned(16))) uint16_t s_mil[LDS ? DEC_LDS_ROWS * 8 : 8];
     __shared__ __attribute__((aligned(16))) uint16_t s_man[LDS ? DEC_LDS_ROWS * 8 : 8];
-    __shared__ DecMaps lds[SCAN_WAVES];
+    __shared__ QMaps lds[SCAN_WAVES];
     __shared__ FramePk lds2[SCAN_WAVES];
     __shared__ uint32_t s_needs;
+    const uint32_t ident = 4u * (uint32_t)T.nd;   // the identity row of both map tables
     if (LDS) {
         const int rows = 4 * T.nd;
-        for (int i = threadIdx.x; i < rows; i += SCAN_BLOCK) {
-            if (T.reader) s_milmap[i] = T.mil_map[i];
+        for (int i = threadIdx.x; i <= rows; i += SCAN_BLOCK) {
+            if (T.reader) s_milmap[i] = T.qmil_map[i];
             if (T.tag) s_manmap[i] = T.man_map[i];
         }
-        if (T.reader)
-            for (int i = threadIdx.x; i < rows * 2; i += SCAN_BLOCK) ((uint4 *)s_mil)[i] = ((const uint4 *)T.mil_step)[i];
-        if (T.tag)
-            for (int i = threadIdx.x; i < rows; i += SCAN_BLOCK) ((uint4 *)s_man)[i] = ((const uint4 *)T.man_step)[i];
+        for (int i = threadIdx.x; i < rows; i += SCAN_BLOCK) {
+            if (T.reader) ((uint4 *)s_mil)[i] = ((const uint4 *)T.qmil_step)[i];
+            if (T.tag) ((uint4 *)s_man)[i] = ((const uint4 *)T.man_step)[i];
+        }
     }
     if (threadIdx.x == 0) s_needs = 0u;
     const size_t tid = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
@@ -416,46 +442,62 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
     }
     __syncthreads();   // the tables are staged
     TP_MARK();   // 1: tables, codes
-    auto compose = [&](DecMaps &agg, uint32_t code, uint32_t &seen) __attribute__((always_inline)) {
-        const uint32_t li = code & 0x3FFFu, route = code >> 14;
-        if (route == 2u && T.reader) {
-            const uint4 v = LDS ? s_milmap[li] : T.mil_map[li];
-#pragma unroll
-            for (int q = 0; q < 4; q++) agg.mil[q] = lookup16x4(v.x, v.y, v.z, v.w, agg.mil[q]);
-            seen |= 1u;
-        } else if (route == 1u && T.tag) {
-            const uint2 v = LDS ? s_manmap[li] : T.man_map[li];
-            agg.man[0] = __builtin_amdgcn_perm(v.y, v.x, agg.man[0]);
-            agg.man[1] = __builtin_amdgcn_perm(v.y, v.x, agg.man[1]);
-            seen |= 2u;
-        }
+    // An edge that is not routed to a decoder takes that table's identity row: a select on the index, no branch.  Four edges are
+    // composed as a tree (two pairs, then the pair of pairs) before they meet the accumulated map: a chain of 8 dependent
+    // look-ups per 32 edges instead of 32.
+    auto mil_row = [&](uint32_t code) __attribute__((always_inline)) -> uint2 {
+        const uint32_t idx = (code >> 14) == 2u ? (code & 0x3FFFu) : ident;
+        return LDS ? s_milmap[idx] : T.qmil_map[idx];
     };
-    DecMaps runin = ComposeDec::identity();
+    auto man_row = [&](uint32_t code) __attribute__((always_inline)) -> uint2 {
+        const uint32_t idx = (code >> 14) == 1u ? (code & 0x3FFFu) : ident;
+        return LDS ? s_manmap[idx] : T.man_map[idx];
+    };
+    auto then = [](const uint2 &a, const uint2 &b) __attribute__((always_inline)) -> uint2 {   // a, then b
+        return make_uint2(__builtin_amdgcn_perm(b.y, b.x, a.x), __builtin_amdgcn_perm(b.y, b.x, a.y));
+    };
+    auto routes_of = [](uint32_t pair) __attribute__((always_inline)) -> uint32_t {   // bit 0 / 1: a Miller / Manchester edge among the two codes of a word
+        const uint32_t r0 = (pair >> 14) & 3u, r1 = pair >> 30;
+        return ((r0 == 2u || r1 == 2u) ? 1u : 0u) | ((r0 == 1u || r1 == 1u) ? 2u : 0u);
+    };
+    auto compose4 = [&](uint2 &am, uint2 &an, uint32_t w0, uint32_t w1) __attribute__((always_inline)) {   // four edges (two words of codes)
+        const uint32_t c0 = w0 & 0xFFFFu, c1 = w0 >> 16, c2 = w1 & 0xFFFFu, c3 = w1 >> 16;
+        if (T.reader) am = then(am, then(then(mil_row(c0), mil_row(c1)), then(mil_row(c2), mil_row(c3))));
+        if (T.tag) an = then(an, then(then(man_row(c0), man_row(c1)), then(man_row(c2), man_row(c3))));
+    };
+    const QMaps idm = ComposeQ::identity();
+    QMaps runin = idm;
     if (have_runin) {   // (uniform)
-        uint32_t seen_r = 0u;
-        DecMaps ra = ComposeDec::identity();
+        uint2 am = make_uint2(idm.mil[0], idm.mil[1]), an = make_uint2(idm.man[0], idm.man[1]);
 #pragma unroll
-        for (int k = 0; k < DEC_RUNIN_MAX; k++)
-            if (k < runin_per_thread) compose(ra, (rc[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, seen_r);
-        (void)block_exclusive<ComposeDec>(ra, lds, runin);
+        for (int k = 0; k < DEC_RUNIN_MAX / 2; k += 2)
+            if (2 * k < runin_per_thread) compose4(am, an, rc[k], rc[k + 1]);   // (words past the run-in hold code 0: not routed)
+        const QMaps ra{{am.x, am.y}, {an.x, an.y}};
+        (void)block_exclusive<ComposeQ>(ra, lds, runin);
     }
-    DecMaps agg = ComposeDec::identity();
     uint32_t seen = 0u;
+    uint2 am = make_uint2(idm.mil[0], idm.mil[1]), an = make_uint2(idm.man[0], idm.man[1]);
 #pragma unroll
     for (int g = 0; g < DEC_GROUPS; g++) {
 #pragma unroll
-        for (int k = 0; k < DEC_ITEMS; k++) compose(agg, (c[g][k >> 1] >> (16 * (k & 1))) & 0xFFFFu, seen);
+        for (int k = 0; k < 8; k += 2) {
+            compose4(am, an, c[g][k], c[g][k + 1]);
+            seen |= routes_of(c[g][k]) | routes_of(c[g][k + 1]);
+        }
     }
+    if (!T.reader) seen &= ~1u;
+    if (!T.tag) seen &= ~2u;
+    const QMaps agg{{am.x, am.y}, {an.x, an.y}};
     TP_MARK();   // 2: the compositions
-    DecMaps total;
-    const DecMaps excl = block_exclusive<ComposeDec>(agg, lds, total);
+    QMaps total;
+    const QMaps excl = block_exclusive<ComposeQ>(agg, lds, total);
     // the map from the run-in's first edge to this thread's first: constant for a decoder = its state here is known whatever came before
-    const DecMaps upto = ComposeDec::op(runin, excl);
-    uint32_t st = ComposeDec::step(upto, state0);
-    const uint32_t dep = ((seen & 1u) && !mil_map_constant(upto) ? 1u : 0u) | ((seen & 2u) && !man_map_constant(upto) ? 2u : 0u);
+    const QMaps upto = ComposeQ::op(runin, excl);
+    uint32_t st = ComposeQ::step(upto, state0);
+    const uint32_t dep = ((seen & 1u) && !map8_constant(upto.mil) ? 1u : 0u) | ((seen & 2u) && !map8_constant(upto.man) ? 2u : 0u);
     if (blockIdx.x > 0 && dep) atomicOr(&s_needs, dep);   // (rare; tile 0 starts from the carried state itself)
     TP_MARK();   // 3: block scans, incoming states
-    const uint16_t *mil = LDS ? s_mil : T.mil_step;
+    const uint16_t *mil = LDS ? s_mil : T.qmil_step;
     const uint16_t *man = LDS ? s_man : T.man_step;
     FramePk mine = FramePkOp::identity();
 #pragma unroll
@@ -467,7 +509,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
             const uint32_t li = code & 0x3FFFu, route = code >> 14;
             uint32_t w = 0;
             if (route == 2u && T.reader) {
-                const uint32_t e = mil[li * 16u + (st & 15u)];
+                const uint32_t e = mil[li * 8u + (st & 7u)];
                 w = e >> 8;
                 st = (st & ~15u) | (e & 15u);
             } else if (route == 1u && T.tag) {
@@ -488,11 +530,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
     (void)block_exclusive<FramePkOp>(mine, lds2, total_fa);   // (its barriers: every thread's atomicOr has landed)
     if (threadIdx.x == 0) {
         frame_aggs[blockIdx.x] = FramePkOp::unpack(total_fa);
-        DecSpec sp;
-        sp.map = total;
-        sp.s_in = ComposeDec::step(runin, state0);
-        sp.needs = s_needs;
-        spec[blockIdx.x] = sp;
+        const uint32_t s_in = ComposeQ::step(runin, state0);
+        ((uint4 *)(spec + blockIdx.x))[0] = make_uint4(total.mil[0], total.mil[1], total.man[0], total.man[1]);
+        ((uint4 *)(spec + blockIdx.x))[1] = make_uint4(s_in, s_needs, 0u, 0u);
     }
     TP_DONE(1);   // 5: block scan
 }
@@ -501,47 +541,49 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
 // assumed with the true one wherever the tile said its outputs depend on it, and publishes the decoder states after the batch.
 struct DecVerify {
     const DecSpec *spec;   // NULL: the three-launch form ran (nothing to check)
-    uint32_t state0;
+    uint32_t state0;       // miller CLASS | manchester state << 4
+    uint32_t q_rep[2];     // Miller class -> canonical state
     DecCarry *carry;
     uint32_t *verdict;     // 0: every assumption that mattered was right
 };
 constexpr int DV_ITEMS = 4;
-__device__ __forceinline__ void dec_verify(const DecVerify &V, size_t ntiles, DecMaps *lds) {
-    DecMaps before = ComposeDec::identity();   // the map of all tiles before this round's
+__device__ __forceinline__ void dec_verify(const DecVerify &V, size_t ntiles, QMaps *lds) {
+    QMaps before = ComposeQ::identity();   // the map of all tiles before this round's
     int bad = 0;
     for (size_t b0 = 0; b0 < ntiles; b0 += (size_t)SCAN_BLOCK * DV_ITEMS) {
         const size_t i0 = b0 + (size_t)threadIdx.x * DV_ITEMS;
-        DecSpec sp[DV_ITEMS];
+        QMaps mp[DV_ITEMS];
+        uint32_t s_in[DV_ITEMS], needs[DV_ITEMS];
 #pragma unroll
         for (int k = 0; k < DV_ITEMS; k++) {
             if (i0 + k < ntiles) {
                 const uint4 a = ((const uint4 *)(V.spec + i0 + k))[0], b = ((const uint4 *)(V.spec + i0 + k))[1];
-                sp[k].map = DecMaps{{a.x, a.y, a.z, a.w}, {b.x, b.y}};
-                sp[k].s_in = b.z;
-                sp[k].needs = b.w;
+                mp[k] = QMaps{{a.x, a.y}, {a.z, a.w}};
+                s_in[k] = b.x;
+                needs[k] = b.y;
             } else {
-                sp[k].map = ComposeDec::identity();
-                sp[k].s_in = 0u;
-                sp[k].needs = 0u;
+                mp[k] = ComposeQ::identity();
+                s_in[k] = 0u;
+                needs[k] = 0u;
             }
         }
-        DecMaps agg = sp[0].map;
+        QMaps agg = mp[0];
 #pragma unroll
-        for (int k = 1; k < DV_ITEMS; k++) agg = ComposeDec::op(agg, sp[k].map);
-        DecMaps total;
-        DecMaps run = ComposeDec::op(before, block_exclusive<ComposeDec>(agg, lds, total));
+        for (int k = 1; k < DV_ITEMS; k++) agg = ComposeQ::op(agg, mp[k]);
+        QMaps total;
+        QMaps run = ComposeQ::op(before, block_exclusive<ComposeQ>(agg, lds, total));
 #pragma unroll
         for (int k = 0; k < DV_ITEMS; k++) {
-            const uint32_t diff = ComposeDec::step(run, V.state0) ^ sp[k].s_in;
-            if (((sp[k].needs & 1u) && (diff & 15u)) || ((sp[k].needs & 2u) && (diff >> 4))) bad = 1;
-            run = ComposeDec::op(run, sp[k].map);
+            const uint32_t diff = ComposeQ::step(run, V.state0) ^ s_in[k];
+            if (((needs[k] & 1u) && (diff & 15u)) || ((needs[k] & 2u) && (diff >> 4))) bad = 1;
+            run = ComposeQ::op(run, mp[k]);
         }
-        before = ComposeDec::op(before, total);
+        before = ComposeQ::op(before, total);
     }
     bad = __syncthreads_or(bad);
     if (threadIdx.x == 0) {
-        const uint32_t st = ComposeDec::step(before, V.state0);
-        V.carry->mil_state = (int32_t)(st & 15u);
+        const uint32_t st = ComposeQ::step(before, V.state0);
+        V.carry->mil_state = (int32_t)byte_of(V.q_rep, st & 7u);
         V.carry->man_state = (int32_t)(st >> 4);
         *V.verdict = bad ? 1u : 0u;
     }
@@ -638,10 +680,11 @@ struct DecCarryEpilogue {
     uint32_t *nsym;
     PktCnt *pk_total;
     uint32_t pend[2], started_in[2];
+    uint32_t canon[4];
     __device__ __forceinline__ void operator()(const FrameAgg &ft) const {
         if (total) {   // (NULL: the speculative decode ran -- dec_verify publishes the decoder states from its own scan)
             const uint32_t st = ComposeDec::step(*total, state_in);
-            carry->mil_state = (int32_t)(st & 15u);
+            carry->mil_state = (int32_t)byte_of(canon, st & 15u);   // (the canonical state of its class: DecTables)
             carry->man_state = (int32_t)(st >> 4);
         }
         nsym[1] = ft.cnt[1];   // Miller / reader
@@ -659,7 +702,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
     if (n_dev) n = min(n, (size_t)*n_dev);
     if (V.spec) {
         if (blockIdx.x == 0) {
-            __shared__ DecMaps lds_v[SCAN_WAVES];
+            __shared__ QMaps lds_v[SCAN_WAVES];
             dec_verify(V, (n + DEC_TILE - 1) / DEC_TILE, lds_v);
             return;
         }

@@ -195,4 +195,88 @@ inline DecoderTables build_tables(double samp_rate, int max_len) {
     return t;
 }
 
+// ---- the Miller decoder's quotient machine ----------------------------------------------------------------------------
+// Two states are EQUIVALENT when no sequence of edges tells them apart: the same symbols come out of both, for ever
+// (Moore / Mealy minimisation over every row of the table: partition refinement on (out byte, class of the next state)).
+// miller.py's `_prev` is read in one place only -- stage BEGINNING of a started frame (miller.py:81) -- and every path into that
+// situation writes it first, so the 16 states (stage x has_started x prev) fall into 9 classes, and the states reachable from the
+// initial one (has_started == False only with stage BEGINNING: reset() sets both, miller.py:65-67) into 6.  A class map is then 8
+// bytes and the composition of two is two v_perm_b32; outputs are those of the 16-state machine by construction.
+// q_of[state]: class 0..7, or 0xFF for a state outside the reachable classes (only nfc_set_state can produce one: such a batch
+// takes the 16-state kernels); rep[class] / canon[state]: the lowest state of the class -- `prev` reads 0 wherever the decoder
+// cannot see it (what every decode path publishes as the carried state, so that equal decoder states compare equal).
+struct MillerQuotient {
+    bool ok = false;
+    int classes = 0;
+    uint8_t q_of[16], rep[8], canon[16];
+    std::vector<uint64_t> map;    // per row: 8 classes, one byte each (unused class ids follow class 0)
+    std::vector<uint16_t> step;   // per (row, class): next class | out byte << 8
+};
+inline MillerQuotient miller_quotient(const DecoderTables &t) {
+    MillerQuotient q;
+    const size_t rows = t.miller_map.size();
+    int cls[16] = {0};
+    for (;;) {   // refine until stable
+        int ncls[16], nid = 0;
+        std::vector<std::vector<int>> sigs;
+        for (int s = 0; s < 16; s++) {
+            std::vector<int> sig{cls[s]};
+            for (size_t r = 0; r < rows; r++) {
+                sig.push_back(t.miller_out[r * 16 + s]);
+                sig.push_back(cls[(t.miller_map[r] >> (4 * s)) & 15]);
+            }
+            int id = -1;
+            for (int k = 0; k < nid; k++)
+                if (sigs[k] == sig) id = k;
+            if (id < 0) {
+                id = nid++;
+                sigs.push_back(sig);
+            }
+            ncls[s] = id;
+        }
+        bool same = true;
+        for (int s = 0; s < 16; s++) same = same && ncls[s] == cls[s];
+        for (int s = 0; s < 16; s++) cls[s] = ncls[s];
+        if (same) break;
+    }
+    bool reach[16] = {false};   // from the initial state (miller.py:22,29: stage BEGINNING, not started, prev 0)
+    reach[0] = true;
+    for (bool grew = true; grew;) {
+        grew = false;
+        for (int s = 0; s < 16; s++)
+            if (reach[s])
+                for (size_t r = 0; r < rows; r++) {
+                    const int nx = (int)((t.miller_map[r] >> (4 * s)) & 15);
+                    if (!reach[nx]) reach[nx] = grew = true;
+                }
+    }
+    int qid[16];
+    for (int k = 0; k < 16; k++) qid[k] = -1;
+    for (int s = 0; s < 16; s++)
+        if (reach[s] && qid[cls[s]] < 0) {
+            if (q.classes == 8) return q;   // (does not fit: the caller keeps the 16 states)
+            q.rep[q.classes] = (uint8_t)s;   // (states ascend: the lowest of the class, prev == 0 where both are in it)
+            qid[cls[s]] = q.classes++;
+        }
+    for (int s = 0; s < 16; s++) {
+        q.q_of[s] = qid[cls[s]] >= 0 ? (uint8_t)qid[cls[s]] : (uint8_t)0xFF;
+        q.canon[s] = qid[cls[s]] >= 0 ? q.rep[qid[cls[s]]] : (uint8_t)s;
+    }
+    for (int k = q.classes; k < 8; k++) q.rep[k] = q.rep[0];
+    q.map.assign(rows, 0);
+    q.step.assign(rows * 8, 0);
+    for (size_t r = 0; r < rows; r++) {
+        uint64_t m = 0;
+        for (int k = 0; k < 8; k++) {
+            const int s = q.rep[k < q.classes ? k : 0];
+            const int nx = q.q_of[(t.miller_map[r] >> (4 * s)) & 15];   // (a reachable state's successor is reachable)
+            m |= (uint64_t)nx << (8 * k);
+            q.step[r * 8 + k] = (uint16_t)(nx | (t.miller_out[r * 16 + s] << 8));
+        }
+        q.map[r] = m;
+    }
+    q.ok = true;
+    return q;
+}
+
 }  // namespace nfc

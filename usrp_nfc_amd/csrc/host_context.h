@@ -135,7 +135,8 @@ struct nfc_ctx {
     LaunchError launch_err;   // the first launch of the batch in work that the runtime rejected (launch_check.h)
 
     // tables
-    DevBuf d_mil_map, d_man_map, d_mil_out, d_man_out;
+    DevBuf d_mil_map, d_man_map, d_mil_out, d_man_out, d_qmil_map, d_qmil_step;
+    uint8_t mil_q_of[16], mil_canon[16];   // Miller state -> class of the quotient machine (0xFF: none) / -> canonical state (decoder_tables.h)
     DecTables T;
 
     // carried state

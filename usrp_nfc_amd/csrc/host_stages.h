@@ -123,20 +123,22 @@ int run_decode(nfc_ctx *c, bool force_classic = false) {
     DecMaps *map_total = (DecMaps *)(tot + TOT_DECMAP);
     // the speculative form (k_dec_spec: reduce + apply in one launch, every tile's incoming states from a run-in of its
     // predecessor's last edges) unless it is switched off, or the stream's last batches needed the three-launch form
-    const bool spec = c->dec_spec && c->spec_off_left == 0 && !force_classic;
+    const uint32_t mil_class_in = (c->h_dcarry.mil_state >= 0 && c->h_dcarry.mil_state < 16) ? c->mil_q_of[c->h_dcarry.mil_state] : 0xFFu;
+    const bool spec = c->dec_spec && c->spec_off_left == 0 && !force_classic && c->T.q_ok && mil_class_in != 0xFFu;   // (a state no edge sequence reaches: set from the host)
     c->dec_spec_now = spec;
-    const DecCarryEpilogue epi{spec ? (DecMaps *)nullptr : map_total, dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM), pk_total,
-                               {P.pend[0], P.pend[1]}, {P.started_in[0], P.started_in[1]}};
-    DecVerify V{nullptr, dec_state_in, dD(c), (uint32_t *)(tot + TOT_SPEC)};
+    DecCarryEpilogue epi{spec ? (DecMaps *)nullptr : map_total, dec_state_in, dD(c), (uint32_t *)(tot + TOT_NSYM), pk_total,
+                         {P.pend[0], P.pend[1]}, {P.started_in[0], P.started_in[1]}, {c->T.canon[0], c->T.canon[1], c->T.canon[2], c->T.canon[3]}};
+    const uint32_t spec_state_in = mil_class_in | ((uint32_t)c->h_dcarry.man_state << 4);
+    DecVerify V{nullptr, spec_state_in, {c->T.q_rep[0], c->T.q_rep[1]}, dD(c), (uint32_t *)(tot + TOT_SPEC)};
     if (spec) {
         HIPCHK(c, c->d_spec.ensure((tiles + 1) * sizeof(DecSpec)));
         V.spec = c->d_spec.as<DecSpec>();
         if (tiles) {
             if (lds_tables)
-                NFC_LAUNCH(k_dec_spec<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dec_state_in, c->dec_runin, outw,
+                NFC_LAUNCH(k_dec_spec<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, spec_state_in, c->dec_runin, outw,
                            fparts, c->d_faggs.as<FramePk>(), c->d_spec.as<DecSpec>());
             else
-                NFC_LAUNCH(k_dec_spec<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dec_state_in, c->dec_runin, outw,
+                NFC_LAUNCH(k_dec_spec<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, spec_state_in, c->dec_runin, outw,
                            fparts, c->d_faggs.as<FramePk>(), c->d_spec.as<DecSpec>());
         }
     } else {

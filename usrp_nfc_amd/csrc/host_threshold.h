@@ -295,13 +295,13 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             // summary in the mirrored state block; later rounds (after re-runs) read the per-chunk flags
             CertSummary *d_sum = (CertSummary *)(tot + TOT_CERT);
             auto launch_certify = [&]() {
-                NFC_LAUNCH(k_certify, dim3((np + 3) / 4 + 1), dim3(256), 0, c->st, A, d_cert,
+                NFC_LAUNCH(k_certify, dim3(cert_grid(np)), dim3(256), 0, c->st, A, d_cert,
                                    dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c),
                                    first_round ? d_sum : (CertSummary *)nullptr);
             };
             if (first_round && ahead && !dbg) {
                 // the stages that follow are enqueued now; their first full-width kernel takes the certification along
-                c->cert = CertLaunch{A, d_cert, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c), d_sum, (np + 3) / 4 + 1};
+                c->cert = CertLaunch{A, d_cert, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c), d_sum, cert_grid(np)};
                 c->cert_pending = true;
                 const int rc = (*ahead)();
                 if (c->cert_pending) {   // (a short batch's one-launch stage, or no edge stage at all: on its own then)

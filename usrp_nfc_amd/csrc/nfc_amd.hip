@@ -310,6 +310,10 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     std::vector<uint16_t> mils(milb.size()), mans(manb.size());
     for (size_t i = 0; i < milb.size(); i++) mils[i] = (uint16_t)(milb[i] | (t.miller_out[i] << 8));
     for (size_t i = 0; i < manb.size(); i++) mans[i] = (uint16_t)(manb[i] | (t.manch_out[i] << 8));
+    // one row more in both map tables, the identity, at index 4 (max_len + 1): what an edge that is not routed to a decoder
+    // looks up in the speculative decode's compositions (decode.hip.h: k_dec_spec)
+    for (int s = 0; s < 16; s++) milb.push_back((uint8_t)s);
+    for (int s = 0; s < 8; s++) manb.push_back((uint8_t)s);
     CRT(c->d_mil_map.ensure(milb.size()));
     CRT(c->d_man_map.ensure(manb.size()));
     CRT(c->d_mil_out.ensure(mils.size() * 2));
@@ -318,6 +322,27 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     CRT(hipMemcpy(c->d_man_map.p, manb.data(), manb.size(), hipMemcpyHostToDevice));
     CRT(hipMemcpy(c->d_mil_out.p, mils.data(), mils.size() * 2, hipMemcpyHostToDevice));
     CRT(hipMemcpy(c->d_man_out.p, mans.data(), mans.size() * 2, hipMemcpyHostToDevice));
+    {   // the Miller decoder's quotient machine (decoder_tables.h): class maps of 8 bytes for the speculative decode
+        const MillerQuotient q = miller_quotient(t);
+        c->T.q_ok = q.ok ? 1 : 0;
+        for (int k = 0; k < 16; k++) c->mil_q_of[k] = q.ok ? q.q_of[k] : (uint8_t)0xFF;
+        uint8_t canon[16], rep[8] = {0};
+        for (int k = 0; k < 16; k++) canon[k] = q.ok ? q.canon[k] : (uint8_t)k;
+        if (q.ok) memcpy(rep, q.rep, 8);
+        memcpy(c->T.canon, canon, 16);
+        memcpy(c->T.q_rep, rep, 8);
+        memcpy(c->mil_canon, canon, 16);
+        if (q.ok) {
+            std::vector<uint64_t> qm(q.map);
+            qm.push_back(0x0706050403020100ull);   // the identity row at index 4 (max_len + 1)
+            CRT(c->d_qmil_map.ensure(qm.size() * 8));
+            CRT(c->d_qmil_step.ensure(q.step.size() * 2 + 16));
+            CRT(hipMemcpy(c->d_qmil_map.p, qm.data(), qm.size() * 8, hipMemcpyHostToDevice));
+            CRT(hipMemcpy(c->d_qmil_step.p, q.step.data(), q.step.size() * 2, hipMemcpyHostToDevice));
+            c->T.qmil_map = c->d_qmil_map.as<uint2>();
+            c->T.qmil_step = c->d_qmil_step.as<uint16_t>();
+        }
+    }
     c->T.mil_map = c->d_mil_map.as<uint4>();
     c->T.man_map = c->d_man_map.as<uint2>();
     c->T.mil_step = c->d_mil_out.as<uint16_t>();
@@ -351,7 +376,7 @@ void nfc_destroy(nfc_ctx *c) {
     if (c->st_a) (void)hipStreamSynchronize(c->st_a);
     if (c->st && c->st == c->own_st) (void)hipStreamSynchronize(c->st);
     else (void)hipDeviceSynchronize();   // on a caller's stream (nfc_set_stream): the handle may be gone by now
-    DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_state,
+    DevBuf *all[] = {&c->d_mil_map, &c->d_man_map, &c->d_mil_out, &c->d_man_out, &c->d_qmil_map, &c->d_qmil_step, &c->d_state,
                      &c->d_ring[0], &c->d_ring[1], &c->d_ring[2], &c->d_ring[3], &c->d_neg_alt[0], &c->d_pos_alt[0], &c->d_neg_alt[1], &c->d_pos_alt[1], &c->d_certinfo, &c->d_in, &c->d_neg, &c->d_pos, &c->d_ringin, &c->d_meta, &c->d_ringout[0], &c->d_ringout[1], &c->d_touched[0],
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ecode, &c->d_epos, &c->d_eidx, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
@@ -838,7 +863,7 @@ int nfc_set_state(nfc_ctx *c, const nfc_state_header *h, const float *ring, size
     c->h_ecarry.state = h->cur_state;
     c->h_ecarry.last_bit = h->last_bit;
     c->h_ecarry.dur = h->dur;
-    c->h_dcarry.mil_state = h->miller_state;
+    c->h_dcarry.mil_state = (h->miller_state >= 0 && h->miller_state < 16) ? (int32_t)c->mil_canon[h->miller_state] : h->miller_state;
     c->h_dcarry.man_state = h->manch_state;
     for (int t = 0; t < 2; t++) {
         c->h_dcarry.pkt_started[t] = h->pkt_started[t];
@@ -1145,17 +1170,28 @@ int nfc_host_decode_steps(int type, const int8_t *cur, const double *dur_us, siz
 
 int nfc_host_decode_lut(const nfc_params *p, int type, const int8_t *cur, const int32_t *d, size_t n, uint8_t *sym_out,
                         size_t cap, size_t *n_out) {
-    if (!p || !cur || !d || !n_out || type < 0 || type > 1) return NFC_ERR_ARG;
+    if (!p || !cur || !d || !n_out || type < 0 || type > 2) return NFC_ERR_ARG;
     if (!(p->samp_rate > 0) || p->max_len < 1) return NFC_ERR_ARG;
     const DecoderTables t = build_tables(p->samp_rate, p->max_len);
     const int nd = p->max_len + 1;
     int state = type ? 0 : ((0 + 1) << 1);
+    MillerQuotient q;
+    if (type == 2) {   // the Miller decoder's quotient machine, as the speculative decode kernel walks it (classes, 8 per row)
+        q = miller_quotient(t);
+        if (!q.ok) return NFC_ERR_INTERNAL;
+        state = q.q_of[0];
+    }
     size_t k = 0;
     for (size_t i = 0; i < n; i++) {
         if (cur[i] < -1 || cur[i] > 2 || d[i] < 0 || d[i] > p->max_len) return NFC_ERR_ARG;
         const int li = (cur[i] + 1) * nd + d[i];
         uint8_t w;
-        if (type) {
+        if (type == 2) {
+            const uint16_t e = q.step[(size_t)li * 8 + state];
+            if ((int)((q.map[li] >> (8 * state)) & 0xFF) != (e & 15)) return NFC_ERR_INTERNAL;   // (the two tables of the kernel agree)
+            w = (uint8_t)(e >> 8);
+            state = e & 15;
+        } else if (type) {
             w = t.miller_out[(size_t)li * kMillerStates + state];
             state = (int)((t.miller_map[li] >> (4 * state)) & 15u);
         } else {
@@ -1167,6 +1203,16 @@ int nfc_host_decode_lut(const nfc_params *p, int type, const int8_t *cur, const 
         if (no >= 2) { if (k < cap) sym_out[k] = (w >> 5) & 7; k++; }
     }
     *n_out = k;
+    return NFC_OK;
+}
+
+int nfc_host_miller_classes(const nfc_params *p, uint8_t class_of[16], uint8_t canonical[16], int *n_classes) {
+    if (!p || !class_of || !canonical || !n_classes || !(p->samp_rate > 0) || p->max_len < 1) return NFC_ERR_ARG;
+    const MillerQuotient q = miller_quotient(build_tables(p->samp_rate, p->max_len));
+    if (!q.ok) return NFC_ERR_INTERNAL;
+    memcpy(class_of, q.q_of, 16);
+    memcpy(canonical, q.canon, 16);
+    *n_classes = q.classes;
     return NFC_OK;
 }
 

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
             *A.tot_decmap = run_map;
             *A.tot_frame = run_fa;
             const uint32_t st = ComposeDec::step(run_map, A.dec_state_in);
-            A.dcarry->mil_state = (int32_t)(st & 15u);
+            A.dcarry->mil_state = (int32_t)byte_of(A.T.canon, st & 15u);   // (the canonical state of its class: DecTables)
             A.dcarry->man_state = (int32_t)(st >> 4);
             A.tot_nsym[1] = run_fa.cnt[1];   // Miller / reader
             A.tot_nsym[0] = run_fa.cnt[0];   // Manchester / tag

@@ -1162,18 +1162,22 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
         finalize_state(A, ring_next, carry, sum);
         return;
     }
-    const uint32_t slotid = bid * (blockDim.x >> 6) + wave;
+    // a chunk per WORKGROUP (round 4; a chunk per wave before): the window's slots are one round of loads for 256 threads at the
+    // bench's window instead of four dependent rounds for 64 -- the launch was as long as its longest chain of loads
+    const uint32_t slotid = bid;
     if (slotid >= A.nlist) return;
     const uint32_t c = A.list ? A.list[slotid] : slotid + 1;
     if (c == 0) {   // (chunk 0 re-run from the carried state: nothing it could disagree with -- unless the re-run itself gave up)
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             const bool ok0 = !(A.gflags[0] & 4u);
             cert[0] = ok0 ? 1 : 0;
             if (!ok0 && sum) atomicAdd(&sum->n_fail, 1u);
         }
         return;
     }
+    __shared__ float s_d[4];
     const int L = A.L;
+    const int tid = (int)threadIdx.x;
     const float *rin = A.ring_in + (size_t)c * L;
     const RunMeta mt = A.meta[c];
     const int vb = A.ver[c - 1];
@@ -1181,13 +1185,13 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     const float *ro = A.ring_out[vb] + (size_t)(c - 1) * L;
     float d = 0.f;
     bool differ = false;
-    constexpr int CK = 8;    // slots per lane and round: every load of a round is in flight at once (16 costs the fused launch its occupancy)
-    for (int s0 = 0; s0 < L; s0 += 64 * CK) {
+    constexpr int CK = 8;    // slots per thread and round: every load of a round is in flight at once
+    for (int s0 = 0; s0 < L; s0 += 256 * CK) {
         float t[CK], u[CK];
         uint32_t w[CK];
 #pragma unroll
         for (int k = 0; k < CK; k++) {
-            const int s = s0 + 64 * k + lane;
+            const int s = s0 + 256 * k + tid;
             const bool in = s < L;
             t[k] = in ? ro[s] : 0.f;
             u[k] = in ? rin[s] : 0.f;
@@ -1195,7 +1199,7 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
         }
 #pragma unroll
         for (int k = 0; k < CK; k++) {
-            const int s = s0 + 64 * k + lane;
+            const int s = s0 + 256 * k + tid;
             if (s < L) {
                 if (!((w[k] >> (s & 31)) & 1u)) t[k] = resolve_slot(A, (int)c, s);   // rare: look further back
                 d += fabsf(t[k] - u[k]);
@@ -1203,7 +1207,11 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
             }
         }
     }
-    d = wave_sum_f32(d) * 1.001f;
+    d = wave_sum_f32(d);
+    if (lane == 0) s_d[wave] = d;
+    const int any_differ = __syncthreads_or(differ ? 1 : 0);   // (its barrier also publishes the waves' sums)
+    d = ((s_d[0] + s_d[1]) + (s_d[2] + s_d[3])) * 1.001f;
+    if (tid != 0) return;
     int nl, kl;
     resolve_low_state(A, (int)c, nl, kl);
     const int m0 = (int)(c * (uint32_t)A.C) - A.off;
@@ -1212,13 +1220,13 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     const bool low_ok = (nl == mt.nl_in) && ((kl == mt.kl_in) || (!live(kl) && !live(mt.kl_in)));
     bool ok;
     if (mt.eps > 0.f) ok = mt.all_robust && (d <= mt.eps * mt.min_ss * 0.999f) && low_ok;
-    else ok = !__any(differ) && (nl == mt.nl_in) && (kl == mt.kl_in) && !(A.gflags[c] & 4u);   // (flag 4: a re-run by k_threshold_wg that gave up)
-    if (lane == 0) {
-        cert[c] = ok ? 1 : 0;
-        if (!ok && sum) atomicAdd(&sum->n_fail, 1u);
-        if (dbg) dbg[c] = CertInfo{d, mt.eps * mt.min_ss, mt.all_robust, (uint32_t)low_ok};
-    }
+    else ok = !any_differ && (nl == mt.nl_in) && (kl == mt.kl_in) && !(A.gflags[c] & 4u);   // (flag 4: a re-run by k_threshold_wg that gave up)
+    cert[c] = ok ? 1 : 0;
+    if (!ok && sum) atomicAdd(&sum->n_fail, 1u);
+    if (dbg) dbg[c] = CertInfo{d, mt.eps * mt.min_ss, mt.all_robust, (uint32_t)low_ok};
 }
+// the certification's grid: a workgroup per pending chunk, and one more that resolves the end-of-batch state
+inline uint32_t cert_grid(uint32_t pending) { return pending + 1u; }
 __global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertInfo *dbg, float *ring_next, Carry *carry,
                                                  CertSummary *sum) {
     certify_block(A, cert, dbg, ring_next, carry, sum, blockIdx.x, gridDim.x);
