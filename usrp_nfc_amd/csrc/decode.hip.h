@@ -233,16 +233,60 @@ __device__ __forceinline__ FrameAgg frame_agg_of(const uint32_t (&ow)[4]) {
     }
     return a;
 }
+// ---- packet bits leave the multi-launch stage PACKED, 32 to a word (round 4) ---------------------------------------------
+// A thread's appended bits are its symbols' low bits at the slots of `appended`, in slot order: compress (Hacker's Delight 7-4,
+// the parallel-suffix form: five rounds of shifts and xors, no loop over the symbols and nothing that diverges) squeezes them to
+// the bottom of a word, and the words of a tile are or-ed together in LDS and stored whole.  Before: a loop per symbol with a
+// byte store each -- two thirds of k_frame_write's time.  nfc_read_packet_bits unpacks (one byte per bit, as ever).
+__device__ __forceinline__ uint32_t compress32(uint32_t x, uint32_t m) {
+    x &= m;
+    uint32_t mk = ~m << 1;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        uint32_t mp = mk ^ (mk << 1);
+        mp ^= mp << 2;
+        mp ^= mp << 4;
+        mp ^= mp << 8;
+        mp ^= mp << 16;
+        const uint32_t mv = mp & m;
+        m = (m ^ mv) | (mv >> (1 << i));
+        const uint32_t t = x & mv;
+        x = (x ^ t) | (t >> (1 << i));
+        mk &= ~mp;
+    }
+    return x;
+}
+// bit 0 of the symbol in every slot (slot 2k + j: symbol j of edge k), in slot order
+__device__ __forceinline__ uint32_t symbol_low_bits(const uint32_t (&ow)[4]) {
+    constexpr uint32_t M = 0x01010101u;
+    uint32_t b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) b[i] = ((ow[i] >> 2) & M) | (((ow[i] >> 5) & M) << 1);
+    return transpose_pairs(b[0], b[1], b[2], b[3]);
+}
+
 // per type: appended bits in the low half, closes in the high half
 struct PktCnt {
     uint64_t v[2];
 };
 
+// The packed bit arrays are or-ed into (k_frame_write): the stage's first launch clears their words, all its workgroups together.
+struct ZeroJob {
+    uint32_t *p[2];
+    uint32_t n[2];   // words
+};
+__device__ __forceinline__ void zero_words(const ZeroJob &Z) {
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < Z.n[t]; i += gridDim.x * blockDim.x) Z.p[t][i] = 0u;
+}
+
 // ---- pass 1: every edge is a pair of state maps (Miller, Manchester); a thread composes its sixteen ----
 // Each edge is routed as background.py:30-35 does: route 2 -> Miller, 1 -> Manchester, 0 dropped.
 template <bool LDS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_reduce(const uint16_t *ecode, size_t n, const uint32_t *n_dev, DecTables T,
-                                                          DecMaps *partials, DecMaps *aggs) {
+                                                          DecMaps *partials, DecMaps *aggs, ZeroJob Z) {
+    zero_words(Z);
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
     TP_DECL();
@@ -403,7 +447,8 @@ __device__ __forceinline__ bool map8_constant(const uint32_t (&m)[2]) { return m
 constexpr int DEC_RUNIN_MAX = 8;   // run-in edges per thread at most (runin = 2, 4 or 8 x SCAN_BLOCK: 512, 1024 or 2048 edges)
 template <bool LDS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, size_t n, const uint32_t *n_dev, DecTables T, uint32_t state0, int runin_per_thread,
-                                                        uint8_t *outw, FrameAgg *frame_aggs, FramePk *thread_aggs, DecSpec *spec) {
+                                                        uint8_t *outw, FrameAgg *frame_aggs, FramePk *thread_aggs, DecSpec *spec, ZeroJob Z) {
+    zero_words(Z);
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
     TP_DECL();
@@ -477,10 +522,17 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
     }
     uint32_t seen = 0u;
     uint2 am = make_uint2(idm.mil[0], idm.mil[1]), an = make_uint2(idm.man[0], idm.man[1]);
+    // (the maps of the thread's first 8, 16, 24 ... edges are kept: the walk below runs a chain per eight edges)
+    constexpr int NCH = 2 * DEC_GROUPS;   // chains of eight edges
+    uint2 pm[NCH], pn[NCH];
 #pragma unroll
     for (int g = 0; g < DEC_GROUPS; g++) {
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
+            if (k == 0 || k == 4) {
+                pm[2 * g + k / 4] = am;
+                pn[2 * g + k / 4] = an;
+            }
             compose4(am, an, c[g][k], c[g][k + 1]);
             seen |= routes_of(c[g][k]) | routes_of(c[g][k + 1]);
         }
@@ -493,36 +545,46 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
     const QMaps excl = block_exclusive<ComposeQ>(agg, lds, total);
     // the map from the run-in's first edge to this thread's first: constant for a decoder = its state here is known whatever came before
     const QMaps upto = ComposeQ::op(runin, excl);
-    uint32_t st = ComposeQ::step(upto, state0);
     const uint32_t dep = ((seen & 1u) && !map8_constant(upto.mil) ? 1u : 0u) | ((seen & 2u) && !map8_constant(upto.man) ? 2u : 0u);
     if (blockIdx.x > 0 && dep) atomicOr(&s_needs, dep);   // (rare; tile 0 starts from the carried state itself)
+    // The walk: one table look-up per edge from the state before it -- a chain of dependent LDS reads.  A thread's 32 edges are
+    // FOUR chains of eight, each started from the state the maps composed above give it, and walked side by side.
+    uint32_t st[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; j++) st[j] = ComposeQ::step(ComposeQ::op(upto, QMaps{{pm[j].x, pm[j].y}, {pn[j].x, pn[j].y}}), state0);
     TP_MARK();   // 3: block scans, incoming states
     const uint16_t *mil = LDS ? s_mil : T.qmil_step;
     const uint16_t *man = LDS ? s_man : T.man_step;
-    FramePk mine = FramePkOp::identity();
+    uint32_t ow[DEC_GROUPS][4];
 #pragma unroll
-    for (int g = 0; g < DEC_GROUPS; g++) {
-        uint32_t ow[4] = {0u, 0u, 0u, 0u};
+    for (int g = 0; g < DEC_GROUPS; g++) ow[g][0] = ow[g][1] = ow[g][2] = ow[g][3] = 0u;
 #pragma unroll
-        for (int k = 0; k < DEC_ITEMS; k++) {
+    for (int e = 0; e < 8; e++) {
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            const int g = j >> 1, k = (j & 1) * 8 + e;
             const uint32_t code = (c[g][k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
             const uint32_t li = code & 0x3FFFu, route = code >> 14;
             uint32_t w = 0;
             if (route == 2u && T.reader) {
-                const uint32_t e = mil[li * 8u + (st & 7u)];
-                w = e >> 8;
-                st = (st & ~15u) | (e & 15u);
+                const uint32_t en = mil[li * 8u + (st[j] & 7u)];
+                w = en >> 8;
+                st[j] = (st[j] & ~15u) | (en & 15u);
             } else if (route == 1u && T.tag) {
-                const uint32_t e = man[li * 8u + ((st >> 4) & 7u)];
-                const uint32_t m = e >> 8;
+                const uint32_t en = man[li * 8u + ((st[j] >> 4) & 7u)];
+                const uint32_t m = en >> 8;
                 w = (m & 3u) ? ((m & 0xFCu) | 3u) : 0u;
-                st = (st & 15u) | ((e & 15u) << 4);
+                st[j] = (st[j] & 15u) | ((en & 15u) << 4);
             }
-            ow[k >> 2] |= w << (8 * (k & 3));
+            ow[g][k >> 2] |= w << (8 * (k & 3));
         }
+    }
+    FramePk mine = FramePkOp::identity();
+#pragma unroll
+    for (int g = 0; g < DEC_GROUPS; g++) {
         const size_t gb = base + (size_t)DEC_ITEMS * g;
-        if (gb < n) *(uint4 *)(outw + gb) = make_uint4(ow[0], ow[1], ow[2], ow[3]);   // outw has 16 bytes of slack
-        mine = FramePkOp::op(mine, FramePkOp::pack(frame_agg_of(ow)));
+        if (gb < n) *(uint4 *)(outw + gb) = make_uint4(ow[g][0], ow[g][1], ow[g][2], ow[g][3]);   // outw has 16 bytes of slack
+        mine = FramePkOp::op(mine, FramePkOp::pack(frame_agg_of(ow[g])));
     }
     TP_MARK();   // 4: the walk
     FramePk total_fa;
@@ -602,6 +664,9 @@ struct FrameOut {
     uint32_t cap_bits[2], cap_close[2];
     const uint8_t *pending[2];   // the open packets' bits of earlier batches (workgroup 0 puts them in front)
     uint32_t pend[2], started_in[2];
+    // (the multi-launch stage: bits[t] holds WORDS, bit i of the stream at word i / 32, bit i % 32; cap_bits counts bits as ever.
+    // The one-launch stage of short batches keeps a byte per bit.  The symbol arrays are only written when somebody reads
+    // them: k_symbols_write.)
 };
 __device__ __forceinline__ void copy_pending(const FrameOut &P, int tid, int nthreads) {
 #pragma unroll
@@ -696,6 +761,16 @@ struct DecCarryEpilogue {
 };
 
 // (V.spec set: the grid has ONE workgroup more, in front -- the check of the speculative decode, dec_verify, beside the tiles)
+constexpr int FW_WORDS = DEC_TILE * 2 / 32 + 4;   // bit words of a tile in LDS: two symbols per edge at most, the tile's phase in its first word
+__device__ __forceinline__ void pack_pending(const FrameOut &P, int tid, int nthreads) {   // the open packets' bits of earlier batches go in front
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (!P.bits[t]) continue;
+        uint32_t *gb = (uint32_t *)P.bits[t];
+        for (uint32_t i = tid; i < P.pend[t] && i < P.cap_bits[t]; i += nthreads)
+            if (P.pending[t][i] & 1u) atomicOr(gb + (i >> 5), 1u << (i & 31));
+    }
+}
 __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw, size_t n, const uint32_t *n_dev, const FrameAgg *tile_pre,
                                                            const FramePk *thread_aggs, FrameOut P, bool own_prefix, FrameAgg *total_out,
                                                            DecCarryEpilogue epi, DecVerify V) {
@@ -708,7 +783,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
         }
     }
     const uint32_t bid = blockIdx.x - (V.spec ? 1u : 0u);   // the tile
-    if (bid == 0) copy_pending(P, threadIdx.x, SCAN_BLOCK);
+    if (bid == 0) pack_pending(P, threadIdx.x, SCAN_BLOCK);
     if (own_prefix && n == 0 && bid == 0 && threadIdx.x == 0) {
         *total_out = FrameAggOp::identity();
         epi(FrameAggOp::identity());
@@ -717,6 +792,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
     TP_DECL();
     __shared__ FramePk lds[SCAN_WAVES];
     __shared__ FrameAgg lds_pre[SCAN_WAVES];
+    __shared__ uint32_t s_bits[2][FW_WORDS];
+    for (int i = threadIdx.x; i < 2 * FW_WORDS; i += SCAN_BLOCK) (&s_bits[0][0])[i] = 0u;   // (the scans' barriers come before the first or)
     // own_prefix: tile_pre still holds the tiles' aggregates (scan.hip.h: tile_prefix; first, while few registers are live)
     const FrameAgg pre = own_prefix ? tile_prefix<FrameAggOp, SCAN_BLOCK>(tile_pre, bid, lds_pre) : tile_pre[bid];
     const size_t base = ((size_t)bid * SCAN_BLOCK + threadIdx.x) * DEC_PER_THREAD;
@@ -726,7 +803,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
     for (int g = 0; g < DEC_GROUPS; g++) {
         ow[g][0] = ow[g][1] = ow[g][2] = ow[g][3] = 0u;
         const size_t gb = base + (size_t)DEC_ITEMS * g;
-        if (gb < n) {   // k_dec_apply wrote whole 16-byte groups, zero past n
+        if (gb < n) {   // the decode pass wrote whole 16-byte groups, zero past n
             const uint4 a = *(const uint4 *)(outw + gb);
             ow[g][0] = a.x; ow[g][1] = a.y; ow[g][2] = a.z; ow[g][3] = a.w;
         }
@@ -734,24 +811,125 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
     const uint4 m4 = *(const uint4 *)(thread_aggs + (size_t)bid * SCAN_BLOCK + threadIdx.x);
     FramePk total;
     const FramePk in_tile = block_exclusive<FramePkOp>(FramePk{{m4.x, m4.y}, {m4.z, m4.w}}, lds, total);
-    // (staging the tile's symbols and bits in LDS to store whole words measured slower: 32 vs 26 us)
+    const FrameAgg all = FrameAggOp::op(pre, FramePkOp::unpack(total));
     // (own_prefix: the last tile publishes the total and the carries)
     if (own_prefix && threadIdx.x == 0 && ((size_t)bid + 1) * DEC_TILE >= n) {
-        const FrameAgg all = FrameAggOp::op(pre, FramePkOp::unpack(total));
         *total_out = all;
         epi(all);
     }
-    // a thread's groups in order: each starts from everything before it
     TP_MARK();   // 2: loads + block scan
+    // a thread's groups in order, each from everything before it: the appended bits squeezed together (compress32), up to 64 of
+    // them per thread and packet type, then or-ed into the tile's words in LDS at the phase the tile has in the stream
     FrameAgg before = FrameAggOp::op(pre, FramePkOp::unpack(in_tile));
+    uint64_t acc[2] = {0ull, 0ull};
+    uint32_t cnt[2] = {0u, 0u}, bo0[2], tile_bit0[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        bo0[t] = P.pend[t] + fa_bits(before, t, P.started_in[t]);        // the thread's first bit in the stream
+        tile_bit0[t] = P.pend[t] + fa_bits(pre, t, P.started_in[t]);     // the tile's
+    }
 #pragma unroll
     for (int g = 0; g < DEC_GROUPS; g++) {
         if (ow[g][0] | ow[g][1] | ow[g][2] | ow[g][3]) {
-            frame_write(P, before, ow[g], base + (size_t)DEC_ITEMS * g);
+            const SlotMasks m = slot_masks(ow[g]);
+            const uint32_t low = symbol_low_bits(ow[g]);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (!m.V[t] || !P.bits[t]) continue;
+                const uint32_t started = pm_apply(before.fl[t], P.started_in[t]);
+                const uint32_t bef = started_before(m, t, started);
+                const uint32_t appended = m.V[t] & ~m.ST[t] & (bef | ~m.SA[t]);
+                uint32_t cl = m.ST[t] & bef;
+                const uint32_t bo = bo0[t] + cnt[t];
+                acc[t] |= (uint64_t)compress32(low, appended) << cnt[t];
+                cnt[t] += (uint32_t)__popc(appended);
+                if (cl) {   // packet ends: rare (one per frame)
+                    const uint32_t co = fa_closes(before, t, P.started_in[t]);
+                    const uint32_t closes = cl;
+                    while (cl) {
+                        const uint32_t lowb = cl & (0u - cl);
+                        const int k = (__ffs((int)cl) - 1) >> 1;
+                        cl ^= lowb;
+                        const uint32_t j = co + (uint32_t)__popc(closes & (lowb - 1u));
+                        if (j < P.cap_close[t]) {
+                            P.close_end[t][j] = bo + (uint32_t)__popc(appended & (lowb - 1u));
+                            const size_t e = base + (size_t)DEC_ITEMS * g + k;
+                            P.close_idx[t][j] = P.idx64 ? P.idx64[e] : P.g0 + (uint64_t)P.epos[e];
+                        }
+                    }
+                }
+            }
             if (g + 1 < DEC_GROUPS) before = FrameAggOp::op(before, frame_agg_of(ow[g]));
         }
     }
-    TP_DONE(3);   // 3: the scatter
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (!cnt[t]) continue;
+        const uint32_t lb = (tile_bit0[t] & 31u) + (bo0[t] - tile_bit0[t]);   // the thread's first bit in the tile's words
+        const uint32_t w = lb >> 5, sh = lb & 31u;
+        const uint64_t lo = acc[t] << sh;
+        const uint32_t hi = sh ? (uint32_t)(acc[t] >> (64u - sh)) : 0u;
+        if (w + 2 < (uint32_t)FW_WORDS) {
+            if ((uint32_t)lo) atomicOr(&s_bits[t][w], (uint32_t)lo);
+            if ((uint32_t)(lo >> 32)) atomicOr(&s_bits[t][w + 1], (uint32_t)(lo >> 32));
+            if (hi) atomicOr(&s_bits[t][w + 2], hi);
+        }
+    }
+    TP_MARK();   // 3: compress + or
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (!P.bits[t]) continue;
+        const uint32_t nbits = P.pend[t] + fa_bits(all, t, P.started_in[t]) - tile_bit0[t];   // the tile's appended bits
+        if (!nbits) continue;
+        uint32_t *gb = (uint32_t *)P.bits[t];
+        const uint32_t w0 = tile_bit0[t] >> 5, nw = ((tile_bit0[t] & 31u) + nbits + 31u) >> 5, capw = (P.cap_bits[t] + 31u) >> 5;
+        for (uint32_t j = threadIdx.x; j < nw; j += SCAN_BLOCK) {
+            if (w0 + j >= capw) break;   // (an estimate too small: the host sees it in the totals and repeats the stage with room)
+            const uint32_t v = s_bits[t][j];
+            if (j == 0 || j == nw - 1) atomicOr(gb + w0 + j, v);   // (words shared with the neighbouring tiles, or with the pending bits)
+            else gb[w0 + j] = v;
+        }
+    }
+    TP_DONE(3);   // 4: the stores
+}
+
+// The symbol arrays (what the decoders emitted, error codes included: the reference hands them to PacketProcessor.append_bit and
+// keeps nothing) are written when somebody asks for them -- nfc_read_symbols -- from what the decode pass left per edge.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_symbols_write(const uint8_t *outw, size_t n, const uint32_t *n_dev, const FrameAgg *tile_pre,
+                                                             const FramePk *thread_aggs, FrameOut P, bool own_prefix) {
+    if (n_dev) n = min(n, (size_t)*n_dev);
+    if ((size_t)blockIdx.x * DEC_TILE >= n) return;
+    __shared__ FramePk lds[SCAN_WAVES];
+    __shared__ FrameAgg lds_pre[SCAN_WAVES];
+    const FrameAgg pre = own_prefix ? tile_prefix<FrameAggOp, SCAN_BLOCK>(tile_pre, blockIdx.x, lds_pre) : tile_pre[blockIdx.x];
+    const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_PER_THREAD;
+    const uint4 m4 = *(const uint4 *)(thread_aggs + (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x);
+    FramePk total;
+    const FramePk in_tile = block_exclusive<FramePkOp>(FramePk{{m4.x, m4.y}, {m4.z, m4.w}}, lds, total);
+    FrameAgg before = FrameAggOp::op(pre, FramePkOp::unpack(in_tile));
+#pragma unroll
+    for (int g = 0; g < DEC_GROUPS; g++) {
+        const size_t gb = base + (size_t)DEC_ITEMS * g;
+        if (gb >= n) break;
+        const uint4 a = *(const uint4 *)(outw + gb);
+        const uint32_t ow[4] = {a.x, a.y, a.z, a.w};
+        if (!(ow[0] | ow[1] | ow[2] | ow[3])) continue;
+        const SlotMasks m = slot_masks(ow);
+        const uint64_t lo = (uint64_t)ow[0] | ((uint64_t)ow[1] << 32), hi = (uint64_t)ow[2] | ((uint64_t)ow[3] << 32);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            uint32_t v = m.V[t], off = before.cnt[t];
+            while (v) {
+                const int slot = __ffs((int)v) - 1, k = slot >> 1;
+                v &= v - 1u;
+                const uint32_t byte = (uint32_t)((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFFu;
+                if (off + 1 < P.cap_sym[t]) P.sym[t][off] = (uint8_t)((byte >> ((slot & 1) ? 5 : 2)) & 7u);
+                off++;
+            }
+        }
+        before = FrameAggOp::op(before, frame_agg_of(ow));
+    }
 }
 
 // After framing: keep the open packets' bits for the next batch and publish the carry.  Reads nothing that it (or a
@@ -772,6 +950,7 @@ struct PktFinish {
     uint32_t *mirror_dst;         // the host mirror as the device sees it
     uint32_t mirror_words;
     uint32_t stamp_word, stamp;   // the batch's number, written into word stamp_word of the mirror: this launch wrote it
+    int32_t packed;               // bits[t] holds words (the multi-launch stage), not a byte per bit
 };
 __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
     for (int t = 0; t < 2; t++) {
@@ -781,7 +960,9 @@ __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
         if (nbits > F.cap_bits[t] || ncl > F.cap_close[t]) continue;   // the host repeats the stage with room
         const uint32_t from = ncl ? F.close_end[t][ncl - 1] : 0u;
         const uint32_t keep = nbits - from;
-        for (uint32_t i = threadIdx.x; i < keep && i < F.pending_cap[t]; i += blockDim.x) F.pending_next[t][i] = F.bits[t][from + i];
+        const uint32_t *bw = (const uint32_t *)F.bits[t];
+        for (uint32_t i = threadIdx.x; i < keep && i < F.pending_cap[t]; i += blockDim.x)
+            F.pending_next[t][i] = F.packed ? (uint8_t)((bw[(from + i) >> 5] >> ((from + i) & 31u)) & 1u) : F.bits[t][from + i];
         if (threadIdx.x == 0) {
             F.carry->pending[t] = keep;
             F.carry->pkt_started[t] = (int32_t)pm_apply(F.frame_total->fl[t], (uint32_t)F.started_in[t]);

@@ -238,12 +238,20 @@ struct EdgeAggOp {
     }
 };
 // one word's aggregate from its change mask (w0: its first sample)
-__device__ __forceinline__ EdgeAgg word_agg(const EdgeArgs &A, int32_t w0, uint64_t m) {
+// (a run inside the word can only time out between the word's first and last change, and only if they lie more than max_len apart)
+__device__ __forceinline__ bool word_may_time_out(const EdgeArgs &A, uint64_t m) {
+    return m && (63 - __clzll((long long)m)) - (__ffsll((long long)m) - 1) > A.mx;
+}
+// inner: some lane of the wave holds a word in which a run may time out (word_may_time_out) -- the count is skipped wave-wide
+// otherwise: inside frames the changes lie closer than max_len, in the gaps between them a word has none
+__device__ __forceinline__ EdgeAgg word_agg(const EdgeArgs &A, int32_t w0, uint64_t m, bool inner = true) {
     if (!m) return EdgeAgg{POS_NONE, Last2{POS_NONE, POS_NONE}, 0u};
     const int b0 = __ffsll((long long)m) - 1, b1 = 63 - __clzll((long long)m);
     const uint64_t m2 = m & ~(1ull << b1);
     uint32_t sum = (uint32_t)__popcll(m);
-    if (A.mx >= 32) {
+    if (!inner) {
+        // (uniform: no word of this wave has two changes more than max_len apart)
+    } else if (A.mx >= 32) {
         if (A.mx < 63) {
             // a run inside the word can time out at most once (2 max_len > 63): count the stretches of max_len or more
             // samples without a change between the word's first and last change.  x marks the samples that begin
@@ -349,8 +357,12 @@ __device__ __forceinline__ void edge_reduce_super(const EdgeArgs &A, size_t nwor
     uint64_t ng[ES_ITEMS], ps[ES_ITEMS], m[ES_ITEMS];
     load_words<ES_ITEMS>(A, w, nwords, ng, ps, m);
     EdgeAgg agg = op.identity();
+    bool may = false;
 #pragma unroll
-    for (int i = 0; i < ES_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w + i) * 64), m[i]));
+    for (int i = 0; i < ES_ITEMS; i++) may = may || word_may_time_out(A, m[i]);
+    const bool inner = __any(may);
+#pragma unroll
+    for (int i = 0; i < ES_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w + i) * 64), m[i], inner));
     const EdgeAgg inc = wave_inclusive_with(op, agg);
     if (lane == 63) {
         lds[wave] = inc;
@@ -441,7 +453,33 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
     const int val_before = load_words<EW_ITEMS>(A, w_first, nwords, ng, ps, m);
     EdgeAgg pre;
     if (own_prefix) {
-        pre = tile_prefix_with<SCAN_BLOCK>(op, partials, blockIdx.x, s_agg);
+        // The tile's prefix: the super-aggregates of the groups before its own (one per EW_SUPER tiles, left by the reduce pass) and
+        // the sibling tiles before it in its group -- folded by ONE wave (round 4; all four waves folded the tiles' own aggregates
+        // before and joined in a block scan: this kernel is bound by the number of vector instructions it issues, and three of the
+        // four waves' shares of them are gone; the other waves' words are in flight meanwhile)
+        __shared__ EdgeAgg s_pre;
+        if (threadIdx.x < 64) {
+            const uint32_t g = blockIdx.x / EW_SUPER, q = blockIdx.x % EW_SUPER;
+            const uint32_t per = (g + 63u) / 64u;
+            const uint32_t lo = min(g, (uint32_t)threadIdx.x * per), hi = min(g, lo + per);
+            EdgeAgg acc = op.identity();
+            for (uint32_t i = lo; i < hi; i += 4) {   // four loads in flight per lane
+                EdgeAgg v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = (i + k < hi) ? supers[i + k] : op.identity();
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc = op(acc, v[k]);
+            }
+            EdgeAgg sib[EW_SUPER - 1];
+#pragma unroll
+            for (int k = 0; k < EW_SUPER - 1; k++) sib[k] = (uint32_t)k < q ? partials[(size_t)g * EW_SUPER + k] : op.identity();
+            EdgeAgg tot = wave_inclusive_with(op, acc);   // (lane 63: all groups before this tile's)
+#pragma unroll
+            for (int k = 0; k < EW_SUPER - 1; k++) tot = op(tot, sib[k]);
+            if (threadIdx.x == 63) s_pre = tot;
+        }
+        __syncthreads();
+        pre = s_pre;
     } else {
         // (the prefix launch scanned the super-aggregates: the group's prefix, then the sibling tiles before this one)
         const uint32_t g = blockIdx.x / EW_SUPER, q = blockIdx.x % EW_SUPER;
@@ -455,8 +493,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
     const uint32_t gbase = entries_before(A, pre, (int32_t)(wt * 64));
     TP_MARK();   // 1: words + tile prefix
     EdgeAgg agg = op.identity();
+    bool may = false;
 #pragma unroll
-    for (int i = 0; i < EW_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w_first + i) * 64), m[i]));
+    for (int i = 0; i < EW_ITEMS; i++) may = may || word_may_time_out(A, m[i]);
+    const bool inner = __any(may);
+#pragma unroll
+    for (int i = 0; i < EW_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w_first + i) * 64), m[i], inner));
     EdgeAgg tile_total;
     const EdgeAgg before = op(pre, block_exclusive_with<SCAN_WAVES>(op, agg, s_agg, tile_total));
     const EdgeAgg all = op(pre, tile_total);

@@ -97,6 +97,11 @@ struct nfc_ctx {
     // after a batch whose check failed the next batches take the three-launch form (spec_off_left counts them down)
     bool dec_spec = true, dec_spec_now = false;
     int dec_runin = 2, spec_off_left = 0;
+    // what the decode stage left for the readers: packet bits packed 32 to a word (the multi-launch stage) or a byte each (short
+    // batches); symbol arrays not written yet (materialize_symbols: on the first nfc_read_symbols)
+    bool bits_packed = false, sym_lazy = false, sym_own = false;
+    FrameOut sym_P;
+    uint32_t sym_n = 0, sym_tiles = 0;
     uint32_t decode_respeculated = 0;   // batches whose decode stage was repeated with the three-launch form (nfc_stats)
     int lean = 1, lean_k = 0, lean_rounds = 0, lean_slots = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
     int wg = 1, wg_ok = 0, wg_nr = 4, wg_d = 1, wg_slots = 0, wg_slots_ahead = 0, wg_now = 0, wg_rounds = 0;

@@ -130,23 +130,30 @@ int run_decode(nfc_ctx *c, bool force_classic = false) {
                          {P.pend[0], P.pend[1]}, {P.started_in[0], P.started_in[1]}, {c->T.canon[0], c->T.canon[1], c->T.canon[2], c->T.canon[3]}};
     const uint32_t spec_state_in = mil_class_in | ((uint32_t)c->h_dcarry.man_state << 4);
     DecVerify V{nullptr, spec_state_in, {c->T.q_rep[0], c->T.q_rep[1]}, dD(c), (uint32_t *)(tot + TOT_SPEC)};
+    // the packed bit arrays are or-ed into: the stage's first launch clears them
+    ZeroJob Z;
+    for (int t = 0; t < 2; t++) {
+        Z.p[t] = (uint32_t *)P.bits[t];
+        Z.n[t] = P.bits[t] ? (P.cap_bits[t] + 31u) / 32u + 1u : 0u;
+        if (!tiles && Z.n[t]) HIPCHK(c, hipMemsetAsync(Z.p[t], 0, (size_t)Z.n[t] * 4, c->st));
+    }
     if (spec) {
         HIPCHK(c, c->d_spec.ensure((tiles + 1) * sizeof(DecSpec)));
         V.spec = c->d_spec.as<DecSpec>();
         if (tiles) {
             if (lds_tables)
                 NFC_LAUNCH(k_dec_spec<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, spec_state_in, c->dec_runin, outw,
-                           fparts, c->d_faggs.as<FramePk>(), c->d_spec.as<DecSpec>());
+                           fparts, c->d_faggs.as<FramePk>(), c->d_spec.as<DecSpec>(), Z);
             else
                 NFC_LAUNCH(k_dec_spec<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, spec_state_in, c->dec_runin, outw,
-                           fparts, c->d_faggs.as<FramePk>(), c->d_spec.as<DecSpec>());
+                           fparts, c->d_faggs.as<FramePk>(), c->d_spec.as<DecSpec>(), Z);
         }
     } else {
         if (tiles) {
             if (lds_tables)
-                NFC_LAUNCH(k_dec_reduce<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
+                NFC_LAUNCH(k_dec_reduce<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs, Z);
             else
-                NFC_LAUNCH(k_dec_reduce<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs);
+                NFC_LAUNCH(k_dec_reduce<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, dparts, daggs, Z);
         }
         if (!own) scan_partials<ComposeDec>(c->st, tiles, ne_dev, DEC_TILE, dparts, ComposeDec::identity_host(), map_total);
         if (tiles) {
@@ -161,9 +168,16 @@ int run_decode(nfc_ctx *c, bool force_classic = false) {
     if (!own) scan_partials<FrameAggOp>(c->st, tiles, ne_dev, DEC_TILE, fparts, FrameAggOp::identity(), frame_total, epi);
     NFC_LAUNCH(k_frame_write, dim3((unsigned)(std::max<size_t>(tiles, 1) + (spec ? 1 : 0))), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts,
                        c->d_faggs.as<FramePk>(), P, own, frame_total, epi, V);
+    c->bits_packed = true;
+    c->sym_lazy = true;          // the symbol arrays are written when nfc_read_symbols asks for them (materialize_symbols)
+    c->sym_P = P;
+    c->sym_n = ce;
+    c->sym_tiles = (uint32_t)tiles;
+    c->sym_own = own;
     const int pn = 1 - c->pend_cur;
     PktFinish F;
     memset(&F, 0, sizeof F);
+    F.packed = 1;
     for (int t = 0; t < 2; t++) {
         F.enabled[t] = enabled[t] ? 1 : 0;
         F.bits[t] = P.bits[t];
@@ -202,6 +216,18 @@ void note_respeculation(nfc_ctx *c) {
 }
 void spec_batch_done(nfc_ctx *c) {
     if (!c->dec_spec_now && c->spec_off_left > 0) c->spec_off_left--;
+}
+
+// the symbol arrays of the last batch, on demand (decode.hip.h: k_symbols_write)
+int materialize_symbols(nfc_ctx *c) {
+    if (!c->sym_lazy) return NFC_OK;
+    c->sym_lazy = false;
+    if (!c->sym_tiles) return NFC_OK;
+    NFC_LAUNCH(k_symbols_write, dim3(c->sym_tiles), dim3(SCAN_BLOCK), 0, c->st, c->d_states.as<uint8_t>(), (size_t)c->sym_n,
+               (const uint32_t *)(dT(c) + TOT_EDGES), c->d_partials2.as<FrameAgg>(), c->d_faggs.as<FramePk>(), c->sym_P, c->sym_own);
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    BATCHCHK(c, false);
+    return NFC_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -256,6 +282,8 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     A.stamp_word = (uint32_t)(offsetof(DevState, seq) / 4 + 1);
     A.stamp = c->stamp_b;
     c->dec_spec_now = false;
+    c->bits_packed = false;   // (the one-launch stage keeps a byte per bit and writes the symbols itself)
+    c->sym_lazy = false;
     NFC_LAUNCH(k_small_stage, dim3(1), dim3(SM_BLOCK), 0, c->st, A);
     return NFC_OK;
 }

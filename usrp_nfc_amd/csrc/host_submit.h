@@ -64,6 +64,7 @@ int enqueue_threshold_ahead(nfc_ctx *c, nfc_ctx::Submitted &b) {
     launch_threshold_kind(c, A, P.nch, true, b.timed ? c->kev_sub[b.slot] : nullptr);
     const uint32_t np = P.nch - 1;
     A.nlist = np;
+    A.ver_zero = 1;   // (pass 0 only: every summary is in buffer 0)
     NFC_LAUNCH(k_certify, dim3(cert_grid(np)), dim3(256), 0, c->st, A, P.d_cert, (CertInfo *)nullptr,
                c->d_ring[(b.ring_in + 1) % NRING].as<float>(), dC(c), A.sum);
     hipError_t e = hipMemcpyAsync(c->hs_a[b.slot], c->d_state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->st);

@@ -290,6 +290,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 A.list = c->d_list.as<uint32_t>();
             }
             A.nlist = np;
+            A.ver_zero = first_round ? 1 : 0;   // (pass 0 wrote every chunk's summary into buffer 0: k_fill zeroed the version bytes)
             if (dbg) HIPCHK(c, c->d_certinfo.ensure((size_t)nch * sizeof(CertInfo)));
             // the first round also resolves the end-of-batch state (last workgroup) and leaves its verdict as a
             // summary in the mirrored state block; later rounds (after re-runs) read the per-chunk flags
@@ -363,6 +364,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             }
             if (failing.empty()) break;
             first_round = false;
+            A.ver_zero = 0;
             // A chunk right behind one that is re-run now and that did not give up itself is NOT re-run in this round: its own
             // evaluation may well be sound -- what failed is the comparison with a predecessor whose summary was worthless -- and
             // from the state resolved now it would only be evaluated against that worthless summary again.  It stays pending
@@ -470,6 +472,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
         if (!exact || flagged) need_seq = true;
     }
 
+    A.ver_zero = 0;
     *need_seq_out = need_seq;
     if (!need_seq) {
         // the end-of-batch ring was resolved beside the last certification unless chunks were re-run after it

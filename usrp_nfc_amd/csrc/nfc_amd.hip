@@ -662,6 +662,9 @@ int nfc_read_edges_compact(nfc_ctx *c, size_t first, uint32_t *pos_out, uint16_t
 int nfc_read_symbols(nfc_ctx *c, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out) {
     LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || type < 0 || type > 1) return NFC_ERR_ARG;
+    if (c->have_outputs && c->sym_lazy) {
+        if (int rc = materialize_symbols(c)) return rc;
+    }
     return read_range(c, c->d_sym[type].p, c->n_sym[type], 1, first, out, cap, n_out);
 }
 
@@ -681,7 +684,23 @@ int nfc_read_packets(nfc_ctx *c, int type, nfc_packet *out, size_t cap, size_t *
 int nfc_read_packet_bits(nfc_ctx *c, int type, size_t first, uint8_t *out, size_t cap, size_t *n_out) {
     LaunchScope launch_scope_(c ? &c->launch_err : nullptr);
     if (!c || type < 0 || type > 1) return NFC_ERR_ARG;
-    return read_range(c, c->d_bits[type].p, c->n_bits[type], 1, first, out, cap, n_out);
+    if (!c->bits_packed) return read_range(c, c->d_bits[type].p, c->n_bits[type], 1, first, out, cap, n_out);
+    // the multi-launch stage leaves the bits packed, 32 to a word (decode.hip.h: k_frame_write): fetch the words, hand out a byte per bit
+    if (!c->have_outputs) return fail(c, NFC_ERR_STATE, "no completed batch");
+    size_t n = 0;
+    if (first < c->n_bits[type]) n = std::min(cap, (size_t)c->n_bits[type] - first);
+    if (n && !out) return fail(c, NFC_ERR_ARG, "null output");
+    if (n) {
+        const size_t w0 = first >> 5, w1 = (first + n + 31) >> 5;
+        std::vector<uint32_t> w(w1 - w0);
+        HIPCHK(c, hipMemcpy(w.data(), c->d_bits[type].as<uint32_t>() + w0, (w1 - w0) * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) {
+            const size_t b = first + i - (w0 << 5);
+            out[i] = (uint8_t)((w[b >> 5] >> (b & 31)) & 1u);
+        }
+    }
+    if (n_out) *n_out = n;
+    return NFC_OK;
 }
 
 int nfc_read_val(nfc_ctx *c, size_t first, int8_t *out, size_t cap, size_t *n_out) {

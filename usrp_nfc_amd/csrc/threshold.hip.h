@@ -134,6 +134,7 @@ struct ThrArgs {
     int32_t ksteps;        // steps per superstep
     float gfac, gfloor;    // drift allowance = max(gfac * (largest B needed so far), gfloor * ss)
     int32_t blk;           // a LOW run longer than max_len covers an aligned block of blk samples (a power of two)
+    int32_t ver_zero;              // every version byte is 0 (the certification right behind pass 0): its launches need not load them
     unsigned long long *dbg_clk;   // debugging aid (NFC_DEBUG_CLK): per chunk four s_memtime stamps -- start, incoming state ready, loop done, end
 };
 
@@ -1069,7 +1070,7 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
     // a thread's slots in rounds of eight: the common case (the last chunk accepted a sample into the slot) is two
     // loads per slot, all sixteen in flight at once; only slots it left untouched walk further back
     const int last = A.nchunks - 1;
-    const int vb = A.ver[last];
+    const int vb = A.ver_zero ? 0 : A.ver[last];
     const uint32_t *tw = A.touched[vb] + (size_t)last * A.twords;
     const float *ro = A.ring_out[vb] + (size_t)last * A.L;
     for (int s0 = tid; s0 < A.L; s0 += 8 * FIN_BLOCK) {
@@ -1180,7 +1181,7 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     const int tid = (int)threadIdx.x;
     const float *rin = A.ring_in + (size_t)c * L;
     const RunMeta mt = A.meta[c];
-    const int vb = A.ver[c - 1];
+    const int vb = A.ver_zero ? 0 : A.ver[c - 1];   // (a load the two below would have to wait for)
     const uint32_t *tw = A.touched[vb] + (size_t)(c - 1) * A.twords;
     const float *ro = A.ring_out[vb] + (size_t)(c - 1) * L;
     float d = 0.f;
