@@ -495,6 +495,12 @@ def stress_config(a, name, n, steps=6):
                     'stress_hover': 'tag load modulation at mag^2 x 1.10 = hi_val exactly, five times the noise, drop-outs and level steps: '
                                     'every loaded half bit hovers at the HIGH threshold, no chunk of the speculative pass can be certified'}[name]}
     with api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **stream_params('all'), **decoder_flags('all')) as ctx:
+        # (one batch of the CLEAN -t all capture first: the context's buffers exist and it cuts its batches for a clean stream --
+        # first_step_ms below is then what finding out about the regime costs, not what hipMalloc costs)
+        clean = api.DeviceBuffer(synth.workload('all', n))
+        ctx.push_device(clean, n)
+        ctx.sync()
+        clean.free()
         ts = []
         for k in range(steps):
             ctx.reset()
@@ -504,8 +510,9 @@ def stress_config(a, name, n, steps=6):
             ctx.sync()
             ts.append(time.perf_counter() - t0)
         st = ctx.stats()
-        # (the first step is the stream's first batch in this regime, on the chunking of a clean stream; the context then cuts its
-        # batches four times finer for as long as they need re-runs -- host_threshold.h: fine_left -- which is what the median shows)
+        # (the first step is the stream's first batch in this regime: pass 0 runs on the clean stream's chunking, its verdict says the
+        # stream needs re-runs, and the batch is cut four times finer there and then -- host_threshold.h: recut; the context keeps the
+        # fine cut for as long as batches need re-runs, fine_left -- which is what the median shows)
         out.update({'ms_per_step': float(np.median(ts[1:])) * 1e3, 'steps': steps - 1, 'first_step_ms': ts[0] * 1e3,
                     'threshold_passes': int(st.threshold_passes), 'chunks_rerun': int(st.chunks_rerun), 'n_chunks': int(st.n_chunks),
                     'chunk_samples': int(st.chunk_samples), 'used_sequential': int(st.used_sequential)})

@@ -748,7 +748,7 @@ def test_workgroup_kernel_two_rounds_ahead(monkeypatch):
 
 def test_chunking_adapts_to_a_stream_that_needs_reruns(monkeypatch):
     # A stream whose batches need re-runs (level steps behind losses of signal: the chunk with the step gives up, the one behind it
-    # cannot be certified) is cut four times finer from the next batch on -- a re-run pass is one wave walking a chunk -- and goes back
+    # cannot be certified) is cut four times finer -- from the batch that found out on: a re-run pass is one wave walking a chunk -- and goes back
     # to the clean stream's chunking after eight batches without a re-run.  Same stream, synchronous pushes and batches submitted
     # ahead mixed: the outputs are the single stream's whatever the chunking.
     monkeypatch.setenv('NFC_WG_PER_CU', '1')   # (a chunk per CU: batches of a test's size are then cut well above the smallest chunk)
@@ -784,6 +784,8 @@ def test_chunking_adapts_to_a_stream_that_needs_reruns(monkeypatch):
     assert d is None, 'transition %s' % (d,)
     assert s0 == o.symbols(0).tolist() and s1 == o.symbols(1).tolist() and pk == o.packets()
     assert reruns[0] > 0 and reruns[1] > 0 and reruns[2] > 0 and sum(reruns[4:]) == 0, reruns
-    assert chunks[1] * 2 <= chunks[0] and chunks[2] == chunks[1], chunks   # cut finer after the first dirty batch
+    # (round 4: the FIRST dirty batch is cut finer too -- pass 0's verdict says the stream needs re-runs, and pass 0 is run again on
+    # the fine cut instead of re-running long chunks one wave each)
+    assert chunks[0] == chunks[1] == chunks[2], chunks
     assert chunks[4] == chunks[1], chunks                                  # ... and still, two clean batches later
-    assert chunks[-1] == chunks[0], chunks                                 # back after eight without a re-run
+    assert chunks[0] * 2 <= chunks[-1], chunks                             # back on the clean stream's cut after eight without a re-run

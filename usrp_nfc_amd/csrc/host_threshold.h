@@ -36,6 +36,11 @@ struct ThrPlan {
     bool lean_applies;
     uint8_t *d_cert, *d_gflags, *d_gmin, *d_gmax;
     const uint8_t *h_cert, *h_gflags, *h_gmin, *h_gmax;
+    // pinned staging behind the flag sections (one block, c->h_cflags): the chunks' sum bounds as the device left them, and what the
+    // rounds of re-runs send down -- version bytes, the list of chunks to re-run, the list to certify (copies from pageable
+    // memory are staged by the runtime, 20 us apiece: measured as the gaps between a round's launches)
+    uint32_t *h_gvtop, *h_list_a, *h_list_b;
+    uint8_t *h_ver;
 };
 static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all, uint32_t skip, uint32_t base, uint64_t nseen,
                        const EdgeCarry &ec, int ring_in, DevBuf &planes_neg, DevBuf &planes_pos, bool low_on_device, ThrArgs &A, ThrPlan &P) {
@@ -78,26 +83,39 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     const size_t nwords = ((size_t)n_all + 63) / 64 + 8;
     HIPCHK(c, planes_neg.ensure(nwords * 8));
     HIPCHK(c, planes_pos.ensure(nwords * 8));
+    // The per-chunk buffers are sized for the FINE cut of this batch length straight away (a stream that turns out to need
+    // re-runs is cut fine_mult times finer, host_threshold.h: fine_left -- from within the batch that finds out: an allocation in
+    // the middle of a batch costs milliseconds).  Three windows of summaries per chunk: bounded by the cap on the chunk count.
+    size_t nal = nch;
+    if (c->fine_adapt && c->wg_now && !c->P.chunk_samples && c->fine_left == 0)
+        nal = std::min<size_t>((size_t)nch * (size_t)c->fine_mult, std::max<size_t>(nch, ((size_t)1 << 30) / ((size_t)12 * (size_t)L)));
     for (int b = 0; b < 2; b++) {
-        HIPCHK(c, c->d_ringout[b].ensure((size_t)nch * L * sizeof(float)));
-        HIPCHK(c, c->d_touched[b].ensure((size_t)nch * c->twords * sizeof(uint32_t)));
-        HIPCHK(c, c->d_info[b].ensure((size_t)nch * sizeof(ChunkInfo)));
+        HIPCHK(c, c->d_ringout[b].ensure(nal * L * sizeof(float)));
+        HIPCHK(c, c->d_touched[b].ensure(nal * c->twords * sizeof(uint32_t)));
+        HIPCHK(c, c->d_info[b].ensure(nal * sizeof(ChunkInfo)));
     }
-    HIPCHK(c, c->d_ringin.ensure((size_t)nch * L * sizeof(float)));
-    HIPCHK(c, c->d_meta.ensure((size_t)nch * sizeof(RunMeta)));
-    HIPCHK(c, c->d_ver.ensure(nch));
-    HIPCHK(c, c->d_cflags.ensure((size_t)4 * nch));   // sections: cert | gflags | gmin | gmax
-    if (c->h_cflags_cap < (size_t)4 * nch) {
+    HIPCHK(c, c->d_ringin.ensure(nal * L * sizeof(float)));
+    HIPCHK(c, c->d_meta.ensure(nal * sizeof(RunMeta)));
+    HIPCHK(c, c->d_ver.ensure(nal));
+    HIPCHK(c, c->d_cflags.ensure((size_t)4 * nal));   // sections: cert | gflags | gmin | gmax
+    if (c->h_cflags_cap < (size_t)20 * nal + 64) {
         if (c->h_cflags) (void)hipHostFree(c->h_cflags);
-        c->h_cflags_cap = (size_t)4 * nch + 4096;
+        c->h_cflags_cap = (size_t)20 * nal + 4096;
         HIPCHK(c, hipHostMalloc((void **)&c->h_cflags, c->h_cflags_cap, hipHostMallocDefault));
     }
     uint8_t *d_cert = c->d_cflags.as<uint8_t>(), *d_gflags = d_cert + nch, *d_gmin = d_cert + 2 * (size_t)nch,
             *d_gmax = d_cert + 3 * (size_t)nch;
     const uint8_t *h_cert = c->h_cflags, *h_gflags = c->h_cflags + nch, *h_gmin = c->h_cflags + 2 * (size_t)nch,
                   *h_gmax = c->h_cflags + 3 * (size_t)nch;
-    HIPCHK(c, c->d_list.ensure((size_t)nch * 4));
-    HIPCHK(c, c->d_gvtop.ensure((size_t)nch * 4));
+    {
+        uint8_t *q = c->h_cflags + (((size_t)4 * nch + 15) & ~(size_t)15);
+        P.h_gvtop = (uint32_t *)q;
+        P.h_list_a = (uint32_t *)(q + (size_t)4 * nch);
+        P.h_list_b = (uint32_t *)(q + (size_t)8 * nch);
+        P.h_ver = q + (size_t)12 * nch;
+    }
+    HIPCHK(c, c->d_list.ensure((size_t)nal * 8));   // two lists: the chunks a round re-runs, the chunks it certifies
+    HIPCHK(c, c->d_gvtop.ensure((size_t)nal * 4));
     if (c->gring) HIPCHK(c, c->d_gring.ensure((size_t)nch * c->Lpad * c->lds_per_slot));
     c->h_ver.assign(nch, 0);
 
@@ -178,8 +196,10 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     return NFC_OK;
 }
 
+// *recut_out (optional): pass 0's verdict says the stream is in the regime that needs re-runs and the batch is still on the coarse
+// cut -- nothing of the attempt stands, the caller cuts finer and tries again.
 static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint32_t skip_all, uint32_t base, const EdgeCarry &ec,
-                          const std::function<int()> *ahead, bool *clean, bool *need_seq_out) {
+                          const std::function<int()> *ahead, bool *clean, bool *need_seq_out, bool *recut_out = nullptr) {
     bool ran_ahead = false;
     *clean = false;
     const int L = c->L;
@@ -285,9 +305,10 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             const uint32_t np = (uint32_t)c->h_list.size();
             if (first_round) {
                 A.list = nullptr;   // k_certify: chunks 1 .. nch-1
-            } else {
-                HIPCHK(c, hipMemcpyAsync(c->d_list.p, c->h_list.data(), (size_t)np * 4, hipMemcpyHostToDevice, c->st));
-                A.list = c->d_list.as<uint32_t>();
+            } else {   // (the list to certify: the second half of d_list, sent from pinned staging)
+                memcpy(P.h_list_b, c->h_list.data(), (size_t)np * 4);
+                HIPCHK(c, hipMemcpyAsync(c->d_list.as<uint32_t>() + nch, P.h_list_b, (size_t)np * 4, hipMemcpyHostToDevice, c->st));
+                A.list = c->d_list.as<uint32_t>() + nch;
             }
             A.nlist = np;
             A.ver_zero = first_round ? 1 : 0;   // (pass 0 wrote every chunk's summary into buffer 0: k_fill zeroed the version bytes)
@@ -314,7 +335,10 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 ran_ahead = true;
             } else {
                 launch_certify();
-                if (!first_round) HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
+                if (!first_round) {   // (the flags, and the chunks' sum bounds for the exactness guard: all in the round's one host turn)
+                    HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
+                    HIPCHK(c, hipMemcpyAsync(P.h_gvtop, c->d_gvtop.p, (size_t)nch * 4, hipMemcpyDeviceToHost, c->st));
+                }
                 HIPCHK(c, mirror_async(c));
                 if (first_round && ahead) {
                     const int rc = (*ahead)();
@@ -330,6 +354,15 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 if (summary.n_fail == 0 && !dbg) {
                     have_summary = true;
                     break;
+                }
+                // More than one chunk in 64 failed and the batch was cut for a clean stream: re-running those long chunks one wave
+                // each is the expensive way round (a re-run pass costs what a chunk is long) -- pass 0 again on the fine cut costs
+                // 0.2 ms and leaves short chunks to re-run.  (The next batches are cut fine from the start: fine_left.)
+                if (recut_out && c->fine_adapt && c->wg_now && c->fine_left == 0 && !c->P.chunk_samples && c->fine_mult > 1 &&
+                    (uint64_t)summary.n_fail * 64u > (uint64_t)nch) {
+                    *recut_out = true;
+                    A.ver_zero = 0;
+                    return NFC_OK;
                 }
                 HIPCHK(c, hipMemcpy(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost));
             }
@@ -403,8 +436,19 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 }
             }
             A.mode = 1;
+            // One host turn per round (round 4: two before -- the re-runs were waited for before their certification was enqueued,
+            // and every small copy came out of pageable memory): the lists travel from pinned staging, the version bytes of the
+            // re-run chunks are flipped here and sent right behind the re-run launch, and the list to certify is made up before the
+            // re-runs have run -- a re-run chunk is taken to leave slots untouched (which its new summary will say): a superset of
+            // what has to be certified, and certifying a chunk nothing has changed for gives the verdict it had.
+            {
+                uint32_t *la = P.h_list_a;
+                size_t nl_ = 0;
+                for (uint32_t k : by_wg) la[nl_++] = k;
+                for (uint32_t k : by_general) la[nl_++] = k;
+                HIPCHK(c, hipMemcpyAsync(c->d_list.p, la, nl_ * 4, hipMemcpyHostToDevice, c->st));
+            }
             if (!by_wg.empty()) {
-                HIPCHK(c, hipMemcpyAsync(c->d_list.p, by_wg.data(), by_wg.size() * 4, hipMemcpyHostToDevice, c->st));
                 A.list = c->d_list.as<uint32_t>();
                 A.nlist = (uint32_t)by_wg.size();
                 A.ksteps = 2;
@@ -412,7 +456,6 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 A.ksteps = c->wg_rounds;
             }
             if (!by_general.empty()) {
-                HIPCHK(c, hipMemcpyAsync(c->d_list.as<uint32_t>() + by_wg.size(), by_general.data(), by_general.size() * 4, hipMemcpyHostToDevice, c->st));
                 A.list = c->d_list.as<uint32_t>() + by_wg.size();
                 A.nlist = (uint32_t)by_general.size();
                 launch_threshold_kind(c, A, A.nlist);
@@ -421,21 +464,20 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             c->stats.threshold_passes++;
             passes++;
             c->stats.chunks_rerun += A.nlist;
-            HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
-            HIPCHK(c, hipStreamSynchronize(c->st));
             std::vector<uint8_t> ran(nch, 0);
             for (uint32_t k : failing) {
                 ran[k] = 1;
                 c->h_ver[k] ^= 1;
             }
-            HIPCHK(c, hipMemcpyAsync(c->d_ver.p, c->h_ver.data(), nch, hipMemcpyHostToDevice, c->st));
+            memcpy(P.h_ver, c->h_ver.data(), nch);
+            HIPCHK(c, hipMemcpyAsync(c->d_ver.p, P.h_ver, nch, hipMemcpyHostToDevice, c->st));
             // pending: the re-run chunks (a predecessor may have been re-run beside them) and every
             // chunk that can see one of them through predecessors that left ring slots untouched
             c->h_list.clear();
             bool vis = false;
             for (uint32_t k = 0; k < nch; k++) {
                 if (vis || ran[k]) c->h_list.push_back(k);
-                const bool full = !(h_gflags[k] & 2);
+                const bool full = !ran[k] && !(h_gflags[k] & 2);   // (a re-run chunk: not known yet -- taken as not full)
                 vis = ran[k] || (vis && !full);
             }
             if (++rounds > (int)nch + 2) return fail(c, NFC_ERR_INTERNAL, "threshold passes did not converge");
@@ -451,17 +493,19 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             flagged = summary.flagged != 0;
             vtop = summary.vtop;
         } else {
-            HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
-            HIPCHK(c, mirror_async(c));
-            HIPCHK(c, hipStreamSynchronize(c->st));
-            BATCHCHK(c, true);
-            std::vector<uint32_t> hv(nch);
-            HIPCHK(c, hipMemcpy(hv.data(), c->d_gvtop.p, (size_t)nch * 4, hipMemcpyDeviceToHost));
+            if (first_round) {   // (no round of re-runs has fetched them: the debugging path)
+                HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
+                HIPCHK(c, hipMemcpyAsync(P.h_gvtop, c->d_gvtop.p, (size_t)nch * 4, hipMemcpyDeviceToHost, c->st));
+                HIPCHK(c, mirror_async(c));
+                HIPCHK(c, hipStreamSynchronize(c->st));
+                BATCHCHK(c, true);
+            }
+            // (otherwise the last round's certification brought flags, bounds and the mirror along: nothing ran since)
             for (uint32_t k = 0; k < nch; k++) {
                 emin = std::min(emin, (int)h_gmin[k]);
                 emax = std::max(emax, (int)h_gmax[k]);
                 if (h_gflags[k] & 1) flagged = true;
-                vtop = std::max(vtop, hv[k]);
+                vtop = std::max(vtop, P.h_gvtop[k]);
             }
         }
         c->h_carry = c->hs->carry;
@@ -539,8 +583,19 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
         // (while the stream is in the regime that needs re-runs, the later stages are not enqueued behind pass 0 on the chance that
         // it stands: they would run -- 0.17 ms of the machine -- before the host has seen the verdict, and run again after the re-runs)
         const bool optimistic = base == 0 && !(c->fine_adapt && c->fine_left > 0);
-        const int rc = threshold_span(c, d_in, n, skip, base, ec, optimistic ? ahead : nullptr, &span_clean, &need_seq);
+        bool recut = false;
+        int rc = threshold_span(c, d_in, n, skip, base, ec, optimistic ? ahead : nullptr, &span_clean, &need_seq, &recut);
         if (rc) return rc;
+        if (recut) {
+            // the attempt's end-of-batch sum is void (k_fill's preparation would take it for the carried one), everything else it
+            // wrote is written again
+            c->fine_left = 8;
+            c->cert_pending = false;
+            HIPCHK(c, hipMemsetAsync((char *)dC(c) + offsetof(Carry, fin_valid), 0, sizeof(int32_t), c->st));
+            span_clean = false;
+            rc = threshold_span(c, d_in, n, skip, base, ec, nullptr, &span_clean, &need_seq, nullptr);
+            if (rc) return rc;
+        }
         if (!need_seq) {
             *clean = span_clean && base == 0;
             if (c->fine_adapt) {   // (a hint about the stream, not part of its state: it survives nfc_reset)

@@ -1252,6 +1252,13 @@ extern "C" int nfc_debug_tail_prof(unsigned long long *out, int reset) {
 extern "C" int nfc_debug_gen_prof(unsigned long long *out, int reset) {
     const size_t bytes = sizeof(unsigned long long) * 8192 * 8;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nfc::g_gen_prof), bytes) != hipSuccess) return -1;
+    {
+        unsigned long long ri[2] = {0, 0};
+        if (hipMemcpyFromSymbol(ri, HIP_SYMBOL(nfc::g_row_iters), sizeof ri) == hipSuccess)
+            fprintf(stderr, "[nfc] row_exact: %llu rows, %.2f iterations each\n", ri[0], ri[0] ? (double)ri[1] / (double)ri[0] : 0.0);
+        void *q = nullptr;
+        if (reset && hipGetSymbolAddress(&q, HIP_SYMBOL(nfc::g_row_iters)) == hipSuccess) (void)hipMemset(q, 0, sizeof ri);
+    }
     if (reset) {
         void *p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(nfc::g_gen_prof)) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) return -1;

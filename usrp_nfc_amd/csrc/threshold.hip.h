@@ -369,6 +369,9 @@ __device__ __forceinline__ float resolve_slot(const ThrArgs &A, int c, int s, bo
     return A.ring_carry[s];
 }
 
+#ifdef NFC_GEN_PROF
+__device__ unsigned long long g_row_iters[2];   // (a profiling build: rows walked by row_exact, iterations they took)
+#endif
 // One 64-sample row (lane l = sample m), exact: iterate the accept mask to its fixed point.
 // Updates ss0, w_nl, w_kl; returns the classification through low/pos ballots.
 __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, bool act, float x, float prev, double &ss0,
@@ -376,25 +379,39 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
                                           unsigned long long &lowm, unsigned long long &posm) {
     const int mx = A.mx;
     const double x64 = (double)x;
-    double ss = ss0;
-    bool low = false, acc = false;
+    const int rb = m - lane;   // the row's first sample
+    const unsigned long long lane_lt = (1ull << lane) - 1ull, actm = __ballot(act);
+    double ss = ss0, incs = 0;
+    bool low = false, acc = false, sum_stands = false;
     int val = 0, key = KEY_NONE;
+    unsigned long long low_seen = 0;
+    bool st2 = false;
+    int row_iters = 0;
+    (void)row_iters;
     for (int iter = 0;; iter++) {
         bool lw = false, hg = false;
         if (act) classify_one(A, x64, ss, lw, hg);
         low = lw;
-        // last non-LOW index before this lane
-        const int inc = wave_scan_max_i32((act && !lw) ? m : LL_NONE, LL_NONE);
-        const int nl = max(wave_below_i32(inc, LL_NONE), w_nl);
-        key = KEY_NONE;
-        if (lw) {
-            const int p = m - nl;  // 1-based position in the LOW run
-            const bool bad = (p > mx) && ((p - 1) % mx == 0);
-            key = 2 * m + (bad ? 0 : 1);
+        // "HIGH is ignored" depends on the row's LOW samples (and the carried bookkeeping) only: done again only when the LOW mask
+        // moved since the iteration before (rows that hover at the HIGH threshold keep theirs).  On the row's MASKS, not on scans
+        // (round 4: two six-step DPP scans of dependent moves per iteration before -- a lone wave pays every one of their
+        // latencies): the last sample before a lane that is not LOW / that is LOW is the highest bit below the lane.
+        const unsigned long long low_now = __ballot(lw);
+        if (iter == 0 || low_now != low_seen) {
+            low_seen = low_now;
+            const unsigned long long bn = actm & ~low_now & lane_lt;
+            const int nl = bn ? rb + last_set(bn) : w_nl;   // (a sample of the row lies behind everything carried into it)
+            key = KEY_NONE;
+            if (lw) {
+                const int p = m - nl;  // 1-based position in the LOW run
+                const bool bad = (p > mx) && ((p - 1) % mx == 0);
+                key = 2 * m + (bad ? 0 : 1);
+            }
+            const unsigned long long bl = low_now & lane_lt;
+            const int kq = __shfl(key, bl ? last_set(bl) : 0, 64);   // the key of the last LOW sample below this lane
+            const int kl = bl ? max(kq, w_kl) : w_kl;
+            st2 = (kl & 1) && (m - (kl >> 1)) <= mx + 1;
         }
-        const int kinc = wave_scan_max_i32(key, KEY_NONE);
-        const int kl = max(wave_below_i32(kinc, KEY_NONE), w_kl);
-        const bool st2 = (kl & 1) && (m - (kl >> 1)) <= mx + 1;
         int v = 0;
         if (lw) v = -1;
         else if (hg && !st2) v = 1;
@@ -402,23 +419,31 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
         const bool same = (iter > 0) && (a == acc);
         acc = a;
         val = v;
-        if (iter > 0 && __all(same)) break;
+        row_iters = iter;
+        if (iter > 0 && __all(same)) { sum_stands = true; break; }   // (incs was scanned over exactly this accept mask)
         if (iter >= MAX_FIX_ITERS) { flags |= 1u; break; }   // (iter is uniform: a scalar branch)
-        const double incs = wave_scan_sum_f64(acc ? (x64 - (double)prev) : 0.0);
+        incs = wave_scan_sum_f64(acc ? (x64 - (double)prev) : 0.0);
         ss = ss0 + wave_below_f64(incs);
     }
-    double dl = 0;
-    if (acc) {
-        dl = x64 - (double)prev;
-        if (x != 0.f) {
-            const uint32_t e = max(f32_expfield(x), 1u);
-            emin = min(emin, e);
-            emax = max(emax, e);
-        }
+    if (acc && x != 0.f) {
+        const uint32_t e = max(f32_expfield(x), 1u);
+        emin = min(emin, e);
+        emax = max(emax, e);
     }
-    ss0 = rfl(ss0 + wave_sum_f64(dl));
-    w_nl = max(w_nl, wave_max_i32((act && !low) ? m : LL_NONE));
-    w_kl = max(w_kl, wave_max_i32(key));
+#ifdef NFC_GEN_PROF
+    if (lane == 0) {
+        atomicAdd(&g_row_iters[0], 1ull);
+        atomicAdd(&g_row_iters[1], (unsigned long long)(row_iters + 1));
+    }
+#endif
+    // the row's accepted differences: the last scan's total (lane 63 of its inclusive prefix), the LOW bookkeeping off the masks
+    double total;
+    if (sum_stands) total = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(incs), 63), __builtin_amdgcn_readlane(__double2loint(incs), 63));
+    else total = wave_sum_f64(acc ? (x64 - (double)prev) : 0.0);
+    ss0 = rfl(ss0 + total);
+    const unsigned long long lowf = __ballot(low), nonlowf = actm & ~lowf;
+    w_nl = nonlowf ? rb + last_set(nonlowf) : w_nl;
+    if (lowf) w_kl = max(w_kl, __builtin_amdgcn_readlane(key, last_set(lowf)));
     lowm = __ballot(low);
     posm = __ballot(val == 1);
     return acc;   // the caller stores x into the ring slot
