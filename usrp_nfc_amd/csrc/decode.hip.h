@@ -418,6 +418,41 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_apply(const uint16_t *ecode,
 // states after the batch from the true scan, and leaves a verdict in the state block.  The host repeats the decode stage with
 // the three-launch form (k_dec_reduce / k_dec_apply: exact whatever the edges look like) when a tile was wrong.
 // The Miller decoder runs as its quotient machine here (DecTables: classes, not states): maps of 8 bytes for both decoders.
+// What a tile of the speculative decode leaves for k_concat (round 4: the bits and packet ends of a tile are worked out where its
+// symbols are, in k_dec_spec -- no second pass over the out-bytes, no second block scan): per packet type the tile's appended bits
+// and packet ends AS IF THE TILE WERE ENTERED IN STATE "started" (tile-local offsets), and which of its bits is not appended when
+// it is entered "not started" -- the two cases differ in the tile's first start-bit value or in its first packet end, FrameAgg's
+// FA_DB / FA_DC.  k_concat knows the state every tile is really entered in (the scan of the tiles' FrameAgg) and moves the bits to
+// their place in the stream.
+constexpr int FW_WORDS = DEC_TILE * 2 / 32 + 4;   // bit words of a tile: two symbols per edge at most (+ the tile's phase in the stream, k_frame_write)
+constexpr uint32_t ST_CLOSES = 1024;              // packet ends staged per tile and type (125 on the bench captures); a tile with more fails the check
+struct TileStage {
+    uint32_t *bits[2];        // [tile][FW_WORDS], NULL: packet type not decoded
+    uint32_t *close_bit[2];   // [tile][ST_CLOSES]: bits of the tile appended before the packet end
+    uint64_t *close_idx[2];   // [tile][ST_CLOSES]: sample index of the closing edge
+    uint32_t *drop_bit[2];    // [tile]: the tile-local bit that is dropped when the tile is entered "not started" (FA_DB set)
+    FrameAgg *own;            // [tile]: the tile's own aggregate (the scan may overwrite the other copy with prefixes)
+    const uint32_t *epos;     // per edge: batch-local sample position ...
+    uint64_t g0;
+    const uint64_t *idx64;    // ... or the caller's own indices (nfc_push_edges)
+};
+// nbits bits from bit src_bit of src to bit dst_bit of dst (zeroed words, shared with other copies: or-ed in), by the whole workgroup
+__device__ __forceinline__ void bitcopy_or(uint32_t *dst, uint32_t dst_bit, const uint32_t *src, uint32_t src_bit, uint32_t nbits, uint32_t cap_bits) {
+    if (!nbits) return;
+    const uint32_t w0 = dst_bit >> 5, nw = ((dst_bit & 31u) + nbits + 31u) >> 5, capw = (cap_bits + 31u) >> 5;
+    for (uint32_t j = threadIdx.x; j < nw; j += blockDim.x) {
+        if (w0 + j >= capw) break;   // (an estimate too small: the host sees it in the totals and repeats the stage with room)
+        const uint32_t lo = max(dst_bit, (w0 + j) << 5), hi = min(dst_bit + nbits, (w0 + j + 1u) << 5);   // this word's bits of the range
+        const uint32_t sb = src_bit + (lo - dst_bit), k = sb & 31u;
+        const uint32_t a = src[sb >> 5], b = k ? src[(sb >> 5) + 1u] : 0u;
+        uint32_t v = (a >> k) | (k ? b << (32u - k) : 0u);
+        const uint32_t cnt = hi - lo;
+        if (cnt < 32u) v &= (1u << cnt) - 1u;
+        v <<= (lo & 31u);
+        if (v) atomicOr(dst + w0 + j, v);
+    }
+}
+
 struct QMaps {
     uint32_t mil[2];   // Miller: class -> class, one byte each
     uint32_t man[2];   // Manchester: state -> state
@@ -447,7 +482,7 @@ __device__ __forceinline__ bool map8_constant(const uint32_t (&m)[2]) { return m
 constexpr int DEC_RUNIN_MAX = 8;   // run-in edges per thread at most (runin = 2, 4 or 8 x SCAN_BLOCK: 512, 1024 or 2048 edges)
 template <bool LDS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, size_t n, const uint32_t *n_dev, DecTables T, uint32_t state0, int runin_per_thread,
-                                                        uint8_t *outw, FrameAgg *frame_aggs, FramePk *thread_aggs, DecSpec *spec, ZeroJob Z) {
+                                                        uint8_t *outw, FrameAgg *frame_aggs, DecSpec *spec, ZeroJob Z, TileStage S) {
     zero_words(Z);
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
@@ -459,6 +494,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
     __shared__ QMaps lds[SCAN_WAVES];
     __shared__ FramePk lds2[SCAN_WAVES];
     __shared__ uint32_t s_needs;
+    __shared__ uint32_t s_bits[2][FW_WORDS];   // the tile's appended bits, entered "started"
+    __shared__ uint32_t s_drop[2];             // the bit that is dropped when it is entered "not started"
+    for (int i = threadIdx.x; i < 2 * FW_WORDS; i += SCAN_BLOCK) (&s_bits[0][0])[i] = 0u;
+    if (threadIdx.x < 2) s_drop[threadIdx.x] = 0xFFFFFFFFu;
     const uint32_t ident = 4u * (uint32_t)T.nd;   // the identity row of both map tables
     if (LDS) {
         const int rows = 4 * T.nd;
@@ -588,10 +627,80 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
     }
     TP_MARK();   // 4: the walk
     FramePk total_fa;
-    *(uint4 *)(thread_aggs + tid) = make_uint4(mine.a[0], mine.a[1], mine.b[0], mine.b[1]);   // (k_frame_write scans them again)
-    (void)block_exclusive<FramePkOp>(mine, lds2, total_fa);   // (its barriers: every thread's atomicOr has landed)
+    const FramePk in_tile = block_exclusive<FramePkOp>(mine, lds2, total_fa);   // (its barriers: every thread's atomicOr has landed)
+    // The tile's packet bits and packet ends, entered "started": a thread's groups in order, each from everything before it in the
+    // tile -- the appended bits squeezed together (compress32), up to 64 per thread and type, or-ed into the tile's words in LDS.
+    {
+        FrameAgg before = FramePkOp::unpack(in_tile);
+        uint64_t acc[2] = {0ull, 0ull};
+        uint32_t cnt[2] = {0u, 0u};
+        const uint32_t bo0[2] = {before.nb[0], before.nb[1]};   // (fa_bits entered "started")
+#pragma unroll
+        for (int g = 0; g < DEC_GROUPS; g++) {
+            if (ow[g][0] | ow[g][1] | ow[g][2] | ow[g][3]) {
+                const SlotMasks m = slot_masks(ow[g]);
+                const uint32_t low = symbol_low_bits(ow[g]);
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    if (!m.V[t] || !S.bits[t]) continue;
+                    const uint32_t started = pm_apply(before.fl[t], 1u);
+                    const uint32_t bef = started_before(m, t, started);
+                    const uint32_t appended = m.V[t] & ~m.ST[t] & (bef | ~m.SA[t]);
+                    uint32_t cl = m.ST[t] & bef;
+                    const uint32_t bo = bo0[t] + cnt[t];
+                    const uint32_t nonid = m.ST[t] | m.SA[t];
+                    if ((before.fl[t] & 3u) == PM_ID && nonid) {   // the tile's first symbol that is not the identity lies here
+                        const uint32_t first = nonid & (0u - nonid);
+                        if (first & m.SA[t]) s_drop[t] = bo + (uint32_t)__popc(appended & (first - 1u));   // (appended now, dropped if "not started")
+                    }
+                    acc[t] |= (uint64_t)compress32(low, appended) << cnt[t];
+                    cnt[t] += (uint32_t)__popc(appended);
+                    if (cl) {   // packet ends: one per frame
+                        const uint32_t co = before.nc[t], closes = cl;
+                        while (cl) {
+                            const uint32_t lowb = cl & (0u - cl);
+                            const int k = (__ffs((int)cl) - 1) >> 1;
+                            cl ^= lowb;
+                            const uint32_t j = co + (uint32_t)__popc(closes & (lowb - 1u));
+                            if (j < ST_CLOSES) {
+                                const size_t e = base + (size_t)DEC_ITEMS * g + k;
+                                S.close_bit[t][(size_t)blockIdx.x * ST_CLOSES + j] = bo + (uint32_t)__popc(appended & (lowb - 1u));
+                                S.close_idx[t][(size_t)blockIdx.x * ST_CLOSES + j] = S.idx64 ? S.idx64[e] : S.g0 + (uint64_t)S.epos[e];
+                            } else {
+                                atomicOr(&s_needs, 4u);   // (more packet ends than a tile stages: the three-launch form takes the batch)
+                            }
+                        }
+                    }
+                }
+                if (g + 1 < DEC_GROUPS) before = FrameAggOp::op(before, frame_agg_of(ow[g]));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            if (!cnt[t]) continue;
+            const uint32_t w = bo0[t] >> 5, sh = bo0[t] & 31u;
+            const uint64_t lo = acc[t] << sh;
+            const uint32_t hi = sh ? (uint32_t)(acc[t] >> (64u - sh)) : 0u;
+            if (w + 2 < (uint32_t)FW_WORDS) {
+                if ((uint32_t)lo) atomicOr(&s_bits[t][w], (uint32_t)lo);
+                if ((uint32_t)(lo >> 32)) atomicOr(&s_bits[t][w + 1], (uint32_t)(lo >> 32));
+                if (hi) atomicOr(&s_bits[t][w + 2], hi);
+            }
+        }
+    }
+    __syncthreads();
+    const FrameAgg tile_fa = FramePkOp::unpack(total_fa);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (!S.bits[t]) continue;
+        const uint32_t nw = min((uint32_t)FW_WORDS, (tile_fa.nb[t] + 31u) / 32u + 1u);   // (one word more: k_concat reads pairs)
+        for (uint32_t j = threadIdx.x; j < nw; j += SCAN_BLOCK) S.bits[t][(size_t)blockIdx.x * FW_WORDS + j] = s_bits[t][j];
+    }
     if (threadIdx.x == 0) {
-        frame_aggs[blockIdx.x] = FramePkOp::unpack(total_fa);
+        frame_aggs[blockIdx.x] = tile_fa;
+        S.own[blockIdx.x] = tile_fa;
+        if (S.bits[0]) S.drop_bit[0][blockIdx.x] = s_drop[0];
+        if (S.bits[1]) S.drop_bit[1][blockIdx.x] = s_drop[1];
         const uint32_t s_in = ComposeQ::step(runin, state0);
         ((uint4 *)(spec + blockIdx.x))[0] = make_uint4(total.mil[0], total.mil[1], total.man[0], total.man[1]);
         ((uint4 *)(spec + blockIdx.x))[1] = make_uint4(s_in, s_needs, 0u, 0u);
@@ -637,7 +746,7 @@ __device__ __forceinline__ void dec_verify(const DecVerify &V, size_t ntiles, QM
 #pragma unroll
         for (int k = 0; k < DV_ITEMS; k++) {
             const uint32_t diff = ComposeQ::step(run, V.state0) ^ s_in[k];
-            if (((needs[k] & 1u) && (diff & 15u)) || ((needs[k] & 2u) && (diff >> 4))) bad = 1;
+            if (((needs[k] & 1u) && (diff & 15u)) || ((needs[k] & 2u) && (diff >> 4)) || (needs[k] & 4u)) bad = 1;   // (4: more packet ends than a tile stages)
             run = ComposeQ::op(run, mp[k]);
         }
         before = ComposeQ::op(before, total);
@@ -761,7 +870,6 @@ struct DecCarryEpilogue {
 };
 
 // (V.spec set: the grid has ONE workgroup more, in front -- the check of the speculative decode, dec_verify, beside the tiles)
-constexpr int FW_WORDS = DEC_TILE * 2 / 32 + 4;   // bit words of a tile in LDS: two symbols per edge at most, the tile's phase in its first word
 __device__ __forceinline__ void pack_pending(const FrameOut &P, int tid, int nthreads) {   // the open packets' bits of earlier batches go in front
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -894,26 +1002,92 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_frame_write(const uint8_t *outw,
     TP_DONE(3);   // 4: the stores
 }
 
+// The speculative decode's second launch: every tile's staged bits and packet ends (TileStage, entered "started") to their place
+// in the stream, from the state the tile is really entered in -- the scan of the tiles' FrameAgg says it.  Entered "not started",
+// the tile's first start-bit value is not appended (FA_DB: one bit fewer, everything behind it one place down) or its first
+// packet end does not happen (FA_DC).  One workgroup more in front: dec_verify.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_concat(size_t n, const uint32_t *n_dev, const FrameAgg *tile_pre, TileStage S, FrameOut P, bool own_prefix,
+                                                      FrameAgg *total_out, DecCarryEpilogue epi, DecVerify V) {
+    if (n_dev) n = min(n, (size_t)*n_dev);
+    if (blockIdx.x == 0) {
+        __shared__ QMaps lds_v[SCAN_WAVES];
+        dec_verify(V, (n + DEC_TILE - 1) / DEC_TILE, lds_v);
+        return;
+    }
+    const uint32_t bid = blockIdx.x - 1u;   // the tile
+    if (bid == 0) pack_pending(P, threadIdx.x, SCAN_BLOCK);
+    if (own_prefix && n == 0 && bid == 0 && threadIdx.x == 0) {
+        *total_out = FrameAggOp::identity();
+        epi(FrameAggOp::identity());
+    }
+    if ((size_t)bid * DEC_TILE >= n) return;
+    __shared__ FrameAgg lds_pre[SCAN_WAVES];
+    const FrameAgg pre = own_prefix ? tile_prefix<FrameAggOp, SCAN_BLOCK>(tile_pre, bid, lds_pre) : tile_pre[bid];
+    const FrameAgg own = S.own[bid];
+    if (own_prefix && threadIdx.x == 0 && ((size_t)bid + 1) * DEC_TILE >= n) {   // the last tile publishes the total and the carries
+        const FrameAgg all = FrameAggOp::op(pre, own);
+        *total_out = all;
+        epi(all);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (!P.bits[t] || !S.bits[t]) continue;
+        const uint32_t started = pm_apply(pre.fl[t], P.started_in[t]);
+        const uint32_t bit0 = P.pend[t] + fa_bits(pre, t, P.started_in[t]);   // the tile's first bit in the stream
+        const uint32_t nb = own.nb[t];                                        // staged (entered "started")
+        const bool drop = !started && (own.fl[t] & FA_DB);
+        const uint32_t q = drop ? S.drop_bit[t][bid] : 0xFFFFFFFFu;
+        const uint32_t *src = S.bits[t] + (size_t)bid * FW_WORDS;
+        uint32_t *dst = (uint32_t *)P.bits[t];
+        if (!drop) {
+            bitcopy_or(dst, bit0, src, 0u, nb, P.cap_bits[t]);
+        } else if (q < nb) {
+            bitcopy_or(dst, bit0, src, 0u, q, P.cap_bits[t]);
+            bitcopy_or(dst, bit0 + q, src, q + 1u, nb - 1u - q, P.cap_bits[t]);
+        }
+        const bool dropc = !started && (own.fl[t] & FA_DC);
+        const uint32_t ncl = min(own.nc[t], ST_CLOSES), co = fa_closes(pre, t, P.started_in[t]);
+        for (uint32_t i = threadIdx.x; i < ncl; i += SCAN_BLOCK) {
+            if (dropc && i == 0) continue;
+            const uint32_t j = co + i - (dropc ? 1u : 0u);
+            if (j >= P.cap_close[t]) continue;
+            const uint32_t e = S.close_bit[t][(size_t)bid * ST_CLOSES + i];
+            P.close_end[t][j] = bit0 + e - ((drop && e > q) ? 1u : 0u);
+            P.close_idx[t][j] = S.close_idx[t][(size_t)bid * ST_CLOSES + i];
+        }
+    }
+}
+
 // The symbol arrays (what the decoders emitted, error codes included: the reference hands them to PacketProcessor.append_bit and
 // keeps nothing) are written when somebody asks for them -- nfc_read_symbols -- from what the decode pass left per edge.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_symbols_write(const uint8_t *outw, size_t n, const uint32_t *n_dev, const FrameAgg *tile_pre,
-                                                             const FramePk *thread_aggs, FrameOut P, bool own_prefix) {
+                                                             FrameOut P, bool own_prefix) {
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * DEC_TILE >= n) return;
     __shared__ FramePk lds[SCAN_WAVES];
     __shared__ FrameAgg lds_pre[SCAN_WAVES];
     const FrameAgg pre = own_prefix ? tile_prefix<FrameAggOp, SCAN_BLOCK>(tile_pre, blockIdx.x, lds_pre) : tile_pre[blockIdx.x];
     const size_t base = ((size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * DEC_PER_THREAD;
-    const uint4 m4 = *(const uint4 *)(thread_aggs + (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x);
+    uint32_t owa[DEC_GROUPS][4];
+    FramePk mine = FramePkOp::identity();   // (the thread's aggregate again, from its out-bytes)
+#pragma unroll
+    for (int g = 0; g < DEC_GROUPS; g++) {
+        owa[g][0] = owa[g][1] = owa[g][2] = owa[g][3] = 0u;
+        const size_t gb = base + (size_t)DEC_ITEMS * g;
+        if (gb < n) {
+            const uint4 a = *(const uint4 *)(outw + gb);
+            owa[g][0] = a.x; owa[g][1] = a.y; owa[g][2] = a.z; owa[g][3] = a.w;
+        }
+        mine = FramePkOp::op(mine, FramePkOp::pack(frame_agg_of(owa[g])));
+    }
     FramePk total;
-    const FramePk in_tile = block_exclusive<FramePkOp>(FramePk{{m4.x, m4.y}, {m4.z, m4.w}}, lds, total);
+    const FramePk in_tile = block_exclusive<FramePkOp>(mine, lds, total);
     FrameAgg before = FrameAggOp::op(pre, FramePkOp::unpack(in_tile));
 #pragma unroll
     for (int g = 0; g < DEC_GROUPS; g++) {
         const size_t gb = base + (size_t)DEC_ITEMS * g;
         if (gb >= n) break;
-        const uint4 a = *(const uint4 *)(outw + gb);
-        const uint32_t ow[4] = {a.x, a.y, a.z, a.w};
+        const uint32_t ow[4] = {owa[g][0], owa[g][1], owa[g][2], owa[g][3]};
         if (!(ow[0] | ow[1] | ow[2] | ow[3])) continue;
         const SlotMasks m = slot_masks(ow);
         const uint64_t lo = (uint64_t)ow[0] | ((uint64_t)ow[1] << 32), hi = (uint64_t)ow[2] | ((uint64_t)ow[3] << 32);

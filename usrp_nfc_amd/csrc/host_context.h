@@ -197,6 +197,7 @@ struct nfc_ctx {
         d_close_idx[2];
     DevBuf d_partials, d_partials2, d_aggs, d_faggs;  // scan scratch
     DevBuf d_spec;                           // per decode tile: its map, the state it assumed (decode.hip.h: DecSpec)
+    DevBuf d_stage_bits[2], d_stage_cb[2], d_stage_ci[2], d_stage_q[2], d_stage_own;   // ... and what it stages for k_concat (TileStage)
     DevBuf d_pack;                           // nfc_get_state staging
     DevBuf d_gvtop;                          // per chunk: bound of the ring values (guard of the fp64 sums)
     DevBuf d_seqout;                         // sequential kernel: edge-timing state after its last sample

@@ -137,16 +137,35 @@ int run_decode(nfc_ctx *c, bool force_classic = false) {
         Z.n[t] = P.bits[t] ? (P.cap_bits[t] + 31u) / 32u + 1u : 0u;
         if (!tiles && Z.n[t]) HIPCHK(c, hipMemsetAsync(Z.p[t], 0, (size_t)Z.n[t] * 4, c->st));
     }
+    TileStage S;
+    memset(&S, 0, sizeof S);
     if (spec) {
         HIPCHK(c, c->d_spec.ensure((tiles + 1) * sizeof(DecSpec)));
         V.spec = c->d_spec.as<DecSpec>();
+        // what the tiles stage for k_concat: bits and packet ends entered "started", per enabled packet type
+        HIPCHK(c, c->d_stage_own.ensure((tiles + 1) * sizeof(FrameAgg)));
+        S.own = c->d_stage_own.as<FrameAgg>();
+        S.epos = P.epos;
+        S.g0 = P.g0;
+        S.idx64 = P.idx64;
+        for (int t = 0; t < 2; t++) {
+            if (!P.bits[t]) continue;
+            HIPCHK(c, c->d_stage_bits[t].ensure((tiles + 1) * (size_t)FW_WORDS * 4));
+            HIPCHK(c, c->d_stage_cb[t].ensure((tiles + 1) * (size_t)ST_CLOSES * 4));
+            HIPCHK(c, c->d_stage_ci[t].ensure((tiles + 1) * (size_t)ST_CLOSES * 8));
+            HIPCHK(c, c->d_stage_q[t].ensure((tiles + 1) * 4));
+            S.bits[t] = c->d_stage_bits[t].as<uint32_t>();
+            S.close_bit[t] = c->d_stage_cb[t].as<uint32_t>();
+            S.close_idx[t] = c->d_stage_ci[t].as<uint64_t>();
+            S.drop_bit[t] = c->d_stage_q[t].as<uint32_t>();
+        }
         if (tiles) {
             if (lds_tables)
                 NFC_LAUNCH(k_dec_spec<true>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, spec_state_in, c->dec_runin, outw,
-                           fparts, c->d_faggs.as<FramePk>(), c->d_spec.as<DecSpec>(), Z);
+                           fparts, c->d_spec.as<DecSpec>(), Z, S);
             else
                 NFC_LAUNCH(k_dec_spec<false>, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, ecode, (size_t)ce, ne_dev, c->T, spec_state_in, c->dec_runin, outw,
-                           fparts, c->d_faggs.as<FramePk>(), c->d_spec.as<DecSpec>(), Z);
+                           fparts, c->d_spec.as<DecSpec>(), Z, S);
         }
     } else {
         if (tiles) {
@@ -166,8 +185,11 @@ int run_decode(nfc_ctx *c, bool force_classic = false) {
         }
     }
     if (!own) scan_partials<FrameAggOp>(c->st, tiles, ne_dev, DEC_TILE, fparts, FrameAggOp::identity(), frame_total, epi);
-    NFC_LAUNCH(k_frame_write, dim3((unsigned)(std::max<size_t>(tiles, 1) + (spec ? 1 : 0))), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts,
-                       c->d_faggs.as<FramePk>(), P, own, frame_total, epi, V);
+    if (spec)   // (the tiles' staged bits and packet ends to their places; its first workgroup checks the tiles' assumptions)
+        NFC_LAUNCH(k_concat, dim3((unsigned)(std::max<size_t>(tiles, 1) + 1)), dim3(SCAN_BLOCK), 0, c->st, (size_t)ce, ne_dev, fparts, S, P, own, frame_total, epi, V);
+    else
+        NFC_LAUNCH(k_frame_write, dim3((unsigned)std::max<size_t>(tiles, 1)), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts,
+                           c->d_faggs.as<FramePk>(), P, own, frame_total, epi, V);
     c->bits_packed = true;
     c->sym_lazy = true;          // the symbol arrays are written when nfc_read_symbols asks for them (materialize_symbols)
     c->sym_P = P;
@@ -224,7 +246,7 @@ int materialize_symbols(nfc_ctx *c) {
     c->sym_lazy = false;
     if (!c->sym_tiles) return NFC_OK;
     NFC_LAUNCH(k_symbols_write, dim3(c->sym_tiles), dim3(SCAN_BLOCK), 0, c->st, c->d_states.as<uint8_t>(), (size_t)c->sym_n,
-               (const uint32_t *)(dT(c) + TOT_EDGES), c->d_partials2.as<FrameAgg>(), c->d_faggs.as<FramePk>(), c->sym_P, c->sym_own);
+               (const uint32_t *)(dT(c) + TOT_EDGES), c->d_partials2.as<FrameAgg>(), c->sym_P, c->sym_own);
     HIPCHK(c, hipStreamSynchronize(c->st));
     BATCHCHK(c, false);
     return NFC_OK;

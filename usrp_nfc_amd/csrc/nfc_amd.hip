@@ -381,7 +381,7 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ecode, &c->d_epos, &c->d_eidx, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_spec, &c->d_gring, &c->d_pack, &c->d_gvtop, &c->d_seqout};
+                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_spec, &c->d_stage_bits[0], &c->d_stage_bits[1], &c->d_stage_cb[0], &c->d_stage_cb[1], &c->d_stage_ci[0], &c->d_stage_ci[1], &c->d_stage_q[0], &c->d_stage_q[1], &c->d_stage_own, &c->d_gring, &c->d_pack, &c->d_gvtop, &c->d_seqout};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
