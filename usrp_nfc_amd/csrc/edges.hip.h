@@ -348,35 +348,50 @@ constexpr int EW_SUPER = SCAN_WAVES;               // tiles per super-aggregate
 constexpr int ES_ITEMS = EW_WORDS / 64;            // words per thread here: a wave covers one tile
 static_assert(ES_ITEMS % 2 == 0 && ES_ITEMS * 64 == EW_WORDS, "a wave of the reduce pass covers one writer tile");
 inline size_t edge_num_supers(size_t nwords) { return (edge_num_tiles(nwords) + EW_SUPER - 1) / EW_SUPER; }
+// (round 4: WPT waves per tile -- 512 threads a workgroup at WPT = 2, four words per lane; 4 and 1 measured the same within 1 us: the pass is the first read of the 25 MB of planes the threshold kernel just wrote, not its arithmetic.  With one wave per tile
+// a lane folded eight words one after the other behind one round of loads, at three waves per SIMD: 12 us for 25 MB.)
+#ifndef NFC_ER_WPT
+#define NFC_ER_WPT 2
+#endif
+constexpr int ER_WPT = NFC_ER_WPT;                    // waves per tile
+constexpr int ER_ITEMS = ES_ITEMS / ER_WPT;           // words per lane
+constexpr int ER_BLOCK = 64 * ER_WPT * EW_SUPER;      // threads per workgroup: EW_SUPER tiles
+static_assert(ER_ITEMS >= 2 && ER_ITEMS % 2 == 0 && ER_ITEMS * ER_WPT == ES_ITEMS, "pairs of words per lane");
 __device__ __forceinline__ void edge_reduce_super(const EdgeArgs &A, size_t nwords, uint32_t super, EdgeAgg *partials, EdgeAgg *supers) {
-    __shared__ EdgeAgg lds[SCAN_WAVES];
+    __shared__ EdgeAgg lds[EW_SUPER * ER_WPT];
     const EdgeAggOp op{A.mx, A.mx_magic};
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t tile = (size_t)super * EW_SUPER + wave;
-    const size_t w = tile * EW_WORDS + (size_t)lane * ES_ITEMS;
-    uint64_t ng[ES_ITEMS], ps[ES_ITEMS], m[ES_ITEMS];
-    load_words<ES_ITEMS>(A, w, nwords, ng, ps, m);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // wave: ER_WPT consecutive ones per tile
+    const size_t tile = (size_t)super * EW_SUPER + wave / ER_WPT;
+    const size_t w = tile * EW_WORDS + ((size_t)(wave % ER_WPT) * 64 + lane) * ER_ITEMS;
+    uint64_t ng[ER_ITEMS], ps[ER_ITEMS], m[ER_ITEMS];
+    load_words<ER_ITEMS>(A, w, nwords, ng, ps, m);
     EdgeAgg agg = op.identity();
     bool may = false;
 #pragma unroll
-    for (int i = 0; i < ES_ITEMS; i++) may = may || word_may_time_out(A, m[i]);
+    for (int i = 0; i < ER_ITEMS; i++) may = may || word_may_time_out(A, m[i]);
     const bool inner = __any(may);
 #pragma unroll
-    for (int i = 0; i < ES_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w + i) * 64), m[i], inner));
+    for (int i = 0; i < ER_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w + i) * 64), m[i], inner));
     const EdgeAgg inc = wave_inclusive_with(op, agg);
-    if (lane == 63) {
-        lds[wave] = inc;
-        if (tile * EW_WORDS < nwords) partials[tile] = inc;
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x < EW_SUPER) {   // a lane per tile folds its waves; lane 0 the tiles
+        EdgeAgg t = lds[threadIdx.x * ER_WPT];
+#pragma unroll
+        for (int k = 1; k < ER_WPT; k++) t = op(t, lds[threadIdx.x * ER_WPT + k]);
+        const size_t tl = (size_t)super * EW_SUPER + threadIdx.x;
+        if (tl * EW_WORDS < nwords) partials[tl] = t;
+        lds[threadIdx.x * ER_WPT] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         EdgeAgg t = lds[0];
 #pragma unroll
-        for (int k = 1; k < SCAN_WAVES; k++) t = op(t, lds[k]);
+        for (int k = 1; k < EW_SUPER; k++) t = op(t, lds[k * ER_WPT]);
         supers[super] = t;
     }
 }
-__global__ __launch_bounds__(SCAN_BLOCK) void k_edge_reduce(EdgeArgs A, size_t nwords, EdgeAgg *partials, EdgeAgg *supers) {
+__global__ __launch_bounds__(ER_BLOCK) void k_edge_reduce(EdgeArgs A, size_t nwords, EdgeAgg *partials, EdgeAgg *supers) {
     edge_reduce_super(A, nwords, blockIdx.x, partials, supers);
 }
 
@@ -436,14 +451,15 @@ struct EdgeWalk {
     int32_t q;
     bool timed, carried;
 };
-__global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const EdgeAgg *partials, const EdgeAgg *supers, uint32_t *epos,
-                                                           uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
-                                                           Last2 *last2_total, EdgeCarry *carry_out) {
+// (bid of ntiles: the writer may share a launch with another stage's workgroups -- host_context.h: k_certify_and_write)
+__device__ __forceinline__ void write_edges_tile(const EdgeArgs &A, size_t nwords, const EdgeAgg *partials, const EdgeAgg *supers, uint32_t *epos,
+                                                 uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
+                                                 Last2 *last2_total, EdgeCarry *carry_out, const uint32_t bid, const uint32_t ntiles) {
     __shared__ uint16_t s_pos[EW_CAP];   // (tile-local sample position: a tile is EW_WORDS * 64 <= 65536 samples)
     __shared__ uint16_t s_code[EW_CAP];
     __shared__ EdgeAgg s_agg[SCAN_WAVES];
     TP_DECL();
-    const size_t wt = (size_t)blockIdx.x * EW_WORDS;   // first word of the tile
+    const size_t wt = (size_t)bid * EW_WORDS;   // first word of the tile
     const size_t w_first = wt + (size_t)threadIdx.x * EW_ITEMS;
     // own_prefix: partials still holds the tiles' aggregates and the workgroup folds its predecessors' itself
     // (first, while few registers are live); the last tile then publishes the totals and the carry
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
         // four waves' shares of them are gone; the other waves' words are in flight meanwhile)
         __shared__ EdgeAgg s_pre;
         if (threadIdx.x < 64) {
-            const uint32_t g = blockIdx.x / EW_SUPER, q = blockIdx.x % EW_SUPER;
+            const uint32_t g = bid / EW_SUPER, q = bid % EW_SUPER;
             const uint32_t per = (g + 63u) / 64u;
             const uint32_t lo = min(g, (uint32_t)threadIdx.x * per), hi = min(g, lo + per);
             EdgeAgg acc = op.identity();
@@ -482,7 +498,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
         pre = s_pre;
     } else {
         // (the prefix launch scanned the super-aggregates: the group's prefix, then the sibling tiles before this one)
-        const uint32_t g = blockIdx.x / EW_SUPER, q = blockIdx.x % EW_SUPER;
+        const uint32_t g = bid / EW_SUPER, q = bid % EW_SUPER;
         EdgeAgg sib[EW_SUPER - 1];
 #pragma unroll
         for (int k = 0; k < EW_SUPER - 1; k++) sib[k] = (uint32_t)k < q ? partials[(size_t)g * EW_SUPER + k] : op.identity();
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
     const int32_t T = (int32_t)min(w_first * 64, (size_t)A.n), tile_end = (int32_t)min((wt + EW_WORDS) * 64, (size_t)A.n);
     const uint32_t off = entries_before(A, before, T) - gbase;
     const uint32_t total = entries_before(A, all, tile_end) - gbase;
-    if (own_prefix && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (own_prefix && bid == ntiles - 1 && threadIdx.x == 0) {
         *total_out = gbase + total;
         *last2_total = all.l;
         edge_carry_out(A, all.l, carry_out);
@@ -587,6 +603,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t n
         __syncthreads();
     }
     TP_DONE(0);   // 5: the stores
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_write_edges(EdgeArgs A, size_t nwords, const EdgeAgg *partials, const EdgeAgg *supers, uint32_t *epos,
+                                                           uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
+                                                           Last2 *last2_total, EdgeCarry *carry_out) {
+    write_edges_tile(A, nwords, partials, supers, epos, ecode, cap, own_prefix, total_out, last2_total, carry_out, blockIdx.x, gridDim.x);
 }
 
 }  // namespace nfc

@@ -7,9 +7,9 @@ namespace {
 
 std::string g_create_error;
 
-// The first certification of a batch and the edge stage's reduce pass both depend on k_threshold only, so they share
-// a launch: the first cert_blocks workgroups certify (the last of them resolves the end-of-batch state), the others
-// reduce their tile of the planes to its aggregate (edges.hip.h).
+// The first certification of a batch depends on k_threshold only and nothing of the later stages depends on it, so it shares a
+// launch with one of them: the first cert_blocks workgroups certify (the last of them resolves the end-of-batch state), the
+// others are the edge stage's writer (edges.hip.h).
 struct CertLaunch {
     ThrArgs A;
     uint8_t *cert;
@@ -18,12 +18,17 @@ struct CertLaunch {
     CertSummary *sum;
     uint32_t blocks;
 };
-__global__ __launch_bounds__(256) void k_certify_and_reduce(CertLaunch C, EdgeArgs E, size_t nwords, EdgeAgg *partials, EdgeAgg *supers) {
+// (With the writer since round 4, with the reduce pass before: what the certification leaves -- its verdict, the end-of-batch
+// state -- travels to the host in the mirror the stage's last launch fills; its workgroups are a few dependent rounds of loads
+// long and pass unnoticed beside the writer's 40 us of vector instructions.  They come first in the grid.)
+__global__ __launch_bounds__(256) void k_certify_and_write(CertLaunch C, EdgeArgs E, size_t nwords, const EdgeAgg *partials, const EdgeAgg *supers,
+                                                          uint32_t *epos, uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
+                                                          Last2 *last2_total, EdgeCarry *carry_out) {
     if (blockIdx.x < C.blocks) {
         certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, blockIdx.x, C.blocks);
         return;
     }
-    edge_reduce_super(E, nwords, blockIdx.x - C.blocks, partials, supers);
+    write_edges_tile(E, nwords, partials, supers, epos, ecode, cap, own_prefix, total_out, last2_total, carry_out, blockIdx.x - C.blocks, gridDim.x - C.blocks);
 }
 
 struct DevBuf {

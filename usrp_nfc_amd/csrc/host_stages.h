@@ -40,21 +40,22 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     Last2 *last2_total = (Last2 *)(tot + TOT_LAST2);
     uint32_t *edges_total = (uint32_t *)(tot + TOT_EDGES);
     const EdgeAggOp op{E.mx, E.mx_magic};
-    if (c->cert_pending && tiles) {
-        c->cert_pending = false;
-        NFC_LAUNCH(k_certify_and_reduce, dim3((unsigned)(c->cert.blocks + supers)), dim3(256), 0, c->st, c->cert, E, nwords, parts, sups);
-    } else if (tiles) {
-        NFC_LAUNCH(k_edge_reduce, dim3((unsigned)supers), dim3(SCAN_BLOCK), 0, c->st, E, nwords, parts, sups);
-    }
+    // (the first certification of the batch, when it is still to be launched, rides with the WRITER below: host_context.h)
+    if (tiles) NFC_LAUNCH(k_edge_reduce, dim3((unsigned)supers), dim3(ER_BLOCK), 0, c->st, E, nwords, parts, sups);
     if (!own || !tiles)   // (long batches: the prefix launch over the SUPER-aggregates; the totals and the carry in its epilogue)
         scan_partials_with(c->st, op, supers, nullptr, (uint32_t)(EW_WORDS * EW_SUPER), sups, op.identity(), (EdgeAgg *)nullptr,
                            EdgeTotalEpilogue{E, edges_total, last2_total, dE(c)});
     const uint32_t cap = c->cap_edges;
     HIPCHK(c, c->d_epos.ensure(((size_t)cap + 8) * 4));
     HIPCHK(c, c->d_ecode.ensure(((size_t)cap + 8) * 2));
-    if (tiles)
+    if (c->cert_pending && tiles) {
+        c->cert_pending = false;
+        NFC_LAUNCH(k_certify_and_write, dim3((unsigned)(c->cert.blocks + tiles)), dim3(SCAN_BLOCK), 0, c->st, c->cert, E, nwords, parts, sups,
+                   c->d_epos.as<uint32_t>(), c->d_ecode.as<uint16_t>(), cap, own, edges_total, last2_total, dE(c));
+    } else if (tiles) {
         NFC_LAUNCH(k_write_edges, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, c->st, E, nwords, parts, sups, c->d_epos.as<uint32_t>(),
                    c->d_ecode.as<uint16_t>(), cap, own, edges_total, last2_total, dE(c));
+    }
     c->edges_from_host = false;
     return NFC_OK;
 }
