@@ -29,8 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-STREAM_CEILING_GBS = 6070.0   # what a read-only kernel with the threshold kernel's access pattern (one wave per 49 152-sample chunk,
-                              # 2 KB per wave and step) reaches on this machine: tools/ubench/stream_chunks.hip, profiles/r02_stream_ceiling.txt
+STREAM_CEILING_GBS = 5970.0   # what a read-only kernel with k_threshold_wg's access pattern (a 98 304-sample chunk per 256-thread workgroup,
+                              # four per CU; a wave's 2 KB step of every 1 024-sample round asked for one round ahead, a barrier per round)
+                              # reaches on this machine: tools/ubench/stream_chunks.hip, profiles/r04_stream_ceiling.txt
 
 
 def parse():

@@ -31,7 +31,7 @@ with api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **bench.stream_params(wl), **b
     st = ctx.stats()
     print('stage ms: threshold %.4f edges %.4f decode %.4f total %.4f' % (st.ms_threshold, st.ms_edges, st.ms_decode, st.ms_total))
     print('edges', ctx.counts().n_edges)
-names = ['k_write_edges', 'k_dec_reduce', 'k_dec_apply', 'k_frame_write']
+names = ['k_write_edges', 'k_dec_spec (k_dec_reduce with NFC_DEC_SPEC=0)', 'k_dec_apply (NFC_DEC_SPEC=0)', 'k_concat (k_frame_write with NFC_DEC_SPEC=0)']
 a = np.frombuffer(out, np.uint64).reshape(4, 4096, 8).astype(np.int64)
 for k, nm in enumerate(names):
     v = a[k]
@@ -40,4 +40,4 @@ for k, nm in enumerate(names):
         continue
     nst = int((v[0] != 0).sum())
     d = np.diff(v[:, :nst], axis=1)
-    print('%-14s %5d WG; mean ticks per phase:' % (nm, len(v)), ' '.join('%8.0f' % x for x in d.mean(0)), ' total mean %.0f max %.0f' % (d.sum(1).mean(), d.sum(1).max()))
+    print('%-44s %5d WG; mean ticks per phase:' % (nm, len(v)), ' '.join('%8.0f' % x for x in d.mean(0)), ' total mean %.0f max %.0f' % (d.sum(1).mean(), d.sum(1).max()))

@@ -62,6 +62,37 @@ __global__ __launch_bounds__(256) void k_chunks_wg(const float2 *in, size_t n, u
     if (acc == 12345.f) out[0] = acc;
 }
 
+// the round-3/4 threshold kernel's pattern (k_threshold_wg): a chunk per 256-thread workgroup, four resident per CU; a ROUND is 1024
+// samples, wave w takes its 256-sample step (four 512-byte rows) of every round, asked for D rounds ahead; one barrier per round
+template <int D>
+__global__ __launch_bounds__(256) void k_chunks_round(const float2 *in, size_t n, uint32_t C, float *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t m0 = (size_t)blockIdx.x * C;
+    if (m0 >= n) return;
+    const size_t m1 = m0 + C < n ? m0 + C : n;
+    const size_t rounds = (m1 - m0) / 1024;
+    float2 r[D][4];
+    float acc = 0.f;
+    auto at = [&](size_t rd, int j) { const size_t q = rd < rounds ? rd : rounds - 1; return in[m0 + q * 1024 + 256 * wave + 64 * j + lane]; };
+#pragma unroll
+    for (int k = 0; k < D; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[k][j] = at(k, j);
+    for (size_t rd = 0; rd < rounds; rd += D) {
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) s += r[k][j].x * r[k][j].x + r[k][j].y * r[k][j].y;
+            acc += s;
+#pragma unroll
+            for (int j = 0; j < 4; j++) r[k][j] = at(rd + k + D, j);
+            __syncthreads();
+        }
+    }
+    if (acc == 12345.f) out[0] = acc;
+}
+
 template <class F>
 float timeit(F f) {
     hipEvent_t e0, e1;
@@ -115,6 +146,16 @@ int main() {
         hipFuncSetAttribute((const void *)k_chunks_wg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         float ms = timeit([&] { hipLaunchKernelGGL(k_chunks_wg<4>, dim3(blocks), dim3(256), lds, 0, d, n, C, o); });
         printf("workgroup chunks (C %u, %u blocks) 4 loads in flight per lane: %.3f ms  %.2f TB/s\n", C, blocks, ms, gb / ms);
+    }
+    for (int per_cu : {4, 3, 8}) {
+        const uint32_t wgs = 256 * per_cu;
+        uint32_t C = (uint32_t)((n + wgs - 1) / wgs);
+        C = (C + 1023) / 1024 * 1024;
+        const uint32_t blocks = (uint32_t)((n + C - 1) / C);
+        float ms = timeit([&] { hipLaunchKernelGGL(k_chunks_round<1>, dim3(blocks), dim3(256), 0, 0, d, n, C, o); });
+        printf("k_threshold_wg's pattern (chunk per workgroup, %d per CU: C %u, %u blocks; a wave's step of every 1024-sample round, 1 round ahead, a barrier per round): %.3f ms  %.2f TB/s\n", per_cu, C, blocks, ms, gb / ms);
+        ms = timeit([&] { hipLaunchKernelGGL(k_chunks_round<2>, dim3(blocks), dim3(256), 0, 0, d, n, C, o); });
+        printf("   ... 2 rounds ahead: %.3f ms  %.2f TB/s\n", ms, gb / ms);
     }
     for (int g : {256 * 8, 256 * 20, 256 * 64}) {
         float ms = timeit([&] { hipLaunchKernelGGL(k_plain, dim3(g), dim3(256), 0, 0, (const float4 *)d, n / 2, o); });

@@ -1021,9 +1021,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_concat(size_t n, const uint32_t 
         epi(FrameAggOp::identity());
     }
     if ((size_t)bid * DEC_TILE >= n) return;
+    TP_DECL();
     __shared__ FrameAgg lds_pre[SCAN_WAVES];
     const FrameAgg pre = own_prefix ? tile_prefix<FrameAggOp, SCAN_BLOCK>(tile_pre, bid, lds_pre) : tile_pre[bid];
     const FrameAgg own = S.own[bid];
+    TP_MARK();   // 1: tile prefix
     if (own_prefix && threadIdx.x == 0 && ((size_t)bid + 1) * DEC_TILE >= n) {   // the last tile publishes the total and the carries
         const FrameAgg all = FrameAggOp::op(pre, own);
         *total_out = all;
@@ -1056,6 +1058,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_concat(size_t n, const uint32_t 
             P.close_idx[t][j] = S.close_idx[t][(size_t)bid * ST_CLOSES + i];
         }
     }
+    TP_DONE(3);   // 2: bits and packet ends to their places
+    // (Measured and dropped, round 4: what k_pkt_finish does -- the open packets' bits, the carry, the mirror -- by the first
+    // workgroup of this launch behind dec_verify, from the tiles' staging and a scan of their aggregates of its own.  Exact, but
+    // that workgroup is a chain of 20 us (two scans over the tiles, dependent loads, the mirror) beside tiles that live 8:
+    // the launch took 22-30 us against 8 + 4 for k_pkt_finish and the boundary before it.)
 }
 
 // The symbol arrays (what the decoders emitted, error codes included: the reference hands them to PacketProcessor.append_bit and
