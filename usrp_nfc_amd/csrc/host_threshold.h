@@ -70,7 +70,9 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
         slots = std::min<uint64_t>(slots, std::max<uint64_t>(256, ((uint64_t)1 << 30) / ((uint64_t)12 * (uint64_t)c->L)));
         // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps;
         // the workgroup kernel whole rounds of four)
-        const int stp = c->wg_now ? wg_round_samples(c->wg_nr) : 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
+        // (... whole PAIRS of rounds with two rounds of samples asked for ahead, wg_d == 2)
+        const int stp = c->wg_now ? wg_round_samples(c->wg_nr) * ((c->wg_d == 2 && c->wg_nr == 4 && c->P.input_kind == NFC_IN_IQ_F32) ? 2 : 1)
+                                  : 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
         uint64_t want = ((uint64_t)n + slots - 1) / slots;
         want = (want + stp - 1) / stp * stp;
         c->C = (int)std::max<uint64_t>(want, (uint64_t)c->C_min);

@@ -606,10 +606,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // A SUPERSTEP is `sup` regular rounds classified against one set of thresholds (A.ksteps), or ONE round that is not four whole
     // steps of stable samples (the stream's first stable sample, a batch's ragged end): its
     // rounds are separated by the first barrier only, the second one and the exchange behind it close the superstep.
-    const int sup = max(1, A.ksteps);   // the longest superstep
-    int cur_sup = 1;                    // rounds of the next one (it adapts: see the close)
-    bool primed = false, need_open = true, just_primed = false;
-    int ks = 0;   // (D == 2) which registers hold this round's samples
+    const int sup = (D == 2) ? max(2, A.ksteps & ~1) : max(1, A.ksteps);   // the longest superstep
+    int cur_sup = D;                    // rounds of the next one (it adapts: see the close; D == 2: whole pairs of rounds)
+    bool primed = false, need_open = true;
     uint32_t rbase = m_chunk;   // base of the round
     // which of the three mask buffers this round publishes in, and the round before it did (byte offsets of this wave's row)
     uint32_t mo = 0u, mo_prev = 2u * (uint32_t)sizeof(sh->msk[0]);
@@ -644,27 +643,23 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         }
     };
     while (good_run && rbase < n1) {
-        const bool regular = rbase >= m_start && rbase + (uint32_t)WG_ROUND <= n1;
+        // (D == 2: regular rounds come in PAIRS -- the two register sets of samples asked for ahead alternate statically, set 0
+        // first in every superstep; a single whole round left over at a ragged end takes the masked form)
+        const bool regular = rbase >= m_start && rbase + (uint32_t)(D * WG_ROUND) <= n1;
         int nr = 1;
         uint32_t whole = 0u;   // regular rounds from here on
         if (regular) {
             whole = (n1 - rbase) / (uint32_t)WG_ROUND;
+            if constexpr (D == 2) whole &= ~1u;
             nr = (int)min((uint32_t)cur_sup, whole);
             if (!primed) {
                 // this wave's step of the first regular round is asked for
                 if constexpr (D == 1) {
                     wg_load_step<KIND, NR>(voff, in_wave);
                 } else {
-                    // (this round into the set `ks` names, the next one into the other: asked for again if the chunk has none)
-                    const char *nx = whole > 1u ? in_wave + (size_t)WG_ROUND * RB : in_wave;
-                    if (ks) {
-                        wg_load_step_iq4<1>(voff, in_wave);
-                        wg_load_step_iq4<0>(voff, nx);
-                    } else {
-                        wg_load_step_iq4<0>(voff, in_wave);
-                        wg_load_step_iq4<1>(voff, nx);
-                    }
-                    just_primed = true;
+                    // (this round into set 0, the next one into set 1)
+                    wg_load_step_iq4<0>(voff, in_wave);
+                    wg_load_step_iq4<1>(voff, in_wave + (size_t)WG_ROUND * RB);   // (whole >= 2)
                 }
                 primed = true;
                 need_open = true;
@@ -678,7 +673,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         }
         need_open = !regular;
 
-        for (int k = 0; k < nr; k++) {
+        auto one_round = [&](auto set_tag, const int k) __attribute__((always_inline)) {
+            constexpr int SET = decltype(set_tag)::value;   // (D == 2) which registers hold this round's samples
+            (void)SET;
             const uint32_t base = rbase + STEPN * (uint32_t)wave;
             float x[NR];
             int pk = 0;
@@ -689,15 +686,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 if constexpr (D == 1) {
                     wg_take<KIND, NR>(x, i16s);
                 } else {
-                    // (right after the requests of a chunk's first rounds nothing has been stored in between: everything is waited for)
-                    if (just_primed) {
-                        if (ks) wg_take_iq4<1, true>(x, i16s);
-                        else wg_take_iq4<0, true>(x, i16s);
-                        just_primed = false;
-                    } else {
-                        if (ks) wg_take_iq4<1, false>(x, i16s);
-                        else wg_take_iq4<0, false>(x, i16s);
-                    }
+                    // (at most the four loads of the OTHER set are younger than this set's, and loads complete in order among
+                    // themselves: "at most four operations left" means this set is in, whatever the stores in flight do)
+                    wg_take_iq4<SET, false>(x, i16s);
                 }
                 WG_PF_END(pf_take);
                 // the plane words of the round before leave, and the registers take the next round (if the chunk has one: past
@@ -712,9 +703,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 } else {
                     // (the registers just read take the round after next)
                     const char *nx = (uint32_t)(k + 2) < whole ? in_wave + (size_t)(2 * WG_ROUND) * RB : in_wave;
-                    if (ks) wg_load_step_iq4<1>(voff, nx);
-                    else wg_load_step_iq4<0>(voff, nx);
-                    ks ^= 1;
+                    wg_load_step_iq4<SET>(voff, nx);
                 }
                 uint32_t xlo = __float_as_uint(x[0]), xhi = __float_as_uint(x[0]);   // (envelopes are >= 0: their raw bits order like their values)
 #pragma unroll
@@ -875,6 +864,18 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             rbase += (uint32_t)WG_ROUND;
             mo_prev = mo;
             mo = (mo == 2u * (uint32_t)sizeof(sh->msk[0])) ? 0u : mo + (uint32_t)sizeof(sh->msk[0]);
+        };
+        if constexpr (D == 1) {
+            for (int k = 0; k < nr; k++) one_round(std::integral_constant<int, 0>{}, k);
+        } else {
+            if (regular) {   // (nr is even)
+                for (int k = 0; k < nr; k += 2) {
+                    one_round(std::integral_constant<int, 0>{}, k);
+                    one_round(std::integral_constant<int, 1>{}, k + 1);
+                }
+            } else {
+                one_round(std::integral_constant<int, 0>{}, 0);
+            }
         }
 
         // ---- the superstep closes: did every sample keep clear of the thresholds by more than the window sum drifted?  Every lane
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                     const float M2 = (2.f * B + (eps + RND_SUM) * ssf) * slU + ssf * 7.62939453125e-06f;
                     const float head = fminf(dlmin / fmaxf(need_lo, 1e-30f), dhmin / fmaxf(need_hi, 1e-30f));
                     const float head2 = fminf(dlmin / fmaxf(M2 * loLf, 1e-30f), dhmin / fmaxf(M2 * hiLf, 1e-30f));
-                    if (regular) next_sup = head2 > 2.f ? min(2 * cur_sup, sup) : (head < 1.5f ? max(1, cur_sup / 2) : cur_sup);
+                    if (regular) next_sup = head2 > 2.f ? min(2 * cur_sup, sup) : (head < 1.5f ? max(D, cur_sup / 2) : cur_sup);
                     ssf = rfl(ssf + Dt);
                     if (resync) {   // (the ring is quiescent: the other waves wait for the verdict)
                         double part = 0;
