@@ -112,7 +112,8 @@ struct nfc_ctx {
     int wg = 1, wg_ok = 0, wg_nr = 4, wg_d = 1, wg_slots = 0, wg_slots_ahead = 0, wg_now = 0, wg_rounds = 0;
     int fine_left = 0, fine_adapt = 1, fine_mult = 4;   // batches still to be cut into fine_mult times as many chunks (after a batch that needed re-runs); NFC_CHUNK_ADAPT=0 turns it off   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
                                                                  // rows of 64 samples per step (NFC_WG_NR), resident workgroups, this batch uses it, rounds per superstep
-    size_t wg_lds = 0;
+    size_t wg_lds = 0, wg_lds_base = 0, wg_lds_bulk_max = 0;   // dynamic LDS of k_threshold_wg: with the staging ring / without any staging / the most a whole chunk's planes may bring it to
+    bool wg_bulk = true, wg_bulk_now = false;                  // a chunk's plane words leave when the chunk is done (NFC_WG_BULK=0: always the ring); this launch may
     int wg_rerun = 0;   // certification-only failures re-run by k_threshold_wg in mode 1 (NFC_WG_RERUN=1; see host_threshold.h)
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
@@ -350,10 +351,22 @@ void launch_threshold(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e
 // ... or, where it applies, with a chunk per workgroup (threshold_wg.hip.h)
 template <int KIND>
 void launch_wg(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipEvent_t e1) {
-    const size_t lds = c->wg_lds + (c->dbg_bad_launch ? (size_t)1 << 20 : 0);
+    // the staging of the plane words (threshold_wg.hip.h): the whole chunk's when this launch may and the LDS has room, else the ring
+    ThrArgs B = A;
+    size_t lds = c->wg_lds;
+    B.wg_stage_rounds = 2 * wg_flush_rounds(c->wg_nr);
+    {
+        const int rounds = A.C / wg_round_samples(c->wg_nr) + 2;
+        const size_t need = c->wg_lds_base + wg_stage_bytes(c->wg_nr, rounds);
+        if (c->wg_bulk_now && c->wg_lds_bulk_max && need <= c->wg_lds_bulk_max) {
+            B.wg_stage_rounds = rounds;
+            lds = need;
+        }
+    }
+    if (c->dbg_bad_launch) lds += (size_t)1 << 20;
     auto go = [&](auto kern) {
-        if (e0) NFC_LAUNCH_EXT(kern, dim3(nwork), dim3(256), lds, c->st, e0, e1, 0, A);
-        else NFC_LAUNCH(kern, dim3(nwork), dim3(256), lds, c->st, A);
+        if (e0) NFC_LAUNCH_EXT(kern, dim3(nwork), dim3(256), lds, c->st, e0, e1, 0, B);
+        else NFC_LAUNCH(kern, dim3(nwork), dim3(256), lds, c->st, B);
     };
     switch (c->wg_nr) {
     case 8: go(k_threshold_wg<KIND, 8>); break;

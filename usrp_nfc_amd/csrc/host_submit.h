@@ -61,6 +61,7 @@ int enqueue_threshold_ahead(nfc_ctx *c, nfc_ctx::Submitted &b) {
     A.gfloor = c->lean_gmin;
     A.blk = 1 << c->nfold;
     b.timed = b.timing >= 1;
+    c->wg_bulk_now = false;   // (the other stages' workgroups run beside this kernel: its LDS stays small)
     launch_threshold_kind(c, A, P.nch, true, b.timed ? c->kev_sub[b.slot] : nullptr);
     const uint32_t np = P.nch - 1;
     A.nlist = np;

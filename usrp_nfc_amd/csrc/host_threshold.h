@@ -242,6 +242,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             HIPCHK(c, c->d_certinfo.ensure((size_t)nch * 32 * 5));   // (+ 4 waves x 4 counters per chunk in a profiling build)
             A.dbg_clk = c->d_certinfo.as<unsigned long long>();
         }
+        c->wg_bulk_now = c->wg_bulk;   // (one batch at a time: nothing else wants the CU's LDS)
         launch_threshold_kind(c, A, nch, lean);
         if (dbg_clk) {
             std::vector<unsigned long long> h((size_t)nch * 4);

@@ -126,6 +126,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     if (const char *e = getenv("NFC_WG")) c->wg = atoi(e) != 0;
     if (const char *e = getenv("NFC_WG_ROUNDS")) c->wg_rounds = std::max(1, atoi(e));
     if (const char *e = getenv("NFC_WG_D")) c->wg_d = atoi(e) >= 2 ? 2 : 1;
+    if (const char *e = getenv("NFC_WG_BULK")) c->wg_bulk = atoi(e) != 0;
     if (const char *e = getenv("NFC_WG_RERUN")) c->wg_rerun = atoi(e) != 0;
     if (const char *e = getenv("NFC_LEAN")) c->lean = atoi(e) != 0;
     c->lean_k = 0;        // chosen below from the occupancy the LDS ring allows, unless set here
@@ -220,7 +221,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         c->lean_lds_per_cu = (size_t)((c->lean_slots + prop.multiProcessorCount - 1) / prop.multiProcessorCount) * lds_wave;
         c->ahead_lds_per_cu = c->lean_lds_per_cu;
         // the workgroup kernel: one chunk per 256-thread workgroup, as many resident per CU as LDS and registers admit
-        c->wg_lds = (size_t)c->Lpad * 4 + WG_SHARED_BYTES;
+        c->wg_lds_base = (size_t)c->Lpad * 4 + WG_SHARED_BYTES;
         // rows per step: the largest of 8 / 6 / 4 that leaves a superstep of at least two rounds within 0.8 windows (measured at
         // av_window 2000: six rows with one-round supersteps lose to four rows with two; at 10000 eight rows gain 2 %); a round
         // (four steps) must fit the window, max_len must lie within one step
@@ -231,6 +232,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             const int v = atoi(e);
             if ((v == 4 || v == 6 || v == 8) && c->L >= wg_round_samples(v)) c->wg_nr = v;
         }
+        // (+ the staging of the plane words: a ring of 2 FR rounds; a whole chunk's where the LDS has room, launch_wg)
+        c->wg_lds = c->wg_lds_base + wg_stage_bytes(c->wg_nr, 2 * wg_flush_rounds(c->wg_nr));
         c->wg_ok = c->mx <= 64 * c->wg_nr - 2 && c->L >= wg_round_samples(c->wg_nr) && c->wg_lds <= 160 * 1024;
         if (c->wg_ok) {
             const void *kern = wg_kernel_of(p->input_kind, c->wg_nr, c->wg_d);
@@ -242,6 +245,20 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             per_cu_wg = std::max(1, std::min(4, per_cu_wg));   // (measured: four resident workgroups per CU -- four waves per SIMD -- beat five and three)
             if (const char *e = getenv("NFC_WG_PER_CU")) per_cu_wg = std::max(1, std::min(per_cu_max, atoi(e)));
             c->wg_slots = prop.multiProcessorCount * per_cu_wg;
+            // the most dynamic LDS a workgroup may ask for with per_cu_wg of them still resident per CU: what a chunk's planes may
+            // take when they are kept until the chunk is done (one batch at a time only: launch_wg)
+            c->wg_lds_bulk_max = 0;
+            if (c->wg_bulk) {
+                size_t cand = ((size_t)160 * 1024 / (size_t)per_cu_wg) & ~(size_t)1023;
+                while (cand > c->wg_lds) {
+                    int fit = 0;
+                    if (cand > 64 * 1024) CRT(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cand));
+                    CRT(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, 256, cand));
+                    if (fit >= per_cu_wg) break;
+                    cand -= 1024;
+                }
+                if (cand > c->wg_lds) c->wg_lds_bulk_max = cand;
+            }
             // Batches submitted ahead run beside the edge and decode stages of the batch before them, and those need registers to
             // be resident at all: four workgroups of this kernel per CU hold 4 x 96 of a SIMD's 512 registers and leave the stages
             // ONE wave per SIMD (measured: k_dec_apply 19 -> 102 us beside it, the stages' chain -- not this kernel -- then sets the

@@ -135,6 +135,7 @@ struct ThrArgs {
     float gfac, gfloor;    // drift allowance = max(gfac * (largest B needed so far), gfloor * ss)
     int32_t blk;           // a LOW run longer than max_len covers an aligned block of blk samples (a power of two)
     int32_t ver_zero;              // every version byte is 0 (the certification right behind pass 0): its launches need not load them
+    int32_t wg_stage_rounds;       // k_threshold_wg: rounds of plane words its LDS staging holds per plane (threshold_wg.hip.h; launch_wg sets it)
     unsigned long long *dbg_clk;   // debugging aid (NFC_DEBUG_CLK): per chunk four s_memtime stamps -- start, incoming state ready, loop done, end
 };
 

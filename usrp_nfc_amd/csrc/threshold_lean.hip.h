@@ -123,6 +123,8 @@ __device__ __forceinline__ void lean_take(float (&x)[4], float i16_scale) {
 template <int KIND> struct LeanRaw { static constexpr int BYTES = (KIND == IN_IQ_F32) ? 8 : (KIND == IN_I16_SQ) ? 2 : 4; };
 typedef __attribute__((address_space(3))) float lean_lds_f;
 typedef __attribute__((address_space(1))) uint32_t lean_g_u32;   // (an address computed from integers must not become a flat access)
+typedef uint32_t lean_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) lean_u32x4 lean_g_u128;
 __device__ __forceinline__ uint32_t lean_dpp_shl8(uint32_t v) {   // lane l <- lane l + 8 of its row of 16 (0 where that leaves the row)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xF, 0xF, true);
 }

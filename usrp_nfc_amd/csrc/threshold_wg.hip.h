@@ -39,6 +39,19 @@ constexpr int WG_WAVES = 4;
 // costs once (barriers, bookkeeping, the form dispatch) is spread over that many samples.
 constexpr int wg_round_samples(int nr) { return 64 * nr * WG_WAVES; }
 constexpr int WG_NR_MAX = 8;
+// The plane words of a regular round (a step's 2 NR dwords per plane and wave) are STAGED in LDS behind WgShared, in the planes' own
+// order (per plane: round, wave, dword).  Measured (round 4): with the plane stores taken out the kernel runs 0.158 instead of 0.183 ms,
+// and the same with every store aimed at one 64 KB region -- what costs is not the store instructions but 25 MB of WRITES reaching
+// the HBM in a trickle between the reads of 800 MB (the 16 MB of ring summaries, written in bulk at a chunk's ends, cost 3 us).  So:
+//   * where a CU's LDS holds the planes of its workgroups' whole chunks (2 bits per sample: 24 KB for the 98 304 samples of a chunk
+//     at 1e8 samples per batch, four workgroups per CU) they leave when the chunk is done, all of them at once;
+//   * otherwise (long windows, batches submitted ahead -- the other stages' workgroups need the LDS --, longer chunks) they leave FR
+//     rounds at a time as one wave's 16-byte stores of whole lines, from a ring of 2 FR rounds.
+#ifndef NFC_WG_FR
+#define NFC_WG_FR 8
+#endif
+constexpr int wg_flush_rounds(int nr) { return nr == 4 ? NFC_WG_FR : NFC_WG_FR / 2; }   // 1 KB (768 B at six rows) per plane and flush
+constexpr size_t wg_stage_bytes(int nr, int rounds) { return (size_t)rounds * (size_t)(2 * WG_WAVES * 2 * nr * 4); }   // both planes
 // LDS behind the ring: LOW masks of the rounds' steps, the close exchange, scratch for workgroup reductions
 struct WgShared {
     uint32_t msk[3][WG_WAVES][4 * WG_NR_MAX + 4];   // per round (modulo three) and wave: the LOW masks of its step (dwords 0 .. 2 NR - 1), dword 4 NR: any LOW sample
@@ -159,10 +172,10 @@ __device__ __forceinline__ void wg_take(float (&x)[NR], float i16_scale) {
     }
 }
 // Two rounds of samples asked for ahead (IQ input, four rows per step): a second set of registers, a[8 .. 15], and a wait that
-// lets the younger request stay in flight.  A round issues exactly four loads and one store, in that order after its take: at
-// the take of round r the operations still in flight are -- oldest first -- the loads of round r, the store of round r - 2, the
-// loads of round r + 1 and the store of round r - 1; loads complete in order among themselves, so "at most four left" means
-// the loads of round r are in, whatever the stores do.
+// lets the younger request stay in flight.  A round issues exactly four loads after its take (and, every few rounds in one wave,
+// the two stores of flush_block): at the take of round r the operations still in flight are the loads of round r, the loads of
+// round r + 1 and perhaps stores; loads complete in order among themselves, so "at most four left" means the loads of round r
+// are in, whatever the stores do.
 template <int SET>
 __device__ __forceinline__ void wg_load_step_iq4(uint32_t voff, const char *base) {
     if constexpr (SET == 0) WG_LD4("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", 512, WG_A03, WG_A47);
@@ -615,8 +628,19 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     uint32_t fail = good_run ? 0u : 1u;
     // the plane words of a regular round leave one round later, beside the next request for samples (a store between a request
     // and its use would be waited for with it)
-    int pk_prev = 0;
-    bool pk_pending = false;
+    constexpr int FR = wg_flush_rounds(NR);
+    constexpr uint32_t PST_ROUND = (uint32_t)(WG_WAVES * 2 * NR);     // dwords of a round in one plane's staging
+    // the staging holds A.wg_stage_rounds rounds per plane: the whole chunk (bulk: nothing leaves before the chunk is done), or 2 FR
+    const int st_cap = A.wg_stage_rounds;
+    const bool bulk = (uint32_t)st_cap * (uint32_t)WG_ROUND >= (uint32_t)A.C + (uint32_t)WG_ROUND;
+    const uint32_t PST_PLANE = (uint32_t)st_cap * PST_ROUND;          // dwords of one plane's staging
+    uint32_t *const pst = (uint32_t *)(smem + (size_t)A.Lpad * 4 + WG_SHARED_BYTES);
+    const int st_wrap = bulk ? st_cap : 2 * FR;
+    int st_w = 0, st_a = 0, st_cnt = 0;   // the slot the next round stages in, the oldest staged slot (0 or FR), rounds staged
+    uint32_t st_base = 0u;                // the sample base of the oldest staged round
+    int st_flusher = 0;                   // the wave that sends the next block off (they take turns)
+    // where this lane's dword of a step goes in the staging ring (its plane, its wave's row)
+    const uint32_t st_lane = ((lane >= 2 * NR) ? PST_PLANE : 0u) + (uint32_t)wave * (uint32_t)(2 * NR) + (uint32_t)plane_dword;
     uint32_t hot_last = 0u;   // base of this wave's step in the last regular round done
     int hot_done = 0;         // regular rounds done
     // this lane's dword of its wave's plane store, advanced round by round
@@ -636,10 +660,54 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         }
         // (the first round's first barrier orders this before any read)
     }
+    // FR staged rounds from slot a (0 or FR: contiguous in the ring) to both planes: 16 bytes per lane
+    auto flush_block = [&](const int a, const uint32_t base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            const uintptr_t g = (uintptr_t)(pl ? pos_p : neg_p) + 8 * (uintptr_t)(base >> 6);
+            const uint32_t *src = pst + (pl ? PST_PLANE : 0u) + (uint32_t)a * PST_ROUND;
+#pragma unroll
+            for (uint32_t i0 = 0; i0 < (uint32_t)FR * PST_ROUND; i0 += 256u) {
+                const uint32_t i = i0 + 4u * (uint32_t)lane;
+                if (i < (uint32_t)FR * PST_ROUND) {
+                    const lean_u32x4 v = *(const lean_u32x4 *)(src + i);
+                    *(lean_g_u128 *)(g + 4 * (uintptr_t)i) = v;
+                }
+            }
+        }
+    };
+    // everything still staged (before a round that is not regular, at the chunk's end): wave 0, once every wave has staged its
+    // words -- the caller's condition is uniform
     auto flush_planes = [&]() __attribute__((always_inline)) {
-        if (pk_pending) {
-            if (lane < 4 * NR) *(lean_g_u32 *)(pl_addr - (uintptr_t)(WG_ROUND / 8)) = (uint32_t)pk_prev;
-            pk_pending = false;
+        if (st_cnt) {
+            wg_barrier();
+            if (bulk) {
+                // (the chunk's planes at once, every thread 16 bytes at a time: slots 0 .. st_cnt - 1, contiguous per plane)
+                const uint32_t ndw = (uint32_t)st_cnt * PST_ROUND;
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                    const uintptr_t g = (uintptr_t)(pl ? pos_p : neg_p) + 8 * (uintptr_t)(st_base >> 6);
+                    const uint32_t *src = pst + (pl ? PST_PLANE : 0u);
+                    for (uint32_t i = 4u * (uint32_t)tid; i < ndw; i += 1024u) {
+                        const lean_u32x4 v = *(const lean_u32x4 *)(src + i);
+                        *(lean_g_u128 *)(g + 4 * (uintptr_t)i) = v;
+                    }
+                }
+            } else if (wave == 0) {
+                int slot = st_a;
+                uint32_t base = st_base;
+                for (int r = 0; r < st_cnt; r++) {
+                    for (uint32_t e = (uint32_t)lane; e < 2u * PST_ROUND; e += 64u) {   // (plane, wave, dword) of the round
+                        const uint32_t pl = e / PST_ROUND, wd = e % PST_ROUND;
+                        const uintptr_t g = (uintptr_t)(pl ? pos_p : neg_p) + 8 * (uintptr_t)(base >> 6) + 4 * (uintptr_t)wd;
+                        *(lean_g_u32 *)g = pst[pl * PST_PLANE + (uint32_t)slot * PST_ROUND + wd];
+                    }
+                    slot = (slot + 1 == st_wrap) ? 0 : slot + 1;
+                    base += (uint32_t)WG_ROUND;
+                }
+            }
+            st_cnt = 0;
+            st_w = st_a = 0;   // (the next regular round stages behind a round's barrier: wave 0 is through by then)
         }
     };
     while (good_run && rbase < n1) {
@@ -693,8 +761,13 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 WG_PF_END(pf_take);
                 // the plane words of the round before leave, and the registers take the next round (if the chunk has one: past
                 // its end may be past the caller's buffer)
-                if (pk_pending) {
-                    if (lane < 4 * NR) *(lean_g_u32 *)(pl_addr - (uintptr_t)(WG_ROUND / 8)) = (uint32_t)pk_prev;
+                // (the plane words of the rounds before: staged in LDS, see flush_block)
+                if (!bulk && st_cnt > FR) {   // (uniform) the FR oldest staged rounds are complete in every wave: one wave sends them off
+                    if (wave == st_flusher) flush_block(st_a, st_base);
+                    st_a = (st_a == FR) ? 0 : FR;
+                    st_base += (uint32_t)(FR * WG_ROUND);
+                    st_cnt -= FR;
+                    st_flusher = (st_flusher + 1) & (WG_WAVES - 1);
                 }
                 // (asked for unconditionally; in the chunk's last regular round this round's samples are asked for again and the
                 // values are never used)
@@ -848,8 +921,10 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 }
             }
             if (regular) {
-                pk_prev = pk;
-                pk_pending = true;
+                if (st_cnt == 0) st_base = rbase;
+                if (lane < 4 * NR) pst[st_lane + (uint32_t)st_w * PST_ROUND] = (uint32_t)pk;
+                st_w = (st_w + 1 == st_wrap) ? 0 : st_w + 1;
+                st_cnt++;
                 hot_last = base;
                 hot_done++;
             }
@@ -955,6 +1030,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     }
     flush_planes();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the rounds' loads and stores is left in flight)
+    wg_barrier();   // (the summary below reads plane words that another wave of the workgroup stored)
 
     // ---------------- the chunk's summary ----------------
     // LOW bookkeeping at the chunk's end: the last non-LOW sample and the last LOW sample lie in its last steps (a LOW sample
