@@ -736,6 +736,37 @@ def test_workgroup_kernel_low_runs_time_outs_and_seams(monkeypatch, nr, chunk):
     assert r['stats'].used_sequential == 0 and len(o.transitions()) > 30000
 
 
+@pytest.mark.parametrize('bulk', ['1', '0'])
+@pytest.mark.parametrize('nr', ['4', '8'])
+def test_workgroup_kernel_plane_staging(monkeypatch, bulk, nr):
+    # k_threshold_wg keeps the plane words of its regular rounds in LDS (threshold_wg.hip.h): a whole chunk's, stored when the chunk
+    # is done (bulk), or a ring of 2 FR rounds stored FR at a time by one wave as whole lines (NFC_WG_BULK=0; batches submitted ahead
+    # always).  Chunks of many rounds -- the ring wraps several times, its last flush is a partial one --, a ragged batch end, a
+    # stream that becomes stable in the middle of a chunk (rounds that are not regular store directly, between two flushes), and
+    # the same stream submitted ahead.  Per-sample val, edges, symbols, packets against the C oracle.
+    monkeypatch.setenv('NFC_WG_BULK', bulk)
+    monkeypatch.setenv('NFC_WG_NR', nr)
+    L = {'4': 2000, '8': 2560}[nr]
+    rnd = 256 * int(nr)
+    iq = _wg_torture(500 + int(nr), 1_000_000 + 12_345)
+    params = dict(hi_val=1.1, av_window=L)
+    o = oracle_run(iq, params, api.NFC_IN_IQ_F32)
+    for chunk in (61 * rnd, 23 * rnd):
+        r = run_gpu(iq, params, kind=api.NFC_IN_IQ_F32, chunk_samples=chunk)
+        assert r['stats'].chunk_samples == chunk and r['stats'].used_sequential == 0
+        d = first_diff(r['val'][L:], o.trace().tolist())
+        assert d is None, 'val %s (chunk %d)' % (d, chunk)
+        assert first_diff(r['transitions'], o.transitions()) is None
+        assert r['sym_tag'] == o.symbols(0).tolist() and r['sym_reader'] == o.symbols(1).tolist() and r['packets'] == o.packets()
+    # ... pushed in pieces (the second piece starts in the middle of what was a chunk), then submitted ahead
+    r = run_gpu(iq, params, kind=api.NFC_IN_IQ_F32, chunk_samples=61 * rnd, pushes=[0, 300_001, 777_777, len(iq) // 2])
+    assert first_diff(r['transitions'], o.transitions()) is None and r['packets'] == o.packets()
+    n = len(iq) // 2
+    with api.NfcContext(input_kind=api.NFC_IN_IQ_F32, chunk_samples=61 * rnd, **params) as ctx:
+        tr, s0, s1, pk, ahead = _run_submitted(ctx, iq, [0, 290_000, 610_000, n], 2)
+    assert first_diff(tr, o.transitions()) is None and pk == o.packets()
+
+
 def test_workgroup_kernel_two_rounds_ahead(monkeypatch):
     # the optional second round of samples in flight (NFC_WG_D=2: a second register set and a counted wait)
     monkeypatch.setenv('NFC_WG_D', '2')

@@ -446,17 +446,20 @@ constexpr int EW_CAP = NFC_EW_CAP;   // entries staged per round (a tile of 512 
 // 3072 entries of 2 + 2 bytes: 12 KB per workgroup -- six of them fit in the 96 KB of LDS a CU has left while the threshold
 // kernel of the next batch runs on it (batches submitted ahead), which is when this kernel's occupancy matters most.
 static_assert(EW_WORDS * 64 <= 65536, "tile-local positions are staged in 16 bits");
+// (all of it integers: a per-lane bool that lives across the loop's back edge is kept as a lane MASK in scalar registers and costs
+// three scalar instructions per update -- the walk's trip was 54 vector + 30 scalar instructions; round 4)
 struct EdgeWalk {
-    int lb, left;
-    int32_t q;
-    bool timed, carried;
+    int lb;          // _last_bit
+    int32_t q;       // where _dur last restarted
+    int zst;         // _current_state inside a val-0 run: 0 once the run has timed out, else what the previous run left
+    int32_t tq;      // the sample of the latest time-out if that was the latest entry (POS_NONE otherwise)
+    int32_t cskip;   // A.skip while the run carried into the batch is still in progress (POS_NONE otherwise)
 };
 // (bid of ntiles: the writer may share a launch with another stage's workgroups -- host_context.h: k_certify_and_write)
 __device__ __forceinline__ void write_edges_tile(const EdgeArgs &A, size_t nwords, const EdgeAgg *partials, const EdgeAgg *supers, uint32_t *epos,
                                                  uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
                                                  Last2 *last2_total, EdgeCarry *carry_out, const uint32_t bid, const uint32_t ntiles) {
-    __shared__ uint16_t s_pos[EW_CAP];   // (tile-local sample position: a tile is EW_WORDS * 64 <= 65536 samples)
-    __shared__ uint16_t s_code[EW_CAP];
+    __shared__ uint32_t s_ent[EW_CAP + 1];   // tile-local sample position (a tile is EW_WORDS * 64 <= 65536 samples) | code << 16; slot EW_CAP: entries of another round
     __shared__ EdgeAgg s_agg[SCAN_WAVES];
     TP_DECL();
     const size_t wt = (size_t)bid * EW_WORDS;   // first word of the tile
@@ -530,40 +533,37 @@ __device__ __forceinline__ void write_edges_tile(const EdgeArgs &A, size_t nword
     EdgeWalk W0;
     {
         const Last2 c = before.l;
-        W0.carried = c.s1 == POS_NONE;
-        const int32_t s = W0.carried ? (int32_t)A.skip - A.dur_in : c.s1;
+        const bool carried = c.s1 == POS_NONE;
+        const int32_t s = carried ? (int32_t)A.skip - A.dur_in : c.s1;
         const int32_t k = (int32_t)A.timeouts_between(s, T);   // time-outs of the run so far
         W0.q = s + k * A.mx;
-        W0.timed = k > 0;
-        W0.left = A.state_in;
-        if (W0.carried) {
+        const bool timed = k > 0;
+        int left = A.state_in;
+        if (carried) {
             W0.lb = A.last_bit_in;
         } else {
             // (no change between c.s1 and T: val at T - 1 is the run's; T - 1 is the last sample of the word before the
             // thread's, or -- past the end of the batch -- nothing the walk will use)
             W0.lb = val_before;
-            if (W0.lb == 0 && !W0.timed) {   // a val-0 run that has not timed out keeps what the previous run left
+            if (W0.lb == 0 && !timed) {   // a val-0 run that has not timed out keeps what the previous run left
                 int lb, dur;
-                A.state_before(T, c, lb, dur, W0.left);
+                A.state_before(T, c, lb, dur, left);
             }
         }
+        W0.zst = timed ? 0 : left;
+        W0.tq = timed ? W0.q : POS_NONE;
+        W0.cskip = carried ? (int32_t)A.skip : POS_NONE;
     }
     const int32_t tile_p0 = (int32_t)(wt * 64);
     TP_MARK();   // 2: block scan + where the walk stands
     for (uint32_t rbase = 0; rbase < total; rbase += EW_CAP) {   // (a second round walks again: only tiles denser than EW_CAP)
         EdgeWalk W = W0;
-        uint32_t k = off - rbase;   // wraps below the round: the unsigned compare drops those
-        auto emit = [&](int32_t p, int v, int d, int t) {
-            if (k < (uint32_t)EW_CAP) {
-                s_pos[k] = (uint16_t)(p - tile_p0);
-                s_code[k] = edge_code(v, d, t, A.nd);
-            }
-            k++;
-        };
+        uint32_t k4 = (off - rbase) * 4u;   // (byte offset of the next entry's slot) wraps below the round: the unsigned clamp sends those to the spare slot
 #pragma unroll
         for (int i = 0; i < EW_ITEMS; i++) {
             const int32_t w0 = (int32_t)((w_first + i) * 64);
             const int32_t end = min(w0 + 64, (int32_t)A.n);
+            const uint32_t ng_lo = (uint32_t)ng[i], ng_hi = (uint32_t)(ng[i] >> 32), ps_lo = (uint32_t)ps[i], ps_hi = (uint32_t)(ps[i] >> 32);
             uint64_t mm = m[i];
             while (true) {
                 const int b = mm ? __ffsll((long long)mm) - 1 : 64;
@@ -573,20 +573,30 @@ __device__ __forceinline__ void write_edges_tile(const EdgeArgs &A, size_t nword
                 if (!is_to && !mm) break;
                 const int32_t p = is_to ? nt : c;
                 // _current_state before sample p
-                const int run_st = (W.lb == -1) ? 2 : 1;            // inside a LOW / HIGH run ...
-                const int zero_st = W.timed ? 0 : W.left;           // inside a val-0 run
-                int prev_st = (W.lb != 0) ? ((W.timed && W.q == p - 1) ? 0 : run_st) : zero_st;   // ... unless p - 1 timed out
-                if (W.carried && p == (int32_t)A.skip) prev_st = A.state_in;   // the first stable sample: the carried value itself
+                const int run_st = (W.lb == -1) ? 2 : 1;                                  // inside a LOW / HIGH run ...
+                int prev_st = (W.lb != 0) ? ((W.tq == p - 1) ? 0 : run_st) : W.zst;       // ... unless p - 1 timed out; inside a val-0 run
+                prev_st = (p == W.cskip) ? A.state_in : prev_st;                          // the first stable sample: the carried value itself
                 // a time-out keeps val and takes the run's state; a change (transition_sink.py:86-92) takes the new val's
-                const int val = is_to ? W.lb : (((ng[i] >> b) & 1ull) ? -1 : (int)((ps[i] >> b) & 1ull));
-                const int st = is_to ? ((W.lb != 0) ? run_st : zero_st) : ((val == -1) ? 2 : ((val == 1) ? 1 : prev_st));
-                emit(p, st == 2 ? W.lb + 1 : W.lb, (is_to || prev_st == 0) ? A.mx : p - W.q, st - 1);
-                W.left = is_to ? W.left : prev_st;
+                // (val at bit b: the half of the word first -- 64-bit shifts by a register run at a quarter of the rate)
+                const uint32_t nh = b < 32 ? ng_lo : ng_hi, ph = b < 32 ? ps_lo : ps_hi;
+                const int vb = __builtin_amdgcn_ubfe(nh, (uint32_t)b & 31u, 1u) ? -1 : (int)__builtin_amdgcn_ubfe(ph, (uint32_t)b & 31u, 1u);
+                const int val = is_to ? W.lb : vb;
+                const int st = is_to ? ((W.lb != 0) ? run_st : W.zst) : ((val == -1) ? 2 : ((val == 1) ? 1 : prev_st));
+                {
+                    const int v = st == 2 ? W.lb + 1 : W.lb, d = (is_to || prev_st == 0) ? A.mx : p - W.q, t = st - 1;
+                    const int dd = d < A.nd ? d : A.nd - 1;   // (edge_code, with its product of two small numbers at full rate)
+                    uint32_t row;   // (v + 1) * nd + dd: v_mad_u32_u24, one full-rate instruction (the compiler picks the 32-bit product, a quarter of the rate)
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"((uint32_t)(v + 1)), "s"((uint32_t)A.nd), "v"((uint32_t)dd));
+                    const uint32_t code = row | ((uint32_t)(t + 1) << 14);
+                    *(uint32_t *)((char *)s_ent + min(k4, (uint32_t)EW_CAP * 4u)) = (uint32_t)(p - tile_p0) | (code << 16);
+                    k4 += 4u;
+                }
+                W.zst = is_to ? 0 : prev_st;
+                W.tq = is_to ? p : POS_NONE;
+                W.cskip = is_to ? W.cskip : POS_NONE;
                 W.lb = val;
                 W.q = p;
-                W.timed = is_to;
-                W.carried = W.carried && is_to;
-                if (!is_to) mm &= mm - 1;
+                mm &= mm - (is_to ? 0ull : 1ull);
             }
         }
         TP_MARK();   // 3: the walk
@@ -596,8 +606,9 @@ __device__ __forceinline__ void write_edges_tile(const EdgeArgs &A, size_t nword
         for (uint32_t j = threadIdx.x; j < cnt; j += SCAN_BLOCK) {
             const uint32_t g = gbase + rbase + j;
             if (g < cap) {
-                epos[g] = (uint32_t)tile_p0 + s_pos[j];
-                ecode[g] = s_code[j];
+                const uint32_t e = s_ent[j];
+                epos[g] = (uint32_t)tile_p0 + (e & 0xFFFFu);
+                ecode[g] = (uint16_t)(e >> 16);
             }
         }
         __syncthreads();

@@ -1207,6 +1207,15 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     const int tid = (int)threadIdx.x;
     const float *rin = A.ring_in + (size_t)c * L;
     const RunMeta mt = A.meta[c];
+    if (mt.eps > 0.f && !mt.all_robust && !dbg) {
+        // a speculated evaluation that gave up, or left the fast path: it cannot stand whatever its window turns out to be -- no
+        // look-back for it (a stream hovering at a threshold: every chunk of pass 0, 106 -> 10 us of this launch)
+        if (tid == 0) {
+            cert[c] = 0;
+            if (sum) atomicAdd(&sum->n_fail, 1u);
+        }
+        return;
+    }
     const int vb = A.ver_zero ? 0 : A.ver[c - 1];   // (a load the two below would have to wait for)
     const uint32_t *tw = A.touched[vb] + (size_t)(c - 1) * A.twords;
     const float *ro = A.ring_out[vb] + (size_t)(c - 1) * L;
