@@ -514,7 +514,7 @@ def stress_config(a, name, n, steps=6):
         # (the first step is the stream's first batch in this regime: pass 0 runs on the clean stream's chunking, its verdict says the
         # stream needs re-runs, and the batch is cut four times finer there and then -- host_threshold.h: recut; the context keeps the
         # fine cut for as long as batches need re-runs, fine_left -- which is what the median shows)
-        out.update({'ms_per_step': float(np.median(ts[1:])) * 1e3, 'steps': steps - 1, 'first_step_ms': ts[0] * 1e3,
+        out.update({'ms_per_step': float(np.median(ts[1:])) * 1e3, 'steps': steps - 1, 'first_step_ms': ts[0] * 1e3, 'steps_ms': [round(t * 1e3, 4) for t in ts],
                     'threshold_passes': int(st.threshold_passes), 'chunks_rerun': int(st.chunks_rerun), 'n_chunks': int(st.n_chunks),
                     'chunk_samples': int(st.chunk_samples), 'used_sequential': int(st.used_sequential)})
         if not a.no_parity:

@@ -125,6 +125,8 @@ typedef __attribute__((address_space(3))) float lean_lds_f;
 typedef __attribute__((address_space(1))) uint32_t lean_g_u32;   // (an address computed from integers must not become a flat access)
 typedef uint32_t lean_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) lean_u32x4 lean_g_u128;
+typedef __attribute__((address_space(3))) uint32_t lean_lds_u32;
+typedef __attribute__((address_space(3))) lean_u32x4 lean_lds_u128;
 __device__ __forceinline__ uint32_t lean_dpp_shl8(uint32_t v) {   // lane l <- lane l + 8 of its row of 16 (0 where that leaves the row)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xF, 0xF, true);
 }

@@ -634,9 +634,11 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     const int st_cap = A.wg_stage_rounds;
     const bool bulk = (uint32_t)st_cap * (uint32_t)WG_ROUND >= (uint32_t)A.C + (uint32_t)WG_ROUND;
     const uint32_t PST_PLANE = (uint32_t)st_cap * PST_ROUND;          // dwords of one plane's staging
-    uint32_t *const pst = (uint32_t *)(smem + (size_t)A.Lpad * 4 + WG_SHARED_BYTES);
+    lean_lds_u32 *const pst = (lean_lds_u32 *)(uint32_t *)(smem + (size_t)A.Lpad * 4 + WG_SHARED_BYTES);   // (LDS addresses: 32-bit arithmetic)
     const int st_wrap = bulk ? st_cap : 2 * FR;
-    int st_w = 0, st_a = 0, st_cnt = 0;   // the slot the next round stages in, the oldest staged slot (0 or FR), rounds staged
+    const uint32_t st_wrap_off = (uint32_t)st_wrap * PST_ROUND;
+    uint32_t st_off = 0u;                 // the slot the next round stages in, as a dword offset into a plane's staging
+    int st_a = 0, st_cnt = 0;             // the oldest staged slot (0 or FR), rounds staged
     uint32_t st_base = 0u;                // the sample base of the oldest staged round
     int st_flusher = 0;                   // the wave that sends the next block off (they take turns)
     // where this lane's dword of a step goes in the staging ring (its plane, its wave's row)
@@ -665,12 +667,12 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
 #pragma unroll
         for (int pl = 0; pl < 2; pl++) {
             const uintptr_t g = (uintptr_t)(pl ? pos_p : neg_p) + 8 * (uintptr_t)(base >> 6);
-            const uint32_t *src = pst + (pl ? PST_PLANE : 0u) + (uint32_t)a * PST_ROUND;
+            const lean_lds_u32 *src = pst + (pl ? PST_PLANE : 0u) + (uint32_t)a * PST_ROUND;
 #pragma unroll
             for (uint32_t i0 = 0; i0 < (uint32_t)FR * PST_ROUND; i0 += 256u) {
                 const uint32_t i = i0 + 4u * (uint32_t)lane;
                 if (i < (uint32_t)FR * PST_ROUND) {
-                    const lean_u32x4 v = *(const lean_u32x4 *)(src + i);
+                    const lean_u32x4 v = *(const lean_lds_u128 *)(src + i);
                     *(lean_g_u128 *)(g + 4 * (uintptr_t)i) = v;
                 }
             }
@@ -687,9 +689,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
 #pragma unroll
                 for (int pl = 0; pl < 2; pl++) {
                     const uintptr_t g = (uintptr_t)(pl ? pos_p : neg_p) + 8 * (uintptr_t)(st_base >> 6);
-                    const uint32_t *src = pst + (pl ? PST_PLANE : 0u);
+                    const lean_lds_u32 *src = pst + (pl ? PST_PLANE : 0u);
                     for (uint32_t i = 4u * (uint32_t)tid; i < ndw; i += 1024u) {
-                        const lean_u32x4 v = *(const lean_u32x4 *)(src + i);
+                        const lean_u32x4 v = *(const lean_lds_u128 *)(src + i);
                         *(lean_g_u128 *)(g + 4 * (uintptr_t)i) = v;
                     }
                 }
@@ -707,7 +709,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 }
             }
             st_cnt = 0;
-            st_w = st_a = 0;   // (the next regular round stages behind a round's barrier: wave 0 is through by then)
+            st_a = 0;
+            st_off = 0u;   // (the next regular round stages behind a round's barrier: wave 0 is through by then)
         }
     };
     while (good_run && rbase < n1) {
@@ -922,8 +925,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             }
             if (regular) {
                 if (st_cnt == 0) st_base = rbase;
-                if (lane < 4 * NR) pst[st_lane + (uint32_t)st_w * PST_ROUND] = (uint32_t)pk;
-                st_w = (st_w + 1 == st_wrap) ? 0 : st_w + 1;
+                if (lane < 4 * NR) pst[st_lane + st_off] = (uint32_t)pk;
+                st_off += PST_ROUND;
+                st_off = (st_off == st_wrap_off) ? 0u : st_off;
                 st_cnt++;
                 hot_last = base;
                 hot_done++;
