@@ -1387,18 +1387,11 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_fill(const void *in, uint32_t n,
     }
     const int filled = carry->filled;
     const int can = min((int)n, L - filled);
-    for (int i = tid; i < can; i += FILL_BLOCK) ring[filled + i] = envelope_at<KIND>(in, (size_t)i, i16_scale);
-    __syncthreads();
-    if (filled + can != L) {
-        if (tid == 0) carry->filled = filled + can;
-        return;
-    }
     // If the exponent spread of the window proves every partial sum exact, any order gives the reference's
     // sum; otherwise add in the reference's order on one lane and note whether a rounding happened.
     double part = 0;
     uint32_t emin = 255u, emax = 0u;
-    for (int i = tid; i < L; i += FILL_BLOCK) {
-        const float v = ring[i];
+    auto take = [&](int i, float v) {
         lr[i] = v;
         part += (double)v;
         if (v != 0.f) {
@@ -1406,6 +1399,23 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_fill(const void *in, uint32_t n,
             emin = min(emin, e);
             emax = max(emax, e);
         }
+    };
+    if (filled == 0 && can == L) {
+        // a whole window from this batch (a fresh stream's first batch): the samples go to the ring and into the sums in one pass
+        // -- no second trip to the ring behind a barrier (this launch is a chain of dependent round trips: 7.9 us of a batch)
+        for (int i = tid; i < L; i += FILL_BLOCK) {
+            const float v = envelope_at<KIND>(in, (size_t)i, i16_scale);
+            ring[i] = v;
+            take(i, v);
+        }
+    } else {
+        for (int i = tid; i < can; i += FILL_BLOCK) ring[filled + i] = envelope_at<KIND>(in, (size_t)i, i16_scale);
+        __syncthreads();
+        if (filled + can != L) {
+            if (tid == 0) carry->filled = filled + can;
+            return;
+        }
+        for (int i = tid; i < L; i += FILL_BLOCK) take(i, ring[i]);
     }
     fill_reduce(red, part, emin, emax);   // (its barriers also publish lr)
     const double S = part;
