@@ -45,8 +45,9 @@ namespace nfc {
 // touches them unless it spills -- tools/audit_lean_isa.py checks that it does not) and reach the compiler's registers only
 // through the statement that first waits for them: lean_take<K> = s_waitcnt vmcnt(N) + v_accvgpr_read.
 // Step k of a superstep owns a[8 k .. 8 k + 7] (IQ: four pairs; the one-dword kinds use the first four).
+// (non-temporal: the samples are read once -- threshold_wg.hip.h, NFC_WG_LDPOL)
 #define LEAN_LOAD4(OP, R0, R1, R2, R3, STRIDE, ...)                                                                                         \
-    asm volatile(OP " " R0 ", %0, off\n\t" OP " " R1 ", %0, off offset:%1\n\t" OP " " R2 ", %0, off offset:%2\n\t" OP " " R3 ", %0, off offset:%3" \
+    asm volatile(OP " " R0 ", %0, off nt\n\t" OP " " R1 ", %0, off offset:%1 nt\n\t" OP " " R2 ", %0, off offset:%2 nt\n\t" OP " " R3 ", %0, off offset:%3 nt" \
                  :                                                                                                                          \
                  : "v"(p), "n"(STRIDE), "n"(2 * STRIDE), "n"(3 * STRIDE)                                                                    \
                  : "memory", __VA_ARGS__)
