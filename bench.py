@@ -29,9 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-STREAM_CEILING_GBS = 5970.0   # what a read-only kernel with k_threshold_wg's access pattern (a 98 304-sample chunk per 256-thread workgroup,
+STREAM_CEILING_GBS = 7030.0   # what a read-only kernel with k_threshold_wg's access pattern (a 98 304-sample chunk per 256-thread workgroup,
                               # four per CU; a wave's 2 KB step of every 1 024-sample round asked for one round ahead, a barrier per round)
-                              # reaches on this machine: tools/ubench/stream_chunks.hip, profiles/r04_stream_ceiling.txt
+                              # reaches on this machine with non-temporal loads, as the kernel's are (5 970 with plain ones):
+                              # tools/ubench/stream_chunks.hip, profiles/r04_stream_ceiling.txt
 
 
 def parse():

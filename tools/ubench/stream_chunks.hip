@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_chunks_wg(const float2 *in, size_t n, u
 
 // the round-3/4 threshold kernel's pattern (k_threshold_wg): a chunk per 256-thread workgroup, four resident per CU; a ROUND is 1024
 // samples, wave w takes its 256-sample step (four 512-byte rows) of every round, asked for D rounds ahead; one barrier per round
-template <int D>
+template <int D, bool NT = false>
 __global__ __launch_bounds__(256) void k_chunks_round(const float2 *in, size_t n, uint32_t C, float *out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t m0 = (size_t)blockIdx.x * C;
@@ -73,7 +73,17 @@ __global__ __launch_bounds__(256) void k_chunks_round(const float2 *in, size_t n
     const size_t rounds = (m1 - m0) / 1024;
     float2 r[D][4];
     float acc = 0.f;
-    auto at = [&](size_t rd, int j) { const size_t q = rd < rounds ? rd : rounds - 1; return in[m0 + q * 1024 + 256 * wave + 64 * j + lane]; };
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    auto at = [&](size_t rd, int j) {
+        const size_t q = rd < rounds ? rd : rounds - 1;
+        const size_t i = m0 + q * 1024 + 256 * wave + 64 * j + lane;
+        if constexpr (NT) {   // (the non-temporal hint, as k_threshold_wg's loads carry it since the end of round 4)
+            const f32x2_t v = __builtin_nontemporal_load((const f32x2_t *)in + i);
+            return make_float2(v.x, v.y);
+        } else {
+            return in[i];
+        }
+    };
 #pragma unroll
     for (int k = 0; k < D; k++)
 #pragma unroll
@@ -156,6 +166,8 @@ int main() {
         printf("k_threshold_wg's pattern (chunk per workgroup, %d per CU: C %u, %u blocks; a wave's step of every 1024-sample round, 1 round ahead, a barrier per round): %.3f ms  %.2f TB/s\n", per_cu, C, blocks, ms, gb / ms);
         ms = timeit([&] { hipLaunchKernelGGL(k_chunks_round<2>, dim3(blocks), dim3(256), 0, 0, d, n, C, o); });
         printf("   ... 2 rounds ahead: %.3f ms  %.2f TB/s\n", ms, gb / ms);
+        ms = timeit([&] { hipLaunchKernelGGL((k_chunks_round<1, true>), dim3(blocks), dim3(256), 0, 0, d, n, C, o); });
+        printf("   ... 1 round ahead, non-temporal loads: %.3f ms  %.2f TB/s\n", ms, gb / ms);
     }
     for (int g : {256 * 8, 256 * 20, 256 * 64}) {
         float ms = timeit([&] { hipLaunchKernelGGL(k_plain, dim3(g), dim3(256), 0, 0, (const float4 *)d, n / 2, o); });
