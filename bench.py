@@ -368,11 +368,12 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
     def summary(acc):
         ka = float(np.mean(acc['kernel_ms'])) if acc['kernel_ms'] else float('nan')
         ach = float(bps) * n / (ka * 1e-3) / 1e9
-        what = ('consecutive batches of one stream per rank, %d in flight: batch k + %d is submitted before batch k is waited for (%d of %d timed '
-                'steps ran ahead)%s' % (a.in_flight, a.in_flight - 1, acc['n_ahead'], steps,
-                                        '; the rank\'s time shard is that stream: one boundary exchange after its last batch' if sharded else '')
-                if acc['mode'] == 'ahead' else 'a fresh stream per step, pushed synchronously (nfc_push_device): nothing runs beside the threshold kernel')
-        return {'steps_are': what, 'ms_per_step': acc['dt'] / steps * 1e3, 'value': world * n * steps / acc['dt'] / 1e6, 'unit': 'Msamples/s',
+        # stepping: 'sync' = a fresh stream per step, pushed synchronously (nfc_push_device): nothing runs beside the threshold kernel;
+        # 'ahead' = consecutive batches of one stream per rank, in_flight of them submitted before the oldest is waited for (with several
+        # ranks the rank's time shard is that stream: one boundary exchange after its last batch)
+        what = acc['mode']
+        return {'stepping': what, 'in_flight': a.in_flight if what == 'ahead' else 1, 'ran_ahead': acc['n_ahead'] if what == 'ahead' else 0,
+                'ms_per_step': acc['dt'] / steps * 1e3, 'value': world * n * steps / acc['dt'] / 1e6, 'unit': 'Msamples/s',
                 'steps': steps, 'boundary_redos': acc['redo'],
                 'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                              'avg_launch_ms': ka, 'launches_timed': len(acc['kernel_ms']),
@@ -418,22 +419,29 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                        'shard_overlap_samples': overlap_steps(workload, n) if world > 1 else [], 'overlap_used': ov_used,
                        'exchange': backend if world > 1 else 'none',
                        'rccl_ranks_seen': getattr(comm, 'ranks_seen', None),
-                       'steps_are': summary(prim)['steps_are']},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_wg (fused envelope + gated-mean threshold, a time chunk per workgroup; k_threshold_lean / k_threshold where it does not apply)',
+                       'stepping': prim['mode'], 'in_flight': a.in_flight if prim['mode'] == 'ahead' else 1},
+            # (kernel: the fused envelope + gated-mean threshold kernel, a time chunk per workgroup; k_threshold_lean / k_threshold where it does not apply)
+            'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_wg',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': tsrc, 'avg_launch_ms': k_avg, 'launches_timed': len(kernel_ms),
                          'launches_per_step': float(np.mean(n_pass)) if n_pass else None,
                          'algorithmic_bytes_per_launch': thr_bytes,
                          'streaming_read_ceiling': STREAM_CEILING_GBS, 'frac_of_streaming_ceiling': achieved / STREAM_CEILING_GBS,
-                         'note': '%d B/sample only: the 16 B/edge of SURVEY 8(d) are written by the edge stage, listed under edge_stage' % bps
-                                 + ('; the launches of the timed region run BESIDE the previous batch\'s edge and decode stages (batches submitted ahead) and '
-                                    'share the SIMDs\' issue slots with them: one_batch_at_a_time.roofline is the same kernel with the machine to itself' if ahead else
-                                    '; submitted_ahead is the same stream with batches submitted ahead: more samples per second, and the kernel\'s launches '
-                                    'stretched by what runs beside them')},
+                         # (bytes_per_sample only: the 16 B/edge of SURVEY 8(d) are written by the edge stage, listed under edge_stage and
+                         # counted in whole_path; with --primary ahead the timed launches run BESIDE the previous batch's later stages)
+                         'bytes_per_sample': bps,
+                         # what README / DESIGN quote beside frac, inside the object the driver's record keeps:
+                         'whole_path_frac': (thr_bytes + edge_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+                         'tail_us_per_step': (dt / steps * 1e3 - k_avg) * 1e3,   # everything of a step but the threshold kernel: later stages, k_fill, launch gaps, the host's turn
+                         'stages_us_extra_step': {'threshold': st.ms_threshold * 1e3, 'edges': st.ms_edges * 1e3, 'decode': st.ms_decode * 1e3},
+                         ('one_batch_at_a_time_ms_per_step' if ahead else 'submitted_ahead_ms_per_step'): (other['dt'] / steps * 1e3 if other else None),
+                         ('one_batch_at_a_time_avg_launch_ms' if ahead else 'submitted_ahead_avg_launch_ms'):
+                             (float(np.mean(other['kernel_ms'])) if other and other['kernel_ms'] else None),
+                         'submitted_ahead_ran_ahead': ((prim if ahead else other)['n_ahead'] if (ahead or other) else None)},
             'edge_stage': {'algorithmic_bytes': edge_bytes, 'bytes_stored': stored_bytes, 'stage_ms': st.ms_edges,
-                           'achieved_GBs': (edge_bytes / (st.ms_edges * 1e-3) / 1e9) if st.ms_edges > 0 else None,
-                           'note': 'all kernels of the edge stage of the extra, marker-timed step (tile aggregates, writer); algorithmic_bytes '
-                                   'is SURVEY 8(d)\'s 16 B per edge, the stage stores 6 B per entry and nfc_read_edges builds the 16-byte records'},
+                           # (all kernels of the edge stage of the extra, marker-timed step; algorithmic_bytes is SURVEY 8(d)'s 16 B per edge,
+                           # the stage stores 6 B per entry and nfc_read_edges builds the 16-byte records)
+                           'achieved_GBs': (edge_bytes / (st.ms_edges * 1e-3) / 1e9) if st.ms_edges > 0 else None},
             'whole_path': {'algorithmic_bytes': thr_bytes + edge_bytes,
                            'achieved_GBs': (thr_bytes + edge_bytes) / (dt / steps) / 1e9, 'frac': (thr_bytes + edge_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS},
             ('one_batch_at_a_time' if ahead else 'submitted_ahead'): (summary(other) if other else None),
@@ -503,7 +511,7 @@ def stress_config(a, name, n, steps=6):
         ctx.push_device(clean, n)
         ctx.sync()
         clean.free()
-        ts = []
+        ts, allocs = [], []
         for k in range(steps):
             ctx.reset()
             ctx.sync()
@@ -511,11 +519,13 @@ def stress_config(a, name, n, steps=6):
             ctx.push_device(buf, n)
             ctx.sync()
             ts.append(time.perf_counter() - t0)
+            allocs.append(int(ctx.stats().device_allocs))   # (buffers (re)allocated inside the batch: 0 is what a stream may expect)
         st = ctx.stats()
         # (the first step is the stream's first batch in this regime: pass 0 runs on the clean stream's chunking, its verdict says the
         # stream needs re-runs, and the batch is cut four times finer there and then -- host_threshold.h: recut; the context keeps the
         # fine cut for as long as batches need re-runs, fine_left -- which is what the median shows)
         out.update({'ms_per_step': float(np.median(ts[1:])) * 1e3, 'steps': steps - 1, 'first_step_ms': ts[0] * 1e3, 'steps_ms': [round(t * 1e3, 4) for t in ts],
+                    'device_allocs': allocs, 'worst_over_median': float(max(ts[1:]) / np.median(ts[1:])),
                     'threshold_passes': int(st.threshold_passes), 'chunks_rerun': int(st.chunks_rerun), 'n_chunks': int(st.n_chunks),
                     'chunk_samples': int(st.chunk_samples), 'used_sequential': int(st.used_sequential)})
         if not a.no_parity:
@@ -657,11 +667,9 @@ def cpu_baseline(own, flags, params, kind='iq'):
     po.run_path(x, chunk=8192, **params, **flags)
     tp = time.perf_counter() - t0
     return {'value': n / tc / 1e6, 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
-            'sample': 'oracle/nfc_oracle.c (C restatement of transition_sink+decoders), whole %d-sample workload, '
-                      '1 thread; the reference itself is a single-threaded Python loop' % n,
+            'sample': 'oracle/nfc_oracle.c, whole %d-sample workload, 1 thread (the reference is a single-threaded Python loop)' % n,
             'python_restatement_msamples_s': npy / tp / 1e6,
-            'python_sample': 'oracle/py_oracle.py on the first %d samples in 8192-sample work() calls '
-                             '(GNU Radio is not installed: envelope by numpy)' % npy,
+            'python_sample': 'oracle/py_oracle.py, first %d samples, 8192-sample work() calls (no GNU Radio: envelope by numpy)' % npy,
             'host_cpus': os.cpu_count()}
 
 

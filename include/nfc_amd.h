@@ -31,7 +31,8 @@ extern "C" {
 
 /* 2: nfc_stats grew (ran_ahead, redone_total, ring_slots_carried); i16_scale == 0 means sample / 32767 (GNU Radio's wavfile_source), not / 32768 */
 /* 3: nfc_stats.reserved0 became decode_respeculated (same layout); the raw float32 envelope takes the fast threshold kernels */
-#define NFC_AMD_ABI_VERSION 3
+/* 4: nfc_stats grew (device_allocs, reserved1) */
+#define NFC_AMD_ABI_VERSION 4
 
 typedef enum {
     NFC_OK = 0,
@@ -123,6 +124,10 @@ typedef struct {
     uint32_t decode_respeculated; /* batches of this context whose decode stage was repeated in the three-launch form because a tile of the
                                    * speculative form (a run-in of the predecessor tile's last edges instead of a scan over all tiles)
                                    * had assumed a decoder state that the check found wrong: a frame longer than the run-in */
+    uint32_t device_allocs;   /* device / pinned buffers (re)allocated while the last batch was submitted and processed: 0 in the steady state
+                               * of a stream -- the buffers are sized when a stream's first batch of a length is seen, with room for four
+                               * times the transition density of a clean capture, so a stream that turns dense does not pay hipMalloc */
+    uint32_t reserved1;
 } nfc_stats;
 
 /* Everything a successor time chunk needs from its predecessor:

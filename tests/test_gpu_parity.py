@@ -402,6 +402,66 @@ def test_frames_longer_than_the_run_in_take_the_fall_back(monkeypatch, runin):
     assert pk == o.packets() and sum(len(b) > 2000 for _, b in pk) == 6
 
 
+def _long_frame_stream(n_frames, seed=43):
+    """Ordinary reader traffic, then `n_frames` 250-byte reader frames 60 us apart (no gap within a 512-edge run-in at the tile seams
+    inside them), then ordinary traffic again; returns (iq, first sample of the long frames, first sample behind them)."""
+    rng = np.random.default_rng(seed)
+    long_frames = [(synth.READER, synth.frame_bits(rng.integers(0, 256, 250).tolist(), 0)) for _ in range(n_frames)]
+    m_long = synth.modulation_profile(long_frames, rate_msps=2.0, gap_us=60.0, lead_in=3000, tail=400)
+    head = synth.workload('miller', 700_000)
+    tail = synth.workload('miller', 900_000)
+    iq_long = synth.iq_from_profile(m_long)
+    iq = np.concatenate([head, iq_long, tail[2 * 3000:]])
+    return iq, len(head) // 2, (len(head) + len(iq_long)) // 2
+
+
+def test_long_frames_in_batches_submitted_ahead_repeat_the_decode_stage_only():
+    # A batch that ran ahead and whose speculative decode fails its check (a frame longer than the run-in across a tile seam) keeps its
+    # threshold and edge stages: nfc_wait repeats the decode stage alone, in the three-launch form -- the batch is NOT processed again
+    # (redone_total stays 0) and the batches submitted behind it are not restarted; the batches that follow take the three-launch
+    # form straight away, and speculation comes back once the traffic is ordinary again.
+    iq, n0, n1 = _long_frame_stream(40)
+    n = len(iq) // 2
+    o = oracle_run(iq, dict(hi_val=1.1), api.NFC_IN_IQ_F32)
+    step = 330_000
+    cuts = [0, n0] + list(range(n0 + step, n, step)) + [n]
+    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        tr, s0, s1, pk, ahead = _run_submitted(ctx, iq, cuts, 3)
+        st = ctx.stats()
+    d = first_diff(tr, o.transitions())
+    assert d is None, 'transition %s' % (d,)
+    assert s0 == o.symbols(0).tolist() and s1 == o.symbols(1).tolist()
+    assert pk == o.packets() and sum(len(b) > 2000 for _, b in pk) == 40
+    assert st.decode_respeculated >= 1, st.decode_respeculated     # the check failed at least once ...
+    assert st.redone_total == 0, st.redone_total                   # ... and no batch went through the synchronous path again for it
+    assert ahead >= len(cuts) - 3, (ahead, len(cuts))              # every batch behind the window-filling one ran ahead
+
+
+def test_long_frames_through_push_edges_take_the_fall_back():
+    # the same frames as a caller's own transition list (nfc_push_edges: decode and framing alone): the check fails, the stage is
+    # repeated in the three-launch form, symbols and packets are the reference's
+    iq, n0, n1 = _long_frame_stream(8)
+    o = oracle_run(iq, dict(hi_val=1.1), api.NFC_IN_IQ_F32)
+    want_tr = o.transitions()
+    e = np.zeros(len(want_tr), api.EDGE_DTYPE)
+    e['v'] = [v for (v, _), _ in want_tr]
+    e['d'] = [int(round(us / 0.5)) for (_, us), _ in want_tr]
+    e['t'] = [t for _, t in want_tr]
+    e['idx'] = np.arange(len(want_tr), dtype=np.uint64)
+    with api.NfcContext(hi_val=1.1, samp_rate=2e6, max_len=50) as ctx:
+        s0, s1, pk, resp = [], [], [], []
+        third = len(e) // 3
+        for a, b in ((0, third), (third, 2 * third), (2 * third, len(e))):
+            ctx.push_edges(e[a:b])
+            s0 += ctx.symbols(0).tolist()
+            s1 += ctx.symbols(1).tolist()
+            pk += [bits for _, bits in ctx.packets()]
+            resp.append(int(ctx.stats().decode_respeculated))
+    assert resp[-1] >= 1, resp
+    assert s0 == o.symbols(0).tolist() and s1 == o.symbols(1).tolist()
+    assert pk == [bits for _, bits in o.packets()] and sum(len(b) > 2000 for b in pk) == 8
+
+
 def test_stats_after_wait_belong_to_that_batch():
     # nfc_stats.ring_slots_carried is documented as "of the last batch": for a batch submitted ahead it must come from that batch's
     # own snapshot -- by the time nfc_wait returns, the device's summary has been rewritten by the batch submitted behind it
@@ -820,3 +880,44 @@ def test_chunking_adapts_to_a_stream_that_needs_reruns(monkeypatch):
     assert chunks[0] == chunks[1] == chunks[2], chunks
     assert chunks[4] == chunks[1], chunks                                  # ... and still, two clean batches later
     assert chunks[0] * 2 <= chunks[-1], chunks                             # back on the clean stream's cut after eight without a re-run
+
+
+def test_no_device_allocation_in_the_middle_of_a_stream():
+    # A stream whose transition density changes must not grow its buffers in the middle (the hovering stream's second batch
+    # cost 4.4 ms instead of 2.5, all of it hipMalloc).  Clean traffic first, then load modulation hovering at the HIGH threshold with
+    # five times the noise (twice the entries per sample, every chunk re-run on the fine cut), then clean again -- synchronous pushes
+    # and batches submitted ahead: only the stream's FIRST batch of a length may allocate (nfc_stats.device_allocs), outputs exact.
+    n_b = 1_500_000
+    clean = synth.workload('all', 3 * n_b)
+    hover = synth.stress_workload(3 * n_b, every=400_000)
+    iq = np.concatenate([clean[:2 * 2 * n_b], hover, clean[2 * 2 * n_b:]])
+    n = len(iq) // 2
+    assert n == 6 * n_b
+    o = oracle_run(iq, dict(hi_val=1.1), api.NFC_IN_IQ_F32)
+    tr, s0, s1, pk, allocs, edges = [], [], [], [], [], []
+    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        def take():
+            nonlocal tr, s0, s1, pk
+            e = ctx.transitions()
+            tr += e
+            edges.append(len(e))
+            s0 += ctx.symbols(0).tolist()
+            s1 += ctx.symbols(1).tolist()
+            pk += ctx.packets()
+            allocs.append(int(ctx.stats().device_allocs))
+        bufs = [api.DeviceBuffer(iq[2 * k * n_b:2 * (k + 1) * n_b]) for k in range(6)]
+        for k in range(4):                       # clean, clean, hovering, hovering: one batch at a time
+            ctx.push_device(bufs[k], n_b)
+            take()
+        ctx.submit_device(bufs[4], n_b)          # hovering (falls back to the synchronous path inside nfc_wait), clean
+        ctx.submit_device(bufs[5], n_b)
+        for _ in range(2):
+            ctx.wait()
+            take()
+    assert first_diff(tr, o.transitions()) is None
+    assert s0 == o.symbols(0).tolist() and s1 == o.symbols(1).tolist() and pk == o.packets()
+    assert edges[2] > 1.3 * edges[1], edges      # the hovering batches do hold more transitions than the estimate of the clean ones
+    assert allocs[0] > 0, allocs                 # the stream's first batch sizes the buffers ...
+    assert allocs[1:4] == [0, 0, 0], allocs      # ... and nothing grows when the stream turns dense, or when its chunks are cut finer
+    # (the first batches submitted ahead bring the second set of planes and the snapshots' buffers: once)
+    assert allocs[5] == 0, allocs

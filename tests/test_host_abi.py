@@ -156,4 +156,4 @@ def test_ctypes_structures_match_the_header(tmp_path):
     want = [_lib.ABI_VERSION, ctypes.sizeof(_lib.Params), ctypes.sizeof(_lib.Counts), ctypes.sizeof(_lib.Stats), ctypes.sizeof(_lib.StateHeader),
             _lib.EDGE_DTYPE.itemsize, _lib.PACKET_DTYPE.itemsize, ctypes.sizeof(_lib.Frame)]
     assert got == want, (got, want)
-    assert _lib.load().nfc_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.load().nfc_abi_version() == _lib.ABI_VERSION == 4

@@ -12,7 +12,7 @@ from . import build as _build
 
 NFC_IN_IQ_F32, NFC_IN_ENV_F32, NFC_IN_REAL_F32_SQ, NFC_IN_I16_SQ = 0, 1, 2, 3
 NFC_FLAG_FORCE_SEQUENTIAL, NFC_FLAG_NO_EDGES = 1, 2
-ABI_VERSION = 3   # NFC_AMD_ABI_VERSION of the header these structures mirror
+ABI_VERSION = 4   # NFC_AMD_ABI_VERSION of the header these structures mirror
 
 
 class Params(C.Structure):
@@ -33,7 +33,8 @@ class Stats(C.Structure):
                 ('ms_decode', C.c_double), ('threshold_passes', C.c_uint32), ('chunks_rerun', C.c_uint32),
                 ('used_sequential', C.c_uint32), ('n_chunks', C.c_uint32), ('bytes_in', C.c_uint64),
                 ('ms_threshold_kernel', C.c_double * 6), ('n_threshold_timed', C.c_uint32), ('chunk_samples', C.c_uint32),
-                ('ran_ahead', C.c_uint32), ('redone_total', C.c_uint32), ('ring_slots_carried', C.c_uint32), ('decode_respeculated', C.c_uint32)]
+                ('ran_ahead', C.c_uint32), ('redone_total', C.c_uint32), ('ring_slots_carried', C.c_uint32), ('decode_respeculated', C.c_uint32),
+                ('device_allocs', C.c_uint32), ('reserved1', C.c_uint32)]
 
 
 class Frame(C.Structure):   # nfc_frame

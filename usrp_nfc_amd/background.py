@@ -63,9 +63,9 @@ class background(object):
         (background.py:37-52): it goes through the device's decode and framing stages alone (``nfc_push_edges``), synchronously,
         and the packets are delivered as usual.  Entries are ``((v, d * factor), t)`` with ``factor = 1e6 / samp_rate``
         (transition_sink.py:89-90): ``d = round(us / factor)`` is exact for every duration the sink can produce."""
-        if self.transitions is not None:
-            self.transitions.extend(transitions)
         if self._attached or not transitions:
+            if self.transitions is not None:
+                self.transitions.extend(transitions)
             return
         import numpy as np
         from . import api
@@ -78,6 +78,8 @@ class background(object):
             raise ValueError('transition durations are not whole samples within max_len=%d at samp_rate=%g: construct background(..., '
                              'samp_rate=, max_len=) with the values of the transition_sink that produced them'
                              % (self._foreign_args['max_len'], self._foreign_args['samp_rate']))
+        if self.transitions is not None:   # (kept only once the list has been accepted: a rejected call leaves nothing behind)
+            self.transitions.extend(transitions)
         if self._foreign is None:
             a = self._foreign_args
             self._foreign = api.NfcContext(samp_rate=a['samp_rate'], max_len=a['max_len'], reader=self.reader, tag=self.tag, device=a['device'])

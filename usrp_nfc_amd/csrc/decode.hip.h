@@ -480,6 +480,10 @@ struct DecSpec {
 static_assert(sizeof(DecSpec) == 32, "two 16-byte loads");
 __device__ __forceinline__ bool map8_constant(const uint32_t (&m)[2]) { return m[0] == m[1] && m[0] == (m[0] & 0xFFu) * 0x01010101u; }
 constexpr int DEC_RUNIN_MAX = 8;   // run-in edges per thread at most (runin = 2, 4 or 8 x SCAN_BLOCK: 512, 1024 or 2048 edges)
+// (k_dec_spec and k_frame_write squeeze a thread's appended bits -- 32 slots per group -- into one 64-bit accumulator, and the run-in
+// must lie inside the tile before: both break silently with more groups per thread)
+static_assert(DEC_GROUPS >= 1 && DEC_GROUPS <= 2, "NFC_DEC_GROUPS: a thread's packed bits are accumulated in 64 bits (32 slots per group)");
+static_assert(DEC_RUNIN_MAX * SCAN_BLOCK <= DEC_TILE, "the longest run-in fits inside the tile before");
 template <bool LDS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, size_t n, const uint32_t *n_dev, DecTables T, uint32_t state0, int runin_per_thread,
                                                         uint8_t *outw, FrameAgg *frame_aggs, DecSpec *spec, ZeroJob Z, TileStage S) {

@@ -31,11 +31,18 @@ __global__ __launch_bounds__(256) void k_certify_and_write(CertLaunch C, EdgeArg
     write_edges_tile(E, nwords, partials, supers, epos, ecode, cap, own_prefix, total_out, last2_total, carry_out, blockIdx.x - C.blocks, gridDim.x - C.blocks);
 }
 
+// (re)allocations of device buffers by the calling thread: a batch's share is nfc_stats.device_allocs -- a stream in its steady state
+// must show 0 (an allocation in the middle of a stream costs milliseconds: VERDICT r4, the hovering stream's second batch)
+inline uint64_t &devbuf_allocs() {
+    static thread_local uint64_t n = 0;
+    return n;
+}
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes, bool keep = false, hipStream_t st = nullptr) {
         if (bytes <= cap) return hipSuccess;
+        devbuf_allocs()++;
         size_t ncap = std::max(bytes, cap + cap / 2);
         ncap = (ncap + 255) & ~(size_t)255;
         void *np = nullptr;
@@ -101,7 +108,7 @@ struct nfc_ctx {
     // the decode stage's speculative form (decode.hip.h: k_dec_spec): on unless NFC_DEC_SPEC=0; run-in edges per thread (2 / 4 / 8);
     // after a batch whose check failed the next batches take the three-launch form (spec_off_left counts them down)
     bool dec_spec = true, dec_spec_now = false;
-    int dec_runin = 2, spec_off_left = 0;
+    int dec_runin = 2, spec_off_left = 0, spec_fail_streak = 0;   // (streak: speculative attempts that failed in a row: the back-off doubles)
     // what the decode stage left for the readers: packet bits packed 32 to a word (the multi-launch stage) or a byte each (short
     // batches); symbol arrays not written yet (materialize_symbols: on the first nfc_read_symbols)
     bool bits_packed = false, sym_lazy = false, sym_own = false;
@@ -177,6 +184,7 @@ struct nfc_ctx {
         uint32_t n = 0, seq = 0, nch = 0, chunk = 0;
         uint64_t g0 = 0;
         int slot = 0, planes = -1, ring_in = 0, timing = 0;   // (timing: nfc_set_timing's level when the batch was submitted)
+        uint32_t allocs = 0;   // buffers (re)allocated on its behalf so far (nfc_stats.device_allocs)
         bool fast = false, b_enqueued = false, timed = false, spec = false;   // (spec: its decode stage ran in the speculative form)
     } sub[NSUB];
     int sub_count = 0;             // batches submitted and not yet waited for (sub[0] the oldest)
@@ -208,6 +216,11 @@ struct nfc_ctx {
     DevBuf d_gvtop;                          // per chunk: bound of the ring values (guard of the fp64 sums)
     DevBuf d_seqout;                         // sequential kernel: edge-timing state after its last sample
     uint32_t cap_edges = 0, cap_sym[2] = {0, 0};   // capacity estimates of the edge / symbol buffers
+    // what the buffers behind those estimates are ALLOCATED for: at least the estimates, and room for a quarter of an entry per
+    // sample (four times a clean capture's density; hovering load modulation doubles it) -- the estimates size the grids and follow
+    // the stream, the allocations are made once per batch length (size_capacities)
+    uint32_t alloc_edges = 0, alloc_sym[2] = {0, 0};
+    uint64_t alloc_mark = 0;                       // devbuf_allocs() when the batch in work began
     uint64_t cap_edges_floor = 0, cap_sym_floor[2] = {0, 0};   // raised when an estimate proved too small for this batch
     double edge_rate = 0.125;                      // entries per sample seen lately (peak-hold with slow decay)
     double sym_rate[2] = {1.0, 2.0};               // symbols per entry, per type (start at the upper bounds)

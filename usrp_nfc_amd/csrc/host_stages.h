@@ -46,8 +46,9 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
         scan_partials_with(c->st, op, supers, nullptr, (uint32_t)(EW_WORDS * EW_SUPER), sups, op.identity(), (EdgeAgg *)nullptr,
                            EdgeTotalEpilogue{E, edges_total, last2_total, dE(c)});
     const uint32_t cap = c->cap_edges;
-    HIPCHK(c, c->d_epos.ensure(((size_t)cap + 8) * 4));
-    HIPCHK(c, c->d_ecode.ensure(((size_t)cap + 8) * 2));
+    const size_t cap_al = std::max(cap, c->alloc_edges);
+    HIPCHK(c, c->d_epos.ensure((cap_al + 8) * 4));
+    HIPCHK(c, c->d_ecode.ensure((cap_al + 8) * 2));
     if (c->cert_pending && tiles) {
         c->cert_pending = false;
         NFC_LAUNCH(k_certify_and_write, dim3((unsigned)(c->cert.blocks + tiles)), dim3(SCAN_BLOCK), 0, c->st, c->cert, E, nwords, parts, sups,
@@ -73,16 +74,17 @@ int frame_out(nfc_ctx *c, FrameOut &P, const bool (&enabled)[2]) {
     P.idx64 = c->edges_from_host ? c->d_eidx.as<uint64_t>() : nullptr;
     for (int t = 0; t < 2; t++) {
         const uint32_t cs = c->cap_sym[t];
-        HIPCHK(c, c->d_sym[t].ensure((size_t)cs + 16));
+        const size_t cs_al = c->edges_from_host ? cs : std::max(cs, c->alloc_sym[t]);   // (allocated with room: size_capacities)
+        HIPCHK(c, c->d_sym[t].ensure(cs_al + 16));
         P.sym[t] = c->d_sym[t].as<uint8_t>();
         P.cap_sym[t] = cs;
         P.started_in[t] = (uint32_t)c->h_dcarry.pkt_started[t];
         if (!enabled[t]) continue;   // no symbols of this type (background.py:17-25); its carry stays
         const uint32_t pend = c->h_dcarry.pending[t];
-        HIPCHK(c, c->d_bits[t].ensure((size_t)pend + cs + 16));
-        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend + cs + 16));
-        HIPCHK(c, c->d_close_end[t].ensure(((size_t)cs + 4) * 4));
-        HIPCHK(c, c->d_close_idx[t].ensure(((size_t)cs + 4) * 8));
+        HIPCHK(c, c->d_bits[t].ensure((size_t)pend + cs_al + 16));
+        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend + cs_al + 16));
+        HIPCHK(c, c->d_close_end[t].ensure((cs_al + 4) * 4));
+        HIPCHK(c, c->d_close_idx[t].ensure((cs_al + 4) * 8));
         P.bits[t] = c->d_bits[t].as<uint8_t>();
         P.close_end[t] = c->d_close_end[t].as<uint32_t>();
         P.close_idx[t] = c->d_close_idx[t].as<uint64_t>();
@@ -99,11 +101,15 @@ int run_decode(nfc_ctx *c, bool force_classic = false) {
     const uint32_t ce = c->cap_edges;                      // capacity; the count is on the device
     const uint32_t *ne_dev = (const uint32_t *)(tot + TOT_EDGES);
     const size_t tiles = dec_num_tiles(ce);
-    HIPCHK(c, c->d_states.ensure((size_t)ce + 16));   // one out-byte per edge
-    HIPCHK(c, c->d_partials.ensure((tiles + 1) * sizeof(DecMaps)));
-    HIPCHK(c, c->d_partials2.ensure((tiles + 1) * sizeof(FrameAgg)));
-    HIPCHK(c, c->d_aggs.ensure((tiles * SCAN_BLOCK + 1) * sizeof(DecMaps)));
-    HIPCHK(c, c->d_faggs.ensure((tiles * SCAN_BLOCK + 1) * sizeof(FramePk)));
+    // (allocated for alloc_edges: size_capacities -- the grids below follow the estimate `ce`)
+    const size_t ce_al = c->edges_from_host ? ce : std::max(ce, c->alloc_edges);
+    const size_t tiles_al = dec_num_tiles(ce_al);
+    HIPCHK(c, c->d_states.ensure(ce_al + 16));   // one out-byte per edge
+    HIPCHK(c, c->d_partials.ensure((tiles_al + 1) * sizeof(DecMaps)));
+    HIPCHK(c, c->d_partials2.ensure((tiles_al + 1) * sizeof(FrameAgg)));
+    // (the per-thread aggregates of the three-launch form: only where that form can run -- 24 + 16 bytes per 32 edges)
+    HIPCHK(c, c->d_aggs.ensure((tiles_al * SCAN_BLOCK + 1) * sizeof(DecMaps)));
+    HIPCHK(c, c->d_faggs.ensure((tiles_al * SCAN_BLOCK + 1) * sizeof(FramePk)));
     const bool enabled[2] = {c->T.tag != 0, c->T.reader != 0};
     FrameOut P;
     const int rf = frame_out(c, P, enabled);
@@ -141,20 +147,20 @@ int run_decode(nfc_ctx *c, bool force_classic = false) {
     TileStage S;
     memset(&S, 0, sizeof S);
     if (spec) {
-        HIPCHK(c, c->d_spec.ensure((tiles + 1) * sizeof(DecSpec)));
+        HIPCHK(c, c->d_spec.ensure((tiles_al + 1) * sizeof(DecSpec)));
         V.spec = c->d_spec.as<DecSpec>();
         // what the tiles stage for k_concat: bits and packet ends entered "started", per enabled packet type
-        HIPCHK(c, c->d_stage_own.ensure((tiles + 1) * sizeof(FrameAgg)));
+        HIPCHK(c, c->d_stage_own.ensure((tiles_al + 1) * sizeof(FrameAgg)));
         S.own = c->d_stage_own.as<FrameAgg>();
         S.epos = P.epos;
         S.g0 = P.g0;
         S.idx64 = P.idx64;
         for (int t = 0; t < 2; t++) {
             if (!P.bits[t]) continue;
-            HIPCHK(c, c->d_stage_bits[t].ensure((tiles + 1) * (size_t)FW_WORDS * 4));
-            HIPCHK(c, c->d_stage_cb[t].ensure((tiles + 1) * (size_t)ST_CLOSES * 4));
-            HIPCHK(c, c->d_stage_ci[t].ensure((tiles + 1) * (size_t)ST_CLOSES * 8));
-            HIPCHK(c, c->d_stage_q[t].ensure((tiles + 1) * 4));
+            HIPCHK(c, c->d_stage_bits[t].ensure((tiles_al + 1) * (size_t)FW_WORDS * 4));
+            HIPCHK(c, c->d_stage_cb[t].ensure((tiles_al + 1) * (size_t)ST_CLOSES * 4));
+            HIPCHK(c, c->d_stage_ci[t].ensure((tiles_al + 1) * (size_t)ST_CLOSES * 8));
+            HIPCHK(c, c->d_stage_q[t].ensure((tiles_al + 1) * 4));
             S.bits[t] = c->d_stage_bits[t].as<uint32_t>();
             S.close_bit[t] = c->d_stage_cb[t].as<uint32_t>();
             S.close_idx[t] = c->d_stage_ci[t].as<uint64_t>();
@@ -232,24 +238,29 @@ bool spec_failed(const nfc_ctx *c) {
     return v != 0;
 }
 // ... then the stage is repeated in the three-launch form, and the next batches of the stream take that form straight away
-// (frames longer than the run-in come in bursts: a long read, a firmware download); speculation is tried again after eight
+// (frames longer than the run-in come in bursts: a long read, a firmware download); speculation is tried again after eight --
+// after 16, 32 ... 256 while the attempts keep failing (a stream of nothing but long frames would otherwise pay a wasted
+// speculative stage every ninth batch for ever); one speculative batch that stands takes the count back to eight
 void note_respeculation(nfc_ctx *c) {
     c->decode_respeculated++;
-    c->spec_off_left = 8;
+    c->spec_off_left = 8 << std::min(c->spec_fail_streak, 5);
+    c->spec_fail_streak++;
 }
 void spec_batch_done(nfc_ctx *c) {
     if (!c->dec_spec_now && c->spec_off_left > 0) c->spec_off_left--;
+    else if (c->dec_spec_now) c->spec_fail_streak = 0;   // (only called for a batch whose speculative stage stood)
 }
 
 // the symbol arrays of the last batch, on demand (decode.hip.h: k_symbols_write)
 int materialize_symbols(nfc_ctx *c) {
     if (!c->sym_lazy) return NFC_OK;
-    c->sym_lazy = false;
-    if (!c->sym_tiles) return NFC_OK;
-    NFC_LAUNCH(k_symbols_write, dim3(c->sym_tiles), dim3(SCAN_BLOCK), 0, c->st, c->d_states.as<uint8_t>(), (size_t)c->sym_n,
-               (const uint32_t *)(dT(c) + TOT_EDGES), c->d_partials2.as<FrameAgg>(), c->sym_P, c->sym_own);
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    BATCHCHK(c, false);
+    if (c->sym_tiles) {
+        NFC_LAUNCH(k_symbols_write, dim3(c->sym_tiles), dim3(SCAN_BLOCK), 0, c->st, c->d_states.as<uint8_t>(), (size_t)c->sym_n,
+                   (const uint32_t *)(dT(c) + TOT_EDGES), c->d_partials2.as<FrameAgg>(), c->sym_P, c->sym_own);
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        BATCHCHK(c, false);
+    }
+    c->sym_lazy = false;   // (only now: a launch or a wait that failed leaves the arrays unwritten, and the next read tries again)
     return NFC_OK;
 }
 
@@ -274,8 +285,9 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     for (int b = 0; b < 64; b += c->mx) A.E.per_mask |= 1ull << b;
     A.nwords = ((size_t)n + 63) / 64;
     const uint32_t ce = c->cap_edges;
-    HIPCHK(c, c->d_epos.ensure(((size_t)ce + 8) * 4));
-    HIPCHK(c, c->d_ecode.ensure(((size_t)ce + 8) * 2));
+    const size_t ce_al = std::max(ce, c->alloc_edges);
+    HIPCHK(c, c->d_epos.ensure((ce_al + 8) * 4));
+    HIPCHK(c, c->d_ecode.ensure((ce_al + 8) * 2));
     c->edges_from_host = false;
     A.epos = c->d_epos.as<uint32_t>();
     A.ecode = c->d_ecode.as<uint16_t>();
@@ -321,6 +333,13 @@ void size_capacities(nfc_ctx *c, uint32_t n) {
         const uint64_t cs = (uint64_t)((double)c->cap_edges * c->sym_rate[t] * 1.1) + 65536;
         c->cap_sym[t] = (uint32_t)std::min<uint64_t>(std::min(ub, std::max<uint64_t>(cs, c->cap_sym_floor[t])), 0xFFFFFF00u);
     }
+    // The ALLOCATIONS behind the estimates: a stream whose transition density changes (load modulation that starts hovering at the
+    // threshold doubles it) must not grow its buffers in the middle -- VERDICT r4: the hovering stream's second batch took 4.4 ms
+    // instead of 2.5, all of it hipMalloc.  Room for n / 4 entries (a clean capture has n / 15) and a symbol per entry; what does not
+    // fit even that is grown by the repeat path of process_batch.  Monotonic: a short batch between long ones does not shrink them.
+    const uint64_t ae = std::min<uint64_t>((uint64_t)n / 4 + 65536, 0xFFFFFF00u);
+    c->alloc_edges = std::max(c->alloc_edges, (uint32_t)std::max<uint64_t>(ae, c->cap_edges));
+    for (int t = 0; t < 2; t++) c->alloc_sym[t] = std::max(c->alloc_sym[t], std::max(c->cap_sym[t], c->alloc_edges));
 }
 // densities for the next batch's estimates
 void update_estimates(nfc_ctx *c, uint32_t n) {
@@ -347,6 +366,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     for (int t = 0; t < 2; t++) c->n_sym[t] = c->n_close[t] = c->n_bits[t] = 0;
     memset(&c->stats, 0, sizeof c->stats);
     c->n_kev = 0;
+    c->alloc_mark = devbuf_allocs();
     if (n64 > (1ull << 30)) return fail(c, NFC_ERR_ARG, "batch of %zu samples exceeds 2^30; push it in pieces", n64);
     const uint32_t n = (uint32_t)n64;
     c->last_n = n;
@@ -426,9 +446,15 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     if (rc) return rc;
     if (want_edges) {
         bool decode_only = false;   // the edges stand, the decode stage is repeated in the form that assumes nothing
+        int respeculated = 0;       // (at most once per batch: the three-launch form assumes nothing -- its own bound, not the capacities')
         for (int attempt = 0;; attempt++) {
-            if (attempt > 0 || !clean) {
-                rc = decode_only ? run_decode(c, true) : edges_and_decode();
+            if (attempt > 0 || !clean || decode_only) {
+                if (decode_only) {
+                    if (c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->st));   // (the decode stage's time is the repeated stage's)
+                    rc = run_decode(c, true);
+                } else {
+                    rc = edges_and_decode();
+                }
                 if (rc) return rc;
                 HIPCHK(c, hipStreamSynchronize(c->st));
             }
@@ -438,9 +464,10 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
             memcpy(ns, c->hs->totals + TOT_NSYM, 8);
             const bool fit = ne <= c->cap_edges && ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1];
             if (fit && spec_failed(c)) {   // (decode.hip.h: dec_verify -- a decode tile's assumed incoming state was wrong)
-                if (attempt >= 3) return fail(c, NFC_ERR_INTERNAL, "edge / symbol capacity did not settle");
+                if (respeculated++) return fail(c, NFC_ERR_INTERNAL, "the decode stage's three-launch form reported a speculation failure");
                 note_respeculation(c);
                 decode_only = true;
+                attempt--;   // (not a capacity attempt)
                 continue;
             }
             if (fit) {
@@ -498,6 +525,7 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
     c->nseen += n;
     c->last_in = d_in;
     c->have_outputs = true;
+    c->stats.device_allocs = (uint32_t)(devbuf_allocs() - c->alloc_mark);
     // (the end-of-batch LOW bookkeeping on the device is what a batch submitted ahead may start from: only when the whole
     // batch went through one parallel attempt, whose last certification workgroup or k_finalize_state wrote it)
     c->low_valid = skip == 0 && c->stats.used_sequential == 0 && c->h_carry.stable;

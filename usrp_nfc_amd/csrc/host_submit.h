@@ -35,6 +35,11 @@ int enqueue_threshold_ahead(nfc_ctx *c, nfc_ctx::Submitted &b) {
     ThrArgs A;
     ThrPlan P;
     const EdgeCarry unused{0, 0, 0, 0};
+    struct AllocNote {   // (whatever path leaves: the buffers (re)allocated here are this batch's)
+        nfc_ctx::Submitted &b;
+        uint64_t a0;
+        ~AllocNote() { b.allocs += (uint32_t)(devbuf_allocs() - a0); }
+    } alloc_note{b, devbuf_allocs()};
     const nfc_stats keep_stats = c->stats;   // (the context's statistics are those of the last completed batch until this one is)
     const int rc_prep = thr_prepare(c, b.d_in, b.n, b.n, 0u, 0u, b.g0, unused, b.ring_in, c->d_neg_alt[b.planes], c->d_pos_alt[b.planes], true, A, P);
     c->stats = keep_stats;
@@ -85,6 +90,11 @@ void take_planes(nfc_ctx *c, nfc_ctx::Submitted &b) {
 
 // its edge and decode stages, on st behind its threshold stage; from here on the context's per-batch fields are this batch's
 int enqueue_stages_behind(nfc_ctx *c, nfc_ctx::Submitted &b) {
+    struct AllocNote {
+        nfc_ctx::Submitted &b;
+        uint64_t a0;
+        ~AllocNote() { b.allocs += (uint32_t)(devbuf_allocs() - a0); }
+    } alloc_note{b, devbuf_allocs()};
     HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_a[b.slot], 0));
     if (b.planes >= 0) take_planes(c, b);
     c->have_outputs = false;
@@ -247,8 +257,27 @@ int wait_batch(nfc_ctx *c) {
         uint32_t v;
         memcpy(&v, c->hs->totals + TOT_SPEC, 4);
         if (v) {
-            regular = false, why = "a decode tile's assumed state was wrong";
-            note_respeculation(c);   // (the synchronous path below takes the three-launch form straight away)
+            // Only the decode stage was wrong: the threshold and edge stages stand, and so does everything submitted behind this
+            // batch (their threshold stages start from this batch's threshold stage alone).  The decode stage is repeated in the
+            // form that assumes nothing -- same carried values (the host mirrors are adopted below), same buffers -- on the main
+            // stream, where the next batch's later stages are not enqueued before this one is popped; the batches behind it take
+            // that form straight away (note_respeculation).
+            note_respeculation(c);
+            int rc = run_decode(c, true);
+            if (!rc && hipStreamSynchronize(c->st) != hipSuccess) rc = fail(c, NFC_ERR_DEVICE, "waiting for the repeated decode stage failed");
+            if (!rc) rc = batch_ok(c, false);
+            if (!rc && c->hs->seq[1] != b.seq) rc = fail(c, NFC_ERR_DEVICE, "state mirror is stale after the repeated decode stage (batch %u, mirror %u)", b.seq, c->hs->seq[1]);
+            if (!rc) {
+                memcpy(&v, c->hs->totals + TOT_SPEC, 4);
+                if (v) rc = fail(c, NFC_ERR_INTERNAL, "the decode stage's three-launch form reported a speculation failure");
+            }
+            if (rc) {
+                abandon();
+                return rc;
+            }
+            memcpy(ns, c->hs->totals + TOT_NSYM, 8);
+            b.spec = false;
+            if (!(ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1])) regular = false, why = "a capacity estimate was too small";
         }
     }
     if (c->dbg_redo_submitted && (c->dbg_fast_waits++ % 3u) == 2u) regular = false, why = "test hook";   // every third batch that ran ahead
@@ -274,6 +303,7 @@ int wait_batch(nfc_ctx *c) {
             c->stats.ms_threshold_kernel[0] = elapsed_ms(c->kev_sub[b.slot][0], c->kev_sub[b.slot][1]);
             c->stats.n_threshold_timed = 1;
         }
+        c->stats.device_allocs = b.allocs;
         c->ring_carried = summary.n_carried;   // (from this batch's own snapshot: the device's summary belongs to the next batch by now)
         c->ring_cur = (b.ring_in + 1) % NRING;
         c->nseen = b.g0 + b.n;
