@@ -37,12 +37,17 @@ inline uint64_t &devbuf_allocs() {
     static thread_local uint64_t n = 0;
     return n;
 }
+inline bool &devbuf_trace() {   // (test build: NFC_TRACE_ALLOC names every (re)allocation on stderr)
+    static bool on = false;
+    return on;
+}
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes, bool keep = false, hipStream_t st = nullptr) {
         if (bytes <= cap) return hipSuccess;
         devbuf_allocs()++;
+        if (devbuf_trace()) fprintf(stderr, "[nfc] device buffer %p: %zu -> %zu bytes asked for\n", (void *)this, cap, bytes);
         size_t ncap = std::max(bytes, cap + cap / 2);
         ncap = (ncap + 255) & ~(size_t)255;
         void *np = nullptr;
@@ -210,6 +215,15 @@ struct nfc_ctx {
     DevBuf d_states, d_sym[2], d_bits[2], d_pending[2][2], d_close_end[2],
         d_close_idx[2];
     DevBuf d_partials, d_partials2, d_aggs, d_faggs;  // scan scratch
+    // the edge stage's tile / chunk aggregates when the threshold kernel leaves them (threshold_wg.hip.h: wg_chunk_edge_aggs; NFC_EAGG=1
+    // turns it on): a buffer of their own -- d_partials may grow between the two stages --, and what run_edges needs to know.
+    // OFF by default, measured (round 5, configs[1], same-call A/Bs): k_edge_reduce (11.0 us) and its launch boundary go, but the
+    // aggregation is ~1 000 vector instructions per wave wherever it runs -- at a chunk's end, where the four workgroups of a CU
+    // finish together, that is 10 us of the threshold kernel (0.153-0.162 -> 0.162-0.173 ms per launch, from LDS or from the L2
+    // alike) and the writer's prefix fold over 1 018 chunk aggregates instead of 763 costs it 2 us: step 0.2627-0.2738 -> 0.2753.
+    DevBuf d_eaggs;
+    bool eagg = false, eagg_ready = false;
+    uint32_t eagg_sw = 0, eagg_tps = 0, eagg_nch = 0;
     DevBuf d_spec;                           // per decode tile: its map, the state it assumed (decode.hip.h: DecSpec)
     DevBuf d_stage_bits[2], d_stage_cb[2], d_stage_ci[2], d_stage_q[2], d_stage_own;   // ... and what it stages for k_concat (TileStage)
     DevBuf d_pack;                           // nfc_get_state staging

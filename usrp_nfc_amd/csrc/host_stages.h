@@ -28,10 +28,17 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     E.mx_magic = c->mx > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c->mx) : 0xFFFFFFFFu;
     E.per_mask = 0;
     for (int b = 0; b < 64; b += c->mx) E.per_mask |= 1ull << b;
-    const size_t tiles = edge_num_tiles(nwords);   // EW_WORDS words per tile in both launches of the stage
-    const size_t supers = edge_num_supers(nwords);   // the reduce pass: a workgroup per EW_SUPER tiles, both levels of aggregates
+    // the threshold kernel's pass 0 may have left the aggregates (host_threshold.h: eagg_ready; tiles cut per time chunk then)
+    const bool fused = c->eagg_ready && (size_t)c->eagg_nch * c->eagg_sw >= nwords;
+    c->eagg_ready = false;   // (once: a repeat of the stage follows re-runs, or wants room -- either way it reduces the planes itself)
+    c->stats.edge_aggs_fused = fused ? 1u : 0u;
+    E.sw = fused ? c->eagg_sw : (uint32_t)(EW_WORDS * EW_SUPER);
+    E.tps = fused ? c->eagg_tps : (uint32_t)EW_SUPER;
+    E.packed_supers = fused ? 1u : 0u;
+    const size_t tiles = fused ? edge_num_tiles_of(nwords, E.sw, E.tps) : edge_num_tiles(nwords);   // EW_WORDS words per tile in both launches of the stage
+    const size_t supers = fused ? (size_t)c->eagg_nch : edge_num_supers(nwords);   // the reduce pass: a workgroup per EW_SUPER tiles, both levels of aggregates
     HIPCHK(c, c->d_partials.ensure((tiles + supers + 2) * sizeof(EdgeAgg)));
-    EdgeAgg *parts = c->d_partials.as<EdgeAgg>();
+    EdgeAgg *parts = fused ? c->d_eaggs.as<EdgeAgg>() : c->d_partials.as<EdgeAgg>();
     EdgeAgg *sups = parts + tiles + 1;
     // launch 1: one aggregate per tile (first change, last two changes, entries it is sure of).  While the tiles are few,
     // each tile's workgroup of the writer folds its predecessors' aggregates itself (scan.hip.h: tile_prefix) and the
@@ -41,7 +48,7 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     uint32_t *edges_total = (uint32_t *)(tot + TOT_EDGES);
     const EdgeAggOp op{E.mx, E.mx_magic};
     // (the first certification of the batch, when it is still to be launched, rides with the WRITER below: host_context.h)
-    if (tiles) NFC_LAUNCH(k_edge_reduce, dim3((unsigned)supers), dim3(ER_BLOCK), 0, c->st, E, nwords, parts, sups);
+    if (tiles && !fused) NFC_LAUNCH(k_edge_reduce, dim3((unsigned)supers), dim3(ER_BLOCK), 0, c->st, E, nwords, parts, sups);
     if (!own || !tiles)   // (long batches: the prefix launch over the SUPER-aggregates; the totals and the carry in its epilogue)
         scan_partials_with(c->st, op, supers, nullptr, (uint32_t)(EW_WORDS * EW_SUPER), sups, op.identity(), (EdgeAgg *)nullptr,
                            EdgeTotalEpilogue{E, edges_total, last2_total, dE(c)});
@@ -81,8 +88,11 @@ int frame_out(nfc_ctx *c, FrameOut &P, const bool (&enabled)[2]) {
         P.started_in[t] = (uint32_t)c->h_dcarry.pkt_started[t];
         if (!enabled[t]) continue;   // no symbols of this type (background.py:17-25); its carry stays
         const uint32_t pend = c->h_dcarry.pending[t];
-        HIPCHK(c, c->d_bits[t].ensure((size_t)pend + cs_al + 16));
-        HIPCHK(c, c->d_pending[t][pn].ensure((size_t)pend + cs_al + 16));
+        // (the open packet's carried bits come on top: room in steps of 64 K of them, so that a few bits more do not reallocate)
+        const size_t pend_al = c->edges_from_host ? pend : ((((size_t)pend >> 16) + 1) << 16);
+        HIPCHK(c, c->d_bits[t].ensure(pend_al + cs_al + 16));
+        HIPCHK(c, c->d_pending[t][pn].ensure(pend_al + cs_al + 16));
+        HIPCHK(c, c->d_pending[t][1 - pn].ensure(pend_al + cs_al + 16, true, c->st));   // (the other half with it: it is the next batch's, and holds this batch's carried bits)
         HIPCHK(c, c->d_close_end[t].ensure((cs_al + 4) * 4));
         HIPCHK(c, c->d_close_idx[t].ensure((cs_al + 4) * 8));
         P.bits[t] = c->d_bits[t].as<uint8_t>();
@@ -284,6 +294,9 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     A.E.mx_magic = c->mx > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c->mx) : 0xFFFFFFFFu;
     for (int b = 0; b < 64; b += c->mx) A.E.per_mask |= 1ull << b;
     A.nwords = ((size_t)n + 63) / 64;
+    A.E.sw = (uint32_t)(EW_WORDS * EW_SUPER);
+    A.E.tps = (uint32_t)EW_SUPER;
+    c->eagg_ready = false;
     const uint32_t ce = c->cap_edges;
     const size_t ce_al = std::max(ce, c->alloc_edges);
     HIPCHK(c, c->d_epos.ensure((ce_al + 8) * 4));

@@ -117,6 +117,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     c->dbg_redo_submitted = getenv("NFC_DEBUG_REDO_SUBMITTED") != nullptr;
     c->dbg_any = getenv("NFC_DEBUG") != nullptr;
     c->dbg_trace = getenv("NFC_TRACE") != nullptr;
+    devbuf_trace() = getenv("NFC_TRACE_ALLOC") != nullptr;
     if (const char *e = getenv("NFC_DEBUG_CLK")) {
         c->dbg_clk = true;
         c->dbg_clk_path = e;
@@ -137,6 +138,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     if (const char *e = getenv("NFC_LEAN_GMIN")) c->lean_gmin = (float)atof(e);
     if (const char *e = getenv("NFC_OWN_PREFIX_MAX")) c->own_prefix_max = (uint32_t)strtoul(e, nullptr, 10);
     if (const char *e = getenv("NFC_DEC_SPEC")) c->dec_spec = atoi(e) != 0;
+    if (const char *e = getenv("NFC_EAGG")) c->eagg = atoi(e) != 0;   // 1: k_threshold_wg leaves the edge stage's aggregates, no k_edge_reduce (measured: no gain, host_context.h)
     if (const char *e = getenv("NFC_DEC_RUNIN")) {   // run-in edges per decode tile: 512, 1024 or 2048
         const int v = atoi(e);
         c->dec_runin = v >= 2048 ? 8 : (v >= 1024 ? 4 : 2);
@@ -398,7 +400,7 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ecode, &c->d_epos, &c->d_eidx, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_spec, &c->d_stage_bits[0], &c->d_stage_bits[1], &c->d_stage_cb[0], &c->d_stage_cb[1], &c->d_stage_ci[0], &c->d_stage_ci[1], &c->d_stage_q[0], &c->d_stage_q[1], &c->d_stage_own, &c->d_gring, &c->d_pack, &c->d_gvtop, &c->d_seqout};
+                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_spec, &c->d_stage_bits[0], &c->d_stage_bits[1], &c->d_stage_cb[0], &c->d_stage_cb[1], &c->d_stage_ci[0], &c->d_stage_ci[1], &c->d_stage_q[0], &c->d_stage_q[1], &c->d_stage_own, &c->d_gring, &c->d_pack, &c->d_gvtop, &c->d_seqout, &c->d_eaggs};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

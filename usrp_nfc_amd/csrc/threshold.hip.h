@@ -137,6 +137,11 @@ struct ThrArgs {
     int32_t ver_zero;              // every version byte is 0 (the certification right behind pass 0): its launches need not load them
     int32_t wg_stage_rounds;       // k_threshold_wg: rounds of plane words its LDS staging holds per plane (threshold_wg.hip.h; launch_wg sets it)
     unsigned long long *dbg_clk;   // debugging aid (NFC_DEBUG_CLK): per chunk four s_memtime stamps -- start, incoming state ready, loop done, end
+    // k_threshold_wg also leaves the EDGE stage's first-level aggregates (edges.hip.h: EdgeAgg per 512-word tile of the chunk and per
+    // chunk) when these are set: the stage's own reduce pass -- the first read of the planes, a launch -- is then not needed
+    // (threshold_wg.hip.h: wg_chunk_edge_aggs; host_threshold.h decides).  eagg_tps: tiles per chunk, eagg_magic: floor(2^32 / max_len)
+    void *eagg_tiles, *eagg_supers;
+    uint32_t eagg_tps, eagg_magic;
 };
 
 // ---------------------------------------------------------------------------

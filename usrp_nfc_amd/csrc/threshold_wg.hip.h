@@ -29,6 +29,7 @@
 // its chunk, which the host re-runs with k_threshold from the exact state.  Same summaries (ChunkInfo, RunMeta, ring_in,
 // ring_out, touched), so certification and re-runs do not know which kernel ran.
 #pragma once
+#include "edges.hip.h"
 #include "threshold_lean.hip.h"
 
 namespace nfc {
@@ -226,6 +227,107 @@ __device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (
     if constexpr (NR == 8) {
         const unsigned long long m2[4] = {m[4], m[5], m[6], m[7]};
         PLANE_PUT8(pk, m2, 2 * NR + 8);
+    }
+}
+
+// The edge stage's first-level aggregates of a chunk (edges.hip.h), by the workgroup that has just classified it: one EdgeAgg per
+// 512-word tile of the chunk (the writer's tiles are cut per chunk then: EdgeArgs.sw / tps) and one for the chunk.  The stage's own
+// reduce pass was the first read of the 25 MB of planes and a launch of its own (11 us + a launch gap per step on configs[1]);
+// here the words are still in the workgroup's LDS (a chunk whose planes were staged whole: threshold_wg.hip.h, bulk) or come back
+// out of the L2 they were stored to a moment ago.  A wave takes HALF a tile at a time (a lane four consecutive words), the waves
+// go side by side, one barrier joins them.  What a chunk cannot know is the sample BEFORE its first one (another workgroup's, at
+// the same time): its aggregates are those of its words with no change at the chunk's first sample, and the chunk's `sum` carries
+// val + 1 of its first and last sample in its top bits -- the writer's prefix fold puts the change between two chunks in
+// (edges.hip.h: fold_packed_super).
+// (Not inlined, small, and few registers: cold code at a kernel's end is fetched as it runs -- a first form, unrolled over the tiles,
+// was 15 KB and cost the kernel 10 us; one with eight words per lane took 100 vector registers, and a callee's count is its caller's.)
+constexpr int WG_HT_ITEMS = 4;                         // words per lane
+constexpr int WG_HT_WORDS = 64 * WG_HT_ITEMS;          // words per half tile
+static_assert(2 * WG_HT_WORDS == EW_WORDS, "two half tiles per writer tile");
+template <class Get>
+__device__ __forceinline__ void wg_chunk_edge_aggs_from(const EdgeArgs &E, uint32_t chunk, size_t w_chunk, size_t w_stop, uint32_t last, uint32_t tps,
+                                                        EdgeAgg *tiles, EdgeAgg *supers, EdgeAgg *lds, Get get) {
+    const EdgeAggOp op{E.mx, E.mx_magic};
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nht = 2u * tps;
+#pragma unroll 1
+    for (uint32_t h = (uint32_t)wave; h < 2u * (uint32_t)EW_SUPER; h += (uint32_t)WG_WAVES) {   // (uniform per wave)
+        EdgeAgg inc = op.identity();
+        if (h < nht) {
+            const size_t w = w_chunk + (size_t)h * WG_HT_WORDS + (size_t)lane * WG_HT_ITEMS;
+            uint64_t ng[WG_HT_ITEMS], ps[WG_HT_ITEMS], m[WG_HT_ITEMS];
+#pragma unroll
+            for (int i = 0; i < WG_HT_ITEMS; i++) {
+                const bool ok = w + i < w_stop;
+                ng[i] = ok ? get(0, (uint32_t)(w + i - w_chunk)) : 0ull;
+                ps[i] = ok ? get(1, (uint32_t)(w + i - w_chunk)) : 0ull;
+            }
+            uint64_t pn = 0ull, pp = 0ull;   // (the chunk's first word: nobody knows, and its bit 0 is cleared below)
+            if (w > w_chunk && w <= w_stop) {
+                pn = get(0, (uint32_t)(w - 1 - w_chunk)) >> 63;
+                pp = get(1, (uint32_t)(w - 1 - w_chunk)) >> 63;
+            }
+#pragma unroll
+            for (int i = 0; i < WG_HT_ITEMS; i++) {
+                m[i] = (w + i < w_stop) ? E.change_mask_of(w + i, ng[i], ps[i], pn, pp) : 0ull;
+                pn = ng[i] >> 63;
+                pp = ps[i] >> 63;
+            }
+            if (h == 0u && lane == 0) m[0] &= ~1ull;
+            bool may = false;
+#pragma unroll
+            for (int i = 0; i < WG_HT_ITEMS; i++) may = may || word_may_time_out(E, m[i]);
+            const bool inner = __any(may);
+            EdgeAgg agg = op.identity();
+#pragma unroll
+            for (int i = 0; i < WG_HT_ITEMS; i++) agg = op(agg, word_agg(E, (int32_t)((w + i) * 64), m[i], inner));
+            inc = wave_inclusive_with(op, agg);
+        }
+        if (lane == 63) lds[h] = inc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        EdgeAgg tot = op.identity();
+#pragma unroll 1
+        for (uint32_t q = 0; q < tps; q++) {
+            const EdgeAgg t = op(lds[2 * q], lds[2 * q + 1]);
+            tiles[(size_t)chunk * tps + q] = t;
+            tot = op(tot, t);
+        }
+        const uint32_t kl = (uint32_t)((size_t)(last >> 6) - w_chunk);
+        const uint64_t n0 = get(0, 0u), p0 = get(1, 0u), nl = get(0, kl), pl = get(1, kl);
+        const int fv = (n0 & 1ull) ? -1 : (int)(p0 & 1ull);
+        const int lv = ((nl >> (last & 63u)) & 1ull) ? -1 : (int)((pl >> (last & 63u)) & 1ull);
+        tot.sum = super_pack(tot.sum, fv, lv);
+        supers[chunk] = tot;
+    }
+}
+// lds: room for 2 EW_SUPER aggregates; every thread of the workgroup calls it.  pst (or NULL): the chunk's plane words in LDS, word k of
+// a plane at dwords 2 k, 2 k + 1 -- the pos plane pst_plane dwords behind the neg plane; NULL: from global memory, behind a barrier that
+// completes the plane stores.
+__device__ __noinline__ void wg_chunk_edge_aggs(const uint64_t *neg, const uint64_t *pos, uint32_t n, uint32_t skip, int32_t mx, uint32_t mx_magic, uint32_t chunk,
+                                                uint32_t m_chunk, uint32_t n1, uint32_t tps, EdgeAgg *tiles, EdgeAgg *supers, EdgeAgg *lds,
+                                                const lean_lds_u32 *pst, uint32_t pst_plane) {
+    EdgeArgs E;
+    E.neg = neg;
+    E.pos = pos;
+    E.n = n;
+    E.skip = skip;   // (samples before it belong to the fill phase: no changes there, edges.hip.h: change_mask_of)
+    E.mx = mx;
+    E.mx_magic = mx_magic;
+    E.dur_in = 0;
+    E.last_bit_in = 0;
+    E.state_in = 0;
+    const size_t w_chunk = (size_t)m_chunk / 64, w_stop = ((size_t)n1 + 63) / 64;   // the chunk's words: [w_chunk, w_stop)
+    if (pst) {
+        wg_chunk_edge_aggs_from(E, chunk, w_chunk, w_stop, n1 - 1u, tps, tiles, supers, lds, [pst, pst_plane](int pl, uint32_t k) -> uint64_t {
+            const lean_lds_u32 *q = pst + (pl ? pst_plane : 0u) + 2u * k;
+            return (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+        });
+    } else {
+        wg_chunk_edge_aggs_from(E, chunk, w_chunk, w_stop, n1 - 1u, tps, tiles, supers, lds, [neg, pos, w_chunk](int pl, uint32_t k) -> uint64_t {
+            return (pl ? pos : neg)[w_chunk + k];
+        });
     }
 }
 
@@ -1038,9 +1140,17 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             }
         }
     }
+    // (the whole chunk's plane words are in the LDS staging -- every round regular, nothing flushed yet: what the edge aggregates below are made from)
+    const bool staged_all = bulk && st_cnt > 0 && st_base == m_chunk && (uint32_t)st_cnt * (uint32_t)WG_ROUND == n1 - m_chunk;
     flush_planes();
+    if (A.eagg_tiles && n1 > m_chunk && staged_all)   // (... while the stores drain; the staging is not written again)
+        wg_chunk_edge_aggs(neg_p, pos_p, A.n, A.skip, mx, A.eagg_magic, c, m_chunk, n1, A.eagg_tps, (EdgeAgg *)A.eagg_tiles, (EdgeAgg *)A.eagg_supers, (EdgeAgg *)&sh->acc[0][0],
+                           pst, PST_PLANE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the rounds' loads and stores is left in flight)
     wg_barrier();   // (the summary below reads plane words that another wave of the workgroup stored)
+    if (A.eagg_tiles && n1 > m_chunk && !staged_all)
+        wg_chunk_edge_aggs(neg_p, pos_p, A.n, A.skip, mx, A.eagg_magic, c, m_chunk, n1, A.eagg_tps, (EdgeAgg *)A.eagg_tiles, (EdgeAgg *)A.eagg_supers, (EdgeAgg *)&sh->acc[0][0],
+                           nullptr, 0u);
 
     // ---------------- the chunk's summary ----------------
     // LOW bookkeeping at the chunk's end: the last non-LOW sample and the last LOW sample lie in its last steps (a LOW sample
