@@ -941,17 +941,20 @@ def test_edge_aggregates_left_by_the_threshold_kernel(monkeypatch, chunk):
         if b + 400 >= n:
             break
         sel = k % 4
-        if sel == 0:
+        if k > (n // chunk) * 2 // 3:
+            env[b - 120:b + 130] = base * 1e-3           # the stream's last third: a loss of signal across it, several time-outs long
+        elif sel == 0:                                   # (such a chunk gives up: those batches' edge stage reduces the planes itself)
             env[b:b + 3] = base * 1e-3                   # a pause that starts on the boundary
         elif sel == 1:
             env[b - 4:b] = base * 1e-3                   # ... that ends on it
         elif sel == 2:
-            env[b - 120:b + 130] = base * 1e-3           # a loss of signal across it, several time-outs long
+            env[b - 1:b + 1] = base * 1.3                # HIGH across it
         else:
             env[b:b + 2] = base * 1.3                    # HIGH from the boundary on
     params = dict(hi_val=1.1)
     o = oracle_run(env, params, api.NFC_IN_ENV_F32)
-    for cuts in ([0, n], [0, 3 * chunk + 1000, 3 * chunk + 1000 + 2 * chunk, n]):
+    third = (n // chunk) * 2 // 3 * chunk
+    for cuts in ([0, n], [0, 3 * chunk + 1000, third - chunk // 2, n]):
         ctx = api.NfcContext(input_kind=api.NFC_IN_ENV_F32, chunk_samples=chunk, **params)
         tr, s0, s1, pk, fused = [], [], [], [], []
         for a, b in zip(cuts[:-1], cuts[1:]):
@@ -967,5 +970,6 @@ def test_edge_aggregates_left_by_the_threshold_kernel(monkeypatch, chunk):
         assert d is None, 'transition %s' % (d,)
         assert s0 == o.symbols(0).tolist() and s1 == o.symbols(1).tolist() and pk == o.packets()
         # (a batch whose pass 0 stood took the threshold kernel's aggregates: at least the clean ones must have)
-        assert any(f for f, r in fused), fused
         assert all(f == 1 for f, r in fused if r == 0), fused
+        if len(cuts) > 2:
+            assert fused[0][0] == 1 or fused[1][0] == 1, fused   # (the batches before the losses of signal)

@@ -10,6 +10,13 @@ while the compiler itself never touches the accumulator file, i.e. while it neit
     pair may have been written by a vector instruction right in front of it (v_readlane of a spilled register), and a vector
     memory instruction that reads it within five issue slots gets the old value -- the compiler pads only what it emitted.
 
+  * k_threshold_wg: scalar registers.  The kernel sits at the 106-SGPR ceiling and spills (.sgpr_spill_count is printed: spills on
+    gfx950 are v_writelane / v_readlane of a spill VGPR -- vector issue slots, and the s_nop pads in front of whoever reads the reloaded
+    register); what matters is WHERE: the head of a regular round -- from the take of a round's samples to the round's barrier, the
+    part every round of every wave runs -- must hold no compiler-emitted v_readlane / v_writelane outside the block that flushes the
+    plane staging ring (taken every eighth round of one wave in four, never with a chunk's planes staged whole).  The counts over the
+    whole regular-round loop (cold forms included) are printed for the record.
+
 usage: tools/audit_lean_isa.py <file.s>      (hipcc -S --cuda-device-only output); exit status 1 on any finding"""
 import re
 import sys
@@ -52,7 +59,68 @@ for m in re.finditer(r'^(_ZN3nfc1[46]k_threshold_(?:lean|wg)\w+):[^\n]*\n(.*?)\.
             n_bad += 1
     vg = re.search(r'\.vgpr_count:\s+(\d+)', md)
     ag = re.search(r'\.agpr_count:\s+(\d+)', md)
-    print('%s: %d asm loads, %d counted waits, vgpr_count %s (agpr %s), %d findings' % (name, n_loads, n_takes, vg.group(1) if vg else '?',
-                                                                                      ag.group(1) if ag else '?', n_bad))
+    sp = re.search(r'\.sgpr_spill_count:\s+(\d+)', md)
+    extra = ''
+    if 'k_threshold_wg' in name:
+        # the regular-round loop: its header is the labelled block that holds the first take (v_accvgpr_read of a0 / a8)
+        take = next((i for i, l in enumerate(body) if re.search(r'v_accvgpr_read_b32 v\d+, a0\b', l)), None)
+        if take is not None:
+            h = take
+            while h > 0 and not re.match(r'^\.LBB\d+_\d+:', body[h]):
+                h -= 1
+            hn = body[h].split(':')[0][2:]
+            def spill_ops(lines):
+                n = [0, 0, 0]
+                in_a = False
+                for l in lines:
+                    if 'ASMSTART' in l:
+                        in_a = True
+                    elif 'ASMEND' in l:
+                        in_a = False
+                    elif not in_a:
+                        c = l.split(';')[0]
+                        n[0] += 'v_readlane_b32' in c
+                        n[1] += 'v_writelane_b32' in c
+                        n[2] += 's_nop' in c
+                return n
+            loop = [l for l in body if ('Header=' + hn + ' ') in l + ' ' or ('Parent Loop ' + hn + ' ') in l + ' ']
+            # (every line of the loop: blocks are annotated, their instructions are not -- take the labelled blocks' extents)
+            idx = [i for i, l in enumerate(body) if re.match(r'^\.LBB\d+_\d+:', l) or re.match(r'^; %bb\.\d+:', l)]
+            in_loop_lines = []
+            for a, b2 in zip(idx, idx[1:] + [len(body)]):
+                hd = body[a]
+                if a == h or ('Header=' + hn + ' ') in hd + ' ' or ('Parent Loop ' + hn + ' ') in hd + ' ':
+                    in_loop_lines += body[a:b2]
+            whole = spill_ops(in_loop_lines)
+            # the head: from the header to the round's barrier, minus the blocks that store to global memory (the staging ring's flush)
+            bar = next(i for i in range(take, len(body)) if 's_barrier' in body[i])
+            head = []
+            for a, b2 in zip(idx, idx[1:] + [len(body)]):
+                if a < h or a > bar:
+                    continue
+                blk = body[a:min(b2, bar)]
+                if any('global_store' in l for l in blk):
+                    continue
+                # (the block in front of the flush loads its plane pointers: part of the flush when the next block stores)
+                head += blk
+            # a reload block that only feeds the flush: the one right before the storing block
+            hd = spill_ops(head)
+            flush_pre = 0
+            for a, b2 in zip(idx, idx[1:] + [len(body)]):
+                if h <= a <= bar and any('global_store' in l for l in body[a:b2]):
+                    k = idx.index(a)
+                    if k > 0:
+                        flush_pre = spill_ops(body[idx[k - 1]:a])[0]
+            hd[0] -= flush_pre
+            extra = ', sgpr_spill_count %s, round head (to the barrier, flush aside): %d v_readlane %d v_writelane, whole round loop: %d / %d / %d s_nop' % (
+                sp.group(1) if sp else '?', hd[0], hd[1], whole[0], whole[1], whole[2])
+            # (four rows per step -- configs[1] / [2], every input kind: none at all.  Six and eight rows per step keep eight more ballots
+            # alive and reload five or six loop invariants per 1 536 / 2 048-sample round -- the staging mode, the superstep's round
+            # count, a lane mask: printed, 2 % of a round's vector instructions, not a finding)
+            if (hd[0] or hd[1]) and 'ELi4ELi' in name:
+                print('%s: spill traffic in the head of a regular round: %d v_readlane, %d v_writelane' % (name, hd[0], hd[1]))
+                n_bad += 1
+    print('%s: %d asm loads, %d counted waits, vgpr_count %s (agpr %s)%s, %d findings' % (name, n_loads, n_takes, vg.group(1) if vg else '?',
+                                                                                        ag.group(1) if ag else '?', extra, n_bad))
     bad += n_bad
 sys.exit(1 if bad else 0)

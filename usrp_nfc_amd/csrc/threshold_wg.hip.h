@@ -60,6 +60,14 @@ struct WgShared {
     int32_t fin[WG_WAVES][4];          // chunk end: last LOW index, last non-LOW index, latest step with LOW samples
     float4 acc[WG_WAVES][64];          // close of a superstep: every lane's (sum |x - prev|, sum (x - prev)) over what it accepted, its smallest distances to the thresholds
     uint32_t flag[WG_WAVES];           // ... and every wave's failure code
+    // What only the GENERAL form of a step produces, per wave (lane 0 keeps it up to date, the chunk's summary reads it): this wave's
+    // last LOW sample, its last sample that is not LOW, the smallest / largest raw bits it accepted.  In LDS and not in registers
+    // because the general form runs rarely and the rounds run always: values that one cold path writes are carried through every
+    // round as copies -- the compiler moved eight registers to and fro per round for these four (17 v_mov per round in all, of
+    // ~120 vector instructions: round 5, read off the ISA).
+    // ... and (slots 4, 5) how close a sample of such a step came to the LOW / to the HIGH threshold in the superstep in progress
+    // (f32 bits; lane 0 takes them into what it hands in when the superstep closes, and resets them).
+    uint32_t cold[WG_WAVES][8];
     float bc[8];                       // ... and what wave 0 makes of them: the next thresholds, the sum, the allowance, the verdict
 };
 constexpr size_t WG_SHARED_BYTES = (sizeof(WgShared) + 15) & ~(size_t)15;
@@ -348,6 +356,26 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     const uint32_t m_chunk = c * (uint32_t)A.C;
     const uint32_t n1 = min(A.n, m_chunk + (uint32_t)A.C);
     const uint32_t m_start = max(m_chunk, A.skip);
+    constexpr int RB = LeanRaw<KIND>::BYTES;
+    const uint32_t wbase0 = m_chunk + STEPN * (uint32_t)wave;   // this wave's step of round 0
+    const char *const in_first = (const char *)A.in + (size_t)wbase0 * RB;   // this wave's step of the chunk's first round (uniform)
+    // (Measured and dropped, round 5: the scalar base fixed and the LANE offset walking the chunk -- one vector addition and one
+    // minimum per round instead of seven scalar instructions -- and the per-step selects of xlo_acc / xhi_acc made per lane, on the
+    // compare the ballot needs anyway: 0.1463 -> 0.1482 ms per launch.  Vector issue slots are what this kernel is short of.)
+    const uint32_t voff = (uint32_t)lane * (uint32_t)RB;
+    // The chunk's first round is asked for NOW when it is a regular one (four whole steps of stable samples): its samples arrive
+    // while the state the chunk starts from is put together below -- the first take found them 2-3 us away otherwise, once per chunk,
+    // with every workgroup of the launch asking at the same time.  (Into accumulator registers nothing below touches.)
+    bool primed = false;
+    if (m_chunk >= m_start && m_chunk + (uint32_t)(D * wg_round_samples(NR)) <= n1) {
+        if constexpr (D == 1) {
+            wg_load_step<KIND, NR>(voff, in_first);
+        } else {
+            wg_load_step_iq4<0>(voff, in_first);
+            wg_load_step_iq4<1>(voff, in_first + (size_t)wg_round_samples(NR) * RB);
+        }
+        primed = true;
+    }
     const Carry cr = *A.carry;
     uint64_t *const neg_p = A.neg, *const pos_p = A.pos;
     // lanes 0 .. 2 NR - 1 hold the neg plane's dwords of a step, 2 NR .. 4 NR - 1 the pos plane's
@@ -369,6 +397,13 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // (steps before the chunk's first one have published nothing: their masks read as "no LOW sample"; the barriers of the
     // prologue order this before the first round)
     for (int i = tid; i < (int)(sizeof(sh->msk) / 4); i += 256) ((uint32_t *)sh->msk)[i] = 0u;
+    if (lane == 0) {
+        sh->cold[wave][0] = (uint32_t)LL_NONE;
+        sh->cold[wave][1] = (uint32_t)LL_NONE;
+        sh->cold[wave][2] = 0xFFFFFFFFu;
+        sh->cold[wave][3] = 0u;
+        sh->cold[wave][4] = sh->cold[wave][5] = 0x7F61B1E6u;   // 3.0e38f
+    }
     // does a step's LOW mask hold an aligned block of A.blk LOW samples?  (A LOW run longer than max_len covers one, wherever
     // step seams fall: the last max_len + 1 samples of such a run do.)
     auto blk_hit = [&](const unsigned long long (&m)[NR]) __attribute__((always_inline)) -> bool {
@@ -538,12 +573,10 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     if constexpr (KIND == IN_ENV_F32) good_run = good_run && vtop0 < 0x7F800000u;
     uint32_t why = good_run ? 0u : 1u;   // 1 parameters / sums out of range, 2 a sample inside a band, 3 LOW run, 4 allowance, 5 first stable sample
     float min_ss = 3.0e38f;
-    uint32_t vmin = 0xFFFFFFFFu, vmax = vtop0;
+    uint32_t vmin = 0xFFFFFFFFu, vmax = vtop0;   // (wave 0's: what the superstep closes add; the general steps' share is in sh->cold)
     const float etaD = 1.0f - 9.5367431640625e-07f;  // 1 - 2^-20
     const float slU = 1.0f + 3.814697265625e-06f;
     const float loLf = (float)A.lo_L, hiLf = (float)A.hi_L;
-    constexpr int RB = LeanRaw<KIND>::BYTES;
-    const uint32_t wbase0 = m_chunk + STEPN * (uint32_t)wave;   // this wave's step of round 0
     uint32_t slot_step = (A.g0modL + wbase0) % (uint32_t)L;
     const uint32_t slot_adv = (uint32_t)WG_ROUND % (uint32_t)L;
     float b_acc = 0.f, dl_acc = 0.f;
@@ -552,7 +585,6 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // turned out to have.  Per-sample distances where a step holds classified samples, the step's extremes otherwise.
     float dlo = 3.0e38f, dhi = 3.0e38f;
     uint32_t xlo_acc = 0x7F7FFFFFu, xhi_acc = 0u;   // (raw bits: envelopes are >= 0)
-    int my_ll = LL_NONE, my_nl = LL_NONE;   // last LOW / non-LOW sample of this wave's steps (kept exactly over the chunk's last rounds)
     int lz_base = LL_NONE;                  // base of this wave's latest step with LOW samples
     int rounds_since_sync = 0;
 
@@ -579,6 +611,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                             const uint32_t pred_off, const uint32_t ppred_off, int &pk) __attribute__((always_inline)) -> uint32_t {
         float prev[NR];
         uint32_t slot[NR];
+        uint32_t gmin = 0xFFFFFFFFu, gmax = 0u;   // raw bits of what this step accepts
+        float gdlo = 3.0e38f, gdhi = 3.0e38f;     // how close its samples come to the thresholds
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             uint32_t s = slot_step + 64u * j + lane;
@@ -609,8 +643,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             const bool act = (am[j] >> lane) & 1ull;
             lowm[j] = __ballot(x[j] < tlo) & am[j];
             posm[j] = __ballot(x[j] > thi) & am[j];
-            dlo = fminf(dlo, act ? fabsf(x[j] - tlo) : 3.0e38f);
-            dhi = fminf(dhi, act ? fabsf(x[j] - thi) : 3.0e38f);
+            gdlo = fminf(gdlo, act ? fabsf(x[j] - tlo) : 3.0e38f);
+            gdhi = fminf(gdhi, act ? fabsf(x[j] - thi) : 3.0e38f);
             anylow |= lowm[j];
         }
         if (anylow && masked && base < m_start) return 5u;   // (a LOW run across the first stable sample: leave it to the exact kernel)
@@ -694,8 +728,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 ring[slot[j]] = x[j];
             }
             const uint32_t xb = __float_as_uint(x[j]);
-            vmin = min(vmin, (a && xb != 0u) ? xb : 0xFFFFFFFFu);
-            vmax = max(vmax, a ? xb : 0u);
+            gmin = min(gmin, (a && xb != 0u) ? xb : 0xFFFFFFFFu);
+            gmax = max(gmax, a ? xb : 0u);
             posm[j] = __ballot(ps);
             posm[j] &= am[j];
             before = lowm[j] ? rb + last_set(lowm[j]) : before;
@@ -710,9 +744,19 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             step_ll = lowm[j] ? rb + last_set(lowm[j]) : step_ll;
             step_nl = nonlow ? rb + last_set(nonlow) : step_nl;
         }
-        my_ll = (step_ll != LL_NONE) ? step_ll : my_ll;
-        my_nl = (step_nl != LL_NONE) ? step_nl : my_nl;
-        lz_base = anylow ? (int)base : lz_base;
+        {   // (sh->cold: this wave's own slots)
+            const uint32_t wmin = wave_min_u32(gmin), wmax = wave_max_u32(gmax);
+            const float wdlo = wg_wave_min_f32(gdlo), wdhi = wg_wave_min_f32(gdhi);
+            if (lane == 0) {
+                sh->cold[wave][4] = __float_as_uint(fminf(__uint_as_float(sh->cold[wave][4]), wdlo));
+                sh->cold[wave][5] = __float_as_uint(fminf(__uint_as_float(sh->cold[wave][5]), wdhi));
+                if (step_ll != LL_NONE) sh->cold[wave][0] = (uint32_t)step_ll;
+                if (step_nl != LL_NONE) sh->cold[wave][1] = (uint32_t)step_nl;
+                sh->cold[wave][2] = min(sh->cold[wave][2], wmin);
+                sh->cold[wave][3] = max(sh->cold[wave][3], wmax);
+            }
+        }
+        lz_base = rfl(anylow ? (int)base : lz_base);
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             PLANE_PUT(pk, lowm[k], 2 * k);
@@ -729,7 +773,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // rounds are separated by the first barrier only, the second one and the exchange behind it close the superstep.
     const int sup = (D == 2) ? max(2, A.ksteps & ~1) : max(1, A.ksteps);   // the longest superstep
     int cur_sup = D;                    // rounds of the next one (it adapts: see the close; D == 2: whole pairs of rounds)
-    bool primed = false, need_open = true;
+    bool need_open = true;
     uint32_t rbase = m_chunk;   // base of the round
     // which of the three mask buffers this round publishes in, and the round before it did (byte offsets of this wave's row)
     uint32_t mo = 0u, mo_prev = 2u * (uint32_t)sizeof(sh->msk[0]);
@@ -751,13 +795,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     int st_flusher = 0;                   // the wave that sends the next block off (they take turns)
     // where this lane's dword of a step goes in the staging ring (its plane, its wave's row)
     const uint32_t st_lane = ((lane >= 2 * NR) ? PST_PLANE : 0u) + (uint32_t)wave * (uint32_t)(2 * NR) + (uint32_t)plane_dword;
+    const char *in_wave = in_first;   // this wave's step of the round in progress
     uint32_t hot_last = 0u;   // base of this wave's step in the last regular round done
     int hot_done = 0;         // regular rounds done
-    // this lane's dword of its wave's plane store, advanced round by round
-    uintptr_t pl_addr = plane_of_lane + 4 * (2 * (uintptr_t)(wbase0 >> 6) + (uintptr_t)plane_dword);
-    const char *const in_first = (const char *)A.in + (size_t)wbase0 * RB;   // this wave's step of the chunk's first round (uniform)
-    const char *in_wave = in_first;   // ... of the round in progress
-    const uint32_t voff = (uint32_t)lane * (uint32_t)RB;
     {
         // what the step before the chunk's first one "published": the last LOW sample before the chunk, if it is in reach
         if (tid <= 4 * NR) {
@@ -852,7 +892,13 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         }
         need_open = !regular;
 
-        auto one_round = [&](auto set_tag, const int k) __attribute__((always_inline)) {
+        // One round.  REG (compile time): four whole steps of stable samples, asked for a round ahead -- the loop below runs the
+        // regular rounds of a superstep through an instantiation that holds nothing of the other kind (round 5: with `regular` a run-
+        // time flag the compiler kept one merged body and steered it with flag registers -- 80 scalar instructions per round, most
+        // of them moves and tests of those flags); the rounds that are not (the stream's first stable sample, a ragged end) take the
+        // masked general form in every wave, on synchronously loaded samples.
+        auto one_round = [&](auto reg_tag, auto set_tag, const int k) __attribute__((always_inline)) {
+            constexpr bool REG = decltype(reg_tag)::value;
             constexpr int SET = decltype(set_tag)::value;   // (D == 2) which registers hold this round's samples
             (void)SET;
             const uint32_t base = rbase + STEPN * (uint32_t)wave;
@@ -860,7 +906,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             int pk = 0;
             unsigned long long lowany, highany;
             // ---- phase A: this step's envelopes, what can classify at all, its LOW masks for the step after it ----
-            if (__builtin_expect(regular, 1)) {
+            if constexpr (REG) {
                 WG_PF_BEGIN();
                 if constexpr (D == 1) {
                     wg_take<KIND, NR>(x, i16s);
@@ -930,22 +976,22 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             WG_PF_END(pf_b1);
 
             // ---- phase B: the ring, the drift accumulators, the HIGH plane ----
-            int form = 0;   // 0 nothing classifies, 1 only LOW, 2 only HIGH with no LOW sample in reach, 3 the general step
+            // which form: nothing classifies / only LOW / only HIGH with no LOW sample in reach / the general step.
+            bool general = !REG;
             int before = LL_NONE;   // the last LOW sample before this step, if it can matter
             bool ext_hit = false;   // the two steps before this one may hold a LOW run longer than max_len
             // where the LOW masks of the step before this one and of the one before that lie: the waves before this one in the
             // round, or the last waves of the round before
             const uint32_t wrow = (uint32_t)sizeof(sh->msk[0][0]);
-            const uint32_t own_off = mo + (uint32_t)wave * wrow;
-            const uint32_t pred_off = (wave == 0) ? mo_prev + (uint32_t)(WG_WAVES - 1) * wrow : mo + (uint32_t)(wave - 1) * wrow;
-            const uint32_t ppred_off = (wave >= 2) ? mo + (uint32_t)(wave - 2) * wrow : mo_prev + (uint32_t)(wave + 2) * wrow;
             if (highany) {
-                form = lowany ? 3 : 2;
-                if (!regular && base == m_chunk) {   // a chunk's first step in the general form: what the speculation (chunk 0: the carried state) says
+                const uint32_t pred_off = (wave == 0) ? mo_prev + (uint32_t)(WG_WAVES - 1) * wrow : mo + (uint32_t)(wave - 1) * wrow;
+                if (!REG && base == m_chunk) {   // a chunk's first step in the general form: what the speculation (chunk 0: the carried state) says
                     before = (kl_in & 1) ? (kl_in >> 1) : LL_NONE;
                 } else {
                     const uint32_t *pm = (const uint32_t *)((const char *)&sh->msk[0][0][0] + pred_off);
+                    general = general || lowany != 0ull;
                     if (rfl(pm[4 * NR]) || lowany) {
+                        const uint32_t ppred_off = (wave >= 2) ? mo + (uint32_t)(wave - 2) * wrow : mo_prev + (uint32_t)(wave + 2) * wrow;
                         unsigned long long pmk[NR], ppk[NR];
                         const uint32_t *pp = (const uint32_t *)((const char *)&sh->msk[0][0][0] + ppred_off);
                         const int pb = (int)base - (int)STEPN;
@@ -955,19 +1001,22 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                             ppk[j] = (unsigned long long)rfl(pp[2 * j]) | ((unsigned long long)rfl(pp[2 * j + 1]) << 32);
                             before = pmk[j] ? pb + 64 * j + last_set(pmk[j]) : before;
                         }
-                        if (before != LL_NONE && ((int)base - before) <= mx + 1) form = 3;
+                        if (before != LL_NONE && ((int)base - before) <= mx + 1) general = true;
                         else before = LL_NONE;
-                        if (form == 3) ext_hit = blk_hit(pmk) || blk_hit(ppk);
+                        if (general) ext_hit = blk_hit(pmk) || blk_hit(ppk);
                     }
                 }
-            } else if (lowany) {
-                form = 1;
             }
-            if (__builtin_expect(form == 3, 0)) {
+            if (__builtin_expect(general, 0)) {
                 if (base < n1 && !fail) {
-                    fail = general_step(x, base, !regular, before, ext_hit, own_off, pred_off, ppred_off, pk);
-                    if (!regular) {
+                    const uint32_t own_off = mo + (uint32_t)wave * wrow;
+                    const uint32_t pred_off = (wave == 0) ? mo_prev + (uint32_t)(WG_WAVES - 1) * wrow : mo + (uint32_t)(wave - 1) * wrow;
+                    const uint32_t ppred_off = (wave >= 2) ? mo + (uint32_t)(wave - 2) * wrow : mo_prev + (uint32_t)(wave + 2) * wrow;
+                    fail = general_step(x, base, !REG, before, ext_hit, own_off, pred_off, ppred_off, pk);
+                    if constexpr (!REG) {
                         const uint32_t w = (base >> 6) + (uint32_t)(plane_dword >> 1);
+                        // this lane's dword of its wave's plane words of the step
+                        const uintptr_t pl_addr = plane_of_lane + 4 * (2 * (uintptr_t)(base >> 6) + (uintptr_t)plane_dword);
                         if (!fail && lane < 4 * NR && (size_t)w * 64 < A.n) *(lean_g_u32 *)pl_addr = (uint32_t)pk;
                     }
                 }
@@ -990,30 +1039,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 float praw[NR];
 #pragma unroll
                 for (int j = 0; j < NR; j++) praw[j] = *pa[j];
-                if (form == 0) {
-                    // nothing classifies: every sample is accepted
-#pragma unroll
-                    for (int j = 0; j < NR; j++) {
-                        const float t = x[j] - fabsf(praw[j]);
-                        b_acc += fabsf(t);
-                        dl_acc += t;
-                        *pa[j] = x[j];
-                    }
-                } else if (form == 1) {
-                    // LOW samples only: rejected ones keep their slot (value and sign bit)
-#pragma unroll
-                    for (int j = 0; j < NR; j++) {
-                        const float dx = x[j] - tlo;
-                        const bool lo = dx < 0.f;
-                        const float val = lo ? praw[j] : x[j];
-                        const float ts = fabsf(val) - fabsf(praw[j]);   // 0 for a rejected sample
-                        b_acc += fabsf(ts);
-                        dl_acc += ts;
-                        dlo = fminf(dlo, fabsf(dx));
-                        *pa[j] = val;
-                    }
-                    lz_base = (int)base;
-                } else {
+                if (highany) {
                     // HIGH samples only, no LOW sample in reach: all of them are rejected (transition_sink.py:71-74)
                     unsigned long long hw[NR];
 #pragma unroll
@@ -1029,22 +1055,40 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                         *pa[j] = val;
                     }
                     wg_put_masks<NR>(pk, hw, std::integral_constant<int, 1>{});
+                } else if (lowany) {
+                    // LOW samples only: rejected ones keep their slot (value and sign bit)
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
+                        const float dx = x[j] - tlo;
+                        const bool lo = dx < 0.f;
+                        const float val = lo ? praw[j] : x[j];
+                        const float ts = fabsf(val) - fabsf(praw[j]);   // 0 for a rejected sample
+                        b_acc += fabsf(ts);
+                        dl_acc += ts;
+                        dlo = fminf(dlo, fabsf(dx));
+                        *pa[j] = val;
+                    }
+                    lz_base = (int)base;
+                } else {
+                    // nothing classifies: every sample is accepted
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
+                        const float t = x[j] - fabsf(praw[j]);
+                        b_acc += fabsf(t);
+                        dl_acc += t;
+                        *pa[j] = x[j];
+                    }
                 }
             }
-            if (regular) {
-                if (st_cnt == 0) st_base = rbase;
+            if constexpr (REG) {
                 if (lane < 4 * NR) pst[st_lane + st_off] = (uint32_t)pk;
                 st_off += PST_ROUND;
                 st_off = (st_off == st_wrap_off) ? 0u : st_off;
                 st_cnt++;
-                hot_last = base;
-                hot_done++;
             }
-            pl_addr += (uintptr_t)(WG_ROUND / 8);
             in_wave += (size_t)WG_ROUND * RB;
             slot_step += slot_adv;
             slot_step = (slot_step >= (uint32_t)L) ? slot_step - (uint32_t)L : slot_step;
-            rounds_since_sync++;
 #ifdef NFC_WG_PROF
             pf_rounds++;
 #endif
@@ -1052,18 +1096,25 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             mo_prev = mo;
             mo = (mo == 2u * (uint32_t)sizeof(sh->msk[0])) ? 0u : mo + (uint32_t)sizeof(sh->msk[0]);
         };
-        if constexpr (D == 1) {
-            for (int k = 0; k < nr; k++) one_round(std::integral_constant<int, 0>{}, k);
-        } else {
-            if (regular) {   // (nr is even)
+        using RegT = std::integral_constant<bool, true>;
+        using IrrT = std::integral_constant<bool, false>;
+        if (regular) {
+            if (st_cnt == 0) st_base = rbase;   // (the staging is empty: the superstep's first round is its oldest)
+            if constexpr (D == 1) {
+                for (int k = 0; k < nr; k++) one_round(RegT{}, std::integral_constant<int, 0>{}, k);
+            } else {   // (nr is even)
                 for (int k = 0; k < nr; k += 2) {
-                    one_round(std::integral_constant<int, 0>{}, k);
-                    one_round(std::integral_constant<int, 1>{}, k + 1);
+                    one_round(RegT{}, std::integral_constant<int, 0>{}, k);
+                    one_round(RegT{}, std::integral_constant<int, 1>{}, k + 1);
                 }
-            } else {
-                one_round(std::integral_constant<int, 0>{}, 0);
             }
+            // (what the chunk's summary asks of the regular rounds: how many, and this wave's step of the last of them)
+            hot_done += nr;
+            hot_last = rbase - (uint32_t)WG_ROUND + STEPN * (uint32_t)wave;
+        } else {
+            one_round(IrrT{}, std::integral_constant<int, 0>{}, 0);
         }
+        rounds_since_sync += nr;
 
         // ---- the superstep closes: did every sample keep clear of the thresholds by more than the window sum drifted?  Every lane
         // hands in its sums and distances and every wave its verdict; WAVE 0 adds them up, moves the tracked sum on, chooses the
@@ -1071,7 +1122,12 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         // the others only read the thresholds it leaves behind.
         {
             // every lane hands in (sum |x - prev|, sum (x - prev), its smallest distance to the LOW threshold, to the HIGH threshold)
-            const float dl2 = fminf(dlo, __uint_as_float(xlo_acc) - tlo), dh2 = fminf(dhi, thi - __uint_as_float(xhi_acc));
+            float dl2 = fminf(dlo, __uint_as_float(xlo_acc) - tlo), dh2 = fminf(dhi, thi - __uint_as_float(xhi_acc));
+            if (lane == 0) {   // (what the steps in the general form measured: sh->cold)
+                dl2 = fminf(dl2, __uint_as_float(sh->cold[wave][4]));
+                dh2 = fminf(dh2, __uint_as_float(sh->cold[wave][5]));
+                sh->cold[wave][4] = sh->cold[wave][5] = 0x7F61B1E6u;
+            }
             sh->acc[wave][lane] = make_float4(b_acc, dl_acc, dl2, dh2);
             b_acc = 0.f;
             dl_acc = 0.f;
@@ -1159,6 +1215,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     int chunk_nl = LL_NONE, chunk_kl = KEY_NONE;
     {
         bool tail_hit = false;   // an aligned block of LOW samples in this wave's last two regular steps
+        // last LOW / non-LOW sample of this wave's steps in the general form (kept exactly over the chunk's last rounds)
+        int my_ll = (int)rfl(sh->cold[wave][0]), my_nl = (int)rfl(sh->cold[wave][1]);
         if (good_run && hot_done > 0) {
             const int which = (lane >= NR) ? 1 : 0;   // lanes 0 .. NR - 1 the last regular step's words, NR .. 2 NR - 1 the one a round before
             const int wi = lane - which * NR;
@@ -1221,8 +1279,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     {
         // fold the raw-bit extremes of the rounds into the exponent guard
         uint32_t v[8], g[WG_WAVES][8];
-        v[0] = wave_min_u32(vmin);
-        v[1] = wave_max_u32(vmax);
+        v[0] = min(wave_min_u32(vmin), rfl(sh->cold[wave][2]));
+        v[1] = max(wave_max_u32(vmax), rfl(sh->cold[wave][3]));
         // pass 0 fills the buffer the version byte names (0: prepare_batch zeroes them), a re-run the other one
         const int vb_new = (A.mode == 1) ? 1 - (int)A.ver[c] : (int)A.ver[c];
         float *ro = (vb_new ? A.ring_out[1] : A.ring_out[0]) + (size_t)c * L;
