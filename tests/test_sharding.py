@@ -625,3 +625,33 @@ def test_bench_capture_slices_agree_on_the_samples_they_share():
     assert np.array_equal(ov1, own0[-len(ov1):])
     ov2, _ = bench.make_capture_slice('miller', n, 2, 3)
     assert np.array_equal(ov2, own1[-len(ov2):])
+
+
+def test_bench_parity_legs_of_an_eight_gpu_run_fit_the_drivers_clock():
+    # The driver runs `python bench.py --gpus 8 --steps K --warmup W` (no --workload) inside a 1 800 s limit.  Beside the GPU work that
+    # run checks EVERY rank against the pinned C oracle on rank 0's host (bench.sharded_parity): the 8 x 1e8-sample Miller capture is
+    # REGENERATED shard by shard and decoded by one core, then configs[4]'s 8 x 1e9-sample tiled capture is decoded tile by tile.  Both
+    # legs are linear in the sample count: timed here at a fraction of the size, extrapolated, and held against a budget that leaves
+    # the GPU legs the larger part of the limit -- so that the first real SCALE run does not die on a timeout.
+    import time
+    import bench
+    flags = bench.decoder_flags('miller')
+    n_small, world = 10_000_000, 8
+    t0 = time.perf_counter()
+    out = bench.sharded_parity('miller', n_small, world, flags, [None] * world)
+    t_gen = time.perf_counter() - t0
+    assert 'ranks_equal' in out and len(out['ranks_equal']) == world and min(out['n_edges']) > 1000
+    full_generated = t_gen * (100_000_000 / n_small)
+    # the tiled capture: one rank's share in miniature (the tile again and again), eight ranks of 1e9 samples in the real run
+    # (the tile is generated ONCE, then decoded again and again: two sizes give the cost per tile)
+    ts = []
+    for tiles in (2, 4):
+        t0 = time.perf_counter()
+        out4 = bench.sharded_parity('classic1k', tiles * bench.TILE, 1, bench.decoder_flags('classic1k'), [None])
+        ts.append(time.perf_counter() - t0)
+        assert 'ranks_equal' in out4 and out4['n_edges'][0] > 1000
+    per_tile = max(0.0, (ts[1] - ts[0]) / 2.0)
+    full_tiled = ts[0] + per_tile * (8 * 1_000_000_000 / bench.TILE - 2)
+    assert 8 * 100_000_000 <= bench.SHARDED_PARITY_CAP   # (the default run's generated capture is not skipped)
+    # this container's cores are slower than the GPU host's; even so both legs together stay under a third of the driver's limit
+    assert full_generated + full_tiled < 600.0, (full_generated, full_tiled)
