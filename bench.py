@@ -767,8 +767,10 @@ def rank_main(a):
             others = []
             for wl, nn, st in (('manchester', 100_000_000, 20), ('classic1k', 1_000_000_000, 10)):
                 o2, _, _ = run_config(a, wl, nn, st, 3, 0, 1, 0, sharding.LocalComm(), 'none', not a.no_parity)
+                sa = o2.get('submitted_ahead') or {}
                 others.append({'workload': WORKLOAD_NAMES[wl], 'samples': nn, 'steps': st, 'ms_per_step': o2['ms_per_step'], 'value': o2['value'],
                                'unit': 'Msamples/s', 'roofline': o2['roofline'], 'time_chunks': o2['config']['time_chunks'],
+                               'submitted_ahead': {k: sa.get(k) for k in ('ms_per_step', 'value', 'ran_ahead', 'steps')} if sa else None,
                                'parity': o2.get('parity')})
             # the other input kinds of the boundary on configs[1]'s capture: the float32 envelope the reference's own sink is handed
             # (4 B/sample) and 16-bit PCM (2 B/sample).  Same kernel, same ~0.19 ms launch -- it is bound by instruction issue,

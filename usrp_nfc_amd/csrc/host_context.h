@@ -100,6 +100,9 @@ struct DevState {
                        // does not carry the current number was not written by this batch's kernels
 };
 
+// what the threshold kernel of a batch submitted ahead may hold of a CU's 160 KB of LDS: the later stages of the batch before it run
+// beside it (the writer stages 12 KB per workgroup, the speculative decode 25 KB)
+constexpr size_t AHEAD_LDS_MAX = 96 * 1024;
 constexpr int NRING = 4;   // window buffers: the carried one + one per batch that may be in flight (they rotate)
 constexpr int NSUB = 3;    // batches that may be submitted and not yet waited for
 

@@ -21,7 +21,7 @@ namespace {
 // batch submitted ahead against 2.7 ms one after the other) -- such batches take the synchronous path inside nfc_wait.
 bool submit_fast_ok(const nfc_ctx *c, uint32_t n) {
     return c->h_carry.stable && !(c->P.flags & (NFC_FLAG_NO_EDGES | NFC_FLAG_FORCE_SEQUENTIAL)) && c->L >= STEP && c->timing < 2 &&
-           !(c->use_small && n <= SM_MAX_SAMPLES) && n > 0 && c->ahead_lds_per_cu <= 96 * 1024 && !c->dbg_any && !c->dbg_clk && !c->dbg_no_submit_ahead;
+           !(c->use_small && n <= SM_MAX_SAMPLES) && n > 0 && c->ahead_lds_per_cu <= AHEAD_LDS_MAX && !c->dbg_any && !c->dbg_clk && !c->dbg_no_submit_ahead;
 }
 
 // the threshold stage of a submitted batch, on st_a, into a free set of planes; b.fast is cleared when the batch turns out

@@ -266,6 +266,11 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             // ONE wave per SIMD (measured: k_dec_apply 19 -> 102 us beside it, the stages' chain -- not this kernel -- then sets the
             // period).  Three per CU leave them two or three: 0.263 -> 0.241 ms per batch (two: 0.254).
             int per_cu_ahead = std::min(per_cu_wg, 3);
+            // (... and LDS: the later stages' workgroups want 12-29 KB each beside it.  A long window's ring -- av_window 10 000: 40 KB, 52 KB
+            // with the rest -- fills the CU at three per CU, so such streams take the synchronous path: host_submit.h, submit_fast_ok.
+            // Measured in round 5, configs[3], with TWO per CU for batches submitted ahead (56 KB left; the kernel alone loses 3 % to it,
+            // 1.589 -> 1.637 ms per launch; one per CU: 2.31): 1.87-2.02 ms per batch against 1.92 one batch at a time -- the kernel
+            // stretches to 1.69-2.0 ms beside the other stages, which are 0.35 ms of a 1.95 ms step to begin with.  Not taken.)
             if (const char *e = getenv("NFC_WG_PER_CU_AHEAD")) per_cu_ahead = std::max(1, std::min(per_cu_max, atoi(e)));
             c->wg_slots_ahead = prop.multiProcessorCount * per_cu_ahead;
             // (what a batch submitted ahead holds of a CU's LDS is this kernel's, not the lean kernel's: host_submit.h, submit_fast_ok)
