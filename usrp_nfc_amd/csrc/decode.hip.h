@@ -1156,7 +1156,16 @@ __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
     if (F.mirror_src) {
         __threadfence();
         __syncthreads();   // thread 0's carry words are part of the block
-        for (uint32_t i = threadIdx.x; i < F.mirror_words; i += blockDim.x) F.mirror_dst[i] = (i == F.stamp_word) ? F.stamp : F.mirror_src[i];
+        // (the stamp LAST, behind a system-scope fence: a host that watches the stamp instead of waiting for the stream -- host_threshold.h:
+        // wait_for_stamp -- finds every other word of the block in place when it sees it)
+        for (uint32_t i = threadIdx.x; i < F.mirror_words; i += blockDim.x)
+            if (i != F.stamp_word) F.mirror_dst[i] = F.mirror_src[i];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            ((volatile uint32_t *)F.mirror_dst)[F.stamp_word] = F.stamp;
+        }
     }
 }
 

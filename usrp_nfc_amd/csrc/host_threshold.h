@@ -31,6 +31,28 @@ static bool sums_exact(const Carry &hc, int emin, int emax, uint32_t vtop) {
 // What one parallel attempt at [base, n_all) needs before anything is launched: the chunking, room in every per-chunk
 // buffer, and the kernels' argument block.  (Shared by the synchronous path and by a batch submitted ahead, which works
 // on the other pair of planes, from the window the batch before it leaves, with the LOW bookkeeping read on the device.)
+// The batch's last launch (k_pkt_finish) writes the state block into the host's mapped mirror and, last of all and behind a system
+// fence, the batch's number into the mirror's stamp word.  Watching that word costs the host a few hundred nanoseconds after the
+// write lands; hipStreamSynchronize comes back 8-10 us after the kernel has ended (the completion signal's way through the runtime) --
+// and with one batch at a time the host's turn between two batches IS the step's idle time.  Bounded: after 2 ms without the stamp (a
+// kernel that faulted never writes it) the stream is waited for in the ordinary way, which also reports the fault.  NFC_SPIN_WAIT=0.
+static hipError_t wait_for_stamp(nfc_ctx *c) {
+    if (c->spin_wait) {
+        const volatile uint32_t *p = &c->hs->seq[1];
+        const uint32_t want = c->stamp_b;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t k = 0;; k++) {
+            if (*p == want) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return hipSuccess;
+            }
+            if ((k & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+            __builtin_ia32_pause();
+        }
+    }
+    return hipStreamSynchronize(c->st);
+}
+
 struct ThrPlan {
     uint32_t nch;
     bool lean_applies;
@@ -343,6 +365,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                                    dbg ? c->d_certinfo.as<CertInfo>() : nullptr, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c),
                                    first_round ? d_sum : (CertSummary *)nullptr);
             };
+            bool stamped_last = false;   // the round's last launch is the one that stamps the mirror (k_pkt_finish behind the writer)
             if (first_round && ahead && !dbg) {
                 // the stages that follow are enqueued now; their first full-width kernel takes the certification along
                 c->cert = CertLaunch{A, d_cert, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c), d_sum, cert_grid(np)};
@@ -352,6 +375,8 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                     c->cert_pending = false;
                     launch_certify();
                     HIPCHK(c, mirror_async(c));
+                } else {
+                    stamped_last = c->timing < 2;   // (stream markers behind the stages: the stream is waited for)
                 }
                 if (rc) return rc;
                 ran_ahead = true;
@@ -368,7 +393,8 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                     ran_ahead = true;
                 }
             }
-            HIPCHK(c, hipStreamSynchronize(c->st));
+            if (stamped_last) HIPCHK(c, wait_for_stamp(c));
+            else HIPCHK(c, hipStreamSynchronize(c->st));
             BATCHCHK(c, true);   // (the verdict summary and the totals are about to be read out of the mirror)
             std::vector<uint32_t> failing;
             if (first_round) {

@@ -24,6 +24,8 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -138,6 +140,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     if (const char *e = getenv("NFC_LEAN_GMIN")) c->lean_gmin = (float)atof(e);
     if (const char *e = getenv("NFC_OWN_PREFIX_MAX")) c->own_prefix_max = (uint32_t)strtoul(e, nullptr, 10);
     if (const char *e = getenv("NFC_DEC_SPEC")) c->dec_spec = atoi(e) != 0;
+    if (const char *e = getenv("NFC_SPIN_WAIT")) c->spin_wait = atoi(e) != 0;
     if (const char *e = getenv("NFC_EAGG")) c->eagg = atoi(e) != 0;   // 1: k_threshold_wg leaves the edge stage's aggregates, no k_edge_reduce (measured: no gain, host_context.h)
     if (const char *e = getenv("NFC_DEC_RUNIN")) {   // run-in edges per decode tile: 512, 1024 or 2048
         const int v = atoi(e);
