@@ -24,13 +24,13 @@ for kd in i16; do
 done
 # what a read-only kernel with the threshold kernel's access pattern reaches on this box (tools/ubench/stream_chunks.hip)
 [ -x tools/ubench/stream_chunks ] && tools/ubench/stream_chunks > $out/${tag}_stream_ceiling.txt 2>&1
-# where the workgroups of the later stages spend their time (a build with -DNFC_TAIL_PROF: scratch/r4/tailprof.so), and the waves of
-# the re-run kernel on the stress captures (-DNFC_GEN_PROF: scratch/r4/genprof.so)
-if [ -f scratch/r4/tailprof.so ]; then
-  { echo "# NFC_AMD_LIB=<-DNFC_TAIL_PROF build> python tools/tailprof.py miller 1e8   (s_memtime ticks, thread 0 of every workgroup)"; NFC_AMD_LIB=scratch/r4/tailprof.so python3 tools/tailprof.py miller 1e8; echo "# ... NFC_DEC_SPEC=0: the three-launch decode"; NFC_DEC_SPEC=0 NFC_AMD_LIB=scratch/r4/tailprof.so python3 tools/tailprof.py miller 1e8; } > $out/${tag}_tail_phases.txt 2>&1
+# where the workgroups of the later stages spend their time (a build with -DNFC_TAIL_PROF: scratch/r5/tailprof.so), and the waves of
+# the re-run kernel on the stress captures (-DNFC_GEN_PROF: scratch/r5/genprof.so)
+if [ -f scratch/r5/tailprof.so ]; then
+  { echo "# NFC_AMD_LIB=<-DNFC_TAIL_PROF build> python tools/tailprof.py miller 1e8   (s_memtime ticks, thread 0 of every workgroup)"; NFC_AMD_LIB=scratch/r5/tailprof.so python3 tools/tailprof.py miller 1e8; echo "# ... NFC_DEC_SPEC=0: the three-launch decode"; NFC_DEC_SPEC=0 NFC_AMD_LIB=scratch/r5/tailprof.so python3 tools/tailprof.py miller 1e8; } > $out/${tag}_tail_phases.txt 2>&1
 fi
-if [ -f scratch/r4/genprof.so ]; then
-  { echo "# NFC_AMD_LIB=<-DNFC_GEN_PROF build> python tools/genprof.py hover / dropsteps   (the atomics of the iteration counter stretch the ticks: read the counts)"; NFC_AMD_LIB=scratch/r4/genprof.so python3 tools/genprof.py hover; NFC_AMD_LIB=scratch/r4/genprof.so python3 tools/genprof.py dropsteps; } > $out/${tag}_rerun_phases.txt 2>&1
+if [ -f scratch/r5/genprof.so ]; then
+  { echo "# NFC_AMD_LIB=<-DNFC_GEN_PROF build> python tools/genprof.py hover / dropsteps   (the atomics of the iteration counter stretch the ticks: read the counts)"; NFC_AMD_LIB=scratch/r5/genprof.so python3 tools/genprof.py hover; NFC_AMD_LIB=scratch/r5/genprof.so python3 tools/genprof.py dropsteps; } > $out/${tag}_rerun_phases.txt 2>&1
 fi
 for nm in stress_dropouts_steps stress_hover; do tools/stress_timeline.sh $nm > $out/${tag}_timeline_$nm.txt 2>&1; done
 timeout 600 python3 bench.py > $out/${tag}_bench.json 2> $out/bench.log
