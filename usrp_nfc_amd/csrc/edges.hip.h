@@ -59,6 +59,12 @@ struct Last2Op {
     }
 };
 
+struct MinI32 {
+    using T = int32_t;
+    static __device__ __forceinline__ T identity() { return INT32_MAX; }
+    static __device__ __forceinline__ T op(T a, T b) { return a < b ? a : b; }
+};
+
 struct EdgeArgs {
     const uint64_t *neg, *pos;  // classification bit planes (LOW / HIGH), 64 samples per word
     uint32_t n, skip;           // samples in the batch; samples before skip belong to the fill phase
@@ -381,8 +387,16 @@ __device__ __forceinline__ void edge_reduce_super(const EdgeArgs &A, size_t nwor
     const bool inner = __any(may);
 #pragma unroll
     for (int i = 0; i < ER_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w + i) * 64), m[i], inner));
-    const EdgeAgg inc = wave_inclusive_with(op, agg);
-    if (lane == 63) lds[wave] = inc;
+    // The wave's aggregate without scanning the whole aggregate (round 5; the operator's division by max_len is then paid once per lane
+    // instead of once per lane and scan step): the last two changes by a scan of selects, the first change by a minimum, and the entries
+    // by a sum -- a lane adds the time-outs of the run that ENDS at its first change, which it knows from the changes before it in the wave
+    // (none before it: the run began outside the wave, and whoever joins the waves adds its time-outs -- the operator, below).
+    const Last2 l_inc = wave_inclusive<Last2Op>(agg.l);
+    const Last2 l_exc = wave_shift_up1<Last2Op>(l_inc);
+    const uint32_t cross = (agg.first != POS_NONE && l_exc.s1 != POS_NONE) ? A.timeouts_between(l_exc.s1, agg.first) : 0u;
+    const uint32_t sum_inc = wave_inclusive<AddU32>(agg.sum + cross);
+    const int32_t first_inc = wave_inclusive<MinI32>(agg.first != POS_NONE ? agg.first : INT32_MAX);
+    if (lane == 63) lds[wave] = EdgeAgg{first_inc != INT32_MAX ? first_inc : POS_NONE, l_inc, sum_inc};
     __syncthreads();
     if (threadIdx.x < EW_SUPER) {   // a lane per tile folds its waves; lane 0 the tiles
         EdgeAgg t = lds[threadIdx.x * ER_WPT];
@@ -504,7 +518,6 @@ __device__ __forceinline__ void write_edges_tile(const EdgeArgs &A, size_t nword
                                                  uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
                                                  Last2 *last2_total, EdgeCarry *carry_out, const uint32_t bid, const uint32_t ntiles) {
     __shared__ uint32_t s_ent[EW_CAP + 1];   // tile-local sample position (a tile is EW_WORDS * 64 <= 65536 samples) | code << 16; slot EW_CAP: entries of another round
-    __shared__ EdgeAgg s_agg[SCAN_WAVES];
     TP_DECL();
     const TileSpan ts = tile_span(A, nwords, bid);
     const size_t wt = ts.w0;                    // first word of the tile
@@ -581,24 +594,39 @@ __device__ __forceinline__ void write_edges_tile(const EdgeArgs &A, size_t nword
     const bool inner = __any(may);
 #pragma unroll
     for (int i = 0; i < EW_ITEMS; i++) agg = op(agg, word_agg(A, (int32_t)((w_first + i) * 64), m[i], inner));
-    EdgeAgg tile_total;
-    const EdgeAgg before = op(pre, block_exclusive_with<SCAN_WAVES>(op, agg, s_agg, tile_total));
-    const EdgeAgg all = op(pre, tile_total);
+    // Where a thread's entries go, in TWO cheap block scans instead of one of the whole aggregate (round 5: the aggregate's operator is
+    // 25 vector instructions, two of them quarter-rate multiplies for the division by max_len, and a block scan applies it 16 times per
+    // thread -- 420 of the writer's 1 390 vector instructions per wave).  Entries before a position are its val changes, plus per change
+    // the time-outs of the run that ENDS there, plus those of the run in progress (entries_before); the time-outs of the run that ends at
+    // a thread's first change need the change before it, which is all the first scan carries (Last2: selects only); the second scan adds
+    // counts.  Same numbers as entries_before(op(pre, exclusive aggregate), T): the gap between two spans is counted where it ends.
+    const int32_t s0 = (int32_t)A.skip - A.dur_in;   // where the run carried into the batch "starts"
+    __shared__ Last2 s_l2[SCAN_WAVES];
+    __shared__ uint32_t s_cnt[SCAN_WAVES];
+    Last2 tile_l;
+    const Last2 before_l = Last2Op::op(pre.l, block_exclusive<Last2Op>(agg.l, s_l2, tile_l));
+    const Last2 all_l = Last2Op::op(pre.l, tile_l);
+    const uint32_t cross = (agg.first != POS_NONE) ? A.timeouts_between(before_l.s1 != POS_NONE ? before_l.s1 : s0, agg.first) : 0u;
+    uint32_t tile_cnt;
+    const uint32_t excl_cnt = block_exclusive<AddU32>(agg.sum + cross, s_cnt, tile_cnt);
     const int32_t tile_end = (int32_t)min(wend * 64, (size_t)A.n), T = (int32_t)min(w_first * 64, (size_t)tile_end);
-    const uint32_t off = entries_before(A, before, T) - gbase;
-    const uint32_t total = entries_before(A, all, tile_end) - gbase;
+    // (entries before the tile that do not depend on where the tile begins: pre.sum and the carried run's time-outs up to the batch's first change)
+    const uint32_t run_k = A.timeouts_between(before_l.s1 != POS_NONE ? before_l.s1 : s0, T);   // time-outs so far of the run in progress at T
+    const uint32_t in_progress0 = A.timeouts_between(pre.l.s1 != POS_NONE ? pre.l.s1 : s0, tile_p0);   // ... at the tile's first sample (gbase holds them)
+    const uint32_t off = excl_cnt + run_k - in_progress0;
+    const uint32_t total = tile_cnt + A.timeouts_between(all_l.s1 != POS_NONE ? all_l.s1 : s0, tile_end) - in_progress0;
     if (own_prefix && bid == ntiles - 1 && threadIdx.x == 0) {
         *total_out = gbase + total;
-        *last2_total = all.l;
-        edge_carry_out(A, all.l, carry_out);
+        *last2_total = all_l;
+        edge_carry_out(A, all_l, carry_out);
     }
     // where the walk stands at the thread's first sample
     EdgeWalk W0;
     {
-        const Last2 c = before.l;
+        const Last2 c = before_l;
         const bool carried = c.s1 == POS_NONE;
-        const int32_t s = carried ? (int32_t)A.skip - A.dur_in : c.s1;
-        const int32_t k = (int32_t)A.timeouts_between(s, T);   // time-outs of the run so far
+        const int32_t s = carried ? s0 : c.s1;
+        const int32_t k = (int32_t)run_k;   // time-outs of the run so far
         W0.q = s + k * A.mx;
         const bool timed = k > 0;
         int left = A.state_in;
