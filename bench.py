@@ -696,6 +696,7 @@ def end_to_end(workload, own, flags):
         assert L.nfc_device_upload(0, bufs[k & 1].ptr, pin.value + 8 * o, 8 * m) == 0
 
     n_edges = n_frames = 0
+    t_push = t_read = t_fsm = t_join = 0.0   # where the main thread's time goes: GPU path, read-back, protocol layer, waiting for the upload
     t0 = time.perf_counter()
     upload(0)
     for k, (o, m) in enumerate(pieces):
@@ -703,26 +704,36 @@ def end_to_end(workload, own, flags):
         if k + 1 < len(pieces):
             th = threading.Thread(target=upload, args=(k + 1,))
             th.start()
+        ta = time.perf_counter()
         ctx.push_device(bufs[k & 1], m)
+        tb = time.perf_counter()
+        t_push += tb - ta
         n_edges += len(ctx.edges_compact()[0])
         tabs = [ctx.packet_table(t) for t in (0, 1)]
         bits = [ctx.packet_bits(t) for t in (0, 1)]
         table = np.concatenate(tabs)
         table = table[np.argsort(table['idx'], kind='stable')]
         table = table[table['n_bits'] > 0]
+        tc = time.perf_counter()
+        t_read += tc - tb
         if len(table):
             frames, _ = machine.process_packets(table, bits[0], bits[1], dispatch=False)
             n_frames += len(frames)
+        td = time.perf_counter()
+        t_fsm += td - tc
         if th:
             th.join()
+        t_join += time.perf_counter() - td
     dt = time.perf_counter() - t0
     ctx.close()
     L.nfc_host_free_pinned(pin)
     return {'value': n / dt / 1e6, 'unit': 'Msamples/s', 'ms_total': dt * 1e3, 'samples': n, 'edges_to_host': n_edges,
             'commands': n_frames, 'piece_samples': piece,
             'what': 'pinned host IQ -> H2D (overlapped, second thread) -> GPU path -> transitions (compact: 6 B each) + packets D2H -> fsm (C) on the host',
-            'bound': 'PCIe: %.0f MB in + %.0f MB out per pass = %.1f GB/s over the link' % (8 * n / 1e6, 6 * n_edges / 1e6,
-                                                                                           (8 * n + 6 * n_edges) / dt / 1e9)}
+            # (the link itself moves 57 GB/s either way from pinned memory, measured with a bare hipMemcpy on this pool: when link_GBs is
+            # well below that the pass is bound by the main thread's own turn per piece -- main_thread_ms says which part)
+            'link_GBs': (8 * n + 6 * n_edges) / dt / 1e9, 'mb_in': 8 * n / 1e6, 'mb_out': 6 * n_edges / 1e6,
+            'main_thread_ms': {'gpu_path': t_push * 1e3, 'read_back': t_read * 1e3, 'fsm': t_fsm * 1e3, 'waiting_for_upload': t_join * 1e3}}
 
 
 def rank_main(a):

@@ -173,6 +173,8 @@ struct nfc_ctx {
     void *hs_dev = nullptr;        // the same memory as the device addresses it (kernels may fill the mirror themselves)
     uint8_t *h_stage = nullptr;    // pinned staging for nfc_get_state
     size_t h_stage_cap = 0;
+    uint8_t *h_pk_stage = nullptr;     // pinned staging for the packet tables (build_packets)
+    size_t h_pk_stage_cap = 0;
     uint8_t *h_edge_stage = nullptr;   // pinned staging for nfc_read_edges / nfc_read_edges_compact (two pieces)
     size_t h_edge_stage_cap = 0;
     std::vector<uint64_t> edge_lut;    // per LUT row: the (d, v) half of an nfc_edge record

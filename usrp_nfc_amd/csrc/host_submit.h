@@ -338,11 +338,26 @@ int build_packets(nfc_ctx *c, int t) {
     if (c->pk_ready[t]) return NFC_OK;
     c->pk[t].clear();
     const uint32_t nc = c->n_close[t];
+    const auto t_bp0 = std::chrono::steady_clock::now();
     if (nc) {
-        std::vector<uint32_t> ends(nc);
-        std::vector<uint64_t> idx(nc);
-        HIPCHK(c, hipMemcpy(ends.data(), c->d_close_end[t].p, (size_t)nc * 4, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(idx.data(), c->d_close_idx[t].p, (size_t)nc * 8, hipMemcpyDeviceToHost));
+        // (through pinned staging: two copies of a few tens of KB into pageable vectors took 1.4 ms per batch -- the runtime stages
+        // those itself, synchronously -- and were most of what `end_to_end` spent per piece: round 5)
+        const size_t need = (size_t)nc * 12 + 64;
+        if (c->h_pk_stage_cap < need) {
+            if (c->h_pk_stage) (void)hipHostFree(c->h_pk_stage);
+            c->h_pk_stage = nullptr;
+            c->h_pk_stage_cap = 0;
+            const size_t cap = need + need / 2 + 65536;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_pk_stage, cap, hipHostMallocDefault));
+            c->h_pk_stage_cap = cap;
+        }
+        uint64_t *idx = (uint64_t *)c->h_pk_stage;
+        uint32_t *ends = (uint32_t *)(c->h_pk_stage + (size_t)nc * 8);
+        HIPCHK(c, hipMemcpyAsync(idx, c->d_close_idx[t].p, (size_t)nc * 8, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(ends, c->d_close_end[t].p, (size_t)nc * 4, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        if (c->dbg_trace) fprintf(stderr, "[nfc] build_packets(%d): %u closes, copies %.3f ms\n", t, nc, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bp0).count());
+        c->pk[t].reserve(nc);
         uint32_t prev = 0;
         for (uint32_t k = 0; k < nc; k++) {
             if (ends[k] > prev) {  // packets.py:97 -- empty lists never reach the fsm
@@ -356,6 +371,7 @@ int build_packets(nfc_ctx *c, int t) {
             prev = ends[k];
         }
     }
+    if (c->dbg_trace) fprintf(stderr, "[nfc] build_packets(%d): %zu packets, %.3f ms\n", t, c->pk[t].size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bp0).count());
     c->pk_ready[t] = true;
     return NFC_OK;
 }

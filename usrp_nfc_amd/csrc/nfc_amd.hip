@@ -413,6 +413,7 @@ void nfc_destroy(nfc_ctx *c) {
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_edge_stage) (void)hipHostFree(c->h_edge_stage);
+    if (c->h_pk_stage) (void)hipHostFree(c->h_pk_stage);
     if (c->h_cflags) (void)hipHostFree(c->h_cflags);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -719,8 +720,19 @@ int nfc_read_packet_bits(nfc_ctx *c, int type, size_t first, uint8_t *out, size_
     if (n && !out) return fail(c, NFC_ERR_ARG, "null output");
     if (n) {
         const size_t w0 = first >> 5, w1 = (first + n + 31) >> 5;
-        std::vector<uint32_t> w(w1 - w0);
-        HIPCHK(c, hipMemcpy(w.data(), c->d_bits[type].as<uint32_t>() + w0, (w1 - w0) * 4, hipMemcpyDeviceToHost));
+        // (the words through pinned staging: a pageable destination makes the runtime stage the copy itself, synchronously)
+        const size_t need = (w1 - w0) * 4 + 64;
+        if (c->h_pk_stage_cap < need) {
+            if (c->h_pk_stage) (void)hipHostFree(c->h_pk_stage);
+            c->h_pk_stage = nullptr;
+            c->h_pk_stage_cap = 0;
+            const size_t cap2 = need + need / 2 + 65536;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_pk_stage, cap2, hipHostMallocDefault));
+            c->h_pk_stage_cap = cap2;
+        }
+        const uint32_t *w = (const uint32_t *)c->h_pk_stage;
+        HIPCHK(c, hipMemcpyAsync(c->h_pk_stage, c->d_bits[type].as<uint32_t>() + w0, (w1 - w0) * 4, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
         for (size_t i = 0; i < n; i++) {
             const size_t b = first + i - (w0 << 5);
             out[i] = (uint8_t)((w[b >> 5] >> (b & 31)) & 1u);
