@@ -828,6 +828,40 @@ def test_workgroup_kernel_plane_staging(monkeypatch, bulk, nr):
     assert first_diff(tr, o.transitions()) is None and pk == o.packets()
 
 
+@pytest.mark.parametrize('stream', ['torture', 'all'])
+def test_chunks_cut_by_dispatch_row(monkeypatch, stream):
+    # host_threshold.h, thr_prepare: a batch that is one full wave of resident workgroups (more than three per CU, at most four) is
+    # cut into chunks whose length depends on the row of 256 workgroups they are dispatched in -- the first rows longer, the last
+    # shorter (threshold.hip.h: chunk_span).  20 M samples: 21 / 20 / 20 / 16 rounds per chunk where the equal cut has 20.
+    # The torture stream (its level steps have chunks re-run, and the batch cut again, from that first pass) and the `all` workload
+    # (certified as cut: the count of chunks shows which cut it was).  Per-sample val, edges, symbols and packets against the C
+    # oracle, with the equal cut (NFC_WG_ROWBAL=0) beside it; then the stream in two pushes (the second batch starts inside what
+    # was a chunk, and is cut by row itself).
+    n = 20_000_000
+    iq = np.concatenate([_wg_torture(900 + i, n // 10) for i in range(10)]) if stream == 'torture' else synth.workload('all', n)
+    params = dict(hi_val=1.1)
+    o = oracle_run(iq, params, api.NFC_IN_IQ_F32)
+    want_val = np.asarray(o.trace())
+    chunks = {}
+    for rowbal in ('1', '0'):
+        monkeypatch.setenv('NFC_WG_ROWBAL', rowbal)
+        with api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **params) as ctx:
+            ctx.push(iq)
+            st = ctx.stats()
+            chunks[rowbal] = st.n_chunks
+            assert st.used_sequential == 0
+            assert np.array_equal(np.asarray(ctx.val())[2000:], want_val), 'val (NFC_WG_ROWBAL=%s)' % rowbal
+            assert first_diff(ctx.transitions(), o.transitions()) is None
+            assert ctx.symbols(0).tolist() == o.symbols(0).tolist() and ctx.symbols(1).tolist() == o.symbols(1).tolist()
+            assert ctx.packets() == o.packets()
+    if stream == 'all':
+        assert chunks['0'] == (n + 20479) // 20480 and 768 < chunks['1'] <= 1024 and chunks['1'] != chunks['0'], chunks
+    monkeypatch.setenv('NFC_WG_ROWBAL', '1')
+    r = run_gpu(iq, params, kind=api.NFC_IN_IQ_F32, pushes=[0, 16_000_123, n])
+    assert first_diff(r['transitions'], o.transitions()) is None and r['packets'] == o.packets()
+    assert r['sym_tag'] == o.symbols(0).tolist() and r['sym_reader'] == o.symbols(1).tolist()
+
+
 def test_workgroup_kernel_two_rounds_ahead(monkeypatch):
     # the optional second round of samples in flight (NFC_WG_D=2: a second register set and a counted wait)
     monkeypatch.setenv('NFC_WG_D', '2')

@@ -124,6 +124,9 @@ struct nfc_ctx {
     uint32_t sym_n = 0, sym_tiles = 0;
     uint32_t decode_respeculated = 0;   // batches whose decode stage was repeated with the three-launch form (nfc_stats)
     int lean = 1, lean_k = 0, lean_rounds = 0, lean_slots = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
+    int n_cus = 1;                                             // compute units of the device
+    double rowbal_f[3] = {1.036, 1.015, 0.990};                // ... the first three rows' lengths over the equal cut's (NFC_WG_ROWBAL=a,b,c)
+    bool wg_rowbal = true, rowbal_now = false;                 // chunks cut by dispatch row (host_threshold.h: thr_prepare; NFC_WG_ROWBAL=0: the equal cut); this batch is
     int wg = 1, wg_ok = 0, wg_nr = 4, wg_d = 1, wg_slots = 0, wg_slots_ahead = 0, wg_now = 0, wg_rounds = 0;
     int fine_left = 0, fine_adapt = 1, fine_mult = 4;   // batches still to be cut into fine_mult times as many chunks (after a batch that needed re-runs); NFC_CHUNK_ADAPT=0 turns it off   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
                                                                  // rows of 64 samples per step (NFC_WG_NR), resident workgroups, this batch uses it, rounds per superstep
@@ -389,7 +392,7 @@ void launch_wg(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipE
     size_t lds = c->wg_lds;
     B.wg_stage_rounds = 2 * wg_flush_rounds(c->wg_nr);
     {
-        const int rounds = A.C / wg_round_samples(c->wg_nr) + 2;
+        const int rounds = A.C_max / wg_round_samples(c->wg_nr) + 2;   // (the longest chunk of the cut: thr_prepare)
         const size_t need = c->wg_lds_base + wg_stage_bytes(c->wg_nr, rounds);
         if (c->wg_bulk_now && c->wg_lds_bulk_max && need <= c->wg_lds_bulk_max) {
             B.wg_stage_rounds = rounds;

@@ -141,6 +141,12 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     if (const char *e = getenv("NFC_OWN_PREFIX_MAX")) c->own_prefix_max = (uint32_t)strtoul(e, nullptr, 10);
     if (const char *e = getenv("NFC_DEC_SPEC")) c->dec_spec = atoi(e) != 0;
     if (const char *e = getenv("NFC_SPIN_WAIT")) c->spin_wait = atoi(e) != 0;
+    if (const char *e = getenv("NFC_WG_ROWBAL")) {   // 0: chunks of equal length (host_threshold.h: the cut by dispatch row); a,b,c: the rows' factors
+        double f[3];
+        if (sscanf(e, "%lf,%lf,%lf", &f[0], &f[1], &f[2]) == 3 && f[0] > 0.5 && f[0] < 1.5 && f[1] > 0.5 && f[1] < 1.5 && f[2] > 0.5 && f[2] < 1.5)
+            memcpy(c->rowbal_f, f, sizeof f);
+        else c->wg_rowbal = atoi(e) != 0;
+    }
     if (const char *e = getenv("NFC_EAGG")) c->eagg = atoi(e) != 0;   // 1: k_threshold_wg leaves the edge stage's aggregates, no k_edge_reduce (measured: no gain, host_context.h)
     if (const char *e = getenv("NFC_DEC_RUNIN")) {   // run-in edges per decode tile: 512, 1024 or 2048
         const int v = atoi(e);
@@ -209,6 +215,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         CRT(hipGetDeviceProperties(&prop, p->device));
         const size_t lds_wave = (size_t)c->Lpad * c->lds_per_slot;
         int per_cu = (int)std::min<size_t>(20, (size_t)(160 * 1024) / (lds_wave * c->wpb) * c->wpb);   // LDS- and VGPR-bound
+        c->n_cus = std::max(1, prop.multiProcessorCount);
         c->wave_slots = std::max(1, prop.multiProcessorCount * std::max(1, per_cu));
         // lean kernel: four steps ahead (104 registers: at most four waves per SIMD); a superstep long enough that its fixed cost
         // fades -- the drift allowance grows with its length relative to the window (about half the window at most: beyond, the

@@ -142,7 +142,20 @@ struct ThrArgs {
     // (threshold_wg.hip.h: wg_chunk_edge_aggs; host_threshold.h decides).  eagg_tps: tiles per chunk, eagg_magic: floor(2^32 / max_len)
     void *eagg_tiles, *eagg_supers;
     uint32_t eagg_tps, eagg_magic;
+    // Chunks of UNEQUAL length by dispatch row (round 5; chunk_span below).  The k-th workgroup a CU is given is the k-th slowest
+    // (measured: the lives of k_threshold_wg's workgroups fall in four steps by block index -- 0.965, 0.985, 1.010, 1.042 of the mean
+    // for blocks 0-255, 256-511, ... --, and the launch is as long as its slowest workgroup): the chunks of row r are row_len[r] samples
+    // long, row r begins at sample row_start[r] and holds row_div chunks; rows past the third go on like the third.  With every
+    // row_len = C and row_start[r] = r * row_div * C this is the equal cut, c * C.
+    uint32_t row_len[4], row_start[4], row_div;
+    int C_max;   // the longest row's chunk length (the sizing of a workgroup's plane staging: launch_wg)
 };
+// chunk c covers the batch's samples [m_chunk, m_chunk + len)
+__device__ __forceinline__ void chunk_span(const ThrArgs &A, uint32_t c, uint32_t &m_chunk, uint32_t &len) {
+    const uint32_t row = min(c / A.row_div, 3u);
+    len = A.row_len[row];
+    m_chunk = A.row_start[row] + (c - row * A.row_div) * len;
+}
 
 // ---------------------------------------------------------------------------
 // cross-lane helpers
@@ -689,8 +702,9 @@ __global__ __launch_bounds__(256) void k_threshold(ThrArgs A) {
     auto mark = [&](uint32_t sl) { if constexpr (!SIGN_T) tch[sl] = 1; };
     const int L = A.L;
     const int mx = A.mx;
-    const uint32_t m_chunk = c * (uint32_t)A.C;   // this kernel runs with A.off == 0
-    const uint32_t n1 = min(A.n, m_chunk + (uint32_t)A.C);
+    uint32_t m_chunk, chunk_len;   // (this kernel runs with A.off == 0)
+    chunk_span(A, c, m_chunk, chunk_len);
+    const uint32_t n1 = min(A.n, m_chunk + chunk_len);
     const uint32_t m_start = max(m_chunk, A.skip);
     const Carry cr = *A.carry;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -1255,7 +1269,9 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     if (tid != 0) return;
     int nl, kl;
     resolve_low_state(A, (int)c, nl, kl);
-    const int m0 = (int)(c * (uint32_t)A.C) - A.off;
+    uint32_t m0u, len0;
+    chunk_span(A, c, m0u, len0);
+    const int m0 = (int)m0u - A.off;
     const int mx = A.mx;
     auto live = [&](int k) { return (k & 1) && (m0 - (k >> 1)) <= mx + 1; };
     const bool low_ok = (nl == mt.nl_in) && ((kl == mt.kl_in) || (!live(kl) && !live(mt.kl_in)));

@@ -150,8 +150,9 @@ __global__ __launch_bounds__(256) void k_threshold_lean(ThrArgs A) {
     lean_lds_f *const rl = (lean_lds_f *)ring;
     const int L = A.L;
     const int mx = A.mx;
-    const uint32_t m_chunk = c * (uint32_t)A.C;
-    const uint32_t n1 = min(A.n, m_chunk + (uint32_t)A.C);
+    uint32_t m_chunk, chunk_len;
+    chunk_span(A, c, m_chunk, chunk_len);
+    const uint32_t n1 = min(A.n, m_chunk + chunk_len);
     const uint32_t m_start = max(m_chunk, A.skip);
     const Carry cr = *A.carry;
     uint64_t *const neg_p = A.neg, *const pos_p = A.pos;   // (by value: a per-lane choice between two kernel-argument FIELDS would be a vector load)

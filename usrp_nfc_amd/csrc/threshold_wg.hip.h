@@ -353,8 +353,10 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     WgShared *const sh = (WgShared *)(smem + (size_t)A.Lpad * 4);
     const int L = A.L;
     const int mx = A.mx;
-    const uint32_t m_chunk = c * (uint32_t)A.C;
-    const uint32_t n1 = min(A.n, m_chunk + (uint32_t)A.C);
+    uint32_t m_chunk_v, chunk_len_v;
+    chunk_span(A, c, m_chunk_v, chunk_len_v);
+    const uint32_t m_chunk = rfl(m_chunk_v), chunk_len = rfl(chunk_len_v);
+    const uint32_t n1 = min(A.n, m_chunk + chunk_len);
     const uint32_t m_start = max(m_chunk, A.skip);
     constexpr int RB = LeanRaw<KIND>::BYTES;
     const uint32_t wbase0 = m_chunk + STEPN * (uint32_t)wave;   // this wave's step of round 0
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     constexpr uint32_t PST_ROUND = (uint32_t)(WG_WAVES * 2 * NR);     // dwords of a round in one plane's staging
     // the staging holds A.wg_stage_rounds rounds per plane: the whole chunk (bulk: nothing leaves before the chunk is done), or 2 FR
     const int st_cap = A.wg_stage_rounds;
-    const bool bulk = (uint32_t)st_cap * (uint32_t)WG_ROUND >= (uint32_t)A.C + (uint32_t)WG_ROUND;
+    const bool bulk = (uint32_t)st_cap * (uint32_t)WG_ROUND >= chunk_len + (uint32_t)WG_ROUND;
     const uint32_t PST_PLANE = (uint32_t)st_cap * PST_ROUND;          // dwords of one plane's staging
     lean_lds_u32 *const pst = (lean_lds_u32 *)(uint32_t *)(smem + (size_t)A.Lpad * 4 + WG_SHARED_BYTES);   // (LDS addresses: 32-bit arithmetic)
     const int st_wrap = bulk ? st_cap : 2 * FR;
