@@ -125,7 +125,9 @@ struct nfc_ctx {
     uint32_t decode_respeculated = 0;   // batches whose decode stage was repeated with the three-launch form (nfc_stats)
     int lean = 1, lean_k = 0, lean_rounds = 0, lean_slots = 0;   // pass 0 by k_threshold_lean (NFC_LEAN=0 turns it off), steps per superstep (NFC_LEAN_K)
     int n_cus = 1;                                             // compute units of the device
-    double rowbal_f[3] = {1.036, 1.015, 0.990};                // ... the first three rows' lengths over the equal cut's (NFC_WG_ROWBAL=a,b,c)
+    // ... the rows' chunk lengths over the equal cut's, all but the last row's, by workgroups per CU (measured: host_threshold.h); [0]: NFC_WG_ROWBAL=a,b,c
+    double rowbal_f[5][3] = {{1, 1, 1}, {1, 1, 1}, {1.02, 1, 1}, {1.045, 1.004, 1}, {1.036, 1.015, 0.990}};
+    bool rowbal_set = false, rowbal_ahead = false;
     bool wg_rowbal = true, rowbal_now = false;                 // chunks cut by dispatch row (host_threshold.h: thr_prepare; NFC_WG_ROWBAL=0: the equal cut); this batch is
     int wg = 1, wg_ok = 0, wg_nr = 4, wg_d = 1, wg_slots = 0, wg_slots_ahead = 0, wg_now = 0, wg_rounds = 0;
     int fine_left = 0, fine_adapt = 1, fine_mult = 4;   // batches still to be cut into fine_mult times as many chunks (after a batch that needed re-runs); NFC_CHUNK_ADAPT=0 turns it off   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
@@ -464,6 +466,7 @@ void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n, int nchunks, int r
     CertSummary *sum = (CertSummary *)(dT(c) + TOT_CERT);
     StateInit init;
     memset(&init, 0, sizeof init);
+    int fresh = 0;
     if (c->state_dirty) {
         static_assert(offsetof(DevState, totals) <= sizeof init.words && offsetof(DevState, totals) % 4 == 0, "state head fits");
         DevState h;
@@ -478,12 +481,14 @@ void launch_fill_kind(nfc_ctx *c, const void *in, uint32_t n, int nchunks, int r
         init.fill = c->dirty_fill;
         init.ring_len = c->Lpad;
         c->state_dirty = c->dirty_fill_ring = false;
+        // (a stream that starts here with a whole window in the batch: k_fill's short form)
+        fresh = h.carry.stable == 0 && h.carry.filled == 0 && n >= (uint32_t)c->L && (void *)cr == c->d_state.p;
     }
     switch (c->P.input_kind) {
-    case NFC_IN_IQ_F32: NFC_LAUNCH((k_fill<IN_IQ_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq); break;
-    case NFC_IN_ENV_F32: NFC_LAUNCH((k_fill<IN_ENV_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq); break;
-    case NFC_IN_REAL_F32_SQ: NFC_LAUNCH((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq); break;
-    default: NFC_LAUNCH((k_fill<IN_I16_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq); break;
+    case NFC_IN_IQ_F32: NFC_LAUNCH((k_fill<IN_IQ_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq, fresh); break;
+    case NFC_IN_ENV_F32: NFC_LAUNCH((k_fill<IN_ENV_F32>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq, fresh); break;
+    case NFC_IN_REAL_F32_SQ: NFC_LAUNCH((k_fill<IN_REAL_F32_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq, fresh); break;
+    default: NFC_LAUNCH((k_fill<IN_I16_SQ>), dim3(1), dim3(FILL_BLOCK), (size_t)c->Lpad * 4, c->st, in, n, c->i16_scale, c->L, ring, cr, eci, ver, nchunks, sum, init, &((DevState *)c->d_state.p)->seq[0], c->batch_seq, fresh); break;
     }
 }
 void launch_seq_kind(nfc_ctx *c, const SeqArgs &A) {

@@ -102,11 +102,12 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     if (c->wg_now && c->C % wg_round_samples(c->wg_nr) != 0) c->wg_now = 0;   // (a configured chunk length that is not whole rounds: the one-wave kernel)
     const uint32_t off = 0u;   // (chunk c covers samples [c*C - off, (c+1)*C - off): the kernels here use off = 0)
     // The cut by dispatch row (threshold.hip.h: chunk_span).  The k-th workgroup the dispatcher hands a CU starts behind the k-1
-    // before it and shares the CU with them for its whole life: measured with the cycle counter (round 5, 1e8 samples, 1018
-    // chunks of 98 304), the lives of the four rows of 256 are 0.965 / 0.985 / 1.010 / 1.042 of their mean, and the launch ends
-    // with the last row.  So the rows get chunks whose lengths undo that -- the first rows longer, the last shorter, whole rounds
-    // each, the last row's length whatever covers the batch -- when the batch is one full wave of resident workgroups (four
-    // per CU) and the chunk length is this file's own choice.  NFC_WG_ROWBAL=0: the equal cut.
+    // before it and shares the CU with them for its whole life: measured with the cycle counter (round 5), the lives of the rows of
+    // 256 workgroups are 0.965 / 0.985 / 1.010 / 1.042 of their mean with four per CU (1e8 samples, 1018 chunks of 98 304) and
+    // 0.962 / 0.997 / 1.042 with three (av_window 10 000, 1e9 samples, 768 chunks), and the launch ends with the last row.  So the
+    // rows get chunks whose lengths undo that -- the first rows longer, the last shorter, whole rounds each, the last row's length
+    // whatever covers the batch -- when the batch is one full wave of resident workgroups and the chunk length is this file's own
+    // choice.  NFC_WG_ROWBAL=0: the equal cut.
     const uint32_t cus = (uint32_t)std::max(1, c->n_cus);
     uint32_t row_len[4], row_start[4];
     for (int r = 0; r < 4; r++) {
@@ -115,24 +116,31 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     }
     uint32_t nch = (uint32_t)(((uint64_t)n + off + c->C - 1) / c->C);
     c->rowbal_now = false;
-    if (c->wg_rowbal && c->wg_now && !c->P.chunk_samples && !low_on_device && c->fine_left == 0 && (uint32_t)c->wg_slots == 4u * cus &&
-        nch > 3u * cus && nch <= 4u * cus) {
-        const double *f = c->rowbal_f;
+    const uint32_t slots_now = (uint32_t)(low_on_device ? c->wg_slots_ahead : c->wg_slots);   // (as the chunk length was chosen above)
+    const uint32_t R = slots_now / cus;   // rows of a full wave: workgroups per CU
+    if (c->wg_rowbal && c->wg_now && !c->P.chunk_samples && (!low_on_device || c->rowbal_ahead) && c->fine_left == 0 && slots_now == R * cus &&
+        R >= 2 && R <= 4 && nch > (R - 1) * cus && nch <= R * cus) {
+        const double *f = c->rowbal_set ? c->rowbal_f[0] : c->rowbal_f[R];
         const uint32_t rs = (uint32_t)wg_round_samples(c->wg_nr);
         uint32_t len[4], start[4];
         uint64_t at = 0;
-        for (int r = 0; r < 3; r++) {
+        for (uint32_t r = 0; r + 1 < R; r++) {
             len[r] = std::max(rs, (uint32_t)((double)c->C * f[r] / rs + 0.5) * rs);
             start[r] = (uint32_t)at;
             at += (uint64_t)len[r] * cus;
         }
         if (at < (uint64_t)n) {
-            start[3] = (uint32_t)at;
-            len[3] = (uint32_t)((((uint64_t)n - at + cus - 1) / cus + rs - 1) / rs * rs);
-            const uint32_t nch_b = 3u * cus + (uint32_t)(((uint64_t)n - at + len[3] - 1) / len[3]);
-            // (the longest chunk's planes still fit the LDS beside the ring: launch_wg)
+            const uint32_t last = (uint32_t)((((uint64_t)n - at + cus - 1) / cus + rs - 1) / rs * rs);
+            for (uint32_t r = R - 1; r < 4; r++) {   // (rows past the last go on like it: none of their chunks exist)
+                start[r] = (uint32_t)std::min<uint64_t>(at + (uint64_t)(r - (R - 1)) * cus * last, 0xFFFFFFFFull);
+                len[r] = last;
+            }
+            const uint32_t nch_b = (R - 1) * cus + (uint32_t)(((uint64_t)n - at + last - 1) / last);
+            // (where the equal cut's chunks keep their planes in the LDS beside the ring, the longest chunk's must still fit: launch_wg)
+            const size_t need_eq = c->wg_lds_base + wg_stage_bytes(c->wg_nr, c->C / (int)rs + 2);
             const size_t need = c->wg_lds_base + wg_stage_bytes(c->wg_nr, (int)(len[0] / rs) + 2);
-            if (len[3] >= rs && len[3] <= (uint32_t)c->C && nch_b <= 4u * cus && (!c->wg_lds_bulk_max || need <= c->wg_lds_bulk_max)) {
+            const bool bulk_eq = c->wg_lds_bulk_max && need_eq <= c->wg_lds_bulk_max;
+            if (last >= rs && last <= (uint32_t)c->C && nch_b <= R * cus && (!bulk_eq || need <= c->wg_lds_bulk_max)) {
                 memcpy(row_len, len, sizeof len);
                 memcpy(row_start, start, sizeof start);
                 nch = nch_b;
@@ -210,7 +218,7 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
         A.row_start[r] = row_start[r];
     }
     A.row_div = cus;
-    A.C_max = (int)row_len[0];
+    A.C_max = (int)std::max(std::max(row_len[0], row_len[1]), std::max(row_len[2], row_len[3]));
     A.nchunks = (int)nch;
     A.lo = c->P.lo_val;
     A.hi = c->P.hi_val;

@@ -143,10 +143,12 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     if (const char *e = getenv("NFC_SPIN_WAIT")) c->spin_wait = atoi(e) != 0;
     if (const char *e = getenv("NFC_WG_ROWBAL")) {   // 0: chunks of equal length (host_threshold.h: the cut by dispatch row); a,b,c: the rows' factors
         double f[3];
-        if (sscanf(e, "%lf,%lf,%lf", &f[0], &f[1], &f[2]) == 3 && f[0] > 0.5 && f[0] < 1.5 && f[1] > 0.5 && f[1] < 1.5 && f[2] > 0.5 && f[2] < 1.5)
-            memcpy(c->rowbal_f, f, sizeof f);
+        f[1] = f[2] = 1.0;
+        if (sscanf(e, "%lf,%lf,%lf", &f[0], &f[1], &f[2]) >= 2 && f[0] > 0.5 && f[0] < 1.5 && f[1] > 0.5 && f[1] < 1.5 && f[2] > 0.5 && f[2] < 1.5)
+            memcpy(c->rowbal_f[0], f, sizeof f), c->rowbal_set = true;
         else c->wg_rowbal = atoi(e) != 0;
     }
+    if (const char *e = getenv("NFC_WG_ROWBAL_AHEAD")) c->rowbal_ahead = atoi(e) != 0;
     if (const char *e = getenv("NFC_EAGG")) c->eagg = atoi(e) != 0;   // 1: k_threshold_wg leaves the edge stage's aggregates, no k_edge_reduce (measured: no gain, host_context.h)
     if (const char *e = getenv("NFC_DEC_RUNIN")) {   // run-in edges per decode tile: 512, 1024 or 2048
         const int v = atoi(e);

@@ -1351,19 +1351,23 @@ __device__ __forceinline__ void prepare_batch(const float *ring, int L, Carry *c
     prepare_batch_finish(carry, sum, part, emin, emax);
 }
 // (the tail of the above, for a caller that has just summed the same window itself)
+// (on a Carry wherever it lives: the state block, or a copy in registers that is stored once)
+__device__ __forceinline__ void batch_guard(Carry &cr, double S, uint32_t emin, uint32_t emax) {
+    carry_apply_fin(cr);
+    const double ss = cr.ss;
+    const double delta = ss - S;
+    cr.delta = delta;
+    int el, eh, el2, eh2;
+    f64_bit_span(ss, el, eh);
+    f64_bit_span(delta, el2, eh2);
+    cr.ss_emin = min(el, el2);
+    cr.ss_emax = max(eh, eh2);
+    cr.ring_emin = (int)emin;
+    cr.ring_emax = (int)emax;
+}
 __device__ __forceinline__ void prepare_batch_finish(Carry *carry, CertSummary *sum, double S, uint32_t emin, uint32_t emax) {
     if (threadIdx.x == 0) {
-        carry_apply_fin(*carry);
-        const double ss = carry->ss;
-        const double delta = ss - S;
-        carry->delta = delta;
-        int el, eh, el2, eh2;
-        f64_bit_span(ss, el, eh);
-        f64_bit_span(delta, el2, eh2);
-        carry->ss_emin = min(el, el2);
-        carry->ss_emax = max(eh, eh2);
-        carry->ring_emin = (int)emin;
-        carry->ring_emax = (int)emax;
+        batch_guard(*carry, S, emin, emax);
         if (sum) *sum = CertSummary{0u, 255u, 0u, 0u, 0u};
     }
 }
@@ -1390,12 +1394,80 @@ struct StateInit {
 template <int KIND>
 __global__ __launch_bounds__(FILL_BLOCK) void k_fill(const void *in, uint32_t n, float i16_scale, int L, float *ring, Carry *carry,
                                                      EdgeCarryInit eci, uint8_t *ver, int nchunks, CertSummary *sum, StateInit init,
-                                                     uint32_t *seq_dst, uint32_t seq) {
+                                                     uint32_t *seq_dst, uint32_t seq, int fresh) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ FillRed red;
     float *lr = (float *)smem;
     const int tid = threadIdx.x;
     if (tid == 0 && seq_dst) *seq_dst = seq;   // this batch's stamp in the state block (the host checks it in its mirror)
+    if (fresh) {
+        // A reset stream whose first batch holds a whole window (the host knows both: the state rides in `init`, and its carry says
+        // "nothing filled"): nothing of the state block is read back.  This launch stands in front of the batch's every other one
+        // and was a chain of dependent round trips -- the state stored, read again for `stable` / `filled`, the samples, the carry
+        // stored field by field and read again for the batch's preparation: 7.1 us of a 250 us batch.  Here the samples are asked
+        // for at once, the carry is finished in registers and stored once.
+        static_assert(sizeof(Carry) % 4 == 0 && sizeof(Carry) <= sizeof(init.words), "the carry heads the state block");
+        constexpr int CW = (int)(sizeof(Carry) / 4);
+        if (tid >= CW && tid < init.n_words) init.dst[tid] = init.words[tid];   // (the carry's words: thread 0, below)
+        double part = 0;
+        uint32_t emin = 255u, emax = 0u;
+        for (int i0 = tid; i0 < L; i0 += 4 * FILL_BLOCK) {   // (four samples per thread in flight: the stores to the ring may alias the input for all the compiler knows)
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = (i0 + k * FILL_BLOCK < L) ? envelope_at<KIND>(in, (size_t)(i0 + k * FILL_BLOCK), i16_scale) : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = i0 + k * FILL_BLOCK;
+                if (i >= L) break;
+                ring[i] = v[k];
+                lr[i] = v[k];
+                part += (double)v[k];
+                if (v[k] != 0.f) {
+                    const uint32_t e = max(f32_expfield(v[k]), 1u);
+                    emin = min(emin, e);
+                    emax = max(emax, e);
+                }
+            }
+        }
+        if (init.fill_ring)   // (the padding behind the window, as the general path leaves it)
+            for (int i = L + tid; i < init.ring_len; i += FILL_BLOCK) ring[i] = 0.f;
+        for (int i = tid; i < nchunks; i += FILL_BLOCK) ver[i] = 0;
+        fill_reduce(red, part, emin, emax);   // (its barriers also publish lr)
+        if (tid == 0) {
+            const double S = part;
+            int lg = 0;
+            while ((1 << lg) < L) lg++;
+            const bool exact = (emax < 255u) && ((int)emax + 2 + lg - ((int)emin - 23) <= 52);
+            double s = S, err = 0;
+            if (!exact) {
+                s = 0;
+                for (int i = 0; i < L; i++) {
+                    const double v = (double)lr[i];
+                    const double t = s + v;            // transition_sink.py:122, sequential
+                    const double bv = t - s;           // TwoSum residue: was the addition exact?
+                    err += fabs((s - (t - bv)) + (v - bv));
+                    s = t;
+                }
+            }
+            Carry nc;
+            uint32_t cw[CW];
+#pragma unroll
+            for (int k = 0; k < CW; k++) cw[k] = init.words[k];
+            memcpy(&nc, cw, sizeof nc);
+            nc.filled = L;
+            nc.ss = s;
+            nc.stable = 1;
+            if (err != 0.0) nc.inexact = 1;
+            batch_guard(nc, S, emin, emax);
+            *carry = nc;
+            // work has just been rebound to work_stable: _dur = length % max (transition_sink.py:123)
+            eci.dst[0] = 0;
+            eci.dst[1] = 0;
+            eci.dst[2] = eci.dur0;
+            if (sum) *sum = CertSummary{0u, 255u, 0u, 0u, 0u};
+        }
+        return;
+    }
     if (init.apply) {
         if (tid < init.n_words) init.dst[tid] = init.words[tid];
         if (init.fill_ring)
