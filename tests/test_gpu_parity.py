@@ -828,6 +828,38 @@ def test_workgroup_kernel_plane_staging(monkeypatch, bulk, nr):
     assert first_diff(tr, o.transitions()) is None and pk == o.packets()
 
 
+def test_low_runs_across_chunk_ends_are_measured_not_given_up():
+    # k_threshold_wg, a chunk's summary: when the chunk's last LOW sample is in reach of the next chunk and its run may have been
+    # longer than max_len, the key of that sample (did the run end on a time-out? transition_sink.py:95-99) is MEASURED in the plane
+    # words the chunk has stored -- it used to make the chunk give up, and a chunk that gives up is re-run by one wave (0.65 ms for a
+    # chunk of 98 304 samples whenever a cut fell into a loss of signal).  A LOW run across every chunk end: i samples of it before the
+    # end (1 .. 139: every residue of max_len = 50, the time-out cases k * 50 + 1 included), 10 .. 300 behind it, a HIGH burst 0 .. 70
+    # samples after its end.  Per-sample val, edges, symbols, packets against the C oracle -- and (nearly) no chunk re-run.
+    C = 4096 * 3
+    nb = 140
+    rng = np.random.default_rng(4242)
+    m = np.ones(C * (nb + 1), np.float32)
+    for i in range(1, nb):
+        b = (i + 1) * C
+        behind = int(rng.integers(10, 300))
+        m[b - i:b + behind] = 0.0
+        gap = int(rng.integers(0, 70))
+        hl = int(rng.integers(1, 40))
+        m[b + behind + gap:b + behind + gap + hl] = 1.09
+    iq = synth.iq_from_profile(m, seed=4242, sigma=0.0015)
+    params = dict(hi_val=1.1)
+    o = oracle_run(iq, params, api.NFC_IN_IQ_F32)
+    r = run_gpu(iq, params, kind=api.NFC_IN_IQ_F32, chunk_samples=C)
+    d = first_diff(r['val'][2000:], o.trace().tolist())
+    assert d is None, 'val %s' % (d,)
+    assert first_diff(r['transitions'], o.transitions()) is None
+    assert r['sym_tag'] == o.symbols(0).tolist() and r['sym_reader'] == o.symbols(1).tolist() and r['packets'] == o.packets()
+    st = r['stats']
+    assert st.used_sequential == 0 and st.n_chunks == nb + 1
+    # (a run that DID end on a time-out at the chunk's last sample makes the next chunk's speculated key wrong: those few are re-run)
+    assert st.chunks_rerun <= 12, 'chunks re-run: %d of %d' % (st.chunks_rerun, st.n_chunks)
+
+
 @pytest.mark.parametrize('stream', ['torture', 'all'])
 def test_chunks_cut_by_dispatch_row(monkeypatch, stream):
     # host_threshold.h, thr_prepare: a batch that is one full wave of resident workgroups (more than three per CU, at most four) is
