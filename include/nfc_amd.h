@@ -349,6 +349,16 @@ int nfc_host_decode_steps(int type, const int8_t *cur, const double *dur_us, siz
                           size_t cap, size_t *n_out);
 /* the int16 -> float conversion of the NFC_IN_I16_SQ kernels, on the host (i16_scale as in nfc_params) */
 float nfc_host_i16_to_float(int16_t pcm, float i16_scale);
+/* How a batch of n samples is cut into the threshold stage's time chunks when the cut goes by dispatch row (csrc/chunk_cut.h; the
+ * reference has no counterpart: its loop is one chunk, transition_sink.py:37-107 -- this is the parallel restatement's own geometry,
+ * exposed so that the CPU suite can check it covers every sample exactly once).  C: the equal cut's chunk length, rs: samples per
+ * round of the workgroup kernel (C a multiple of it), cus: compute units, rows: workgroups per CU (2 .. 4), factors: rows - 1 length
+ * factors, max_len: longest chunk allowed (0: any).  out[0..3]: chunk length per row, out[4..7]: first sample per row, out[8]:
+ * chunks per row, out[9]: chunks that begin inside the batch.  Returns 1 when the cut goes by row, 0 for the equal cut (the same
+ * table with equal entries), negative on bad arguments.  Chunk c of row r = min(c / out[8], 3) covers
+ * [out[4 + r] + (c - r * out[8]) * out[r], ... + out[r]) cut at n. */
+int nfc_plan_row_cut(uint32_t n, uint32_t C, uint32_t rs, uint32_t cus, uint32_t rows, const double *factors, uint32_t max_len,
+                     uint32_t out[10]);
 
 #ifdef __cplusplus
 }

@@ -157,3 +157,64 @@ def test_ctypes_structures_match_the_header(tmp_path):
             _lib.EDGE_DTYPE.itemsize, _lib.PACKET_DTYPE.itemsize, ctypes.sizeof(_lib.Frame)]
     assert got == want, (got, want)
     assert _lib.load().nfc_abi_version() == _lib.ABI_VERSION == 4
+
+
+def _row_cut(n, C_, rs, cus, rows, factors, max_len=0):
+    import ctypes as C
+    L = _lib.load()
+    f = (C.c_double * 3)(*(list(factors) + [1.0] * 3)[:3])
+    out = (C.c_uint32 * 10)()
+    rc = L.nfc_plan_row_cut(n, C_, rs, cus, rows, f, max_len, out)
+    assert rc >= 0
+    return rc, list(out)
+
+
+def _spans(n, out):
+    """chunk_span of csrc/threshold.hip.h, restated: the chunks of the table that begin inside the batch."""
+    ln, start, div, nch = out[0:4], out[4:8], out[8], out[9]
+    spans = []
+    for c in range(nch):
+        r = min(c // div, 3)
+        a = start[r] + (c - r * div) * ln[r]
+        spans.append((a, min(n, a + ln[r])))
+    return spans
+
+
+@pytest.mark.parametrize('rows,factors', [(4, (1.036, 1.015, 0.990)), (3, (1.045, 1.004)), (2, (1.02,))])
+def test_row_cut_covers_every_sample_once(rows, factors):
+    # csrc/chunk_cut.h (host_threshold.h: the threshold stage's time chunks cut by dispatch row): whatever the batch length, the chunks
+    # of the table are whole rounds, lie end to end from sample 0, cover the batch exactly, are at most rows * cus, the first rows'
+    # are the longest -- or the table is the equal cut.  The reference's loop is one chunk (transition_sink.py:37-107): this is the
+    # geometry of its parallel restatement, and every sample must be classified exactly once.
+    rng = np.random.default_rng(7)
+    cus = 256
+    by_row = 0
+    for trial in range(400):
+        rs = int(rng.choice([1024, 1536, 2048]))
+        n = int(rng.integers(rs * cus, 2_000_000_000)) if trial % 3 else int(rng.integers(1, 4 * cus * rs * 40))
+        slots = rows * cus
+        C_ = max(4096 // rs * rs if 4096 % rs == 0 else rs * 3, -(-(-(-n // slots)) // rs) * rs)   # as thr_prepare picks it: one wave of slots, whole rounds
+        rc, out = _row_cut(n, C_, rs, cus, rows, factors, max_len=int(rng.choice([0, 0, C_ + 8 * rs, C_ + rs])))
+        spans = _spans(n, out)
+        assert spans and spans[0][0] == 0 and spans[-1][1] == n, (n, C_, rs, out)
+        for (a0, a1), (b0, b1) in zip(spans[:-1], spans[1:]):
+            assert a1 == b0 and a1 > a0, (n, C_, rs, out)
+        assert all((b - a) % rs == 0 for a, b in spans[:-1])
+        assert all(l % rs == 0 and l >= rs for l in out[0:4])
+        if rc:
+            by_row += 1
+            assert out[9] <= rows * cus and out[9] > (rows - 1) * cus
+            assert out[0] >= out[rows - 1] and out[0] >= C_ and out[rows - 1] <= C_
+            assert out[8] == cus
+        else:
+            assert out[0:4] == [C_] * 4 and out[9] == -(-n // C_)
+    assert by_row > 100
+
+
+def test_row_cut_is_the_bench_cut():
+    # configs[1] on an MI355X: 1e8 samples, 256 CUs, four workgroups per CU, rounds of 1 024 samples
+    rc, out = _row_cut(100_000_000, 98304, 1024, 256, 4, (1.036, 1.015, 0.990), max_len=101 * 1024)
+    assert rc == 1 and out[0:4] == [101376, 99328, 97280, 93184] and out[8] == 256 and out[9] == 1023
+    # ... and where the longest chunk's plane words would not fit the LDS any more: the equal cut
+    rc, out = _row_cut(100_000_000, 98304, 1024, 256, 4, (1.036, 1.015, 0.990), max_len=98 * 1024)
+    assert rc == 0 and out[0:4] == [98304] * 4 and out[9] == 1018

@@ -66,7 +66,7 @@ SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', '
            'nfc_push_device', 'nfc_submit_device', 'nfc_wait', 'nfc_submitted', 'nfc_push_edges', 'nfc_sync', 'nfc_set_stream', 'nfc_get_counts', 'nfc_read_edges', 'nfc_read_edges_compact', 'nfc_read_symbols', 'nfc_read_packets',
            'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_prime', 'nfc_export_state', 'nfc_get_stats', 'nfc_set_timing',
            'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_stream_create', 'nfc_stream_destroy',
-           'nfc_stream_sync', 'nfc_device_download_async', 'nfc_device_fill', 'nfc_host_alloc_pinned', 'nfc_host_free_pinned', 'nfc_host_decode_lut', 'nfc_host_miller_classes', 'nfc_host_decode_steps', 'nfc_host_i16_to_float',
+           'nfc_stream_sync', 'nfc_device_download_async', 'nfc_device_fill', 'nfc_host_alloc_pinned', 'nfc_host_free_pinned', 'nfc_host_decode_lut', 'nfc_host_miller_classes', 'nfc_host_decode_steps', 'nfc_host_i16_to_float', 'nfc_plan_row_cut',
            'nfc_fsm_create', 'nfc_fsm_destroy', 'nfc_fsm_reset', 'nfc_fsm_process', 'nfc_fsm_process_packets', 'nfc_fsm_set_keys',
            'nfc_command_count', 'nfc_command_get', 'nfc_crc_a', 'nfc_tx_encode', 'nfc_tx_sample_count', 'nfc_tx_render_device']
 
@@ -138,6 +138,8 @@ def load(path=None):
     L.nfc_host_decode_steps.argtypes = [C.c_int, vp, vp, sz, C.POINTER(C.c_int32), vp, sz, psz]
     L.nfc_host_i16_to_float.argtypes = [C.c_int16, C.c_float]
     L.nfc_host_i16_to_float.restype = C.c_float
+    L.nfc_plan_row_cut.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_uint32)]
+    L.nfc_plan_row_cut.restype = C.c_int
     L.nfc_fsm_create.argtypes = [C.POINTER(vp)]
     L.nfc_fsm_destroy.argtypes = [vp]
     L.nfc_fsm_destroy.restype = None

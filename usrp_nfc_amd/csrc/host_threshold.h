@@ -109,45 +109,22 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     // whatever covers the batch -- when the batch is one full wave of resident workgroups and the chunk length is this file's own
     // choice.  NFC_WG_ROWBAL=0: the equal cut.
     const uint32_t cus = (uint32_t)std::max(1, c->n_cus);
-    uint32_t row_len[4], row_start[4];
-    for (int r = 0; r < 4; r++) {
-        row_len[r] = (uint32_t)c->C;
-        row_start[r] = (uint32_t)std::min<uint64_t>((uint64_t)r * cus * (uint64_t)c->C, 0xFFFFFFFFull);
-    }
-    uint32_t nch = (uint32_t)(((uint64_t)n + off + c->C - 1) / c->C);
-    c->rowbal_now = false;
+    RowCut cut = equal_cut(n, (uint32_t)c->C, cus);
     const uint32_t slots_now = (uint32_t)(low_on_device ? c->wg_slots_ahead : c->wg_slots);   // (as the chunk length was chosen above)
     const uint32_t R = slots_now / cus;   // rows of a full wave: workgroups per CU
     if (c->wg_rowbal && c->wg_now && !c->P.chunk_samples && (!low_on_device || c->rowbal_ahead) && c->fine_left == 0 && slots_now == R * cus &&
-        R >= 2 && R <= 4 && nch > (R - 1) * cus && nch <= R * cus) {
-        const double *f = c->rowbal_set ? c->rowbal_f[0] : c->rowbal_f[R];
+        R >= 2 && R <= 4) {
         const uint32_t rs = (uint32_t)wg_round_samples(c->wg_nr);
-        uint32_t len[4], start[4];
-        uint64_t at = 0;
-        for (uint32_t r = 0; r + 1 < R; r++) {
-            len[r] = std::max(rs, (uint32_t)((double)c->C * f[r] / rs + 0.5) * rs);
-            start[r] = (uint32_t)at;
-            at += (uint64_t)len[r] * cus;
+        // (where the equal cut's chunks keep their planes in the LDS beside the ring, the longest chunk's must still fit: launch_wg)
+        uint32_t max_len = 0;
+        if (c->wg_lds_bulk_max && c->wg_lds_base + wg_stage_bytes(c->wg_nr, c->C / (int)rs + 2) <= c->wg_lds_bulk_max) {
+            const size_t rounds = (c->wg_lds_bulk_max - c->wg_lds_base) / wg_stage_bytes(c->wg_nr, 1);
+            max_len = rounds > 2 ? (uint32_t)(rounds - 2) * rs : rs;
         }
-        if (at < (uint64_t)n) {
-            const uint32_t last = (uint32_t)((((uint64_t)n - at + cus - 1) / cus + rs - 1) / rs * rs);
-            for (uint32_t r = R - 1; r < 4; r++) {   // (rows past the last go on like it: none of their chunks exist)
-                start[r] = (uint32_t)std::min<uint64_t>(at + (uint64_t)(r - (R - 1)) * cus * last, 0xFFFFFFFFull);
-                len[r] = last;
-            }
-            const uint32_t nch_b = (R - 1) * cus + (uint32_t)(((uint64_t)n - at + last - 1) / last);
-            // (where the equal cut's chunks keep their planes in the LDS beside the ring, the longest chunk's must still fit: launch_wg)
-            const size_t need_eq = c->wg_lds_base + wg_stage_bytes(c->wg_nr, c->C / (int)rs + 2);
-            const size_t need = c->wg_lds_base + wg_stage_bytes(c->wg_nr, (int)(len[0] / rs) + 2);
-            const bool bulk_eq = c->wg_lds_bulk_max && need_eq <= c->wg_lds_bulk_max;
-            if (last >= rs && last <= (uint32_t)c->C && nch_b <= R * cus && (!bulk_eq || need <= c->wg_lds_bulk_max)) {
-                memcpy(row_len, len, sizeof len);
-                memcpy(row_start, start, sizeof start);
-                nch = nch_b;
-                c->rowbal_now = true;
-            }
-        }
+        cut = plan_row_cut(n, (uint32_t)c->C, rs, cus, R, c->rowbal_set ? c->rowbal_f[0] : c->rowbal_f[R], max_len);
     }
+    c->rowbal_now = cut.by_row;
+    const uint32_t nch = cut.nch;
     c->stats.n_chunks = nch;
     c->stats.chunk_samples = (uint32_t)c->C;
     const size_t nwords = ((size_t)n_all + 63) / 64 + 8;
@@ -214,11 +191,11 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     A.mx = c->mx;
     A.C = c->C;
     for (int r = 0; r < 4; r++) {
-        A.row_len[r] = row_len[r];
-        A.row_start[r] = row_start[r];
+        A.row_len[r] = cut.row_len[r];
+        A.row_start[r] = cut.row_start[r];
     }
-    A.row_div = cus;
-    A.C_max = (int)std::max(std::max(row_len[0], row_len[1]), std::max(row_len[2], row_len[3]));
+    A.row_div = cut.row_div;
+    A.C_max = (int)std::max(std::max(cut.row_len[0], cut.row_len[1]), std::max(cut.row_len[2], cut.row_len[3]));
     A.nchunks = (int)nch;
     A.lo = c->P.lo_val;
     A.hi = c->P.hi_val;

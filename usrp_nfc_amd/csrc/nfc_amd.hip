@@ -50,6 +50,7 @@
 
 using namespace nfc;
 
+#include "chunk_cut.h"
 #include "host_context.h"
 #include "host_threshold.h"
 #include "host_stages.h"
@@ -76,6 +77,18 @@ const void *wg_kernel_of(int kind, int nr, int d) {
 extern "C" {
 
 int nfc_abi_version(void) { return NFC_AMD_ABI_VERSION; }
+
+int nfc_plan_row_cut(uint32_t n, uint32_t C, uint32_t rs, uint32_t cus, uint32_t rows, const double *factors, uint32_t max_len, uint32_t out[10]) {
+    if (!out || !rs || !C || !cus || (rows >= 2 && !factors)) return NFC_ERR_ARG;
+    const RowCut t = (rows >= 2 && rows <= 4) ? plan_row_cut(n, C, rs, cus, rows, factors, max_len) : equal_cut(n, C, cus);
+    for (int r = 0; r < 4; r++) {
+        out[r] = t.row_len[r];
+        out[4 + r] = t.row_start[r];
+    }
+    out[8] = t.row_div;
+    out[9] = t.nch;
+    return t.by_row ? 1 : 0;
+}
 
 int nfc_device_count(void) {
     int n = 0;
