@@ -20,15 +20,23 @@ struct CertLaunch {
 };
 // (With the writer since round 4, with the reduce pass before: what the certification leaves -- its verdict, the end-of-batch
 // state -- travels to the host in the mirror the stage's last launch fills; its workgroups are a few dependent rounds of loads
-// long and pass unnoticed beside the writer's 40 us of vector instructions.  They come first in the grid.)
+// long and pass unnoticed beside the writer's 40 us of vector instructions.)
 __global__ __launch_bounds__(256) void k_certify_and_write(CertLaunch C, EdgeArgs E, size_t nwords, const EdgeAgg *partials, const EdgeAgg *supers,
                                                           uint32_t *epos, uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
                                                           Last2 *last2_total, EdgeCarry *carry_out) {
-    if (blockIdx.x < C.blocks) {
-        certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, blockIdx.x, C.blocks);
+    // (the grid: the workgroup that resolves the end-of-batch state -- a chain of look-backs -- FIRST, the writer's tiles, and the
+    // certifying workgroups LAST: they are light -- a round of loads, a reduction -- and fill the slots the writer's last tiles leave
+    // empty while those finish, instead of holding the writer's first tiles back; measured: 42.9 -> 40.1 us for the launch, the step 0.2494 -> 0.2469 ms)
+    const uint32_t tiles = gridDim.x - C.blocks;
+    if (blockIdx.x == 0) {
+        certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, C.blocks - 1, C.blocks);
         return;
     }
-    write_edges_tile(E, nwords, partials, supers, epos, ecode, cap, own_prefix, total_out, last2_total, carry_out, blockIdx.x - C.blocks, gridDim.x - C.blocks);
+    if (blockIdx.x > tiles) {
+        certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, blockIdx.x - tiles - 1, C.blocks);
+        return;
+    }
+    write_edges_tile(E, nwords, partials, supers, epos, ecode, cap, own_prefix, total_out, last2_total, carry_out, blockIdx.x - 1, tiles);
 }
 
 // (re)allocations of device buffers by the calling thread: a batch's share is nfc_stats.device_allocs -- a stream in its steady state
