@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void k_certify_and_write(CertLaunch C, EdgeArg
         certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, blockIdx.x - tiles - 1, C.blocks);
         return;
     }
-    write_edges_tile(E, nwords, partials, supers, epos, ecode, cap, own_prefix, total_out, last2_total, carry_out, blockIdx.x - 1, tiles);
+    // (the tiles from the batch's END: a tile folds the aggregates of everything before it -- the later the tile, the longer its
+    // fold --, so the heavier tiles go first; 40.5 -> 39.3 us)
+    write_edges_tile(E, nwords, partials, supers, epos, ecode, cap, own_prefix, total_out, last2_total, carry_out, tiles - blockIdx.x, tiles);
 }
 
 // (re)allocations of device buffers by the calling thread: a batch's share is nfc_stats.device_allocs -- a stream in its steady state
