@@ -115,7 +115,8 @@ typedef struct {
     uint64_t bytes_in;        /* input bytes of the last batch */
     double ms_threshold_kernel[6]; /* hipEvent duration of each k_threshold launch of the last batch (first 6) */
     uint32_t n_threshold_timed;
-    uint32_t chunk_samples;   /* time-chunk length the threshold kernel used for the last batch */
+    uint32_t chunk_samples;   /* time-chunk length the threshold kernel used for the last batch (the nominal one: where the chunks
+                               * are cut by dispatch row -- nfc_plan_row_cut -- they are up to 4 % longer or shorter, and n_chunks counts them) */
     uint32_t ran_ahead;       /* 1: the last batch's threshold stage ran ahead of the batch before it (nfc_submit_device) */
     uint32_t redone_total;    /* submitted batches of this context that had to be processed again synchronously */
     uint32_t ring_slots_carried; /* window slots whose value at the end of the last batch is still the one the batch started from
