@@ -566,15 +566,22 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
     uint32_t seen = 0u;
     uint2 am = make_uint2(idm.mil[0], idm.mil[1]), an = make_uint2(idm.man[0], idm.man[1]);
     // (the maps of the thread's first 8, 16, 24 ... edges are kept: the walk below runs a chain per eight edges)
-    constexpr int NCH = 2 * DEC_GROUPS;   // chains of eight edges
+#ifndef NFC_DEC_CHAIN
+#define NFC_DEC_CHAIN 8
+#endif
+    // edges per chain of the walk.  Measured (round 5, -DNFC_DEC_CHAIN): eight chains of 4 -- half the dependent look-ups, twice the
+    // start states to derive -- 24.5 -> 30.2 us for the launch, two chains of 16 the same 24.6: the kernel issues instructions, it does not wait
+    constexpr int CHAIN = NFC_DEC_CHAIN;
+    static_assert(CHAIN == 16 || CHAIN == 8 || CHAIN == 4, "NFC_DEC_CHAIN");
+    constexpr int NCH = DEC_PER_THREAD / CHAIN;        // chains per thread
     uint2 pm[NCH], pn[NCH];
 #pragma unroll
     for (int g = 0; g < DEC_GROUPS; g++) {
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-            if (k == 0 || k == 4) {
-                pm[2 * g + k / 4] = am;
-                pn[2 * g + k / 4] = an;
+            if (k % (CHAIN / 2) == 0) {   // (k counts words of two codes)
+                pm[(16 * g + 2 * k) / CHAIN] = am;
+                pn[(16 * g + 2 * k) / CHAIN] = an;
             }
             compose4(am, an, c[g][k], c[g][k + 1]);
             seen |= routes_of(c[g][k]) | routes_of(c[g][k + 1]);
@@ -602,10 +609,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_dec_spec(const uint16_t *ecode, 
 #pragma unroll
     for (int g = 0; g < DEC_GROUPS; g++) ow[g][0] = ow[g][1] = ow[g][2] = ow[g][3] = 0u;
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
+    for (int e = 0; e < CHAIN; e++) {
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
-            const int g = j >> 1, k = (j & 1) * 8 + e;
+            const int g = (j * CHAIN) / DEC_ITEMS, k = (j * CHAIN) % DEC_ITEMS + e;   // chain j: the thread's edges j CHAIN .. j CHAIN + CHAIN - 1
             const uint32_t code = (c[g][k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
             const uint32_t li = code & 0x3FFFu, route = code >> 14;
             uint32_t w = 0;
