@@ -1161,16 +1161,15 @@ __global__ __launch_bounds__(256) void k_pkt_finish(PktFinish F) {
         }
     }
     if (F.mirror_src) {
-        __threadfence();
+        __threadfence_block();   // (workgroup scope: a device-scope release writes the L2 back, and only this workgroup reads the words)
         __syncthreads();   // thread 0's carry words are part of the block
         // (the stamp LAST, behind a system-scope fence: a host that watches the stamp instead of waiting for the stream -- host_threshold.h:
         // wait_for_stamp -- finds every other word of the block in place when it sees it)
         for (uint32_t i = threadIdx.x; i < F.mirror_words; i += blockDim.x)
             if (i != F.stamp_word) F.mirror_dst[i] = F.mirror_src[i];
-        __threadfence_system();
-        __syncthreads();
+        __threadfence_system();   // (every thread's own words are in place system-wide ...)
+        __syncthreads();          // (... before the barrier lets thread 0 send the stamp)
         if (threadIdx.x == 0) {
-            __threadfence_system();
             ((volatile uint32_t *)F.mirror_dst)[F.stamp_word] = F.stamp;
         }
     }

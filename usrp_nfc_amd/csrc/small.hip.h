@@ -224,14 +224,13 @@ __global__ __launch_bounds__(SM_BLOCK) void k_small_stage(SmallArgs A) {
         }
     }
     if (A.mirror_src) {   // the batch's last launch: the state block goes to the host's mirror from here
-        __threadfence();
+        __threadfence_block();
         __syncthreads();
         for (uint32_t i = tid; i < A.mirror_words; i += SM_BLOCK)
             if (i != A.stamp_word) A.mirror_dst[i] = A.mirror_src[i];
         __threadfence_system();   // (the stamp last: decode.hip.h, k_pkt_finish)
         __syncthreads();
         if (tid == 0) {
-            __threadfence_system();
             ((volatile uint32_t *)A.mirror_dst)[A.stamp_word] = A.stamp;
         }
     }
