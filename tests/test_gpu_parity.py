@@ -894,14 +894,14 @@ def test_chunks_cut_by_dispatch_row(monkeypatch, stream):
     assert r['sym_tag'] == o.symbols(0).tolist() and r['sym_reader'] == o.symbols(1).tolist()
 
 
-def test_chunks_cut_by_dispatch_row_three_workgroups_per_cu(monkeypatch):
-    # the same cut where a window of 10 000 samples leaves room for THREE workgroups per CU (configs[3] / [4]: eight rows per step,
-    # rounds of 2 048 samples): 30 M samples are 733 chunks of 20 rounds in the equal cut and 21 / 20 / rest by row.  Against the C
-    # oracle (val, edges, symbols, packets), with the equal cut beside it.
-    n = 30_000_000
-    w = synth.workload('all', n - 12_000)
-    iq = np.concatenate([w[:6000]] * 4 + [w])   # (the window's fill on bare carrier: 12 000 samples of the workload's own lead-in in front)
-    params = dict(hi_val=1.1, av_window=10000, max_len=250, samp_rate=10e6)
+@pytest.mark.parametrize('window,n,rows', [(10000, 30_000_000, 3), (16000, 20_000_000, 2)])
+def test_chunks_cut_by_dispatch_row_long_windows(monkeypatch, window, n, rows):
+    # the same cut where a long window leaves room for THREE workgroups per CU (10 000 samples: configs[3] / [4], eight rows per step,
+    # rounds of 2 048 samples; 30 M samples are 733 chunks of 20 rounds in the equal cut and 21 / 20 / rest by row) or TWO (16 000
+    # samples: a 64 KB ring).  Against the C oracle (val, edges, symbols, packets), with the equal cut beside it.
+    w = synth.workload('all', n - 21_000)
+    iq = np.concatenate([w[:6000]] * 7 + [w])   # (the window's fill on bare carrier: 21 000 samples of the workload's own lead-in in front)
+    params = dict(hi_val=1.1, av_window=window, max_len=250, samp_rate=10e6)
     o = oracle_run(iq, params, api.NFC_IN_IQ_F32)
     want_val = np.asarray(o.trace())
     chunks = {}
@@ -912,11 +912,11 @@ def test_chunks_cut_by_dispatch_row_three_workgroups_per_cu(monkeypatch):
             st = ctx.stats()
             chunks[rowbal] = st.n_chunks
             assert st.used_sequential == 0 and st.chunk_samples == 40960
-            assert np.array_equal(np.asarray(ctx.val())[10000:], want_val), 'val (NFC_WG_ROWBAL=%s)' % rowbal
+            assert np.array_equal(np.asarray(ctx.val())[window:], want_val), 'val (NFC_WG_ROWBAL=%s)' % rowbal
             assert first_diff(ctx.transitions(), o.transitions()) is None
             assert ctx.symbols(0).tolist() == o.symbols(0).tolist() and ctx.symbols(1).tolist() == o.symbols(1).tolist()
             assert ctx.packets() == o.packets()
-    assert chunks['0'] == (n + 40959) // 40960 and 512 < chunks['1'] <= 768 and chunks['1'] != chunks['0'], chunks
+    assert chunks['0'] == (n + 40959) // 40960 and 256 * (rows - 1) < chunks['1'] <= 256 * rows and chunks['1'] != chunks['0'], chunks
 
 
 def test_workgroup_kernel_two_rounds_ahead(monkeypatch):
