@@ -321,7 +321,84 @@ def main():
     x = x.copy()
     x[:2000] *= np.float32(10.0) ** rng.uniform(-6, 3, 2000).astype(np.float32)
     make_case('fx_stress_dynrange', x)
+    corners()
+
+
+def corners():
+    """Round 6: the two corners that were only checked GPU-vs-oracle (`python3 tests/golden/make_golden.py --corners`
+    writes these alone, leaving the other vectors' files as they are)."""
+    # 12. LOW runs that end exactly on a time-out (transition_sink.py:95-99: the run's last sample resets _current_state to 0,
+    # so the next change reports v = last_bit = -1, and a HIGH sample right behind it is NOT ignored).  Runs of max_len + 1,
+    # 2 max_len + 1 (on a time-out), max_len, max_len + 2, 3 max_len + 1, 1 and 10 max_len samples, each followed by HIGH samples.
+    rng = np.random.default_rng(3)
+    x = (0.25 * (1 + 0.004 * rng.standard_normal(12000))).astype(np.float32)
+    for start, ln in ((3000, 51), (4000, 101), (5000, 50), (6000, 52), (7000, 151), (8000, 1), (9000, 500)):
+        x[start:start + ln] = 1e-6
+        x[start + ln:start + ln + 3] = 0.25 * 1.3
+    x[10500:10505] = 0.25 * 1.3   # HIGH straight into LOW: v = 2
+    x[10505:10510] = 1e-6
+    res = make_case('fx_low_run_timeout', x)
+    vs = [v for (v, d), t in res[0]]
+    assert -1 in vs and 2 in vs, sorted(set(vs))
+    print('fx_low_run_timeout: v values', sorted(set(vs)), ' v = -1 x', vs.count(-1))
+
+    # 13. samples that are not finite (transition_sink.py:58-77).  -Inf: ratio = -inf, LOW.  +Inf while _current_state != 2:
+    # ratio = +inf > hi, HIGH, not stored.  +Inf while _current_state == 2 (right behind a LOW sample): neither test holds, the
+    # sample is ACCEPTED -- the window sum becomes +inf, every later finite sample has ratio 0 and is LOW; a second +Inf then
+    # gives ratio inf / inf = NaN, is accepted too, and inf - inf = NaN poisons the sum for good: every comparison with NaN is
+    # false, every sample after it is val 0.
+    frames = synth.txn_frames()
+    m = synth.modulation_profile(frames, gap_us=100.0, depth=0.12)
+    x0, _ = envelope(m, seed=21)
+    n = len(x0)
+    assert n > 16000, n
+    x = x0.copy()
+    x[2500] = -np.inf            # idle carrier: LOW for one sample
+    x[2600] = np.inf             # state 0: HIGH
+    x[2601] = np.inf             # state 1: HIGH again
+    k = n // 2
+    x[k:k + 4] = 0.0             # a pause ...
+    x[k + 4] = np.inf            # ... and +Inf in state 2: stored, the sum is +inf from here on
+    x[k + 3000] = np.inf         # ratio NaN: accepted; prev is finite, the sum stays +inf
+    x[k + 4 + 2000] = np.inf     # lands on the slot that holds the first +Inf: inf - inf = NaN
+    res = make_case('fx_nonfinite_inf', x)
+    xi = x
+    # a NaN in the middle of a frame: val 0 from there to the end of the stream
+    x = x0.copy()
+    x[2500] = -np.inf
+    x[n // 3] = np.nan
+    res = make_case('fx_nonfinite_nan', x)
+    xn = x
+    assert all(v == 0 or i < 10 for i, v in enumerate([v for (v, d), t in res[0]][-50:]))
+    # a NaN that arrives in the FILL phase (transition_sink.py:109-125: sum(ar) is NaN from the first stable sample on)
+    x = x0.copy()
+    x[1234] = np.nan
+    make_case('fx_nonfinite_fill', x)
+    # the same streams as fc32 IQ whose envelope fl(fl(I I) + fl(Q Q)) is the fixture's, bit for bit (NaN as NaN)
+    def iq_of(env):
+        iq = np.zeros(2 * len(env), np.float32)
+        iq[0::2] = np.sqrt(env.astype(np.float64)).astype(np.float32)
+        return iq
+    out = {}
+    for name, env in (('inf', xi), ('nan', xn)):
+        iq = iq_of(np.where(np.isfinite(env), env, 0).astype(np.float32))
+        bad = np.flatnonzero(~np.isfinite(env))
+        # a non-finite envelope out of IQ: Inf * Inf = Inf, -Inf has no IQ form (a sum of squares) -> +Inf there; NaN: a NaN component
+        e2 = synth.envelope_f32(iq)
+        e2[bad] = np.where(np.isnan(env[bad]), np.nan, np.inf)
+        iq[2 * bad] = np.where(np.isnan(env[bad]), np.nan, np.inf).astype(np.float32)
+        iq[2 * bad + 1] = np.where(np.isnan(env[bad]), 1.0, -np.inf).astype(np.float32)   # (NaN, 1) and (Inf, -Inf)
+        assert np.array_equal(synth.envelope_f32(iq), e2, equal_nan=True)
+        p = dict(DEFAULTS)
+        a = run_reference(e2, chunk=8192, **{k_: p[k_] for k_ in ('samp_rate', 'hi_val', 'lo_val', 'av_window', 'max_len', 'reader', 'tag')})
+        z = pack(e2, p, a)
+        out.update({name + '_iq': iq, **{name + '_' + k_: v for k_, v in z.items()}})
+        print('fx_nonfinite_iq[%s]: N=%d transitions=%d' % (name, len(e2), len(a[0])))
+    np.savez_compressed(os.path.join(HERE, 'fx_nonfinite_iq.npz'), **out)
 
 
 if __name__ == '__main__':
-    main()
+    if '--corners' in sys.argv:
+        corners()
+    else:
+        main()

@@ -8,12 +8,14 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 PATH_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'fx_*.npz'))
-                    if os.path.basename(p) not in ('fx_decoder_vectors.npz', 'fx_ultralight_iq.npz'))
+                    if os.path.basename(p) not in ('fx_decoder_vectors.npz', 'fx_ultralight_iq.npz', 'fx_nonfinite_iq.npz'))
 
 
 class Case(object):
-    def __init__(self, name):
-        z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    def __init__(self, name, prefix='', file=None):
+        z = np.load(os.path.join(GOLDEN, (file or name) + '.npz'))
+        if prefix:   # several cases in one file (fx_nonfinite_iq.npz): keys carry the case's prefix
+            z = {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
         self.name = name
         self.x = z['x']
         p = z['params']

@@ -118,6 +118,16 @@ def test_golden_iq_input():
                           pushes=[0, 1001, 2000, 2001, 7001, len(iq) // 2]))
 
 
+@pytest.mark.parametrize('case', ['inf', 'nan'])
+def test_nonfinite_iq_input(case):
+    # NaN / Inf samples arriving as IQ (transition_sink.py:58-77 on their envelope; the reference's outputs are the fixture's)
+    iq = load_npz('fx_nonfinite_iq.npz')[case + '_iq']
+    c = Case('fx_nonfinite_iq:' + case, prefix=case + '_', file='fx_nonfinite_iq')
+    check_case(c, run_gpu(iq, c.params, kind=api.NFC_IN_IQ_F32))
+    check_case(c, run_gpu(iq, c.params, kind=api.NFC_IN_IQ_F32, chunk_samples=256,
+                          pushes=[0, 1001, 2000, 2001, 7001, len(iq) // 4, len(iq) // 2]))
+
+
 def oracle_run(x, params, kind):
     o = co.COracle(trace=True, **params)
     {api.NFC_IN_ENV_F32: o.push_env, api.NFC_IN_IQ_F32: o.push_iq, api.NFC_IN_REAL_F32_SQ: o.push_real_sq}[kind](x)

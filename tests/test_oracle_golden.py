@@ -76,6 +76,26 @@ def test_envelope_of_iq_fixture():
     assert np.array_equal(po.envelope_iq(iq), c.x)
 
 
+@pytest.mark.parametrize('case', ['inf', 'nan'])
+def test_nonfinite_iq_fixture(case):
+    # samples that are not finite, given as IQ (fx_nonfinite_iq.npz: the reference ran on the envelope of this IQ)
+    iq = load_npz('fx_nonfinite_iq.npz')[case + '_iq']
+    c = Case('fx_nonfinite_iq:' + case, prefix=case + '_', file='fx_nonfinite_iq')
+    assert np.array_equal(po.envelope_iq(iq), c.x, equal_nan=True) and not np.isfinite(c.x).all()
+    r = po.run_path(c.x, **c.params)
+    assert r['transitions'] == c.transitions and r['packets'] == c.packets
+    o = co.COracle(**c.params)
+    o.push_iq(iq)
+    assert o.transitions() == c.transitions and o.packets() == c.packets
+    assert o.symbols(0).tolist() == c.sym_tag.tolist() and o.symbols(1).tolist() == c.sym_reader.tolist()
+
+
+def test_low_run_timeout_fixture_holds_every_v():
+    # SURVEY 7 hard part 4: v in {-1, 0, 1, 2}; v = -1 only behind a LOW run whose last sample fired a time-out
+    c = Case('fx_low_run_timeout')
+    assert set(c.tr_v.tolist()) == {-1, 0, 1, 2}
+
+
 # ---------------------------------------------------------------------------
 # the C restatement (oracle/nfc_oracle.c) against the same vectors
 # ---------------------------------------------------------------------------

@@ -51,7 +51,7 @@ class transition_sink(_Base):
         self._nbuf = 0
         self._ncalls = 0
         self._t_last = time.monotonic()
-        self._dtype = api.INPUT_DTYPES[input_kind][0] if hasattr(api, 'INPUT_DTYPES') else (numpy.int16 if input_kind == api.NFC_IN_I16_SQ else numpy.float32)
+        self._dtype = numpy.int16 if input_kind == api.NFC_IN_I16_SQ else numpy.float32
         back = getattr(callback, '__self__', None)
         self._back = back if hasattr(back, '_deliver') else None
         if self._back is not None:
