@@ -66,8 +66,10 @@ def main():
         return
     for _ in range(rounds):
         for v in rest:
-            if mode == 'env':
-                bench(workload, bench_args, parse_env(v), v)
+            if mode == 'env':   # (the switches exist in the test build only: usrp_nfc_amd/libnfc_amd_hooks.so)
+                sys.path.insert(0, ROOT)
+                from usrp_nfc_amd import _lib
+                bench(workload, bench_args, dict({'NFC_AMD_LIB': _lib.hooks_path()}, **parse_env(v)), v)
             elif mode == 'args':
                 bench(workload, v.split(), {}, v)
             elif mode == 'lib':

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(HERE, 'libnfc_amd.so')
 SO_HOOKS = os.path.join(HERE, 'libnfc_amd_hooks.so')   # the same sources with -DNFC_TEST_HOOKS: test hooks and diagnostics (README.md)
 SOURCES = ['nfc_amd.hip']
-DEPS = ['nfc_amd.hip', 'host_context.h', 'host_threshold.h', 'host_stages.h', 'host_submit.h', 'chunk_cut.h', 'launch_check.h', 'threshold.hip.h', 'threshold_lean.hip.h', 'threshold_wg.hip.h', 'edges.hip.h', 'decode.hip.h', 'scan.hip.h', 'small.hip.h', 'tx.hip.h', 'decoder_tables.h', 'protocol.h',
+DEPS = ['nfc_amd.hip', 'host_context.h', 'host_threshold.h', 'host_stages.h', 'host_submit.h', 'chunk_cut.h', 'launch_check.h', 'threshold.hip.h', 'threshold_lean.hip.h', 'threshold_wg.hip.h', 'edges.hip.h', 'decode.hip.h', 'scan.hip.h', 'small.hip.h', 'tail.hip.h', 'tx.hip.h', 'decoder_tables.h', 'protocol.h',
         os.path.join('..', '..', 'include', 'nfc_amd.h')]
 
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',

@@ -74,15 +74,9 @@ struct EdgeArgs {
     uint32_t mx_magic;          // floor(2^32 / max_len) (0xFFFFFFFF for max_len 1): modulo without a divide
     uint64_t g0;                // global index of batch sample 0
     uint64_t per_mask;          // bits 0, max_len, 2 max_len, ... < 64
-    // How the words are cut into tiles: a SUPER is sw consecutive words -- EW_WORDS * EW_SUPER of them as k_edge_reduce leaves the
-    // aggregates, or a time chunk of the threshold kernel where THAT left them (threshold_wg.hip.h: wg_chunk_edge_aggs) --, cut into
-    // tps tiles of EW_WORDS words, the last of which may be short.  Tile b is tile b % tps of super b / tps.
+    // How the words are cut into tiles: a SUPER is sw consecutive words (EW_WORDS * EW_SUPER as k_edge_reduce leaves the aggregates),
+    // cut into tps tiles of EW_WORDS words, the last of which may be short.  Tile b is tile b % tps of super b / tps.
     uint32_t sw, tps;
-    // The threshold kernel's aggregates: a chunk cannot know the sample before its first one (another workgroup's, at the same
-    // time), so a chunk's aggregates are those of its words with NO change at its first sample, and the super's `sum` carries
-    // val + 1 of the chunk's first and last sample in its top four bits -- whoever folds supers puts the change between two
-    // chunks in where those differ (fold_packed_super; the carried _last_bit stands before chunk 0).
-    uint32_t packed_supers;
 
     __device__ __forceinline__ int mod_mx(int x) const {   // x mod max_len for 0 <= x < 2^31
         const uint32_t q = __umulhi((uint32_t)x, mx_magic);   // floor(x / mx) or one less
@@ -472,24 +466,6 @@ __device__ __forceinline__ TileSpan tile_span(const EdgeArgs &A, size_t nwords, 
     return t;
 }
 inline size_t edge_num_tiles_of(size_t nwords, uint32_t sw, uint32_t tps) { return ((nwords + sw - 1) / sw) * tps; }
-// a change at sample p as a span of its own
-__device__ __forceinline__ EdgeAgg agg_single_change(int32_t p) { return EdgeAgg{p, Last2{p, POS_NONE}, 1u}; }
-constexpr uint32_t SUPER_SUM_MASK = 0x0FFFFFFFu;
-__device__ __forceinline__ uint32_t super_pack(uint32_t sum, int first_val, int last_val) {
-    return (sum & SUPER_SUM_MASK) | ((uint32_t)(first_val + 1) << 28) | ((uint32_t)(last_val + 1) << 30);
-}
-// acc o [the change between super i - 1 and super i, if their samples on either side differ] o supers[i]
-// (prev_lv: val + 1 of the last sample before super i; returns val + 1 of super i's last sample)
-__device__ __forceinline__ uint32_t fold_packed_super(const EdgeArgs &A, const EdgeAggOp &op, EdgeAgg &acc, EdgeAgg v, uint32_t i, uint32_t prev_lv,
-                                                     bool with_body = true) {
-    const uint32_t fv = (v.sum >> 28) & 3u, lv = v.sum >> 30;
-    v.sum &= SUPER_SUM_MASK;
-    const size_t p = (size_t)i * A.sw * 64;   // (samples before skip are the fill phase's: no change there)
-    if (prev_lv != fv && p >= (size_t)A.skip) acc = op(acc, agg_single_change((int32_t)p));
-    if (with_body) acc = op(acc, v);
-    return lv;
-}
-
 // ---- launch 2: the writer.  A workgroup owns EW_WORDS consecutive words; a thread walks its EW_ITEMS words' entries in
 // stream order, which is the reference's own loop restricted to the samples that emit (transition_sink.py:84-99): between
 // entries everything it carries has a closed form, so the walk keeps
@@ -532,8 +508,7 @@ __device__ __forceinline__ void write_edges_tile(const EdgeArgs &A, size_t nword
     EdgeAgg pre;
     const uint32_t g = ts.g, q = ts.q;
     if (own_prefix) {
-        // The tile's prefix: the super-aggregates of the groups before its own (one per super, left by the reduce pass or by the
-        // threshold kernel) and the sibling tiles before it in its group -- folded by ONE wave (round 4; all four waves folded the
+        // The tile's prefix: the super-aggregates of the groups before its own (one per super, left by the reduce pass) and the sibling tiles before it in its group -- folded by ONE wave (round 4; all four waves folded the
         // tiles' own aggregates before and joined in a block scan: this kernel is bound by the number of vector instructions it
         // issues, and three of the four waves' shares of them are gone; the other waves' words are in flight meanwhile)
         __shared__ EdgeAgg s_pre;
@@ -541,34 +516,17 @@ __device__ __forceinline__ void write_edges_tile(const EdgeArgs &A, size_t nword
             const uint32_t per = (g + 63u) / 64u;
             const uint32_t lo = min(g, (uint32_t)threadIdx.x * per), hi = min(g, lo + per);
             EdgeAgg acc = op.identity();
-            if (!A.packed_supers) {
-                for (uint32_t i = lo; i < hi; i += 4) {   // four loads in flight per lane
-                    EdgeAgg v[4];
+            for (uint32_t i = lo; i < hi; i += 4) {   // four loads in flight per lane
+                EdgeAgg v[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) v[k] = (i + k < hi) ? supers[i + k] : op.identity();
+                for (int k = 0; k < 4; k++) v[k] = (i + k < hi) ? supers[i + k] : op.identity();
 #pragma unroll
-                    for (int k = 0; k < 4; k++) acc = op(acc, v[k]);
-                }
-            } else {
-                // (the threshold kernel's aggregates: the change between two chunks is put in here, EdgeArgs.packed_supers)
-                uint32_t plv = (lo > 0 && lo < hi) ? supers[lo - 1].sum >> 30 : (uint32_t)(A.last_bit_in + 1);
-                for (uint32_t i = lo; i < hi; i += 4) {
-                    EdgeAgg v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) v[k] = (i + k < hi) ? supers[i + k] : op.identity();
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (i + k < hi) plv = fold_packed_super(A, op, acc, v[k], i + k, plv);
-                }
+                for (int k = 0; k < 4; k++) acc = op(acc, v[k]);
             }
             EdgeAgg sib[EW_SUPER - 1];
 #pragma unroll
             for (int k = 0; k < EW_SUPER - 1; k++) sib[k] = (uint32_t)k < q ? partials[(size_t)g * A.tps + k] : op.identity();
             EdgeAgg tot = wave_inclusive_with(op, acc);   // (lane 63: all groups before this tile's)
-            if (A.packed_supers && q > 0) {   // the change in front of this tile's own super (the super's first tile finds it in its own words)
-                const uint32_t plv = g ? supers[g - 1].sum >> 30 : (uint32_t)(A.last_bit_in + 1);
-                (void)fold_packed_super(A, op, tot, supers[g], g, plv, false);
-            }
 #pragma unroll
             for (int k = 0; k < EW_SUPER - 1; k++) tot = op(tot, sib[k]);
             if (threadIdx.x == 63) s_pre = tot;

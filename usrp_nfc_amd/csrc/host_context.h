@@ -7,26 +7,10 @@ namespace {
 
 std::string g_create_error;
 
-// The first certification of a batch depends on k_threshold only and nothing of the later stages depends on it, so it shares a
-// launch with one of them: the first cert_blocks workgroups certify (the last of them resolves the end-of-batch state), the
-// others are the edge stage's writer (edges.hip.h).
-struct CertLaunch {
-    ThrArgs A;
-    uint8_t *cert;
-    float *ring_next;
-    Carry *carry;
-    CertSummary *sum;
-    uint32_t blocks;
-};
-// (With the writer since round 4, with the reduce pass before: what the certification leaves -- its verdict, the end-of-batch
-// state -- travels to the host in the mirror the stage's last launch fills; its workgroups are a few dependent rounds of loads
-// long and pass unnoticed beside the writer's 40 us of vector instructions.)
+// (the round-5 form of the tail: the certification shares the edge writer's launch -- kept beside k_tail for the A/B)
 __global__ __launch_bounds__(256) void k_certify_and_write(CertLaunch C, EdgeArgs E, size_t nwords, const EdgeAgg *partials, const EdgeAgg *supers,
                                                           uint32_t *epos, uint16_t *ecode, uint32_t cap, bool own_prefix, uint32_t *total_out,
                                                           Last2 *last2_total, EdgeCarry *carry_out) {
-    // (the grid: the workgroup that resolves the end-of-batch state -- a chain of look-backs -- FIRST, the writer's tiles, and the
-    // certifying workgroups LAST: they are light -- a round of loads, a reduction -- and fill the slots the writer's last tiles leave
-    // empty while those finish, instead of holding the writer's first tiles back; measured: 42.9 -> 40.1 us for the launch, the step 0.2494 -> 0.2469 ms)
     const uint32_t tiles = gridDim.x - C.blocks;
     if (blockIdx.x == 0) {
         certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, C.blocks - 1, C.blocks);
@@ -36,8 +20,6 @@ __global__ __launch_bounds__(256) void k_certify_and_write(CertLaunch C, EdgeArg
         certify_block(C.A, C.cert, nullptr, C.ring_next, C.carry, C.sum, blockIdx.x - tiles - 1, C.blocks);
         return;
     }
-    // (the tiles from the batch's END: a tile folds the aggregates of everything before it -- the later the tile, the longer its
-    // fold --, so the heavier tiles go first; 40.5 -> 39.3 us)
     write_edges_tile(E, nwords, partials, supers, epos, ecode, cap, own_prefix, total_out, last2_total, carry_out, tiles - blockIdx.x, tiles);
 }
 
@@ -137,9 +119,9 @@ struct nfc_ctx {
     int n_cus = 1;                                             // compute units of the device
     // ... the rows' chunk lengths over the equal cut's, all but the last row's, by workgroups per CU (measured: host_threshold.h); [0]: NFC_WG_ROWBAL=a,b,c
     double rowbal_f[5][3] = {{1, 1, 1}, {1, 1, 1}, {1.02, 1, 1}, {1.045, 1.004, 1}, {1.036, 1.015, 0.990}};
-    bool rowbal_set = false, rowbal_ahead = false;
+    bool rowbal_set = false;
     bool wg_rowbal = true, rowbal_now = false;                 // chunks cut by dispatch row (host_threshold.h: thr_prepare; NFC_WG_ROWBAL=0: the equal cut); this batch is
-    int wg = 1, wg_ok = 0, wg_nr = 4, wg_d = 1, wg_slots = 0, wg_slots_ahead = 0, wg_now = 0, wg_rounds = 0;
+    int wg = 1, wg_ok = 0, wg_nr = 4, wg_slots = 0, wg_slots_ahead = 0, wg_now = 0, wg_rounds = 0;
     int fine_left = 0, fine_adapt = 1, fine_mult = 4;   // batches still to be cut into fine_mult times as many chunks (after a batch that needed re-runs); NFC_CHUNK_ADAPT=0 turns it off   // pass 0 by k_threshold_wg (a chunk per workgroup; NFC_WG=0 turns it off), rounds
                                                                  // rows of 64 samples per step (NFC_WG_NR), resident workgroups, this batch uses it, rounds per superstep
     size_t wg_lds = 0, wg_lds_base = 0, wg_lds_bulk_max = 0;   // dynamic LDS of k_threshold_wg: with the staging ring / without any staging / the most a whole chunk's planes may bring it to
@@ -211,7 +193,7 @@ struct nfc_ctx {
         uint64_t g0 = 0;
         int slot = 0, planes = -1, ring_in = 0, timing = 0;   // (timing: nfc_set_timing's level when the batch was submitted)
         uint32_t allocs = 0;   // buffers (re)allocated on its behalf so far (nfc_stats.device_allocs)
-        bool fast = false, b_enqueued = false, timed = false, spec = false;   // (spec: its decode stage ran in the speculative form)
+        bool fast = false, b_enqueued = false, timed = false, spec = false, tail = false;   // (spec: its decode stage ran in the speculative form)
     } sub[NSUB];
     int sub_count = 0;             // batches submitted and not yet waited for (sub[0] the oldest)
     uint32_t slot_next = 0;
@@ -236,15 +218,17 @@ struct nfc_ctx {
     DevBuf d_states, d_sym[2], d_bits[2], d_pending[2][2], d_close_end[2],
         d_close_idx[2];
     DevBuf d_partials, d_partials2, d_aggs, d_faggs;  // scan scratch
-    // the edge stage's tile / chunk aggregates when the threshold kernel leaves them (threshold_wg.hip.h: wg_chunk_edge_aggs; NFC_EAGG=1
-    // turns it on): a buffer of their own -- d_partials may grow between the two stages --, and what run_edges needs to know.
-    // OFF by default, measured (round 5, configs[1], same-call A/Bs): k_edge_reduce (11.0 us) and its launch boundary go, but the
-    // aggregation is ~1 000 vector instructions per wave wherever it runs -- at a chunk's end, where the four workgroups of a CU
-    // finish together, that is 10 us of the threshold kernel (0.153-0.162 -> 0.162-0.173 ms per launch, from LDS or from the L2
-    // alike) and the writer's prefix fold over 1 018 chunk aggregates instead of 763 costs it 2 us: step 0.2627-0.2738 -> 0.2753.
-    DevBuf d_eaggs;
-    bool eagg = false, eagg_ready = false;
-    uint32_t eagg_sw = 0, eagg_tps = 0, eagg_nch = 0;
+    // the fused tail (tail.hip.h: k_tail): status words of its look-backs, the ticket counter, the launch epoch; the packed bit arrays
+    // alternate between two buffers -- a batch's launch clears the one the NEXT batch's tiles will or into
+    DevBuf d_tail_st, d_tail_ticket, d_bits_alt[2];
+    uint32_t tail_epoch = 0, tail_ticket_base = 0, tail_seq = 0xFFFFFFFFu;
+    bool tail_on = false, tail_reset = true, tail_now = false;   // (tail_on: NFC_TAIL=1 in the test build)
+    uint32_t tail_tw_used = 512, tail_dense_repeats = 0, tail_peak = 0, tail_peak_tw = 512;
+    bool sym_from_tail = false;            // the last batch's out-bytes came from k_tail: the symbol reader builds its tile aggregates first
+    uint32_t tail_tw = 512;         // words per tile: halves when a tile's entries did not fit the staging, grows back after calm batches
+    int tail_tw_hold = 0;
+    uint32_t bits_clean[2] = {0, 0}, alt_clean[2] = {0, 0};   // words of d_bits / d_bits_alt known to be zero
+    int tail_occ[2] = {0, 0};                // resident workgroups per CU of k_tail<false / true>
     DevBuf d_spec;                           // per decode tile: its map, the state it assumed (decode.hip.h: DecSpec)
     DevBuf d_stage_bits[2], d_stage_cb[2], d_stage_ci[2], d_stage_q[2], d_stage_own;   // ... and what it stages for k_concat (TileStage)
     DevBuf d_pack;                           // nfc_get_state staging
@@ -284,7 +268,7 @@ int fail(nfc_ctx *c, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf;
+    if (c) c->err = buf, c->tail_reset = true;   // (after any failure the fused tail's ticket counter is re-armed: tail.hip.h)
     else g_create_error = buf;
     return code;
 }
@@ -416,16 +400,10 @@ void launch_wg(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipE
         if (e0) NFC_LAUNCH_EXT(kern, dim3(nwork), dim3(256), lds, c->st, e0, e1, 0, B);
         else NFC_LAUNCH(kern, dim3(nwork), dim3(256), lds, c->st, B);
     };
-    switch (c->wg_nr) {
-    case 8: go(k_threshold_wg<KIND, 8>); break;
-    case 6: go(k_threshold_wg<KIND, 6>); break;
-    default:
-        if constexpr (KIND == IN_IQ_F32) {
-            if (c->wg_d == 2) { go(k_threshold_wg<KIND, 4, 2>); break; }
-        }
-        go(k_threshold_wg<KIND, 4>);
-        break;
+    if constexpr (KIND == IN_IQ_F32 || KIND == IN_ENV_F32) {   // (the kinds eight rows per step are instantiated for: nfc_create chooses wg_nr)
+        if (c->wg_nr == 8) return go(k_threshold_wg<KIND, 8>);
     }
+    go(k_threshold_wg<KIND, 4>);
 }
 template <int KIND>
 void launch_lean(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipEvent_t e1) {
@@ -439,10 +417,8 @@ void launch_lean(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hi
         else NFC_LAUNCH(kern, dim3(blocks), dim3(64 * wpb), lds, c->st, A);
     };
     const bool b16 = (1 << c->nfold) == 16;
-    switch (c->lean_k) {
-    case 2: if (b16) go(k_threshold_lean<KIND, 2, true>); else go(k_threshold_lean<KIND, 2, false>); break;
-    default: if (b16) go(k_threshold_lean<KIND, 4, true>); else go(k_threshold_lean<KIND, 4, false>); break;
-    }
+    if (b16) go(k_threshold_lean<KIND, 4, true>);
+    else go(k_threshold_lean<KIND, 4, false>);
 }
 void launch_threshold_kind(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, bool lean = false, hipEvent_t *own_events = nullptr) {
     const bool timed = !own_events && c->timing >= 1 && c->n_kev < 6;

@@ -28,17 +28,12 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     E.mx_magic = c->mx > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c->mx) : 0xFFFFFFFFu;
     E.per_mask = 0;
     for (int b = 0; b < 64; b += c->mx) E.per_mask |= 1ull << b;
-    // the threshold kernel's pass 0 may have left the aggregates (host_threshold.h: eagg_ready; tiles cut per time chunk then)
-    const bool fused = c->eagg_ready && (size_t)c->eagg_nch * c->eagg_sw >= nwords;
-    c->eagg_ready = false;   // (once: a repeat of the stage follows re-runs, or wants room -- either way it reduces the planes itself)
-    c->stats.edge_aggs_fused = fused ? 1u : 0u;
-    E.sw = fused ? c->eagg_sw : (uint32_t)(EW_WORDS * EW_SUPER);
-    E.tps = fused ? c->eagg_tps : (uint32_t)EW_SUPER;
-    E.packed_supers = fused ? 1u : 0u;
-    const size_t tiles = fused ? edge_num_tiles_of(nwords, E.sw, E.tps) : edge_num_tiles(nwords);   // EW_WORDS words per tile in both launches of the stage
-    const size_t supers = fused ? (size_t)c->eagg_nch : edge_num_supers(nwords);   // the reduce pass: a workgroup per EW_SUPER tiles, both levels of aggregates
+    E.sw = (uint32_t)(EW_WORDS * EW_SUPER);
+    E.tps = (uint32_t)EW_SUPER;
+    const size_t tiles = edge_num_tiles(nwords);    // EW_WORDS words per tile in both launches of the stage
+    const size_t supers = edge_num_supers(nwords);  // the reduce pass: a workgroup per EW_SUPER tiles, both levels of aggregates
     HIPCHK(c, c->d_partials.ensure((tiles + supers + 2) * sizeof(EdgeAgg)));
-    EdgeAgg *parts = fused ? c->d_eaggs.as<EdgeAgg>() : c->d_partials.as<EdgeAgg>();
+    EdgeAgg *parts = c->d_partials.as<EdgeAgg>();
     EdgeAgg *sups = parts + tiles + 1;
     // launch 1: one aggregate per tile (first change, last two changes, entries it is sure of).  While the tiles are few,
     // each tile's workgroup of the writer folds its predecessors' aggregates itself (scan.hip.h: tile_prefix) and the
@@ -48,7 +43,7 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     uint32_t *edges_total = (uint32_t *)(tot + TOT_EDGES);
     const EdgeAggOp op{E.mx, E.mx_magic};
     // (the first certification of the batch, when it is still to be launched, rides with the WRITER below: host_context.h)
-    if (tiles && !fused) NFC_LAUNCH(k_edge_reduce, dim3((unsigned)supers), dim3(ER_BLOCK), 0, c->st, E, nwords, parts, sups);
+    if (tiles) NFC_LAUNCH(k_edge_reduce, dim3((unsigned)supers), dim3(ER_BLOCK), 0, c->st, E, nwords, parts, sups);
     if (!own || !tiles)   // (long batches: the prefix launch over the SUPER-aggregates; the totals and the carry in its epilogue)
         scan_partials_with(c->st, op, supers, nullptr, (uint32_t)(EW_WORDS * EW_SUPER), sups, op.identity(), (EdgeAgg *)nullptr,
                            EdgeTotalEpilogue{E, edges_total, last2_total, dE(c)});
@@ -65,6 +60,7 @@ int run_edges(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
                    c->d_ecode.as<uint16_t>(), cap, own, edges_total, last2_total, dE(c));
     }
     c->edges_from_host = false;
+    c->tail_now = false;
     return NFC_OK;
 }
 
@@ -104,6 +100,35 @@ int frame_out(nfc_ctx *c, FrameOut &P, const bool (&enabled)[2]) {
         P.pend[t] = pend;
     }
     return NFC_OK;
+}
+
+// After framing: the open packets' bits to the other half of the double buffer, the framing carry, the state block into the host's
+// mapped mirror with the batch's stamp (decode.hip.h: k_pkt_finish) -- the last launch of a batch in both forms of the tail.
+void launch_pkt_finish(nfc_ctx *c, const FrameOut &P, const bool (&enabled)[2], PktCnt *pk_total, FrameAgg *frame_total) {
+    const int pn = 1 - c->pend_cur;
+    PktFinish F;
+    memset(&F, 0, sizeof F);
+    F.packed = 1;
+    for (int t = 0; t < 2; t++) {
+        F.enabled[t] = enabled[t] ? 1 : 0;
+        F.bits[t] = P.bits[t];
+        F.pending_next[t] = c->d_pending[t][pn].as<uint8_t>();
+        F.close_end[t] = P.close_end[t];
+        F.started_in[t] = (int32_t)P.started_in[t];
+        F.pending_cap[t] = (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu);
+        F.cap_bits[t] = P.cap_bits[t];
+        F.cap_close[t] = P.cap_close[t];
+    }
+    F.totals = pk_total;
+    F.frame_total = frame_total;
+    F.carry = dD(c);
+    static_assert(sizeof(DevState) % 4 == 0, "whole words");
+    F.mirror_src = (const uint32_t *)c->d_state.p;   // the stage's last launch also fills the host's mirror of the state block
+    F.mirror_dst = (uint32_t *)c->hs_dev;
+    F.mirror_words = (uint32_t)(sizeof(DevState) / 4);
+    F.stamp_word = (uint32_t)(offsetof(DevState, seq) / 4 + 1);
+    F.stamp = c->stamp_b;
+    NFC_LAUNCH(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
 }
 
 int run_decode(nfc_ctx *c, bool force_classic = false) {
@@ -208,37 +233,187 @@ int run_decode(nfc_ctx *c, bool force_classic = false) {
         NFC_LAUNCH(k_frame_write, dim3((unsigned)std::max<size_t>(tiles, 1)), dim3(SCAN_BLOCK), 0, c->st, outw, (size_t)ce, ne_dev, fparts,
                            c->d_faggs.as<FramePk>(), P, own, frame_total, epi, V);
     c->bits_packed = true;
+    c->bits_clean[0] = c->bits_clean[1] = 0;   // (this stage cleared and filled them itself)
+    c->sym_from_tail = false;
     c->sym_lazy = true;          // the symbol arrays are written when nfc_read_symbols asks for them (materialize_symbols)
     c->sym_P = P;
     c->sym_n = ce;
     c->sym_tiles = (uint32_t)tiles;
     c->sym_own = own;
-    const int pn = 1 - c->pend_cur;
-    PktFinish F;
-    memset(&F, 0, sizeof F);
-    F.packed = 1;
-    for (int t = 0; t < 2; t++) {
-        F.enabled[t] = enabled[t] ? 1 : 0;
-        F.bits[t] = P.bits[t];
-        F.pending_next[t] = c->d_pending[t][pn].as<uint8_t>();
-        F.close_end[t] = P.close_end[t];
-        F.started_in[t] = (int32_t)P.started_in[t];
-        F.pending_cap[t] = (uint32_t)std::min<size_t>(c->d_pending[t][pn].cap, 0xFFFFFFFFu);
-        F.cap_bits[t] = P.cap_bits[t];
-        F.cap_close[t] = P.cap_close[t];
-    }
-    F.totals = pk_total;
-    F.frame_total = frame_total;
-    F.carry = dD(c);
-    static_assert(sizeof(DevState) % 4 == 0, "whole words");
-    F.mirror_src = (const uint32_t *)c->d_state.p;   // the stage's last launch also fills the host's mirror of the state block
-    F.mirror_dst = (uint32_t *)c->hs_dev;
-    F.mirror_words = (uint32_t)(sizeof(DevState) / 4);
-    F.stamp_word = (uint32_t)(offsetof(DevState, seq) / 4 + 1);
-    F.stamp = c->stamp_b;
-    NFC_LAUNCH(k_pkt_finish, dim3(1), dim3(256), 0, c->st, F);
+    launch_pkt_finish(c, P, enabled, pk_total, frame_total);
     return NFC_OK;
 }
+
+#ifdef NFC_TEST_HOOKS
+// ---------------------------------------------------------------------------
+// the fused tail: edges, decoders and framing in one persistent launch (tail.hip.h)
+// ---------------------------------------------------------------------------
+// decode: the decoders run in the launch (the Miller decoder as its quotient machine, from a class the carried state belongs to);
+// otherwise the launch is the edge stage alone and the three-launch decode follows.
+bool tail_can_decode(const nfc_ctx *c) {
+    const bool known = c->h_dcarry.mil_state >= 0 && c->h_dcarry.mil_state < 16 && c->mil_q_of[c->h_dcarry.mil_state] != 0xFFu;
+    return c->T.q_ok && known && c->h_dcarry.man_state >= 0 && c->h_dcarry.man_state < 8;
+}
+int run_tail(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
+    uint8_t *tot = dT(c);
+    const size_t nwords = ((size_t)n + 63) / 64;
+    TailArgs A;
+    memset(&A, 0, sizeof A);
+    EdgeArgs &E = A.E;
+    E.neg = c->d_neg.as<uint64_t>();
+    E.pos = c->d_pos.as<uint64_t>();
+    E.n = n;
+    E.skip = skip;
+    E.mx = c->mx;
+    E.dur_in = c->h_ecarry.dur;
+    E.last_bit_in = c->h_ecarry.last_bit;
+    E.state_in = c->h_ecarry.state;
+    E.nd = c->mx + 1;
+    E.g0 = g0;
+    E.mx_magic = c->mx > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c->mx) : 0xFFFFFFFFu;
+    for (int b = 0; b < 64; b += c->mx) E.per_mask |= 1ull << b;
+    const bool fresh = c->tail_seq != c->stamp_b;   // the batch's first attempt (a repeat finds its buffers used)
+    c->tail_seq = c->stamp_b;
+    // tiles: TL_WORDS_MAX words unless the stream's entries have been too dense for the staging lately (or look it by the estimate)
+    if (fresh && c->tail_tw_hold > 0 && --c->tail_tw_hold == 0) c->tail_tw = std::min<uint32_t>(c->tail_tw * 2, TL_WORDS_MAX);
+    // (and by the densest tile the last launch saw, scaled to the tile length: a stream that turns dense is met before it overflows)
+    uint32_t tw = c->tail_tw;
+    while (tw > 32 && (double)c->tail_peak * tw / (double)std::max(1u, c->tail_peak_tw) * 1.25 > (double)TL_CAP) tw /= 2;
+    E.sw = tw;
+    E.tps = 1;
+    A.nwords = nwords;
+    A.tw = tw;
+    const size_t tiles = (nwords + tw - 1) / tw;
+    A.ntiles = (uint32_t)tiles;
+    const uint32_t cap = c->cap_edges;
+    const size_t cap_al = std::max(cap, c->alloc_edges);
+    HIPCHK(c, c->d_epos.ensure((cap_al + 8) * 4));
+    HIPCHK(c, c->d_ecode.ensure((cap_al + 8) * 2));
+    HIPCHK(c, c->d_states.ensure(cap_al + 32));
+    A.epos = c->d_epos.as<uint32_t>();
+    A.ecode = c->d_ecode.as<uint16_t>();
+    A.outw = c->d_states.as<uint8_t>();
+    A.cap = cap;
+    c->edges_from_host = false;
+    const bool decode = tail_can_decode(c);
+    A.decode = decode ? 1 : 0;
+    A.T = c->T;
+    const bool enabled[2] = {c->T.tag != 0, c->T.reader != 0};
+    FrameAgg *frame_total = (FrameAgg *)(tot + TOT_FRAME);
+    PktCnt *pk_total = (PktCnt *)(tot + TOT_PKT0);
+    FrameOut P;
+    memset(&P, 0, sizeof P);
+    if (decode) {
+        // the packed bit arrays: tiles OR their boundary words in, so the words must be clear before ANY tile of the launch gets
+        // there -- the launch of the batch before cleared this batch's buffer (two buffers alternate)
+        if (fresh)
+            for (int t = 0; t < 2; t++) {
+                std::swap(c->d_bits[t], c->d_bits_alt[t]);
+                std::swap(c->bits_clean[t], c->alt_clean[t]);
+            }
+        size_t cap_before[2] = {c->d_bits[0].cap, c->d_bits[1].cap};
+        const int rf = frame_out(c, P, enabled);
+        if (rf) return rf;
+        for (int t = 0; t < 2; t++) {
+            if (!P.bits[t]) continue;
+            if (c->d_bits[t].cap != cap_before[t] || !fresh) c->bits_clean[t] = 0;
+            const uint32_t need = (P.cap_bits[t] + 31u) / 32u + 1u;
+            if (c->bits_clean[t] < need) HIPCHK(c, hipMemsetAsync(P.bits[t], 0, (size_t)need * 4, c->st));
+            c->bits_clean[t] = 0;   // (used from here on)
+            const size_t before = c->d_bits_alt[t].cap;
+            HIPCHK(c, c->d_bits_alt[t].ensure(c->d_bits[t].cap));
+            (void)before;
+            A.Znext.p[t] = c->d_bits_alt[t].as<uint32_t>();
+            A.Znext.n[t] = (uint32_t)std::min<size_t>(need + 4096, c->d_bits_alt[t].cap / 4);   // (room for a next batch that needs a little more)
+            c->alt_clean[t] = A.Znext.n[t];
+        }
+    }
+    A.P = P;
+    const uint32_t mil_class_in = decode ? c->mil_q_of[c->h_dcarry.mil_state] : 0u;
+    A.state0 = mil_class_in | ((uint32_t)(decode ? c->h_dcarry.man_state : 0) << 4);
+    A.epi = DecCarryEpilogue{(DecMaps *)nullptr, 0u, dD(c), (uint32_t *)(tot + TOT_NSYM), pk_total,
+                             {P.pend[0], P.pend[1]}, {P.started_in[0], P.started_in[1]}, {c->T.canon[0], c->T.canon[1], c->T.canon[2], c->T.canon[3]}};
+    A.q_rep[0] = c->T.q_rep[0];
+    A.q_rep[1] = c->T.q_rep[1];
+    A.edges_total = (uint32_t *)(tot + TOT_EDGES);
+    A.last2_total = (Last2 *)(tot + TOT_LAST2);
+    A.carry_out = dE(c);
+    A.frame_total = frame_total;
+    A.verdict = (uint32_t *)(tot + TOT_SPEC);
+    A.peak_out = (uint32_t *)(tot + TOT_RUNS);
+    // the look-backs' status words: validated by the launch epoch, never cleared between launches -- but memory that comes fresh
+    // from the allocator (or an epoch that wraps) is
+    {
+        const size_t need = tail_status_words(tiles) * 8;
+        const size_t before = c->d_tail_st.cap;
+        HIPCHK(c, c->d_tail_st.ensure(need));
+        if (c->d_tail_st.cap != before || c->tail_epoch >= (1u << 30) - 2u) {
+            HIPCHK(c, hipMemsetAsync(c->d_tail_st.p, 0, c->d_tail_st.cap, c->st));
+            if (c->tail_epoch >= (1u << 30) - 2u) c->tail_epoch = 0;
+        }
+        HIPCHK(c, c->d_tail_ticket.ensure(256));
+        if (c->tail_reset) {   // (the first launch, or a call that failed: the counter may not be where the host thinks)
+            HIPCHK(c, hipMemsetAsync(c->d_tail_ticket.p, 0, 256, c->st));
+            c->tail_ticket_base = 0;
+            c->tail_reset = false;
+        }
+    }
+    A.st = c->d_tail_st.as<uint64_t>();
+    A.ticket = c->d_tail_ticket.as<uint32_t>();
+    A.epoch = ++c->tail_epoch;
+    A.ticket_base = c->tail_ticket_base;
+    if (c->cert_pending) {
+        c->cert_pending = false;
+        A.C = c->cert;
+    }
+    const bool lds_tables = 4 * c->T.nd <= DEC_LDS_ROWS;
+    if (!c->tail_occ[lds_tables]) {
+        int occ = 0;
+        const void *k = lds_tables ? (const void *)k_tail<true> : (const void *)k_tail<false>;
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, TL_BLOCK, lds_tables ? tail_table_bytes(c->T.nd) : 0));
+        c->tail_occ[lds_tables] = std::max(1, occ);
+    }
+    const uint32_t njobs = A.ntiles + A.C.blocks;
+    const uint32_t grid = std::min<uint32_t>(njobs, (uint32_t)(c->n_cus * c->tail_occ[lds_tables]));
+    c->tail_ticket_base += njobs + grid;   // (every workgroup takes tickets until it draws one beyond the jobs)
+    const size_t dyn = lds_tables && decode ? tail_table_bytes(c->T.nd) : 0;
+    if (lds_tables) NFC_LAUNCH(k_tail<true>, dim3(grid), dim3(TL_BLOCK), dyn, c->st, A);
+    else NFC_LAUNCH(k_tail<false>, dim3(grid), dim3(TL_BLOCK), dyn, c->st, A);
+    c->tail_now = true;
+    c->stats.tail_fused = 1;
+    c->tail_tw_used = tw;
+    if (!decode) return NFC_OK;   // (the caller goes on with run_decode)
+    c->dec_spec_now = false;
+    c->bits_packed = true;
+    c->sym_lazy = true;
+    c->sym_from_tail = true;
+    c->sym_P = P;
+    c->sym_n = cap;
+    c->sym_tiles = (uint32_t)dec_num_tiles(cap);
+    c->sym_own = c->sym_tiles <= c->own_prefix_max;
+    launch_pkt_finish(c, P, enabled, pk_total, frame_total);
+    return NFC_OK;
+}
+// the fused tail's verdict (host synchronised, mirror of this batch): 0, or TLV_DENSE / TLV_TIMEOUT
+uint32_t tail_verdict(const nfc_ctx *c) {
+    if (!c->tail_now) return 0;
+    uint32_t v;
+    memcpy(&v, c->hs->totals + TOT_SPEC, 4);
+    return v & (TLV_DENSE | TLV_TIMEOUT);
+}
+// a tile's entries did not fit the staging: shorter tiles for this batch's repeat and for a while after
+void tail_note_dense(nfc_ctx *c) {
+    c->tail_tw = std::max<uint32_t>(32, c->tail_tw_used / 2);
+    c->tail_tw_hold = 16;
+    c->tail_dense_repeats++;
+}
+#else
+constexpr uint32_t TLV_DENSE = 2u, TLV_TIMEOUT = 4u;
+inline bool tail_can_decode(const nfc_ctx *) { return false; }
+inline int run_tail(nfc_ctx *c, uint32_t, uint32_t, uint64_t) { return fail(c, NFC_ERR_INTERNAL, "the fused tail is not part of this build"); }
+inline uint32_t tail_verdict(const nfc_ctx *) { return 0; }
+inline void tail_note_dense(nfc_ctx *) {}
+#endif
 
 // The speculative decode's verdict (host synchronised, mirror of this batch): true = a tile's assumed state was wrong where it mattered
 bool spec_failed(const nfc_ctx *c) {
@@ -264,6 +439,16 @@ void spec_batch_done(nfc_ctx *c) {
 // the symbol arrays of the last batch, on demand (decode.hip.h: k_symbols_write)
 int materialize_symbols(nfc_ctx *c) {
     if (!c->sym_lazy) return NFC_OK;
+#ifdef NFC_TEST_HOOKS
+    if (c->sym_tiles && c->sym_from_tail) {   // (k_tail leaves no aggregates per tile of DEC_TILE entries: made here, then scanned as the decode stage would)
+        const uint32_t *ne_dev = (const uint32_t *)(dT(c) + TOT_EDGES);
+        HIPCHK(c, c->d_partials2.ensure(((size_t)c->sym_tiles + 1) * sizeof(FrameAgg)));
+        NFC_LAUNCH(k_sym_reduce, dim3(c->sym_tiles), dim3(SCAN_BLOCK), 0, c->st, c->d_states.as<uint8_t>(), (size_t)c->sym_n, ne_dev, c->d_partials2.as<FrameAgg>());
+        if (!c->sym_own)
+            scan_partials<FrameAggOp>(c->st, c->sym_tiles, ne_dev, DEC_TILE, c->d_partials2.as<FrameAgg>(), FrameAggOp::identity(), (FrameAgg *)nullptr);
+        c->sym_from_tail = false;   // (the aggregates stand for further reads of this batch)
+    }
+#endif
     if (c->sym_tiles) {
         NFC_LAUNCH(k_symbols_write, dim3(c->sym_tiles), dim3(SCAN_BLOCK), 0, c->st, c->d_states.as<uint8_t>(), (size_t)c->sym_n,
                    (const uint32_t *)(dT(c) + TOT_EDGES), c->d_partials2.as<FrameAgg>(), c->sym_P, c->sym_own);
@@ -296,7 +481,6 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     A.nwords = ((size_t)n + 63) / 64;
     A.E.sw = (uint32_t)(EW_WORDS * EW_SUPER);
     A.E.tps = (uint32_t)EW_SUPER;
-    c->eagg_ready = false;
     const uint32_t ce = c->cap_edges;
     const size_t ce_al = std::max(ce, c->alloc_edges);
     HIPCHK(c, c->d_epos.ensure((ce_al + 8) * 4));
@@ -331,6 +515,8 @@ int run_small(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
     A.stamp = c->stamp_b;
     c->dec_spec_now = false;
     c->bits_packed = false;   // (the one-launch stage keeps a byte per bit and writes the symbols itself)
+    c->bits_clean[0] = c->bits_clean[1] = 0;
+    c->tail_now = false;
     c->sym_lazy = false;
     NFC_LAUNCH(k_small_stage, dim3(1), dim3(SM_BLOCK), 0, c->st, A);
     return NFC_OK;
@@ -356,6 +542,13 @@ void size_capacities(nfc_ctx *c, uint32_t n) {
 }
 // densities for the next batch's estimates
 void update_estimates(nfc_ctx *c, uint32_t n) {
+    if (c->tail_now) {   // the densest tile of the batch just adopted (tail.hip.h), at the tile length it ran with
+        uint32_t pk;
+        memcpy(&pk, c->hs->totals + TOT_RUNS, 4);
+        const double old = (double)c->tail_peak * c->tail_tw_used / (double)std::max(1u, c->tail_peak_tw) * 0.8;
+        c->tail_peak = std::max(pk, (uint32_t)old);
+        c->tail_peak_tw = c->tail_tw_used;
+    }
     c->cap_edges_floor = 0;
     c->cap_sym_floor[0] = c->cap_sym_floor[1] = 0;
     c->edge_rate = std::max({(double)c->n_edges / (double)n, c->edge_rate * 0.9, 1.0 / 64});
@@ -447,6 +640,14 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
             ev3_done = true;
             return NFC_OK;
         }
+        if (c->tail_on) {   // one persistent launch for the three stages (tail.hip.h); the edge stage alone where the decoders cannot run in it
+            const bool fused = tail_can_decode(c);
+            int r = run_tail(c, n, skip, g0);
+            if (r) return r;
+            if (!ev3_done && c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
+            ev3_done = true;
+            return fused ? NFC_OK : run_decode(c, true);
+        }
         int r = run_edges(c, n, skip, g0);
         if (r) return r;
         if (!ev3_done && c->timing >= 2) HIPCHK(c, hipEventRecord(c->ev[3], c->st));
@@ -475,6 +676,15 @@ int process_batch(nfc_ctx *c, const void *d_in, size_t n64) {
             uint32_t ne, ns[2];
             memcpy(&ne, c->hs->totals + TOT_EDGES, 4);
             memcpy(ns, c->hs->totals + TOT_NSYM, 8);
+            if (const uint32_t tv = tail_verdict(c)) {   // (tail.hip.h: a tile too dense for the staging -- or a look-back that gave up)
+                if (tv & TLV_TIMEOUT) return fail(c, NFC_ERR_DEVICE, "the fused tail's look-back timed out");
+                if (c->tail_tw_used <= 32) return fail(c, NFC_ERR_INTERNAL, "a tile of 2048 samples did not fit the fused tail's staging");
+                tail_note_dense(c);
+                decode_only = false;
+                attempt--;   // (not a capacity attempt; the tile length at least halves every time)
+                clean = false;
+                continue;
+            }
             const bool fit = ne <= c->cap_edges && ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1];
             if (fit && spec_failed(c)) {   // (decode.hip.h: dec_verify -- a decode tile's assumed incoming state was wrong)
                 if (respeculated++) return fail(c, NFC_ERR_INTERNAL, "the decode stage's three-launch form reported a speculation failure");

@@ -114,10 +114,18 @@ int enqueue_stages_behind(nfc_ctx *c, nfc_ctx::Submitted &b) {
     c->stamp_b = b.seq;
     c->cert_pending = false;
     size_capacities(c, b.n);
-    int rc = run_edges(c, b.n, 0u, b.g0);
-    if (!rc) rc = run_decode(c);   // (its last launch mirrors the state block and stamps it)
+    int rc;
+    if (c->tail_on) {   // (tail.hip.h: one persistent launch; the edge stage alone where the decoders cannot run in it)
+        const bool fused = tail_can_decode(c);
+        rc = run_tail(c, b.n, 0u, b.g0);
+        if (!rc && !fused) rc = run_decode(c, true);
+    } else {
+        rc = run_edges(c, b.n, 0u, b.g0);
+        if (!rc) rc = run_decode(c);   // (its last launch mirrors the state block and stamps it)
+    }
     if (rc) return rc;
     b.spec = c->dec_spec_now;
+    b.tail = c->tail_now;
     HIPCHK(c, hipEventRecord(c->ev_b[b.slot], c->st));
     b.b_enqueued = true;
     return NFC_OK;
@@ -247,12 +255,16 @@ int wait_batch(nfc_ctx *c) {
     memcpy(&summary, sa->totals + TOT_CERT, sizeof summary);
     Carry after = sa->carry;
     carry_apply_fin(after);
-    uint32_t ne, ns[2];
+    uint32_t ne, ns[2], tail_v = 0;
     memcpy(&ne, c->hs->totals + TOT_EDGES, 4);
     memcpy(ns, c->hs->totals + TOT_NSYM, 8);
     if (summary.n_fail != 0) regular = false, why = "a chunk was not certified";
     else if (summary.flagged || !sums_exact(after, (int)summary.emin, (int)summary.emax, summary.vtop)) regular = false, why = "sums not provably exact";
-    else if (!(ne <= c->cap_edges && ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1])) regular = false, why = "a capacity estimate was too small";
+    else if (b.tail && (tail_v = ([&] { uint32_t v; memcpy(&v, c->hs->totals + TOT_SPEC, 4); return v & (TLV_DENSE | TLV_TIMEOUT); })())) {
+        // (tail.hip.h: a tile's entries did not fit the staging -- the synchronous path repeats the batch with shorter tiles)
+        regular = false, why = "a tile too dense for the fused tail";
+        if (tail_v & TLV_DENSE) tail_note_dense(c);
+    } else if (!(ne <= c->cap_edges && ns[0] + 2 <= c->cap_sym[0] && ns[1] + 2 <= c->cap_sym[1])) regular = false, why = "a capacity estimate was too small";
     else if (b.spec) {   // (decode.hip.h: dec_verify's verdict on the speculative decode of THIS batch, in the mirror its last launch wrote)
         uint32_t v;
         memcpy(&v, c->hs->totals + TOT_SPEC, 4);

@@ -92,9 +92,7 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
         slots = std::min<uint64_t>(slots, std::max<uint64_t>(256, ((uint64_t)1 << 30) / ((uint64_t)12 * (uint64_t)c->L)));
         // (the lean kernel walks whole supersteps of lean_k steps: a chunk that is not a multiple of them ends on slow single steps;
         // the workgroup kernel whole rounds of four)
-        // (... whole PAIRS of rounds with two rounds of samples asked for ahead, wg_d == 2)
-        const int stp = c->wg_now ? wg_round_samples(c->wg_nr) * ((c->wg_d == 2 && c->wg_nr == 4 && c->P.input_kind == NFC_IN_IQ_F32) ? 2 : 1)
-                                  : 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
+        const int stp = c->wg_now ? wg_round_samples(c->wg_nr) : 64 * c->rows_per_step * ((c->lean && !c->gring) ? c->lean_k : 1);
         uint64_t want = ((uint64_t)n + slots - 1) / slots;
         want = (want + stp - 1) / stp * stp;
         c->C = (int)std::max<uint64_t>(want, (uint64_t)c->C_min);
@@ -112,7 +110,8 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     RowCut cut = equal_cut(n, (uint32_t)c->C, cus);
     const uint32_t slots_now = (uint32_t)(low_on_device ? c->wg_slots_ahead : c->wg_slots);   // (as the chunk length was chosen above)
     const uint32_t R = slots_now / cus;   // rows of a full wave: workgroups per CU
-    if (c->wg_rowbal && c->wg_now && !c->P.chunk_samples && (!low_on_device || c->rowbal_ahead) && c->fine_left == 0 && slots_now == R * cus &&
+    // (the factors were measured on a 256-CU MI355X -- same-call A/Bs on three boxes, DESIGN.md 5.1c: on any other device the cut is equal)
+    if (c->wg_rowbal && (c->n_cus == 256 || c->rowbal_set) && c->wg_now && !c->P.chunk_samples && !low_on_device && c->fine_left == 0 && slots_now == R * cus &&
         R >= 2 && R <= 4) {
         const uint32_t rs = (uint32_t)wg_round_samples(c->wg_nr);
         // (where the equal cut's chunks keep their planes in the LDS beside the ring, the longest chunk's must still fit: launch_wg)
@@ -294,26 +293,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             A.dbg_clk = c->d_certinfo.as<unsigned long long>();
         }
         c->wg_bulk_now = c->wg_bulk;   // (one batch at a time: nothing else wants the CU's LDS)
-        // The workgroup kernel can leave the edge stage's aggregates behind (wg_chunk_edge_aggs): the planes at the batch's own origin, a chunk of at most EW_SUPER writer tiles, few enough tiles for the writer's own
-        // prefix fold.  They stand while pass 0 stands: a re-run rewrites planes, and the edge stage's own reduce pass runs then.
-        c->eagg_ready = false;
-        {
-            const uint32_t sw = (uint32_t)c->C / 64u, tps = (sw + EW_WORDS - 1) / EW_WORDS;
-            if (c->eagg && !c->rowbal_now && lean && c->wg_now && base == 0 && (uint32_t)c->C % 128u == 0 && tps <= (uint32_t)EW_SUPER &&
-                (size_t)nch * tps <= c->own_prefix_max) {
-                HIPCHK(c, c->d_eaggs.ensure(((size_t)nch * (tps + 1) + 2) * sizeof(EdgeAgg)));
-                A.eagg_tiles = c->d_eaggs.p;
-                A.eagg_supers = c->d_eaggs.as<EdgeAgg>() + (size_t)nch * tps + 1;
-                A.eagg_tps = tps;
-                A.eagg_magic = c->mx > 1 ? (uint32_t)(0x100000000ull / (uint64_t)c->mx) : 0xFFFFFFFFu;
-                c->eagg_ready = true;
-                c->eagg_sw = sw;
-                c->eagg_tps = tps;
-                c->eagg_nch = nch;
-            }
-        }
         launch_threshold_kind(c, A, nch, lean);
-        A.eagg_tiles = A.eagg_supers = nullptr;   // (pass 0 only)
         if (dbg_clk) {
             std::vector<unsigned long long> h((size_t)nch * 4);
             HIPCHK(c, hipStreamSynchronize(c->st));
@@ -439,7 +419,6 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                     (uint64_t)summary.n_fail * 64u > (uint64_t)nch) {
                     *recut_out = true;
                     A.ver_zero = 0;
-                    c->eagg_ready = false;
                     return NFC_OK;
                 }
                 HIPCHK(c, hipMemcpy(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost));
@@ -476,7 +455,6 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             if (failing.empty()) break;
             first_round = false;
             A.ver_zero = 0;
-            c->eagg_ready = false;   // (planes are about to be rewritten: the edge stage reduces them itself)
             // A chunk right behind one that is re-run now and that did not give up itself is NOT re-run in this round: its own
             // evaluation may well be sound -- what failed is the comparison with a predecessor whose summary was worthless -- and
             // from the state resolved now it would only be evaluated against that worthless summary again.  It stays pending
@@ -597,7 +575,6 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
 
     A.ver_zero = 0;
     *need_seq_out = need_seq;
-    if (need_seq) c->eagg_ready = false;
     if (!need_seq) {
         // the end-of-batch ring was resolved beside the last certification unless chunks were re-run after it
         if (passes > 1 || nch == 1)

@@ -44,6 +44,9 @@
 #include "scan.hip.h"
 #include "small.hip.h"
 #include "threshold.hip.h"
+#ifdef NFC_TEST_HOOKS
+#include "tail.hip.h"   // the fused tail: built, measured, not adopted -- the test build keeps it exact
+#endif
 #include "threshold_lean.hip.h"
 #include "threshold_wg.hip.h"
 #include "tx.hip.h"
@@ -61,16 +64,14 @@ using namespace nfc;
 // ===========================================================================
 namespace {
 // the instantiation of k_threshold_wg a context launches (for the occupancy query and the LDS attribute)
-const void *wg_kernel_of(int kind, int nr, int d) {
-    if (kind == NFC_IN_IQ_F32 && nr == 4 && d == 2) return (const void *)k_threshold_wg<IN_IQ_F32, 4, 2>;
-#define WGK(K) (nr == 8 ? (const void *)k_threshold_wg<K, 8> : nr == 6 ? (const void *)k_threshold_wg<K, 6> : (const void *)k_threshold_wg<K, 4>)
+const void *wg_kernel_of(int kind, int nr) {
+    // (six instantiations: four rows per step for every input kind, eight for the two kinds a long-window capture arrives in)
     switch (kind) {
-    case NFC_IN_IQ_F32: return WGK(IN_IQ_F32);
-    case NFC_IN_ENV_F32: return WGK(IN_ENV_F32);
-    case NFC_IN_REAL_F32_SQ: return WGK(IN_REAL_F32_SQ);
-    default: return WGK(IN_I16_SQ);
+    case NFC_IN_IQ_F32: return nr == 8 ? (const void *)k_threshold_wg<IN_IQ_F32, 8> : (const void *)k_threshold_wg<IN_IQ_F32, 4>;
+    case NFC_IN_ENV_F32: return nr == 8 ? (const void *)k_threshold_wg<IN_ENV_F32, 8> : (const void *)k_threshold_wg<IN_ENV_F32, 4>;
+    case NFC_IN_REAL_F32_SQ: return (const void *)k_threshold_wg<IN_REAL_F32_SQ, 4>;
+    default: return (const void *)k_threshold_wg<IN_I16_SQ, 4>;
     }
-#undef WGK
 }
 }  // namespace
 
@@ -122,12 +123,18 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     C = std::max(C, 2 * c->L);
     C = std::max(C, c->mx + 2);
     c->rows_per_step = 4;
-    c->use_small = getenv("NFC_NO_SMALL") ? 0 : 1;
-    // Every switch is read here, once: nothing on the per-launch path looks at the environment.  README.md lists them all.
-    // The switches that make a context misbehave on purpose or talk (test hooks and diagnostics) only exist in the TEST build
-    // (-DNFC_TEST_HOOKS: usrp_nfc_amd/libnfc_amd_hooks.so, build.py) -- an environment inherited by a production process cannot
-    // reach them; what is left below are tuning switches, which select between paths that are all exact.
+    // The PRODUCT build reads no environment variable: which kernels a deployed process runs does not depend on what it inherited.
+    // Every switch below -- the ones that make a context misbehave on purpose or talk, and the ones that select between kernel
+    // forms that are all exact (the A/Bs of DESIGN.md, the tests that keep the less travelled forms exact) -- exists in the TEST
+    // build only (-DNFC_TEST_HOOKS: usrp_nfc_amd/libnfc_amd_hooks.so, build.py), and is read here, once.  README.md lists them.
 #ifdef NFC_TEST_HOOKS
+#define NFC_ENV(name) getenv(name)
+#else
+#define NFC_ENV(name) ((const char *)nullptr)
+#endif
+    c->use_small = NFC_ENV("NFC_NO_SMALL") ? 0 : 1;
+#ifdef NFC_TEST_HOOKS
+    if (const char *e = getenv("NFC_TAIL")) c->tail_on = atoi(e) != 0;   // 1: the fused tail (tail.hip.h) instead of the five launches
     c->dbg_bad_launch = getenv("NFC_DEBUG_BAD_LAUNCH") != nullptr;
     c->dbg_redo_submitted = getenv("NFC_DEBUG_REDO_SUBMITTED") != nullptr;
     c->dbg_any = getenv("NFC_DEBUG") != nullptr;
@@ -138,32 +145,28 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         c->dbg_clk_path = e;
     }
 #endif
-    c->dbg_no_submit_ahead = getenv("NFC_NO_SUBMIT_AHEAD") != nullptr;
-    if (const char *e = getenv("NFC_WG")) c->wg = atoi(e) != 0;
-    if (const char *e = getenv("NFC_WG_ROUNDS")) c->wg_rounds = std::max(1, atoi(e));
-    if (const char *e = getenv("NFC_WG_D")) c->wg_d = atoi(e) >= 2 ? 2 : 1;
-    if (const char *e = getenv("NFC_WG_BULK")) c->wg_bulk = atoi(e) != 0;
-    if (const char *e = getenv("NFC_WG_RERUN")) c->wg_rerun = atoi(e) != 0;
-    if (const char *e = getenv("NFC_LEAN")) c->lean = atoi(e) != 0;
+    c->dbg_no_submit_ahead = NFC_ENV("NFC_NO_SUBMIT_AHEAD") != nullptr;
+    if (const char *e = NFC_ENV("NFC_WG")) c->wg = atoi(e) != 0;
+    if (const char *e = NFC_ENV("NFC_WG_ROUNDS")) c->wg_rounds = std::max(1, atoi(e));
+    if (const char *e = NFC_ENV("NFC_WG_BULK")) c->wg_bulk = atoi(e) != 0;
+    if (const char *e = NFC_ENV("NFC_WG_RERUN")) c->wg_rerun = atoi(e) != 0;
+    if (const char *e = NFC_ENV("NFC_LEAN")) c->lean = atoi(e) != 0;
     c->lean_k = 0;        // chosen below from the occupancy the LDS ring allows, unless set here
     c->lean_rounds = 0;
-    if (const char *e = getenv("NFC_LEAN_K")) c->lean_k = atoi(e) <= 2 ? 2 : 4;   // (steps ahead: the two instantiations)
-    if (const char *e = getenv("NFC_LEAN_ROUNDS")) c->lean_rounds = std::max(1, atoi(e));
-    if (const char *e = getenv("NFC_LEAN_GFAC")) c->lean_gfac = (float)atof(e);
-    if (const char *e = getenv("NFC_LEAN_GMIN")) c->lean_gmin = (float)atof(e);
-    if (const char *e = getenv("NFC_OWN_PREFIX_MAX")) c->own_prefix_max = (uint32_t)strtoul(e, nullptr, 10);
-    if (const char *e = getenv("NFC_DEC_SPEC")) c->dec_spec = atoi(e) != 0;
-    if (const char *e = getenv("NFC_SPIN_WAIT")) c->spin_wait = atoi(e) != 0;
-    if (const char *e = getenv("NFC_WG_ROWBAL")) {   // 0: chunks of equal length (host_threshold.h: the cut by dispatch row); a,b,c: the rows' factors
+    if (const char *e = NFC_ENV("NFC_LEAN_ROUNDS")) c->lean_rounds = std::max(1, atoi(e));
+    if (const char *e = NFC_ENV("NFC_LEAN_GFAC")) c->lean_gfac = (float)atof(e);
+    if (const char *e = NFC_ENV("NFC_LEAN_GMIN")) c->lean_gmin = (float)atof(e);
+    if (const char *e = NFC_ENV("NFC_OWN_PREFIX_MAX")) c->own_prefix_max = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char *e = NFC_ENV("NFC_DEC_SPEC")) c->dec_spec = atoi(e) != 0;
+    if (const char *e = NFC_ENV("NFC_SPIN_WAIT")) c->spin_wait = atoi(e) != 0;
+    if (const char *e = NFC_ENV("NFC_WG_ROWBAL")) {   // 0: chunks of equal length (host_threshold.h: the cut by dispatch row); a,b,c: the rows' factors
         double f[3];
         f[1] = f[2] = 1.0;
         if (sscanf(e, "%lf,%lf,%lf", &f[0], &f[1], &f[2]) >= 2 && f[0] > 0.5 && f[0] < 1.5 && f[1] > 0.5 && f[1] < 1.5 && f[2] > 0.5 && f[2] < 1.5)
             memcpy(c->rowbal_f[0], f, sizeof f), c->rowbal_set = true;
         else c->wg_rowbal = atoi(e) != 0;
     }
-    if (const char *e = getenv("NFC_WG_ROWBAL_AHEAD")) c->rowbal_ahead = atoi(e) != 0;
-    if (const char *e = getenv("NFC_EAGG")) c->eagg = atoi(e) != 0;   // 1: k_threshold_wg leaves the edge stage's aggregates, no k_edge_reduce (measured: no gain, host_context.h)
-    if (const char *e = getenv("NFC_DEC_RUNIN")) {   // run-in edges per decode tile: 512, 1024 or 2048
+    if (const char *e = NFC_ENV("NFC_DEC_RUNIN")) {   // run-in edges per decode tile: 512, 1024 or 2048
         const int v = atoi(e);
         c->dec_runin = v >= 2048 ? 8 : (v >= 1024 ? 4 : 2);
     }
@@ -179,7 +182,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     // An LDS ring beyond 12 KB leaves a SIMD with fewer than four waves: such windows keep the ring in global memory
     // (a delay line read one step ahead), and the registers set the occupancy again.
     c->gring_ok = (size_t)c->Lpad * c->lds_per_slot > 12 * 1024 && c->L >= 2 * STEP;
-    if (const char *e = getenv("NFC_RING")) {
+    if (const char *e = NFC_ENV("NFC_RING")) {
         if (strcmp(e, "global") == 0 && c->L >= 2 * STEP) c->gring_ok = c->gring_force = 1;
         else if (strcmp(e, "lds") == 0) c->gring_ok = 0;
     }
@@ -204,7 +207,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         for (int k = 0; k < 64; k += b) c->selmask |= 1ull << k;
     }
     c->eps = 0.01f;  // certification margin of the speculative pass, relative to the window sum
-    if (const char *e = getenv("NFC_EPS")) c->eps = (float)atof(e);
+    if (const char *e = NFC_ENV("NFC_EPS")) c->eps = (float)atof(e);
     c->i16_scale = p->i16_scale > 0.f ? p->i16_scale : -1.0f;   // (0: GNU Radio's wavfile_source normalisation, sample / 32767; threshold.hip.h: i16_to_float)
     static const size_t bps[4] = {8, 4, 4, 2};
     c->in_bytes_per_sample = bps[p->input_kind];
@@ -240,7 +243,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         // summarised, its summary written) is paid half as often, and two waves already keep a SIMD's issue slots busy.
         if (!c->lean_k) c->lean_k = 4;
         c->lean_slots = std::min(c->wave_slots, prop.multiProcessorCount * 8);
-        if (const char *e = getenv("NFC_LEAN_WAVES")) c->lean_slots = std::min(c->wave_slots, prop.multiProcessorCount * 4 * std::max(1, atoi(e)));
+        if (const char *e = NFC_ENV("NFC_LEAN_WAVES")) c->lean_slots = std::min(c->wave_slots, prop.multiProcessorCount * 4 * std::max(1, atoi(e)));
         if (!c->lean_rounds) c->lean_rounds = std::max(1, (int)(0.4 * c->L / (256.0 * c->lean_k)));
         c->wave_slots_g = prop.multiProcessorCount * 20;   // VGPR-bound: five waves per SIMD
         // LDS the lean kernel's resident waves hold per CU: a batch is only run ahead of its predecessor's edge / decode stages
@@ -249,28 +252,28 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         c->ahead_lds_per_cu = c->lean_lds_per_cu;
         // the workgroup kernel: one chunk per 256-thread workgroup, as many resident per CU as LDS and registers admit
         c->wg_lds_base = (size_t)c->Lpad * 4 + WG_SHARED_BYTES;
-        // rows per step: the largest of 8 / 6 / 4 that leaves a superstep of at least two rounds within 0.8 windows (measured at
-        // av_window 2000: six rows with one-round supersteps lose to four rows with two; at 10000 eight rows gain 2 %); a round
-        // (four steps) must fit the window, max_len must lie within one step
-        c->wg_nr = 4;
-        for (int v : {6, 8})
-            if (0.8 * c->L / (double)wg_round_samples(v) >= 1.5) c->wg_nr = v;
-        if (const char *e = getenv("NFC_WG_NR")) {
+        // rows per step: eight where that leaves a superstep of at least two rounds within 0.8 windows (measured: at av_window 10000
+        // eight rows gain 2 % over four; at 2000 more rows with one-round supersteps lose to four rows with two), else four; a round
+        // (four steps) must fit the window, max_len must lie within one step.  Eight rows are instantiated for fc32 IQ and the
+        // float32 envelope -- what a capture at a rate that wants such a window arrives as.
+        const bool nr8_kind = p->input_kind == NFC_IN_IQ_F32 || p->input_kind == NFC_IN_ENV_F32;
+        c->wg_nr = (nr8_kind && 0.8 * c->L / (double)wg_round_samples(8) >= 1.5) ? 8 : 4;
+        if (const char *e = NFC_ENV("NFC_WG_NR")) {
             const int v = atoi(e);
-            if ((v == 4 || v == 6 || v == 8) && c->L >= wg_round_samples(v)) c->wg_nr = v;
+            if ((v == 4 || (v == 8 && nr8_kind)) && c->L >= wg_round_samples(v)) c->wg_nr = v;
         }
         // (+ the staging of the plane words: a ring of 2 FR rounds; a whole chunk's where the LDS has room, launch_wg)
         c->wg_lds = c->wg_lds_base + wg_stage_bytes(c->wg_nr, 2 * wg_flush_rounds(c->wg_nr));
         c->wg_ok = c->mx <= 64 * c->wg_nr - 2 && c->L >= wg_round_samples(c->wg_nr) && c->wg_lds <= 160 * 1024;
         if (c->wg_ok) {
-            const void *kern = wg_kernel_of(p->input_kind, c->wg_nr, c->wg_d);
+            const void *kern = wg_kernel_of(p->input_kind, c->wg_nr);
             if (c->wg_lds > 64 * 1024) CRT(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->wg_lds));
             int per_cu_wg = 0;
             CRT(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wg, kern, 256, c->wg_lds));
             const int per_cu_max = per_cu_wg;
             if (per_cu_wg < 1) c->wg_ok = 0;   // (the kernel does not fit a CU with this ring: the one-wave kernels)
             per_cu_wg = std::max(1, std::min(4, per_cu_wg));   // (measured: four resident workgroups per CU -- four waves per SIMD -- beat five and three)
-            if (const char *e = getenv("NFC_WG_PER_CU")) per_cu_wg = std::max(1, std::min(per_cu_max, atoi(e)));
+            if (const char *e = NFC_ENV("NFC_WG_PER_CU")) per_cu_wg = std::max(1, std::min(per_cu_max, atoi(e)));
             c->wg_slots = prop.multiProcessorCount * per_cu_wg;
             // the most dynamic LDS a workgroup may ask for with per_cu_wg of them still resident per CU: what a chunk's planes may
             // take when they are kept until the chunk is done (one batch at a time only: launch_wg)
@@ -296,15 +299,15 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             // Measured in round 5, configs[3], with TWO per CU for batches submitted ahead (56 KB left; the kernel alone loses 3 % to it,
             // 1.589 -> 1.637 ms per launch; one per CU: 2.31): 1.87-2.02 ms per batch against 1.92 one batch at a time -- the kernel
             // stretches to 1.69-2.0 ms beside the other stages, which are 0.35 ms of a 1.95 ms step to begin with.  Not taken.)
-            if (const char *e = getenv("NFC_WG_PER_CU_AHEAD")) per_cu_ahead = std::max(1, std::min(per_cu_max, atoi(e)));
+            if (const char *e = NFC_ENV("NFC_WG_PER_CU_AHEAD")) per_cu_ahead = std::max(1, std::min(per_cu_max, atoi(e)));
             c->wg_slots_ahead = prop.multiProcessorCount * per_cu_ahead;
             // (what a batch submitted ahead holds of a CU's LDS is this kernel's, not the lean kernel's: host_submit.h, submit_fast_ok)
             if (c->wg_ok && c->wg && c->lean) c->ahead_lds_per_cu = c->wg_lds * (size_t)per_cu_ahead;
             // the longest superstep (rounds): the kernel lengthens and shortens its supersteps by the head-room it sees between the
             // samples and the thresholds; this caps them
             if (!c->wg_rounds) c->wg_rounds = 8;
-            if (const char *e = getenv("NFC_CHUNK_ADAPT")) c->fine_adapt = atoi(e) != 0;
-            if (const char *e = getenv("NFC_CHUNK_MULT")) c->fine_mult = std::max(1, std::min(16, atoi(e)));
+            if (const char *e = NFC_ENV("NFC_CHUNK_ADAPT")) c->fine_adapt = atoi(e) != 0;
+            if (const char *e = NFC_ENV("NFC_CHUNK_MULT")) c->fine_mult = std::max(1, std::min(16, atoi(e)));
         }
     }
     CRT(hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking));
@@ -331,20 +334,12 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_ENV_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_REAL_F32_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold<IN_I16_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_IQ_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_ENV_F32, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_REAL_F32_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CRT(hipFuncSetAttribute((const void *)k_threshold_lean<IN_I16_SQ, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -430,7 +425,7 @@ void nfc_destroy(nfc_ctx *c) {
                      &c->d_touched[1], &c->d_info[0], &c->d_info[1], &c->d_ver, &c->d_cflags, &c->d_list, &c->d_ecode, &c->d_epos, &c->d_eidx, &c->d_states, &c->d_sym[0], &c->d_sym[1],
                      &c->d_bits[0], &c->d_bits[1], &c->d_pending[0][0], &c->d_pending[0][1],
                      &c->d_pending[1][0], &c->d_pending[1][1], &c->d_partials2, &c->d_close_end[0], &c->d_close_end[1], &c->d_close_idx[0], &c->d_close_idx[1],
-                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_spec, &c->d_stage_bits[0], &c->d_stage_bits[1], &c->d_stage_cb[0], &c->d_stage_cb[1], &c->d_stage_ci[0], &c->d_stage_ci[1], &c->d_stage_q[0], &c->d_stage_q[1], &c->d_stage_own, &c->d_gring, &c->d_pack, &c->d_gvtop, &c->d_seqout, &c->d_eaggs};
+                     &c->d_partials, &c->d_aggs, &c->d_faggs, &c->d_spec, &c->d_stage_bits[0], &c->d_stage_bits[1], &c->d_stage_cb[0], &c->d_stage_cb[1], &c->d_stage_ci[0], &c->d_stage_ci[1], &c->d_stage_q[0], &c->d_stage_q[1], &c->d_stage_own, &c->d_gring, &c->d_pack, &c->d_gvtop, &c->d_seqout, &c->d_tail_st, &c->d_tail_ticket, &c->d_bits_alt[0], &c->d_bits_alt[1]};
     for (DevBuf *b : all) b->release();
     if (c->hs) (void)hipHostFree(c->hs);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -534,6 +529,7 @@ int nfc_push_edges(nfc_ctx *c, const nfc_edge *host_edges, size_t n64) {
         HIPCHK(c, hipMemcpyAsync(c->d_ecode.p, code.data(), (size_t)n * 2, hipMemcpyHostToDevice, c->st));
     }
     HIPCHK(c, hipMemcpyAsync(dT(c) + TOT_EDGES, &n, 4, hipMemcpyHostToDevice, c->st));
+    c->tail_now = false;
     const int rc = run_decode(c);   // k_dec_spec (or k_dec_reduce -> k_dec_apply) -> k_frame_write -> k_pkt_finish (mirrors the state block)
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->st));
@@ -1307,6 +1303,14 @@ extern "C" int nfc_debug_tail_prof(unsigned long long *out, int reset) {
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(nfc::g_tail_prof)) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) return -1;
     }
     return 0;
+}
+#endif
+#ifdef NFC_TAIL_PROF
+extern "C" int nfc_debug_lb_tries(int reset) {
+    uint32_t v = 0, z = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(nfc::g_lb_tries), 4) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(nfc::g_lb_tries), &z, 4) != hipSuccess) return -1;
+    return (int)v;
 }
 #endif
 #ifdef NFC_GEN_PROF

@@ -137,11 +137,6 @@ struct ThrArgs {
     int32_t ver_zero;              // every version byte is 0 (the certification right behind pass 0): its launches need not load them
     int32_t wg_stage_rounds;       // k_threshold_wg: rounds of plane words its LDS staging holds per plane (threshold_wg.hip.h; launch_wg sets it)
     unsigned long long *dbg_clk;   // debugging aid (NFC_DEBUG_CLK): per chunk four s_memtime stamps -- start, incoming state ready, loop done, end
-    // k_threshold_wg also leaves the EDGE stage's first-level aggregates (edges.hip.h: EdgeAgg per 512-word tile of the chunk and per
-    // chunk) when these are set: the stage's own reduce pass -- the first read of the planes, a launch -- is then not needed
-    // (threshold_wg.hip.h: wg_chunk_edge_aggs; host_threshold.h decides).  eagg_tps: tiles per chunk, eagg_magic: floor(2^32 / max_len)
-    void *eagg_tiles, *eagg_supers;
-    uint32_t eagg_tps, eagg_magic;
     // Chunks of UNEQUAL length by dispatch row (round 5; chunk_span below).  The k-th workgroup a CU is given is the k-th slowest
     // (measured: the lives of k_threshold_wg's workgroups fall in four steps by block index -- 0.965, 0.985, 1.010, 1.042 of the mean
     // for blocks 0-255, 256-511, ... --, and the launch is as long as its slowest workgroup): the chunks of row r are row_len[r] samples
@@ -1282,6 +1277,17 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     if (!ok && sum) atomicAdd(&sum->n_fail, 1u);
     if (dbg) dbg[c] = CertInfo{d, mt.eps * mt.min_ss, mt.all_robust, (uint32_t)low_ok};
 }
+// The first certification of a batch depends on the threshold kernel only and nothing of the later stages depends on it, so it shares
+// a launch with the edge stage's writer: `blocks` extra workgroups certify (the last of them resolves the end-of-batch state).
+struct CertLaunch {
+    ThrArgs A;
+    uint8_t *cert;
+    float *ring_next;
+    Carry *carry;
+    CertSummary *sum;
+    uint32_t blocks;
+};
+
 // the certification's grid: a workgroup per pending chunk, and one more that resolves the end-of-batch state
 inline uint32_t cert_grid(uint32_t pending) { return pending + 1u; }
 __global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertInfo *dbg, float *ring_next, Carry *carry,

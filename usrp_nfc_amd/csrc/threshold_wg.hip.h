@@ -127,19 +127,16 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 #define WG_ACF "a12", "a13", "a14", "a15"
 template <int KIND, int NR>
 __device__ __forceinline__ void wg_load_step(uint32_t voff, const char *base) {
-    static_assert(NR == 4 || NR == 6 || NR == 8, "rows per step");
+    static_assert(NR == 4 || NR == 8, "rows per step");
     if constexpr (KIND == IN_IQ_F32) {
         if constexpr (NR == 4) WG_LD4("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", 512, WG_A03, WG_A47);
-        if constexpr (NR == 6) WG_LD6("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", "a[8:9]", "a[10:11]", 512, WG_A03, WG_A47, WG_A8B);
         if constexpr (NR == 8)
             WG_LD8("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", "a[8:9]", "a[10:11]", "a[12:13]", "a[14:15]", 512, WG_A03, WG_A47, WG_A8B, WG_ACF);
     } else if constexpr (KIND == IN_I16_SQ) {
         if constexpr (NR == 4) WG_LD4("global_load_sshort", "a0", "a1", "a2", "a3", 128, WG_A03);
-        if constexpr (NR == 6) WG_LD6("global_load_sshort", "a0", "a1", "a2", "a3", "a4", "a5", 128, WG_A03, "a4", "a5");
         if constexpr (NR == 8) WG_LD8("global_load_sshort", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", 128, WG_A03, WG_A47);
     } else {
         if constexpr (NR == 4) WG_LD4("global_load_dword", "a0", "a1", "a2", "a3", 256, WG_A03);
-        if constexpr (NR == 6) WG_LD6("global_load_dword", "a0", "a1", "a2", "a3", "a4", "a5", 256, WG_A03, "a4", "a5");
         if constexpr (NR == 8) WG_LD8("global_load_dword", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", 256, WG_A03, WG_A47);
     }
 }
@@ -171,7 +168,6 @@ __device__ __forceinline__ void wg_take(float (&x)[NR], float i16_scale) {
     } else {
         float w[NR];
         WG_RD4("s_waitcnt vmcnt(0)\n\t", "a0", "a1", "a2", "a3", 0);
-        if constexpr (NR == 6) WG_RD2("", "a4", "a5", 4);
         if constexpr (NR == 8) WG_RD4("", "a4", "a5", "a6", "a7", 4);
 #pragma unroll
         for (int j = 0; j < NR; j++) {
@@ -186,34 +182,6 @@ __device__ __forceinline__ void wg_take(float (&x)[NR], float i16_scale) {
         }
     }
 }
-// Two rounds of samples asked for ahead (IQ input, four rows per step): a second set of registers, a[8 .. 15], and a wait that
-// lets the younger request stay in flight.  A round issues exactly four loads after its take (and, every few rounds in one wave,
-// the two stores of flush_block): at the take of round r the operations still in flight are the loads of round r, the loads of
-// round r + 1 and perhaps stores; loads complete in order among themselves, so "at most four left" means the loads of round r
-// are in, whatever the stores do.
-template <int SET>
-__device__ __forceinline__ void wg_load_step_iq4(uint32_t voff, const char *base) {
-    if constexpr (SET == 0) WG_LD4("global_load_dwordx2", "a[0:1]", "a[2:3]", "a[4:5]", "a[6:7]", 512, WG_A03, WG_A47);
-    else WG_LD4("global_load_dwordx2", "a[8:9]", "a[10:11]", "a[12:13]", "a[14:15]", 512, WG_A8B, WG_ACF);
-}
-template <int SET, bool ALL>
-__device__ __forceinline__ void wg_take_iq4(float (&x)[4], float) {
-    float w[8];
-    if constexpr (SET == 0) {
-        if constexpr (ALL) WG_RD4("s_waitcnt vmcnt(0)\n\t", "a0", "a1", "a2", "a3", 0);
-        else WG_RD4("s_waitcnt vmcnt(4)\n\t", "a0", "a1", "a2", "a3", 0);
-        WG_RD4("", "a4", "a5", "a6", "a7", 4);
-    } else {
-        if constexpr (ALL) WG_RD4("s_waitcnt vmcnt(0)\n\t", "a8", "a9", "a10", "a11", 0);
-        else WG_RD4("s_waitcnt vmcnt(4)\n\t", "a8", "a9", "a10", "a11", 0);
-        WG_RD4("", "a12", "a13", "a14", "a15", 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float a = w[2 * j] * w[2 * j], b = w[2 * j + 1] * w[2 * j + 1];
-        x[j] = a + b;
-    }
-}
 // the dwords of NR masks into lanes LANE0 .. LANE0 + 2 NR - 1 of pk
 #define PLANE_PUT4(pk, m, I0, LANE0)                                                                                                       \
     asm volatile("s_nop 2\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %5+1\n\tv_writelane_b32 %0, %3, %5+2\n\tv_writelane_b32 %0, %4, %5+3" \
@@ -222,7 +190,6 @@ __device__ __forceinline__ void wg_take_iq4(float (&x)[4], float) {
 template <int NR>
 __device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (&m)[NR], std::integral_constant<int, 0>) {
     PLANE_PUT8(pk, m, 0);
-    if constexpr (NR == 6) PLANE_PUT4(pk, m, 4, 8);
     if constexpr (NR == 8) {
         const unsigned long long m2[4] = {m[4], m[5], m[6], m[7]};
         PLANE_PUT8(pk, m2, 8);
@@ -231,117 +198,14 @@ __device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (
 template <int NR>
 __device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (&m)[NR], std::integral_constant<int, 1>) {   // ... from lane 2 NR on
     PLANE_PUT8(pk, m, 2 * NR);
-    if constexpr (NR == 6) PLANE_PUT4(pk, m, 4, 2 * NR + 8);
     if constexpr (NR == 8) {
         const unsigned long long m2[4] = {m[4], m[5], m[6], m[7]};
         PLANE_PUT8(pk, m2, 2 * NR + 8);
     }
 }
 
-// The edge stage's first-level aggregates of a chunk (edges.hip.h), by the workgroup that has just classified it: one EdgeAgg per
-// 512-word tile of the chunk (the writer's tiles are cut per chunk then: EdgeArgs.sw / tps) and one for the chunk.  The stage's own
-// reduce pass was the first read of the 25 MB of planes and a launch of its own (11 us + a launch gap per step on configs[1]);
-// here the words are still in the workgroup's LDS (a chunk whose planes were staged whole: threshold_wg.hip.h, bulk) or come back
-// out of the L2 they were stored to a moment ago.  A wave takes HALF a tile at a time (a lane four consecutive words), the waves
-// go side by side, one barrier joins them.  What a chunk cannot know is the sample BEFORE its first one (another workgroup's, at
-// the same time): its aggregates are those of its words with no change at the chunk's first sample, and the chunk's `sum` carries
-// val + 1 of its first and last sample in its top bits -- the writer's prefix fold puts the change between two chunks in
-// (edges.hip.h: fold_packed_super).
-// (Not inlined, small, and few registers: cold code at a kernel's end is fetched as it runs -- a first form, unrolled over the tiles,
-// was 15 KB and cost the kernel 10 us; one with eight words per lane took 100 vector registers, and a callee's count is its caller's.)
-constexpr int WG_HT_ITEMS = 4;                         // words per lane
-constexpr int WG_HT_WORDS = 64 * WG_HT_ITEMS;          // words per half tile
-static_assert(2 * WG_HT_WORDS == EW_WORDS, "two half tiles per writer tile");
-template <class Get>
-__device__ __forceinline__ void wg_chunk_edge_aggs_from(const EdgeArgs &E, uint32_t chunk, size_t w_chunk, size_t w_stop, uint32_t last, uint32_t tps,
-                                                        EdgeAgg *tiles, EdgeAgg *supers, EdgeAgg *lds, Get get) {
-    const EdgeAggOp op{E.mx, E.mx_magic};
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nht = 2u * tps;
-#pragma unroll 1
-    for (uint32_t h = (uint32_t)wave; h < 2u * (uint32_t)EW_SUPER; h += (uint32_t)WG_WAVES) {   // (uniform per wave)
-        EdgeAgg inc = op.identity();
-        if (h < nht) {
-            const size_t w = w_chunk + (size_t)h * WG_HT_WORDS + (size_t)lane * WG_HT_ITEMS;
-            uint64_t ng[WG_HT_ITEMS], ps[WG_HT_ITEMS], m[WG_HT_ITEMS];
-#pragma unroll
-            for (int i = 0; i < WG_HT_ITEMS; i++) {
-                const bool ok = w + i < w_stop;
-                ng[i] = ok ? get(0, (uint32_t)(w + i - w_chunk)) : 0ull;
-                ps[i] = ok ? get(1, (uint32_t)(w + i - w_chunk)) : 0ull;
-            }
-            uint64_t pn = 0ull, pp = 0ull;   // (the chunk's first word: nobody knows, and its bit 0 is cleared below)
-            if (w > w_chunk && w <= w_stop) {
-                pn = get(0, (uint32_t)(w - 1 - w_chunk)) >> 63;
-                pp = get(1, (uint32_t)(w - 1 - w_chunk)) >> 63;
-            }
-#pragma unroll
-            for (int i = 0; i < WG_HT_ITEMS; i++) {
-                m[i] = (w + i < w_stop) ? E.change_mask_of(w + i, ng[i], ps[i], pn, pp) : 0ull;
-                pn = ng[i] >> 63;
-                pp = ps[i] >> 63;
-            }
-            if (h == 0u && lane == 0) m[0] &= ~1ull;
-            bool may = false;
-#pragma unroll
-            for (int i = 0; i < WG_HT_ITEMS; i++) may = may || word_may_time_out(E, m[i]);
-            const bool inner = __any(may);
-            EdgeAgg agg = op.identity();
-#pragma unroll
-            for (int i = 0; i < WG_HT_ITEMS; i++) agg = op(agg, word_agg(E, (int32_t)((w + i) * 64), m[i], inner));
-            inc = wave_inclusive_with(op, agg);
-        }
-        if (lane == 63) lds[h] = inc;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        EdgeAgg tot = op.identity();
-#pragma unroll 1
-        for (uint32_t q = 0; q < tps; q++) {
-            const EdgeAgg t = op(lds[2 * q], lds[2 * q + 1]);
-            tiles[(size_t)chunk * tps + q] = t;
-            tot = op(tot, t);
-        }
-        const uint32_t kl = (uint32_t)((size_t)(last >> 6) - w_chunk);
-        const uint64_t n0 = get(0, 0u), p0 = get(1, 0u), nl = get(0, kl), pl = get(1, kl);
-        const int fv = (n0 & 1ull) ? -1 : (int)(p0 & 1ull);
-        const int lv = ((nl >> (last & 63u)) & 1ull) ? -1 : (int)((pl >> (last & 63u)) & 1ull);
-        tot.sum = super_pack(tot.sum, fv, lv);
-        supers[chunk] = tot;
-    }
-}
-// lds: room for 2 EW_SUPER aggregates; every thread of the workgroup calls it.  pst (or NULL): the chunk's plane words in LDS, word k of
-// a plane at dwords 2 k, 2 k + 1 -- the pos plane pst_plane dwords behind the neg plane; NULL: from global memory, behind a barrier that
-// completes the plane stores.
-__device__ __noinline__ void wg_chunk_edge_aggs(const uint64_t *neg, const uint64_t *pos, uint32_t n, uint32_t skip, int32_t mx, uint32_t mx_magic, uint32_t chunk,
-                                                uint32_t m_chunk, uint32_t n1, uint32_t tps, EdgeAgg *tiles, EdgeAgg *supers, EdgeAgg *lds,
-                                                const lean_lds_u32 *pst, uint32_t pst_plane) {
-    EdgeArgs E;
-    E.neg = neg;
-    E.pos = pos;
-    E.n = n;
-    E.skip = skip;   // (samples before it belong to the fill phase: no changes there, edges.hip.h: change_mask_of)
-    E.mx = mx;
-    E.mx_magic = mx_magic;
-    E.dur_in = 0;
-    E.last_bit_in = 0;
-    E.state_in = 0;
-    const size_t w_chunk = (size_t)m_chunk / 64, w_stop = ((size_t)n1 + 63) / 64;   // the chunk's words: [w_chunk, w_stop)
-    if (pst) {
-        wg_chunk_edge_aggs_from(E, chunk, w_chunk, w_stop, n1 - 1u, tps, tiles, supers, lds, [pst, pst_plane](int pl, uint32_t k) -> uint64_t {
-            const lean_lds_u32 *q = pst + (pl ? pst_plane : 0u) + 2u * k;
-            return (uint64_t)q[0] | ((uint64_t)q[1] << 32);
-        });
-    } else {
-        wg_chunk_edge_aggs_from(E, chunk, w_chunk, w_stop, n1 - 1u, tps, tiles, supers, lds, [neg, pos, w_chunk](int pl, uint32_t k) -> uint64_t {
-            return (pl ? pos : neg)[w_chunk + k];
-        });
-    }
-}
-
-template <int KIND, int NR, int D = 1>
+template <int KIND, int NR>
 __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
-    static_assert(D == 1 || (D == 2 && NR == 4 && KIND == IN_IQ_F32), "two rounds ahead: IQ input, four rows per step");
     constexpr uint32_t STEPN = 64u * NR;
     constexpr int WG_ROUND = wg_round_samples(NR);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -369,13 +233,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // while the state the chunk starts from is put together below -- the first take found them 2-3 us away otherwise, once per chunk,
     // with every workgroup of the launch asking at the same time.  (Into accumulator registers nothing below touches.)
     bool primed = false;
-    if (m_chunk >= m_start && m_chunk + (uint32_t)(D * wg_round_samples(NR)) <= n1) {
-        if constexpr (D == 1) {
-            wg_load_step<KIND, NR>(voff, in_first);
-        } else {
-            wg_load_step_iq4<0>(voff, in_first);
-            wg_load_step_iq4<1>(voff, in_first + (size_t)wg_round_samples(NR) * RB);
-        }
+    if (m_chunk >= m_start && m_chunk + (uint32_t)wg_round_samples(NR) <= n1) {
+        wg_load_step<KIND, NR>(voff, in_first);
         primed = true;
     }
     const Carry cr = *A.carry;
@@ -777,8 +636,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // A SUPERSTEP is `sup` regular rounds classified against one set of thresholds (A.ksteps), or ONE round that is not four whole
     // steps of stable samples (the stream's first stable sample, a batch's ragged end): its
     // rounds are separated by the first barrier only, the second one and the exchange behind it close the superstep.
-    const int sup = (D == 2) ? max(2, A.ksteps & ~1) : max(1, A.ksteps);   // the longest superstep
-    int cur_sup = D;                    // rounds of the next one (it adapts: see the close; D == 2: whole pairs of rounds)
+    const int sup = max(1, A.ksteps);   // the longest superstep
+    int cur_sup = 1;                    // rounds of the next one (it adapts: see the close)
     bool need_open = true;
     uint32_t rbase = m_chunk;   // base of the round
     // which of the three mask buffers this round publishes in, and the round before it did (byte offsets of this wave's row)
@@ -868,24 +727,15 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         }
     };
     while (good_run && rbase < n1) {
-        // (D == 2: regular rounds come in PAIRS -- the two register sets of samples asked for ahead alternate statically, set 0
-        // first in every superstep; a single whole round left over at a ragged end takes the masked form)
-        const bool regular = rbase >= m_start && rbase + (uint32_t)(D * WG_ROUND) <= n1;
+        const bool regular = rbase >= m_start && rbase + (uint32_t)WG_ROUND <= n1;
         int nr = 1;
         uint32_t whole = 0u;   // regular rounds from here on
         if (regular) {
             whole = (n1 - rbase) / (uint32_t)WG_ROUND;
-            if constexpr (D == 2) whole &= ~1u;
             nr = (int)min((uint32_t)cur_sup, whole);
             if (!primed) {
                 // this wave's step of the first regular round is asked for
-                if constexpr (D == 1) {
-                    wg_load_step<KIND, NR>(voff, in_wave);
-                } else {
-                    // (this round into set 0, the next one into set 1)
-                    wg_load_step_iq4<0>(voff, in_wave);
-                    wg_load_step_iq4<1>(voff, in_wave + (size_t)WG_ROUND * RB);   // (whole >= 2)
-                }
+                wg_load_step<KIND, NR>(voff, in_wave);
                 primed = true;
                 need_open = true;
             }
@@ -903,10 +753,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         // time flag the compiler kept one merged body and steered it with flag registers -- 80 scalar instructions per round, most
         // of them moves and tests of those flags); the rounds that are not (the stream's first stable sample, a ragged end) take the
         // masked general form in every wave, on synchronously loaded samples.
-        auto one_round = [&](auto reg_tag, auto set_tag, const int k) __attribute__((always_inline)) {
+        auto one_round = [&](auto reg_tag, const int k) __attribute__((always_inline)) {
             constexpr bool REG = decltype(reg_tag)::value;
-            constexpr int SET = decltype(set_tag)::value;   // (D == 2) which registers hold this round's samples
-            (void)SET;
             const uint32_t base = rbase + STEPN * (uint32_t)wave;
             float x[NR];
             int pk = 0;
@@ -914,13 +762,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             // ---- phase A: this step's envelopes, what can classify at all, its LOW masks for the step after it ----
             if constexpr (REG) {
                 WG_PF_BEGIN();
-                if constexpr (D == 1) {
-                    wg_take<KIND, NR>(x, i16s);
-                } else {
-                    // (at most the four loads of the OTHER set are younger than this set's, and loads complete in order among
-                    // themselves: "at most four operations left" means this set is in, whatever the stores in flight do)
-                    wg_take_iq4<SET, false>(x, i16s);
-                }
+                wg_take<KIND, NR>(x, i16s);
                 WG_PF_END(pf_take);
                 // the plane words of the round before leave, and the registers take the next round (if the chunk has one: past
                 // its end may be past the caller's buffer)
@@ -934,13 +776,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 }
                 // (asked for unconditionally; in the chunk's last regular round this round's samples are asked for again and the
                 // values are never used)
-                if constexpr (D == 1) {
-                    wg_load_step<KIND, NR>(voff, (uint32_t)(k + 1) < whole ? in_wave + (size_t)WG_ROUND * RB : in_wave);
-                } else {
-                    // (the registers just read take the round after next)
-                    const char *nx = (uint32_t)(k + 2) < whole ? in_wave + (size_t)(2 * WG_ROUND) * RB : in_wave;
-                    wg_load_step_iq4<SET>(voff, nx);
-                }
+                wg_load_step<KIND, NR>(voff, (uint32_t)(k + 1) < whole ? in_wave + (size_t)WG_ROUND * RB : in_wave);
                 uint32_t xlo = __float_as_uint(x[0]), xhi = __float_as_uint(x[0]);   // (envelopes are >= 0: their raw bits order like their values)
 #pragma unroll
                 for (int j = 1; j < NR; j++) {
@@ -1106,19 +942,12 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         using IrrT = std::integral_constant<bool, false>;
         if (regular) {
             if (st_cnt == 0) st_base = rbase;   // (the staging is empty: the superstep's first round is its oldest)
-            if constexpr (D == 1) {
-                for (int k = 0; k < nr; k++) one_round(RegT{}, std::integral_constant<int, 0>{}, k);
-            } else {   // (nr is even)
-                for (int k = 0; k < nr; k += 2) {
-                    one_round(RegT{}, std::integral_constant<int, 0>{}, k);
-                    one_round(RegT{}, std::integral_constant<int, 1>{}, k + 1);
-                }
-            }
+            for (int k = 0; k < nr; k++) one_round(RegT{}, k);
             // (what the chunk's summary asks of the regular rounds: how many, and this wave's step of the last of them)
             hot_done += nr;
             hot_last = rbase - (uint32_t)WG_ROUND + STEPN * (uint32_t)wave;
         } else {
-            one_round(IrrT{}, std::integral_constant<int, 0>{}, 0);
+            one_round(IrrT{}, 0);
         }
         rounds_since_sync += nr;
 
@@ -1175,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                     const float M2 = (2.f * B + (eps + RND_SUM) * ssf) * slU + ssf * 7.62939453125e-06f;
                     const float head = fminf(dlmin / fmaxf(need_lo, 1e-30f), dhmin / fmaxf(need_hi, 1e-30f));
                     const float head2 = fminf(dlmin / fmaxf(M2 * loLf, 1e-30f), dhmin / fmaxf(M2 * hiLf, 1e-30f));
-                    if (regular) next_sup = head2 > 2.f ? min(2 * cur_sup, sup) : (head < 1.5f ? max(D, cur_sup / 2) : cur_sup);
+                    if (regular) next_sup = head2 > 2.f ? min(2 * cur_sup, sup) : (head < 1.5f ? max(1, cur_sup / 2) : cur_sup);
                     ssf = rfl(ssf + Dt);
                     if (resync) {   // (the ring is quiescent: the other waves wait for the verdict)
                         double part = 0;
@@ -1202,12 +1031,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             }
         }
     }
-    // (the whole chunk's plane words are in the LDS staging -- every round regular, nothing flushed yet: what the edge aggregates below are made from)
+    // (the whole chunk's plane words are in the LDS staging -- every round regular, nothing flushed yet)
     const bool staged_all = bulk && st_cnt > 0 && st_base == m_chunk && (uint32_t)st_cnt * (uint32_t)WG_ROUND == n1 - m_chunk;
     flush_planes();
-    if (A.eagg_tiles && n1 > m_chunk && staged_all)   // (... while the stores drain; the staging is not written again)
-        wg_chunk_edge_aggs(neg_p, pos_p, A.n, A.skip, mx, A.eagg_magic, c, m_chunk, n1, A.eagg_tps, (EdgeAgg *)A.eagg_tiles, (EdgeAgg *)A.eagg_supers, (EdgeAgg *)&sh->acc[0][0],
-                           pst, PST_PLANE);
     // (where the whole chunk's plane words are still in the LDS staging the summary reads them THERE: it need not wait for the stores
     // that have just been asked for -- every workgroup of the launch is at this point at about the same time, and the wait was part of
     // every chunk's last microseconds: 0.1407 -> 0.1397 ms per launch, five alternating rounds)
@@ -1223,9 +1049,6 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         const uint32_t o = r * PST_ROUND + wv * (uint32_t)(2 * NR) + 2u * wd_i;
         return (unsigned long long)pst[o] | ((unsigned long long)pst[o + 1u] << 32);
     };
-    if (A.eagg_tiles && n1 > m_chunk && !staged_all)
-        wg_chunk_edge_aggs(neg_p, pos_p, A.n, A.skip, mx, A.eagg_magic, c, m_chunk, n1, A.eagg_tps, (EdgeAgg *)A.eagg_tiles, (EdgeAgg *)A.eagg_supers, (EdgeAgg *)&sh->acc[0][0],
-                           nullptr, 0u);
 
     // ---------------- the chunk's summary ----------------
     // LOW bookkeeping at the chunk's end: the last non-LOW sample and the last LOW sample lie in its last steps (a LOW sample
