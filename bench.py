@@ -53,7 +53,8 @@ def parse():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the end-to-end figure and the other configurations')
     ap.add_argument('--in-flight', type=int, default=3, choices=[1, 2, 3], help='one GPU: batches submitted and not yet waited for')
-    ap.add_argument('--primary', default='sync', choices=['sync', 'ahead'], help='what the headline steps are -- sync: every step a fresh stream pushed synchronously '
+    ap.add_argument('--primary', default=None, choices=['sync', 'ahead'], help='what the headline steps are (default: sync on one GPU, ahead with several -- a rank\'s time shard is a stream, '
+                    'its boundary protocol is paid once per shard; the per-step protocol is then the figure beside it) -- sync: every step a fresh stream pushed synchronously '
                     '(the threshold kernel with the machine to itself); ahead: consecutive batches of one stream, submitted ahead (nfc_submit_device / nfc_wait). '
                     'The other one is measured beside it unless --no-extras')
     ap.add_argument('--sync-steps', action='store_true', help='(same as --primary sync --no-extras for the stepping: kept for the profiling scripts)')
@@ -379,22 +380,23 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                              'avg_launch_ms': ka, 'launches_timed': len(acc['kernel_ms']),
                              'launches_per_step': float(np.mean(acc['n_pass'])) if acc['n_pass'] else None}}
 
-    ahead = a.primary == 'ahead' and not a.sync_steps
+    primary = a.primary or ('ahead' if world > 1 else 'sync')
+    ahead = primary == 'ahead' and not a.sync_steps
     # (the region that lands beside the headline goes first: the headline's steps then run on a machine that is already at its clocks)
     other = None if (a.no_extras or a.sync_steps) else region('sync' if ahead else 'ahead')
     prim = region('ahead' if ahead else 'sync')
     dt, kernel_ms, n_pass = prim['dt'], prim['kernel_ms'], prim['n_pass']
     redo[0] = prim['redo']
     ctx.set_timing(2)   # one more, untimed, step for the per-stage split reported beside the headline (synchronous: stream markers)
-    if ahead:
+    if ahead and not sharded:
         ctx.push_device(res.buf, n)
     else:
-        one_step()
+        one_step()   # (with several ranks: the whole protocol once more on a fresh stream -- every rank's context then holds the decode of ITS shard)
     st = ctx.stats()
     cnt = ctx.counts()
     n_edges = int(cnt.n_edges)
     gathered = None
-    if want_parity and world > 1 and not ahead:
+    if want_parity and world > 1:
         # that step was the whole sharding protocol once more: every rank's context holds the decode of ITS shard -- digests of
         # it travel to rank 0 (JSON over the communicator), which checks every one against the oracle (sharded_parity)
         gathered = comm.gather_objects(result_digest(ctx.edges(), ctx.symbols(0), ctx.symbols(1), ctx.packets()))
@@ -419,7 +421,11 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                        'shard_overlap_samples': overlap_steps(workload, n) if world > 1 else [], 'overlap_used': ov_used,
                        'exchange': backend if world > 1 else 'none',
                        'rccl_ranks_seen': getattr(comm, 'ranks_seen', None),
-                       'stepping': prim['mode'], 'in_flight': a.in_flight if prim['mode'] == 'ahead' else 1},
+                       'stepping': prim['mode'], 'in_flight': a.in_flight if prim['mode'] == 'ahead' else 1,
+                       # several ranks: what the boundary protocol adds to a step when it is run PER STEP (prime, warm-up on the overlap,
+                       # state export, all-gather, verify) -- the per-step region's step less the device time of the own chunk alone
+                       'protocol_us_per_step': ((((other if ahead else prim)['dt'] / steps * 1e3) - st.ms_total) * 1e3
+                                                if sharded and (other or not ahead) and st.ms_total > 0 else None)},
             # (kernel: the fused envelope + gated-mean threshold kernel, a time chunk per workgroup; k_threshold_lean / k_threshold where it does not apply)
             'roofline': {'bound': 'hbm', 'kernel': 'k_threshold_wg',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -456,8 +462,8 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                     raise SystemExit('bench: a rank\'s shard differs from the oracle\'s cut of the whole capture: %s' % json.dumps(out['parity']['sharded']))
             # the context the timed loop ran in must have produced the same decode: a fresh stream per step / rank 0's shard
             # starts the stream; or, with consecutive batches of one stream, its steady state (when the rounds repeat)
-            want_counts = out['parity'] if ahead else out['parity']['first_round']
-            if ahead and not out['parity'].get('stationary'):
+            want_counts = out['parity'] if (ahead and not sharded) else out['parity']['first_round']
+            if ahead and not sharded and not out['parity'].get('stationary'):
                 out['parity']['timed_loop_counts_equal'] = None
             else:
                 same = bool(n_edges == want_counts['n_edges'] and int(cnt.n_packets[0] + cnt.n_packets[1]) == want_counts['n_packets'])
@@ -673,67 +679,112 @@ def cpu_baseline(own, flags, params, kind='iq'):
             'host_cpus': os.cpu_count()}
 
 
-def end_to_end(workload, own, flags):
-    """Host IQ in, decoded commands out (SURVEY.md 8(d) "separately end-to-end"): pinned host samples -> H2D in pieces (a second
-    thread uploads piece k + 1 while piece k decodes) -> GPU path -> edges, packet tables and packet bits D2H -> packets to
-    bytes / commands on the host (fsm.process_packets, C).  Which link bounds it: PCIe (8 B per sample in, 6 B per transition out)."""
+def _end_to_end_pass(workload, own, flags):
+    """Host IQ in, decoded commands out (SURVEY.md 8(d) "separately end-to-end"): pinned host samples -> H2D in pieces -> GPU path ->
+    transitions (6 B each), packet tables and packet bits D2H -> packets to bytes / commands on the host (fsm.process_packets, C).
+    Three threads, one per resource: the uploader keeps the H2D direction of the link busy (a ring of three device buffers), the main
+    thread pushes a piece and reads its outputs back into pinned arrays (the D2H direction: the copy engine writes them in place),
+    a worker turns packets into commands.  What bounds it: the link, 8 B per sample in."""
     import ctypes as C
+    import queue
     import numpy as np
     from usrp_nfc_amd import api, fsm, _lib
     L = _lib.load()
     n = len(own) // 2
-    piece = 1 << 23
+    piece = 1 << 22
     pin = C.c_void_p()
     assert L.nfc_host_alloc_pinned(own.nbytes, C.byref(pin)) == 0
     C.memmove(pin, own.ctypes.data, own.nbytes)
-    bufs = [api.DeviceBuffer(np.zeros(0, np.float32), 0, nbytes=8 * piece) for _ in range(2)]
+    NB = 3
+    bufs = [api.DeviceBuffer(np.zeros(0, np.float32), 0, nbytes=8 * piece) for _ in range(NB)]
     ctx = api.NfcContext(input_kind=api.NFC_IN_IQ_F32, **stream_params(workload), **flags)
     machine = fsm.fsm(callback=lambda cmd, st: None)
     pieces = [(o, min(piece, n - o)) for o in range(0, n, piece)]
+    outs = [(api.PinnedArray(piece // 4 + 65536, np.uint32), api.PinnedArray(piece // 4 + 65536, np.uint16)) for _ in range(2)]
+    uploaded = [threading.Event() for _ in pieces]
+    consumed = [threading.Event() for _ in pieces]   # piece k's device buffer may be overwritten (its push has returned)
+    err = []
 
-    def upload(k):
-        o, m = pieces[k]
-        assert L.nfc_device_upload(0, bufs[k & 1].ptr, pin.value + 8 * o, 8 * m) == 0
+    def uploader():
+        try:
+            for k, (o, m) in enumerate(pieces):
+                if k >= NB:
+                    consumed[k - NB].wait()
+                assert L.nfc_device_upload(0, bufs[k % NB].ptr, pin.value + 8 * o, 8 * m) == 0
+                uploaded[k].set()
+        except Exception as e:   # (the main thread must not wait for ever)
+            err.append(e)
+            for ev in uploaded:
+                ev.set()
 
-    n_edges = n_frames = 0
-    t_push = t_read = t_fsm = t_join = 0.0   # where the main thread's time goes: GPU path, read-back, protocol layer, waiting for the upload
+    work = queue.Queue()
+    n_frames = [0]
+    t_fsm = [0.0]
+
+    def protocol():
+        while True:
+            item = work.get()
+            if item is None:
+                return
+            tabs, bits = item
+            t1 = time.perf_counter()
+            table = np.concatenate(tabs)
+            table = table[np.argsort(table['idx'], kind='stable')]
+            table = table[table['n_bits'] > 0]
+            if len(table):
+                frames, _ = machine.process_packets(table, bits[0], bits[1], dispatch=False)
+                n_frames[0] += len(frames)
+            t_fsm[0] += time.perf_counter() - t1
+
+    n_edges = 0
+    t_push = t_read = t_join = 0.0   # where the main thread's time goes: GPU path, read-back, waiting for the upload
+    th_u, th_p = threading.Thread(target=uploader), threading.Thread(target=protocol)
     t0 = time.perf_counter()
-    upload(0)
+    th_u.start()
+    th_p.start()
     for k, (o, m) in enumerate(pieces):
-        th = None
-        if k + 1 < len(pieces):
-            th = threading.Thread(target=upload, args=(k + 1,))
-            th.start()
         ta = time.perf_counter()
-        ctx.push_device(bufs[k & 1], m)
+        uploaded[k].wait()
+        if err:
+            raise err[0]
         tb = time.perf_counter()
-        t_push += tb - ta
-        n_edges += len(ctx.edges_compact()[0])
+        t_join += tb - ta
+        ctx.push_device(bufs[k % NB], m)
+        consumed[k].set()
+        tc = time.perf_counter()
+        t_push += tc - tb
+        pos, code = ctx.edges_compact(out=(outs[k & 1][0].array, outs[k & 1][1].array))
+        n_edges += len(pos)
         tabs = [ctx.packet_table(t) for t in (0, 1)]
         bits = [ctx.packet_bits(t) for t in (0, 1)]
-        table = np.concatenate(tabs)
-        table = table[np.argsort(table['idx'], kind='stable')]
-        table = table[table['n_bits'] > 0]
-        tc = time.perf_counter()
-        t_read += tc - tb
-        if len(table):
-            frames, _ = machine.process_packets(table, bits[0], bits[1], dispatch=False)
-            n_frames += len(frames)
-        td = time.perf_counter()
-        t_fsm += td - tc
-        if th:
-            th.join()
-        t_join += time.perf_counter() - td
+        work.put((tabs, bits))
+        t_read += time.perf_counter() - tc
+    work.put(None)
+    th_p.join()
+    th_u.join()
     dt = time.perf_counter() - t0
     ctx.close()
+    for a, b in outs:
+        a.free()
+        b.free()
     L.nfc_host_free_pinned(pin)
     return {'value': n / dt / 1e6, 'unit': 'Msamples/s', 'ms_total': dt * 1e3, 'samples': n, 'edges_to_host': n_edges,
-            'commands': n_frames, 'piece_samples': piece,
-            'what': 'pinned host IQ -> H2D (overlapped, second thread) -> GPU path -> transitions (compact: 6 B each) + packets D2H -> fsm (C) on the host',
-            # (the link itself moves 57 GB/s either way from pinned memory, measured with a bare hipMemcpy on this pool: when link_GBs is
-            # well below that the pass is bound by the main thread's own turn per piece -- main_thread_ms says which part)
-            'link_GBs': (8 * n + 6 * n_edges) / dt / 1e9, 'mb_in': 8 * n / 1e6, 'mb_out': 6 * n_edges / 1e6,
-            'main_thread_ms': {'gpu_path': t_push * 1e3, 'read_back': t_read * 1e3, 'fsm': t_fsm * 1e3, 'waiting_for_upload': t_join * 1e3}}
+            'commands': n_frames[0], 'piece_samples': piece,
+            'what': 'pinned host IQ -> H2D (uploader thread, three device buffers) -> GPU path -> transitions (compact: 6 B each, into pinned arrays) + packets D2H -> fsm (C, worker thread)',
+            # (the link itself moves 57 GB/s either way from pinned memory, measured with a bare hipMemcpy on this pool: link_GBs_in is
+            # what the pass keeps of the H2D direction -- main_thread_ms says where the rest went)
+            'link_GBs': (8 * n + 6 * n_edges) / dt / 1e9, 'link_GBs_in': 8 * n / dt / 1e9, 'mb_in': 8 * n / 1e6, 'mb_out': 6 * n_edges / 1e6,
+            'main_thread_ms': {'gpu_path': t_push * 1e3, 'read_back': t_read * 1e3, 'waiting_for_upload': t_join * 1e3},
+            'worker_ms': {'fsm': t_fsm[0] * 1e3}}
+
+
+def end_to_end(workload, own, flags):
+    """Two passes over the capture, the second reported: the first one sizes the context's buffers and the pinned staging areas
+    (allocations a stream makes once) -- its own figure rides along as first_pass_msamples_s."""
+    first = _end_to_end_pass(workload, own, flags)
+    second = _end_to_end_pass(workload, own, flags)
+    second['first_pass_msamples_s'] = first['value']
+    return second
 
 
 def rank_main(a):
@@ -774,6 +825,9 @@ def rank_main(a):
         if world == 1 and not a.no_extras and a.workload == 'miller' and n == 100_000_000 and kind == 'iq':
             # the figures SURVEY.md 8(d) asks for beside the headline, measured in this same invocation
             line['end_to_end'] = end_to_end(a.workload, own, flags)
+            # (inside the object the driver's record keeps whole: VERDICT r05 item 6)
+            line['roofline']['end_to_end_msamples_s'] = line['end_to_end']['value']
+            line['roofline']['end_to_end_link_GBs_in'] = line['end_to_end']['link_GBs_in']
             del own
             others = []
             for wl, nn, st in (('manchester', 100_000_000, 20), ('classic1k', 1_000_000_000, 10)):

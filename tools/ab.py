@@ -60,7 +60,9 @@ def main():
         for v in rest:
             print('== %s' % v)
             sys.stdout.flush()
-            env = dict(os.environ)
+            sys.path.insert(0, ROOT)
+            from usrp_nfc_amd import _lib
+            env = dict(os.environ, NFC_AMD_LIB=_lib.hooks_path())   # (the switches exist in the test build only)
             env.update(parse_env(v))
             subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stress_step.py'), workload], cwd=ROOT, env=env)
         return

@@ -129,11 +129,16 @@ class NfcContext(object):
     def edges(self):
         return self._read(self.L.nfc_read_edges, self.counts().n_edges, EDGE_DTYPE, 0)
 
-    def edges_compact(self):
+    def edges_compact(self, out=None):
         """(pos, code) of the batch's transitions as the device keeps them (nfc_read_edges_compact): batch-local sample
         position, and ((v + 1) * (max_len + 1) + d) | (t + 1) << 14."""
         n = int(self.counts().n_edges)
-        pos, code = np.zeros(n, np.uint32), np.zeros(n, np.uint16)
+        if out is not None:   # caller's arrays (pinned ones -- pinned_array -- are written by the copy engine in place)
+            if len(out[0]) < n or len(out[1]) < n:
+                raise NfcError('edges_compact: the output arrays hold %d entries, the batch has %d' % (min(len(out[0]), len(out[1])), n))
+            pos, code = out[0][:n], out[1][:n]
+        else:
+            pos, code = np.zeros(n, np.uint32), np.zeros(n, np.uint16)
         got = C.c_size_t(0)
         if n:
             self._chk(self.L.nfc_read_edges_compact(self.h, 0, pos.ctypes.data, code.ctypes.data, n, C.byref(got)), 'nfc_read_edges_compact')
@@ -279,6 +284,27 @@ class DeviceBuffer(object):
     def free(self):
         if getattr(self, 'ptr', None):
             self.L.nfc_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+
+class PinnedArray(object):
+    """A numpy array over pinned host memory (nfc_host_alloc_pinned): the copy engine reads and writes it directly."""
+
+    def __init__(self, count, dtype):
+        self.L = _lib.load()
+        self.ptr = C.c_void_p()
+        dt = np.dtype(dtype)
+        nbytes = max(16, int(count) * dt.itemsize)
+        if self.L.nfc_host_alloc_pinned(nbytes, C.byref(self.ptr)) != 0:
+            raise NfcError('nfc_host_alloc_pinned failed')
+        self.array = np.frombuffer((C.c_char * nbytes).from_address(self.ptr.value), dtype=dt, count=int(count))
+
+    def free(self):
+        if getattr(self, 'ptr', None):
+            self.array = None
+            self.L.nfc_host_free_pinned(self.ptr)
             self.ptr = None
 
     __del__ = free

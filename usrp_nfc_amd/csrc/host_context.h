@@ -133,6 +133,7 @@ struct nfc_ctx {
     DevBuf d_gring;
     uint32_t own_prefix_max = OWN_PREFIX_MAX_TILES;   // tile counts up to this need no prefix launches (NFC_OWN_PREFIX_MAX overrides)
     int use_small = 1;   // short batches take the one-launch edge / decode / framing kernel (NFC_NO_SMALL=1 turns it off)
+    double expect_ms = 0.3;   // how long the stamp of a batch has taken to appear lately (wait_for_stamp)
     bool spin_wait = true;   // a batch's end is seen in the mirror's stamp word, not waited for on the stream (NFC_SPIN_WAIT=0; host_threshold.h)
     uint64_t selmask;
     float eps;

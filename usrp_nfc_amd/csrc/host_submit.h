@@ -142,6 +142,7 @@ int restart_submitted(nfc_ctx *c) {
         nb.g0 = g0;
         nb.ring_in = ring;
         nb.b_enqueued = false;
+        nb.allocs = 0;   // (what the abandoned attempt allocated was charged to the batch that went through the synchronous path)
         nb.fast = fast && submit_fast_ok(c, nb.n);
         if (nb.fast) {
             nb.seq = c->batch_seq + 1;
@@ -275,7 +276,9 @@ int wait_batch(nfc_ctx *c) {
             // stream, where the next batch's later stages are not enqueued before this one is popped; the batches behind it take
             // that form straight away (note_respeculation).
             note_respeculation(c);
-            int rc = run_decode(c, true);
+            // (the context's per-batch fields -- cap_edges, last_g0, h_dcarry, pend_cur -- are still this batch's: the later stages of the
+            // batches behind it are only enqueued once this one is popped)
+            int rc = c->stamp_b == b.seq ? run_decode(c, true) : fail(c, NFC_ERR_INTERNAL, "decode repeat: the context has moved on to batch %u (this is %u)", c->stamp_b, b.seq);
             if (!rc && hipStreamSynchronize(c->st) != hipSuccess) rc = fail(c, NFC_ERR_DEVICE, "waiting for the repeated decode stage failed");
             if (!rc) rc = batch_ok(c, false);
             if (!rc && c->hs->seq[1] != b.seq) rc = fail(c, NFC_ERR_DEVICE, "state mirror is stale after the repeated decode stage (batch %u, mirror %u)", b.seq, c->hs->seq[1]);
@@ -356,6 +359,7 @@ int build_packets(nfc_ctx *c, int t) {
         // those itself, synchronously -- and were most of what `end_to_end` spent per piece: round 5)
         const size_t need = (size_t)nc * 12 + 64;
         if (c->h_pk_stage_cap < need) {
+            devbuf_allocs()++;   // (a pinned regrow costs what a device one does: nfc_stats.device_allocs counts both)
             if (c->h_pk_stage) (void)hipHostFree(c->h_pk_stage);
             c->h_pk_stage = nullptr;
             c->h_pk_stage_cap = 0;

@@ -36,19 +36,35 @@ static bool sums_exact(const Carry &hc, int emin, int emax, uint32_t vtop) {
 // write lands; hipStreamSynchronize comes back 8-10 us after the kernel has ended (the completion signal's way through the runtime) --
 // and with one batch at a time the host's turn between two batches IS the step's idle time.  Bounded: after 2 ms without the stamp (a
 // kernel that faulted never writes it) the stream is waited for in the ordinary way, which also reports the fault.  NFC_SPIN_WAIT=0.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#endif
+}
 static hipError_t wait_for_stamp(nfc_ctx *c) {
-    if (c->spin_wait) {
+    // (a batch expected to take longer than the spin is worth -- a 1e9-sample batch runs 1.8 ms -- waits on the stream straight away)
+    if (c->spin_wait && c->expect_ms < 1.2) {
         const volatile uint32_t *p = &c->hs->seq[1];
         const uint32_t want = c->stamp_b;
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t k = 0;; k++) {
             if (*p == want) {
                 std::atomic_thread_fence(std::memory_order_acquire);
+                c->expect_ms = 0.75 * c->expect_ms + 0.25 * std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 return hipSuccess;
             }
-            if ((k & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-            __builtin_ia32_pause();
+            if ((k & 63u) == 63u) {
+                const auto dt = std::chrono::steady_clock::now() - t0;
+                if (dt > std::chrono::milliseconds(2)) break;
+                if (dt > std::chrono::microseconds(400)) std::this_thread::yield();   // (past a clean batch's length: the core goes to whoever wants it between looks)
+            }
+            cpu_relax();
         }
+        c->expect_ms = 4.0;   // (ran into the bound: the next batches of this stream wait on the stream; the figure decays below)
+    } else if (c->spin_wait) {
+        c->expect_ms *= 0.9;  // (... and the spin is tried again after a while: a stream's batches may have become short)
     }
     return hipStreamSynchronize(c->st);
 }
@@ -145,6 +161,7 @@ static int thr_prepare(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t n_all,
     HIPCHK(c, c->d_ver.ensure(nal));
     HIPCHK(c, c->d_cflags.ensure((size_t)4 * nal));   // sections: cert | gflags | gmin | gmax
     if (c->h_cflags_cap < (size_t)20 * nal + 64) {
+        devbuf_allocs()++;
         if (c->h_cflags) (void)hipHostFree(c->h_cflags);
         c->h_cflags_cap = (size_t)20 * nal + 4096;
         HIPCHK(c, hipHostMalloc((void **)&c->h_cflags, c->h_cflags_cap, hipHostMallocDefault));

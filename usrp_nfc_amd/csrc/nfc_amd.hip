@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <functional>
 #include <vector>
 
@@ -396,7 +397,8 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     c->T.tag = p->enable_tag ? 1 : 0;
     // carried state
     CRT(c->d_state.ensure(sizeof(DevState)));
-    CRT(hipHostMalloc((void **)&c->hs, sizeof(DevState), hipHostMallocMapped));
+    // (mapped AND coherent, explicitly: the host watches the stamp word while the stream runs -- host_threshold.h: wait_for_stamp)
+    CRT(hipHostMalloc((void **)&c->hs, sizeof(DevState), hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->hs, 0, sizeof(DevState));
     CRT(hipHostGetDevicePointer(&c->hs_dev, c->hs, 0));
     for (int b = 0; b < NRING; b++) {
@@ -616,6 +618,7 @@ template <class Consume>
 int fetch_entries(nfc_ctx *c, size_t first, size_t n, Consume consume) {   // consume(pos, code, count, offset)
     const size_t need = 2 * EDGE_PIECE * 6 + 64;
     if (c->h_edge_stage_cap < need) {
+        devbuf_allocs()++;
         if (c->h_edge_stage) (void)hipHostFree(c->h_edge_stage);
         c->h_edge_stage = nullptr;
         c->h_edge_stage_cap = 0;
@@ -699,6 +702,17 @@ int nfc_read_edges_compact(nfc_ctx *c, size_t first, uint32_t *pos_out, uint16_t
     if (rc || !n) return rc;
     if (!code_out) return fail(c, NFC_ERR_ARG, "null output");
     if (c->edges_from_host) return fail(c, NFC_ERR_STATE, "the entries of nfc_push_edges carry the caller's indices: use nfc_read_edges");
+    {   // outputs in PINNED host memory (nfc_host_alloc_pinned): the copy engine writes them in place -- no staging, no second pass on
+        // the host (a streaming caller's read-back was the longest part of its turn per piece: bench.py, end_to_end)
+        unsigned int f0 = 0, f1 = 0;
+        if (hipHostGetFlags(&f0, pos_out) == hipSuccess && hipHostGetFlags(&f1, code_out) == hipSuccess) {
+            HIPCHK(c, hipMemcpyAsync(pos_out, c->d_epos.as<uint32_t>() + first, n * 4, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipMemcpyAsync(code_out, c->d_ecode.as<uint16_t>() + first, n * 2, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            return NFC_OK;
+        }
+        (void)hipGetLastError();   // (not pinned: hipHostGetFlags left its complaint behind)
+    }
     return fetch_entries(c, first, n, [&](const uint32_t *pos, const uint16_t *code, size_t cnt, size_t off) {
         memcpy(pos_out + off, pos, cnt * 4);
         memcpy(code_out + off, code, cnt * 2);
@@ -741,6 +755,7 @@ int nfc_read_packet_bits(nfc_ctx *c, int type, size_t first, uint8_t *out, size_
         // (the words through pinned staging: a pageable destination makes the runtime stage the copy itself, synchronously)
         const size_t need = (w1 - w0) * 4 + 64;
         if (c->h_pk_stage_cap < need) {
+            devbuf_allocs()++;
             if (c->h_pk_stage) (void)hipHostFree(c->h_pk_stage);
             c->h_pk_stage = nullptr;
             c->h_pk_stage_cap = 0;
@@ -751,7 +766,22 @@ int nfc_read_packet_bits(nfc_ctx *c, int type, size_t first, uint8_t *out, size_
         const uint32_t *w = (const uint32_t *)c->h_pk_stage;
         HIPCHK(c, hipMemcpyAsync(c->h_pk_stage, c->d_bits[type].as<uint32_t>() + w0, (w1 - w0) * 4, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
-        for (size_t i = 0; i < n; i++) {
+        // a byte per bit, eight at a time: byte j of (b * 0x0101.. & 0x8040..01) is nonzero exactly when bit j of b is set
+        auto spread8 = [](uint32_t b) -> uint64_t {
+            const uint64_t x = ((uint64_t)(b & 0xFFu) * 0x0101010101010101ull) & 0x8040201008040201ull;
+            return ((x + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+        };
+        size_t i = 0;
+        for (; i < n && ((first + i) & 7u); i++) {   // (up to a byte boundary of the stream)
+            const size_t b = first + i - (w0 << 5);
+            out[i] = (uint8_t)((w[b >> 5] >> (b & 31)) & 1u);
+        }
+        for (; i + 8 <= n; i += 8) {
+            const size_t b = first + i - (w0 << 5);
+            const uint64_t v = spread8(w[b >> 5] >> (b & 31));
+            memcpy(out + i, &v, 8);
+        }
+        for (; i < n; i++) {
             const size_t b = first + i - (w0 << 5);
             out[i] = (uint8_t)((w[b >> 5] >> (b & 31)) & 1u);
         }
