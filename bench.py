@@ -346,12 +346,16 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
             barrier()
             t0 = time.perf_counter()
             for k in range(steps):
-                # every 8th k_threshold launch of the timed region carries its own start / stop HIP events (nfc_amd.h:
-                # nfc_set_timing; a timed launch costs the step ~10 us, so not all of them are)
-                stride = 8 if steps >= 32 else max(2, steps // 5)   # (a short region still times several launches: 10 steps -> 5)
-                timed = k % stride == 1 if stride < 8 else k % 8 == 3   # (not the region's very first launch)
-                if timed or (k and (k - 1) % stride == 1 if stride < 8 else k % 8 == 4):
+                # every 8th k_threshold launch of a long region carries its own start / stop HIP events, every 2nd of a short one
+                # (<= 32 steps: 10 of the driver's 20).  Not every one: a timed launch costs its step 14 us -- measured, round 6, 20 steps
+                # on one box: 0.2545 / 0.2464 / 0.2432 ms per step with every / every 2nd / every 4th launch timed, the launches themselves
+                # 0.139 ms whichever (NFC_BENCH_TIMED_STRIDE=1 times them all)
+                stride = int(os.environ.get('NFC_BENCH_TIMED_STRIDE', '0')) or (8 if steps > 32 else 2)
+                timed = (k % 8 == 3) if stride == 8 else (k % stride == stride - 1)   # (stride 8: not the region's very first launch)
+                if stride > 1 and (timed or (k and ((k - 1) % 8 == 3 if stride == 8 else (k - 1) % stride == stride - 1))):
                     ctx.set_timing(1 if timed else 0)
+                elif stride == 1 and k == 0:
+                    ctx.set_timing(1)
                 one_step()
                 if timed:
                     st = ctx.stats()

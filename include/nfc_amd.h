@@ -278,6 +278,11 @@ int nfc_fsm_reset(nfc_fsm *f);
 /* one packet's bits (as nfc_read_packet_bits returns them); bytes_out needs n_bits / 9 + 1 bytes */
 int nfc_fsm_process(nfc_fsm *f, const uint8_t *bits, size_t n_bits, int packet_type, nfc_frame *out, uint8_t *bytes_out,
                     size_t bytes_cap, uint16_t *enc_out /* NULL, or the same capacity: on-air byte | 0x100 if marked '!' */);
+/* fsm.process_outgoing (fsm.py:68-112, wired at packets.py:88-90 as the emulator's encoder hook): a frame an emulator is about to
+   send, bits with parity as the encoders take them; the machine follows it (tag type from an ATQA, the command in flight) and,
+   while a MIFARE Classic session is up, encrypts it into bits_out (n_bits entries).  Returns 0, or 1 when the tag is an Ultralight:
+   nothing was written, and the reference runs the frame through process_bits instead (the Python fsm does). */
+int nfc_fsm_process_outgoing(nfc_fsm *f, const uint8_t *bits, size_t n_bits, int cmd, uint8_t *bits_out);
 /* MIFARE Classic sector keys A / B (fsm.set_keys, fsm.py:157-160; both default to FF FF FF FF FF FF) */
 int nfc_fsm_set_keys(nfc_fsm *f, const uint8_t key_a[6], const uint8_t key_b[6]);
 /* a batch of packets in stream order: the rows of nfc_read_packets (both types merged by idx) over their bit arrays */

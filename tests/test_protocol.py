@@ -127,6 +127,73 @@ def test_crypto1_wrong_key_is_noticed():
     assert 'AR OK' not in out.getvalue()
 
 
+@pytest.mark.parametrize('role', [0, 1])   # the emulator is the tag (0: sends TAG_TO_READER frames) / the reader (1)
+def test_process_outgoing_puts_the_trace_s_ciphertext_on_the_air(role):
+    # fsm.process_outgoing (fsm.py:68-112; the emulator's encoder hook of packets.py:88-90), pinned to the reference's own trace:
+    # outputs/1k_with_enc.out carries the on-air ciphertext of every frame of 16 authentications (15 nested).  An emulator in
+    # either role that sends the PLAIN frames of that transaction through process_outgoing -- and hears the other side through
+    # process_bits -- must put exactly those ciphertext bits on the air, frame after frame.
+    from usrp_nfc_amd import synth
+    packets, _ = packets_from_trace(GOLD_1K)
+    seen = []
+    monitor = fsm.fsm(callback=lambda cmd, st: seen.append((cmd, st)), out=io.StringIO())
+    plain = []
+    for t, bits in packets:   # what a monitor decodes: the command and the plain bytes of every frame
+        n0 = len(seen)
+        monitor.process_bits(bits, t)
+        assert len(seen) == n0 + 1 and seen[-1][0] is not None, 'the monitor must know every frame of the trace'
+        plain.append((t, seen[-1][0], seen[-1][1].all_bytes()))
+    emu = fsm.fsm(callback=lambda cmd, st: None, out=io.StringIO())
+    sent = encrypted = nested = 0
+    in_session = halted = False
+    for (t, air), (_, cmd, data) in zip(packets, plain):
+        if halted:
+            # (the capture's reader repeats HALT and REQA in the clear once the session is over.  process_outgoing never ends a
+            # session -- it does not run process_command, fsm.py:68-112 -- so an emulated reader would go on encrypting: nothing
+            # of the trace's tail can pin it)
+            break
+        if cmd.name() in ('REQA', 'WUPA', 'HALT'):
+            in_session = False
+            halted = cmd.name() == 'HALT' and t == role
+        if t != role:
+            emu.process_bits(air, t)        # heard
+            continue
+        short = len(air) == 8 and cmd.name() in ('REQA', 'WUPA')
+        bits = synth.frame_bits(data, 7) + [0] if short else synth.frame_bits(data)
+        out = emu.process_outgoing(bits, cmd)
+        if cmd.name() == 'RANDTA' and in_session:
+            # A NESTED tag nonce: the reference's emulator hook sends it under the OLD session's keystream (fsm.py:96-97,
+            # `old_enc.enc_bits(bits)`), a real card -- the trace -- under the new sector key's while uid ^ nonce is fed in.
+            # What process_outgoing leaves behind is the new register either way: the frames that follow (at, the data) must
+            # match the trace again, which is what pins it.
+            assert out != bits and out != list(air)
+            nested += 1
+        else:
+            assert out == list(air), 'frame %d (%s): not what the trace has on the air' % (sent, cmd.name())
+        if cmd.name() == 'RANDTA':
+            in_session = True
+        sent += 1
+        encrypted += int(out != bits)
+    assert sent >= 95 and encrypted > 60 and nested == (15 if role == 0 else 0), (sent, encrypted, nested)
+
+
+def test_process_outgoing_before_a_tag_type_and_with_an_ultralight():
+    # fsm.py:101-108: no tag type yet -- an ATQA sets it, the bits pass; fsm.py:71-72: an Ultralight's frames go through process_bits
+    # (the callback sees them) and pass unchanged
+    from usrp_nfc_amd import synth
+    seen = []
+    m = fsm.fsm(callback=lambda cmd, st: seen.append(cmd.name() if cmd else None), out=io.StringIO())
+    atqa = synth.frame_bits([0x44, 0x00])
+    assert m.process_outgoing(atqa, command.CommandType.ATQAUL) == atqa and seen == []
+    sel = synth.frame_bits([0x04] + fsm.crc_a([0x04]))
+    m.process_bits(synth.frame_bits([0x26], 7) + [0], 1)   # (REQA heard: the machine is at the start of a transaction)
+    seen.clear()
+    m2 = fsm.fsm(callback=lambda cmd, st: seen.append(cmd.name() if cmd else None), out=io.StringIO())
+    assert m2.process_outgoing(atqa, command.CommandType.ATQAUL) == atqa
+    out = m2.process_outgoing(sel, command.CommandType.SEL1U)
+    assert out == sel and len(seen) == 1   # (through process_bits: the callback saw the frame)
+
+
 @pytest.mark.gpu
 def test_classic_1k_capture_to_trace_on_gpu():
     # BASELINE.json configs[3] in miniature: the MIFARE Classic 1K transaction of outputs/1k_with_enc.out, synthesised

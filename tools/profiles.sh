@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the files under profiles/ on the GPU box (outputs land in gpurun_out/prof, copy what is judged).
 # usage: tools/profiles.sh <round-tag>
-tag=${1:-r04}
+tag=${1:-r06}
 out=gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
@@ -26,12 +26,18 @@ done
 [ -x tools/ubench/stream_chunks ] && tools/ubench/stream_chunks > $out/${tag}_stream_ceiling.txt 2>&1
 # where the workgroups of the later stages spend their time (a build with -DNFC_TAIL_PROF: scratch/r5/tailprof.so), and the waves of
 # the re-run kernel on the stress captures (-DNFC_GEN_PROF: scratch/r5/genprof.so)
-if [ -f scratch/r5/tailprof.so ]; then
-  { echo "# NFC_AMD_LIB=<-DNFC_TAIL_PROF build> python tools/tailprof.py miller 1e8   (s_memtime ticks, thread 0 of every workgroup)"; NFC_AMD_LIB=scratch/r5/tailprof.so python3 tools/tailprof.py miller 1e8; echo "# ... NFC_DEC_SPEC=0: the three-launch decode"; NFC_DEC_SPEC=0 NFC_AMD_LIB=scratch/r5/tailprof.so python3 tools/tailprof.py miller 1e8; } > $out/${tag}_tail_phases.txt 2>&1
+# (the switches -- NFC_DEC_SPEC, NFC_TAIL -- exist in the test build only: the profiling builds carry -DNFC_TEST_HOOKS too)
+if [ -f scratch/r6/tailprof.so ]; then
+  { echo "# NFC_AMD_LIB=<-DNFC_TEST_HOOKS -DNFC_TAIL_PROF build> python tools/tailprof.py miller 1e8   (s_memtime ticks, thread 0 of every workgroup)"; NFC_AMD_LIB=scratch/r6/tailprof.so python3 tools/tailprof.py miller 1e8; echo "# ... NFC_DEC_SPEC=0: the three-launch decode"; NFC_DEC_SPEC=0 NFC_AMD_LIB=scratch/r6/tailprof.so python3 tools/tailprof.py miller 1e8;
+    echo "# ... NFC_TAIL=1: the fused tail (tail.hip.h: built, measured, not adopted), ticks summed over a workgroup's tiles"; NFC_TAIL=1 NFC_AMD_LIB=scratch/r6/tailprof.so python3 tools/tailprof6.py miller 1e8; } > $out/${tag}_tail_phases.txt 2>&1
 fi
-if [ -f scratch/r5/genprof.so ]; then
-  { echo "# NFC_AMD_LIB=<-DNFC_GEN_PROF build> python tools/genprof.py hover / dropsteps   (the atomics of the iteration counter stretch the ticks: read the counts)"; NFC_AMD_LIB=scratch/r5/genprof.so python3 tools/genprof.py hover; NFC_AMD_LIB=scratch/r5/genprof.so python3 tools/genprof.py dropsteps; } > $out/${tag}_rerun_phases.txt 2>&1
+if [ -f scratch/r6/genprof.so ]; then
+  { echo "# NFC_AMD_LIB=<-DNFC_GEN_PROF build> python tools/genprof.py hover / dropsteps   (the atomics of the iteration counter stretch the ticks: read the counts)"; NFC_AMD_LIB=scratch/r6/genprof.so python3 tools/genprof.py hover; NFC_AMD_LIB=scratch/r6/genprof.so python3 tools/genprof.py dropsteps; } > $out/${tag}_rerun_phases.txt 2>&1
 fi
+# the fused tail against the five launches it would replace: same call, alternating (tools/ab.py env: the test build)
+{ echo "# python tools/ab.py env miller --rounds 3 NFC_TAIL=0 NFC_TAIL=1"; python3 tools/ab.py env miller --rounds 3 "NFC_TAIL=0" "NFC_TAIL=1";
+  echo "# per kernel under rocprofv3, NFC_TAIL=1 (test build)"; NFC_TAIL=1 NFC_AMD_LIB=usrp_nfc_amd/libnfc_amd_hooks.so bash tools/kstats.sh miller tail1 | grep -v "^$";
+  echo "# chunks cut by dispatch row against the equal cut, same call, alternating"; python3 tools/ab.py env miller --rounds 4 "NFC_WG_ROWBAL=0" "NFC_WG_ROWBAL=1"; } > $out/${tag}_tail_fused_ab.txt 2>&1
 for nm in stress_dropouts_steps stress_hover; do tools/stress_timeline.sh $nm > $out/${tag}_timeline_$nm.txt 2>&1; done
 timeout 600 python3 bench.py > $out/${tag}_bench.json 2> $out/bench.log
 python3 - <<PY

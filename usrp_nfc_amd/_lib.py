@@ -67,7 +67,7 @@ SYMBOLS = ['nfc_abi_version', 'nfc_device_count', 'nfc_create', 'nfc_destroy', '
            'nfc_read_packet_bits', 'nfc_read_val', 'nfc_get_state', 'nfc_set_state', 'nfc_reset', 'nfc_prime', 'nfc_export_state', 'nfc_get_stats', 'nfc_set_timing',
            'nfc_device_alloc', 'nfc_device_free', 'nfc_device_upload', 'nfc_device_download', 'nfc_stream_create', 'nfc_stream_destroy',
            'nfc_stream_sync', 'nfc_device_download_async', 'nfc_device_fill', 'nfc_host_alloc_pinned', 'nfc_host_free_pinned', 'nfc_host_decode_lut', 'nfc_host_miller_classes', 'nfc_host_decode_steps', 'nfc_host_i16_to_float', 'nfc_plan_row_cut',
-           'nfc_fsm_create', 'nfc_fsm_destroy', 'nfc_fsm_reset', 'nfc_fsm_process', 'nfc_fsm_process_packets', 'nfc_fsm_set_keys',
+           'nfc_fsm_create', 'nfc_fsm_destroy', 'nfc_fsm_reset', 'nfc_fsm_process', 'nfc_fsm_process_packets', 'nfc_fsm_process_outgoing', 'nfc_fsm_set_keys',
            'nfc_command_count', 'nfc_command_get', 'nfc_crc_a', 'nfc_tx_encode', 'nfc_tx_sample_count', 'nfc_tx_render_device']
 
 _libs = {}
@@ -146,6 +146,7 @@ def load(path=None):
     L.nfc_fsm_reset.argtypes = [vp]
     L.nfc_fsm_process.argtypes = [vp, vp, sz, C.c_int, C.POINTER(Frame), vp, sz, vp]
     L.nfc_fsm_process_packets.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz, psz, vp]
+    L.nfc_fsm_process_outgoing.argtypes = [vp, vp, sz, C.c_int, vp]
     L.nfc_fsm_set_keys.argtypes = [vp, vp, vp]
     L.nfc_command_count.restype = C.c_int
     L.nfc_command_get.argtypes = [C.c_int, C.POINTER(CommandInfo)]

@@ -50,9 +50,14 @@ class background(object):
                     fsm = _ref_fsm.fsm()
             except Exception:
                 # the reference's fsm is Python 2: use this package's (rows f1 / f3: bytes, parity, CRC, commands, CRYPTO1
-                # sessions; it prints the same trace; the outgoing half for an emulator -- process_outgoing -- is out of scope)
+                # sessions; it prints the same trace) -- with the emulator's encoder hook set as packets.py:88-90 does
                 from . import fsm as _own_fsm
-                fsm = _own_fsm.fsm(emulator.process_packet) if emulator else _own_fsm.fsm()
+                if emulator:
+                    fsm = _own_fsm.fsm(emulator.process_packet)
+                    if hasattr(emulator, 'set_encoder'):
+                        emulator.set_encoder(fsm.process_outgoing)
+                else:
+                    fsm = _own_fsm.fsm()
         self._fsm = fsm
 
     # -- reference surface ---------------------------------------------------------

@@ -1015,6 +1015,10 @@ int nfc_fsm_process(nfc_fsm *f, const uint8_t *bits, size_t n_bits, int packet_t
     fsm_process(*f, bits, n_bits, packet_type, out, bytes_out, enc_out);
     return NFC_OK;
 }
+int nfc_fsm_process_outgoing(nfc_fsm *f, const uint8_t *bits, size_t n_bits, int cmd, uint8_t *bits_out) {
+    if (!f || (n_bits && (!bits || !bits_out)) || cmd < 0 || cmd >= CMD_COUNT) return NFC_ERR_ARG;
+    return fsm_process_outgoing(*f, bits, n_bits, cmd, bits_out);
+}
 int nfc_fsm_set_keys(nfc_fsm *f, const uint8_t key_a[6], const uint8_t key_b[6]) {
     if (!f || !key_a || !key_b) return NFC_ERR_ARG;
     memcpy(f->key_a, key_a, 6);

@@ -426,4 +426,48 @@ inline void fsm_process(nfc_fsm &F, const uint8_t *bits_in, size_t n_bits, int t
     }
 }
 
+
+// fsm.process_outgoing (fsm.py:68-112): what an EMULATOR is about to send.  The machine follows the frame as if it had been heard --
+// tag type from an ATQA, the command in flight -- and, while a MIFARE Classic session is up, encrypts it: the frame's bits (parity
+// bits included, as the encoders take them) in, the bits to put on the air out.  Returns 1 when the tag is an Ultralight: the
+// reference then runs the frame through process_bits "to update state" (fsm.py:71-72) -- the caller does, with its callback.
+inline int fsm_process_outgoing(nfc_fsm &F, const uint8_t *bits, size_t n, int cmd, uint8_t *out) {
+    if (F.tag_type == 0) return 1;
+    for (size_t i = 0; i < n; i++) out[i] = bits[i] & 1;
+    if (F.tag_type == 1) {   // CLASSIC1K (fsm.py:73-99)
+        F.cur_cmd = cmd;
+        if (F.encrypted && cmd != CMD_RANDTA) {
+            if (cmd == CMD_RANDRB) {   // {nr}{ar}: the reader's own nonce feeds the register as it is encrypted
+                const size_t ll = n / 2;
+                F.cipher.crypt(bits, ll, out, 1, 0, 1);
+                F.cipher.crypt(bits + ll, n - ll, out + ll, 0, 0, 1);
+            } else {
+                F.cipher.crypt(bits, n, out, 0, 0, 1);
+            }
+        } else if (cmd == CMD_RANDTA) {
+            // the tag's nonce: a fresh register keyed for the sector takes uid ^ nonce; under a session that is already up
+            // (nested authentication) the OLD register encrypts what goes on the air
+            Crypto1 old = F.cipher;
+            const bool was = F.encrypted != 0;
+            uint8_t nb[32];
+            size_t m = 0;
+            for (size_t i = 0; i < n && m < 32; i++)
+                if (i % 9 != 8) nb[m++] = bits[i] & 1;
+            F.cipher = Crypto1();
+            F.cipher.load_key(F.cur_key);
+            if (m == 32 && F.cipher.set_tag(F.uid, nb, 32, false, nullptr)) F.encrypted = 1;
+            if (was) old.crypt(bits, n, out, 0, 0, 1);
+        }
+        return 0;
+    }
+    switch (cmd) {   // no tag type yet: an ATQA sets it (fsm.py:101-108)
+    case CMD_ATQAUL: F.tag_type = 0; break;
+    case CMD_ATQA1K: F.tag_type = 1; break;
+    case CMD_ATQA4K: F.tag_type = 2; break;
+    case CMD_ATQADS: F.tag_type = 3; break;
+    default: break;
+    }
+    return 0;
+}
+
 }  // namespace nfc

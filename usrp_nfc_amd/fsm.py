@@ -92,6 +92,21 @@ class fsm(object):
         f = frame[0]
         return self._dispatch(f, data[:int(f['n_bytes'])].tolist(), enc[:int(f['n_enc'])])
 
+    def process_outgoing(self, bits, cmd):
+        """A frame an emulator is about to send (fsm.process_outgoing, fsm.py:68-112; the encoder hook of packets.py:88-90):
+        `bits` with parity as the encoders take them, `cmd` the CommandType it is.  Returns the bits to put on the air --
+        encrypted while a MIFARE Classic session is up.  With an Ultralight tag the frame goes through process_bits, as in the
+        reference ("update state": the callback sees it)."""
+        b = np.ascontiguousarray(bits, np.uint8)
+        out = np.zeros(max(1, b.size), np.uint8)
+        rc = self.L.nfc_fsm_process_outgoing(self._h, b.ctypes.data if b.size else None, b.size, int(cmd.index), out.ctypes.data)
+        if rc == 1:
+            self.process_bits(bits, cmd.packet_type())
+            return list(bits)
+        if rc != 0:
+            raise ValueError('nfc_fsm_process_outgoing status %d' % rc)
+        return [int(v) for v in out[:b.size]]
+
     def process_packets(self, table, bits0, bits1, dispatch=True):
         """A batch: `table` rows of nfc_packet (both types, in stream order) over the per-type bit arrays.
         Returns (frames, bytes) as numpy arrays; the callback sees every command in order (dispatch=False: only the

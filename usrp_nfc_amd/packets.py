@@ -67,8 +67,12 @@ class CombinedPacketProcessor:
         self._packet_processors = [PacketProcessor(t) for t in range(PacketType.NUM_TYPES)]
         if fsm is None:
             from . import fsm as _fsm
-            fsm = _fsm.fsm(emulator.process_packet) if emulator else _fsm.fsm()
-            # (emulator.set_encoder(fsm.process_outgoing): the outgoing half of the machine is out of scope)
+            if emulator:   # packets.py:88-90: the emulator's packets come through the machine, and so does what it sends
+                fsm = _fsm.fsm(emulator.process_packet)
+                if hasattr(emulator, 'set_encoder'):
+                    emulator.set_encoder(fsm.process_outgoing)
+            else:
+                fsm = _fsm.fsm()
         self._fsm = fsm
 
     def append_bit(self, bit, packet_type):
