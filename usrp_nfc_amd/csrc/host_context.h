@@ -136,7 +136,7 @@ struct nfc_ctx {
     double expect_ms = 0.3;   // how long the stamp of a batch has taken to appear lately (wait_for_stamp)
     bool spin_wait = true;   // a batch's end is seen in the mirror's stamp word, not waited for on the stream (NFC_SPIN_WAIT=0; host_threshold.h)
     uint64_t selmask;
-    float eps;
+    float eps;               // certification margin of the speculative pass, relative to the window sum (1 %; host_threshold.h: eps_adapt says why it stays there)
     float i16_scale;
     size_t in_bytes_per_sample;
     hipStream_t st = nullptr;

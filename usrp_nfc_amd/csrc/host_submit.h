@@ -259,8 +259,9 @@ int wait_batch(nfc_ctx *c) {
     uint32_t ne, ns[2], tail_v = 0;
     memcpy(&ne, c->hs->totals + TOT_EDGES, 4);
     memcpy(ns, c->hs->totals + TOT_NSYM, 8);
+    eps_adapt(c, summary);
     if (summary.n_fail != 0) regular = false, why = "a chunk was not certified";
-    else if (summary.flagged || !sums_exact(after, (int)summary.emin, (int)summary.emax, summary.vtop)) regular = false, why = "sums not provably exact";
+    else if (summary.flagged || !sums_exact(after, (int)(summary.eminmax & 0xFFFFu), (int)(summary.eminmax >> 16), summary.vtop)) regular = false, why = "sums not provably exact";
     else if (b.tail && (tail_v = ([&] { uint32_t v; memcpy(&v, c->hs->totals + TOT_SPEC, 4); return v & (TLV_DENSE | TLV_TIMEOUT); })())) {
         // (tail.hip.h: a tile's entries did not fit the staging -- the synchronous path repeats the batch with shorter tiles)
         regular = false, why = "a tile too dense for the fused tail";

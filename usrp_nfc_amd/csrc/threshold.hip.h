@@ -1093,7 +1093,9 @@ struct CertInfo {
 // how many chunks failed, and the batch-wide exponent guard of the fp64 sums.
 struct CertSummary {
     uint32_t n_fail;            // chunks whose certification failed (atomic; zeroed by k_fill)
-    uint32_t emin, emax;        // exponent fields over every chunk's accepted values
+    uint32_t eminmax;           // exponent fields over every chunk's accepted values: emin | emax << 16
+    uint32_t worst;             // f32 bits (atomic max): the largest L1 distance between a chunk's speculated and true incoming window, over the
+                                // chunk's smallest window sum -- how much of the margin eps the speculation used (the host sizes eps by it)
     uint32_t flagged;           // some chunk met a value it cannot vouch for
     uint32_t vtop;              // raw bits of an upper bound of every ring value of the batch
     uint32_t n_carried;         // window slots that no chunk of the batch accepted a sample into (their value is the incoming ring's)
@@ -1184,8 +1186,7 @@ __device__ __forceinline__ void finalize_state(const ThrArgs &A, float *ring_nex
         carry->low_nl = (int32_t)rel;
         carry->low_kl = (kl == KEY_NONE || (long long)(kl >> 1) - (long long)A.n < floor_) ? KEY_NONE : kl - 2 * (int32_t)A.n;
         if (sum) {
-            sum->emin = mn;
-            sum->emax = mx;
+            sum->eminmax = mn | (mx << 16);
             sum->flagged = fl;
             sum->vtop = vt;
         }
@@ -1273,6 +1274,8 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     bool ok;
     if (mt.eps > 0.f) ok = mt.all_robust && (d <= mt.eps * mt.min_ss * 0.999f) && low_ok;
     else ok = !any_differ && (nl == mt.nl_in) && (kl == mt.kl_in) && !(A.gflags[c] & 4u);   // (flag 4: a re-run by k_threshold_wg that gave up)
+    // (how much of the margin the speculation used: a diagnostic -- non-negative floats order like their bits)
+    if (sum && mt.eps > 0.f && mt.all_robust && mt.min_ss > 0.f) atomicMax(&sum->worst, __float_as_uint(d / mt.min_ss));
     cert[c] = ok ? 1 : 0;
     if (!ok && sum) atomicAdd(&sum->n_fail, 1u);
     if (dbg) dbg[c] = CertInfo{d, mt.eps * mt.min_ss, mt.all_robust, (uint32_t)low_ok};
@@ -1374,7 +1377,7 @@ __device__ __forceinline__ void batch_guard(Carry &cr, double S, uint32_t emin, 
 __device__ __forceinline__ void prepare_batch_finish(Carry *carry, CertSummary *sum, double S, uint32_t emin, uint32_t emax) {
     if (threadIdx.x == 0) {
         batch_guard(*carry, S, emin, emax);
-        if (sum) *sum = CertSummary{0u, 255u, 0u, 0u, 0u};
+        if (sum) *sum = CertSummary{0u, 255u, 0u, 0u, 0u, 0u};
     }
 }
 
@@ -1470,7 +1473,7 @@ __global__ __launch_bounds__(FILL_BLOCK) void k_fill(const void *in, uint32_t n,
             eci.dst[0] = 0;
             eci.dst[1] = 0;
             eci.dst[2] = eci.dur0;
-            if (sum) *sum = CertSummary{0u, 255u, 0u, 0u, 0u};
+            if (sum) *sum = CertSummary{0u, 255u, 0u, 0u, 0u, 0u};
         }
         return;
     }
