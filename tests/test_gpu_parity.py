@@ -1015,6 +1015,25 @@ def test_no_device_allocation_in_the_middle_of_a_stream():
     assert allocs[5] == 0, allocs
 
 
+@pytest.mark.parametrize('where', [1_500_000, 1_500_000 + 2048, 2_000_001])
+def test_a_lone_failure_is_rerun_by_the_workgroup_kernel(monkeypatch, where):
+    # One level step of +15 % in an otherwise clean stream: the chunk that holds it gives up, the one behind it cannot be certified
+    # against a summary that is worth nothing.  Few failures on a clean batch take k_threshold_wg in mode 1 (from the exact state,
+    # four waves per chunk) instead of the general kernel's one wave (host_threshold.h: `lone`; round 6) -- same result, bit for bit,
+    # as the oracle's and as with the general kernel re-running everything (NFC_WG_RERUN=0).
+    iq = synth.workload('miller', 3_000_000).copy()
+    iq[2 * where:] *= np.float32(np.sqrt(1.15))
+    params = dict(hi_val=1.1, tag=False)
+    r = check_vs_oracle(iq, params, kind=api.NFC_IN_IQ_F32)
+    st = r['stats']
+    assert st.used_sequential == 0 and 1 <= st.chunks_rerun <= 6 and st.threshold_passes <= 4, (st.chunks_rerun, st.threshold_passes)
+    monkeypatch.setenv('NFC_WG_RERUN', '0')
+    r0 = check_vs_oracle(iq, params, kind=api.NFC_IN_IQ_F32)
+    assert r0['transitions'] == r['transitions'] and r0['packets'] == r['packets']
+    # ... and across pushes that put the step on a batch's first chunk
+    check_vs_oracle(iq, params, kind=api.NFC_IN_IQ_F32, pushes=[0, where - 100, where + 50_000, 3_000_000])
+
+
 @pytest.mark.parametrize('name,kw', [('miller', dict(tag=False)), ('manchester', dict(reader=False)), ('all', dict())])
 def test_fused_tail_on_the_workloads(monkeypatch, name, kw):
     # tail.hip.h: edges, decoders and framing in ONE persistent launch -- a tile end to end per workgroup, three decoupled look-backs

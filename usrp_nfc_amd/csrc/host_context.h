@@ -126,6 +126,8 @@ struct nfc_ctx {
                                                                  // rows of 64 samples per step (NFC_WG_NR), resident workgroups, this batch uses it, rounds per superstep
     size_t wg_lds = 0, wg_lds_base = 0, wg_lds_bulk_max = 0;   // dynamic LDS of k_threshold_wg: with the staging ring / without any staging / the most a whole chunk's planes may bring it to
     bool wg_bulk = true, wg_bulk_now = false;                  // a chunk's plane words leave when the chunk is done (NFC_WG_BULK=0: always the ring); this launch may
+    int wg_lone_max = 4, wg_lone_div = 64;   // ... how many failing chunks still count as lone: at most this many, and at most one in wg_lone_div
+    int wg_rerun_lone = 1;   // a lone failing chunk of a clean batch is re-run by k_threshold_wg, gave up or not (host_threshold.h; NFC_WG_RERUN=0 in the test build: never)
     int wg_rerun = 0;   // certification-only failures re-run by k_threshold_wg in mode 1 (NFC_WG_RERUN=1; see host_threshold.h)
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS

@@ -519,10 +519,16 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             // (Off unless NFC_WG_RERUN=1: measured on the stress captures -- level steps, drop-outs -- the chunks behind a chunk that
             // gave up mostly give up themselves when re-run this way, and the rounds take longer to converge: 6 passes / 4.7 ms
             // against 3 passes / 2.1 ms with the general kernel alone.)
+            // A LONE failure on an otherwise clean batch (round 6) -- a superstep that grew on the head-room it saw and met the next frame:
+            // one chunk in a thousand -- takes the workgroup kernel too, gave up or not: from the exact state (no margin for a speculated
+            // window) and with supersteps of at most two rounds it mostly gets through, and four waves walk a 98 304-sample chunk in 70 us
+            // where the general kernel's one wave takes 670 (measured on configs[2] with the margin set to make a chunk give up: the step
+            // 0.927 -> 0.526 ms, same call).  If it gives up again the general kernel takes it in the next round (tried_wg).
+            const bool lone = c->wg_rerun_lone && failing.size() <= (size_t)c->wg_lone_max && (uint64_t)failing.size() * (uint64_t)c->wg_lone_div <= (uint64_t)nch;
             if (tried_wg.empty()) tried_wg.assign(nch, 0);
             std::vector<uint32_t> by_wg, by_general;
             for (uint32_t k : failing) {
-                if (c->wg_now && c->wg_rerun && !tried_wg[k] && !(h_gflags[k] & 4)) {   // (a chunk that GAVE UP needs decisions made in place: the general kernel)
+                if (c->wg_now && !tried_wg[k] && ((c->wg_rerun && !(h_gflags[k] & 4)) || lone)) {   // (a chunk that GAVE UP needs decisions made in place: the general kernel -- unless it stands alone)
                     by_wg.push_back(k);
                     tried_wg[k] = 1;
                 } else {
