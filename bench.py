@@ -442,6 +442,8 @@ def run_config(a, workload, n, steps, warmup, rank, world, local, comm, backend,
                          'bytes_per_sample': bps,
                          # what README / DESIGN quote beside frac, inside the object the driver's record keeps:
                          'whole_path_frac': (thr_bytes + edge_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+                         # ... and with the 6 B per entry the edge stage actually stores instead of SURVEY 8(d)'s 16 B per edge
+                         'whole_path_frac_stored': (thr_bytes + stored_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS,
                          'tail_us_per_step': (dt / steps * 1e3 - k_avg) * 1e3,   # everything of a step but the threshold kernel: later stages, k_fill, launch gaps, the host's turn
                          'stages_us_extra_step': {'threshold': st.ms_threshold * 1e3, 'edges': st.ms_edges * 1e3, 'decode': st.ms_decode * 1e3},
                          ('one_batch_at_a_time_ms_per_step' if ahead else 'submitted_ahead_ms_per_step'): (other['dt'] / steps * 1e3 if other else None),

@@ -36,7 +36,7 @@ namespace nfc {
 
 constexpr int WG_WAVES = 4;
 // A step is NR rows of 64 samples (lane l holds samples l, 64 + l, ...), a round four steps: NR is chosen so that a round fits the
-// window (its steps' ring slots must be disjoint) -- 4, 6 or 8 rows: 1024, 1536 or 2048 samples per round.  Everything a round
+// window (its steps' ring slots must be disjoint) -- 4 or 8 rows: 1024 or 2048 samples per round.  Everything a round
 // costs once (barriers, bookkeeping, the form dispatch) is spread over that many samples.
 constexpr int wg_round_samples(int nr) { return 64 * nr * WG_WAVES; }
 constexpr int WG_NR_MAX = 8;
@@ -51,7 +51,7 @@ constexpr int WG_NR_MAX = 8;
 #ifndef NFC_WG_FR
 #define NFC_WG_FR 8
 #endif
-constexpr int wg_flush_rounds(int nr) { return nr == 4 ? NFC_WG_FR : NFC_WG_FR / 2; }   // 1 KB (768 B at six rows) per plane and flush
+constexpr int wg_flush_rounds(int nr) { return nr == 4 ? NFC_WG_FR : NFC_WG_FR / 2; }   // 1 KB per plane and flush
 constexpr size_t wg_stage_bytes(int nr, int rounds) { return (size_t)rounds * (size_t)(2 * WG_WAVES * 2 * nr * 4); }   // both planes
 // LDS behind the ring: LOW masks of the rounds' steps, the close exchange, scratch for workgroup reductions
 struct WgShared {
@@ -107,12 +107,6 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
     asm volatile("s_nop 4\n\t" WG_LDS_(OP, R0, 2) WG_LDS_(OP, R1, 3) WG_LDS_(OP, R2, 4) OP " " R3 ", %0, %1 offset:%5" NFC_WG_LDPOL         \
                  :                                                                                                           \
                  : "v"(voff), "s"(base), "n"(0), "n"(ST), "n"(2 * (ST)), "n"(3 * (ST))                                       \
-                 : "memory", __VA_ARGS__)
-#define WG_LD6(OP, R0, R1, R2, R3, R4, R5, ST, ...)                                                                          \
-    asm volatile("s_nop 4\n\t" WG_LDS_(OP, R0, 2) WG_LDS_(OP, R1, 3) WG_LDS_(OP, R2, 4) WG_LDS_(OP, R3, 5) WG_LDS_(OP, R4, 6)  \
-                 OP " " R5 ", %0, %1 offset:%7" NFC_WG_LDPOL                                                                 \
-                 :                                                                                                           \
-                 : "v"(voff), "s"(base), "n"(0), "n"(ST), "n"(2 * (ST)), "n"(3 * (ST)), "n"(4 * (ST)), "n"(5 * (ST))         \
                  : "memory", __VA_ARGS__)
 #define WG_LD8(OP, R0, R1, R2, R3, R4, R5, R6, R7, ST, ...)                                                                  \
     asm volatile("s_nop 4\n\t" WG_LDS_(OP, R0, 2) WG_LDS_(OP, R1, 3) WG_LDS_(OP, R2, 4) WG_LDS_(OP, R3, 5) WG_LDS_(OP, R4, 6)  \
