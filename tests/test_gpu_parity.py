@@ -554,6 +554,43 @@ def test_compact_transitions_are_the_records():
                 assert (p7 == pos[5:12]).all() and (c7 == code[5:12]).all()
 
 
+def test_readers_into_pinned_arrays_and_bit_ranges():
+    # round 6: nfc_read_edges_compact copies straight into the caller's arrays when they are pinned (api.PinnedArray: no staging, no
+    # second pass on the host) -- the same entries as through the staged path, whole and from the middle; nfc_read_packet_bits unpacks
+    # the packed words eight bits at a time -- any (first, count) range equals the slice of the whole array
+    import ctypes as C
+    iq = synth.workload('all', 1_500_000)
+    with api.NfcContext(hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as ctx:
+        ctx.push(iq)
+        pos, code = ctx.edges_compact()
+        n = len(pos)
+        assert n > 50_000
+        pp, pc = api.PinnedArray(n + 100, np.uint32), api.PinnedArray(n + 100, np.uint16)
+        pp.array[:] = 0xFFFFFFFF
+        pc.array[:] = 0xFFFF
+        p2, c2 = ctx.edges_compact(out=(pp.array, pc.array))
+        assert len(p2) == n and (p2 == pos).all() and (c2 == code).all()
+        assert (pp.array[n:] == 0xFFFFFFFF).all() and (pc.array[n:] == 0xFFFF).all()   # (nothing written past the batch's entries)
+        got = C.c_size_t(0)
+        assert ctx.L.nfc_read_edges_compact(ctx.h, 12_345, pp.array.ctypes.data, pc.array.ctypes.data, 1000, C.byref(got)) == 0 and got.value == 1000
+        assert (pp.array[:1000] == pos[12_345:13_345]).all() and (pc.array[:1000] == code[12_345:13_345]).all()
+        with pytest.raises(api.NfcError):
+            ctx.edges_compact(out=(pp.array[:10], pc.array[:10]))
+        pp.free()
+        pc.free()
+        rng = np.random.default_rng(5)
+        for t in (0, 1):
+            bits = ctx.packet_bits(t)
+            assert len(bits) > 10_000 and set(np.unique(bits).tolist()) <= {0, 1}
+            for _ in range(40):
+                first = int(rng.integers(0, len(bits) - 1))
+                cnt = int(rng.integers(1, min(3000, len(bits) - first) + 1))
+                out = np.full(cnt + 8, 7, np.uint8)
+                assert ctx.L.nfc_read_packet_bits(ctx.h, t, first, out.ctypes.data, cnt, C.byref(got)) == 0 and got.value == cnt
+                assert (out[:cnt] == bits[first:first + cnt]).all() and (out[cnt:] == 7).all(), (t, first, cnt)
+        assert ctx.packets() == oracle_run(iq, dict(hi_val=1.1), api.NFC_IN_IQ_F32).packets()
+
+
 @pytest.mark.parametrize('dec_spec', ['1', '0'])
 @pytest.mark.parametrize('max_len', [1, 7, 31, 32, 50, 62, 63, 64, 200])
 def test_edge_stage_dense_and_long_runs(monkeypatch, max_len, dec_spec):
