@@ -744,7 +744,7 @@ def _end_to_end_pass(workload, own, flags):
 
     n_edges = 0
     t_push = t_read = t_join = 0.0   # where the main thread's time goes: GPU path, read-back, waiting for the upload
-    th_u, th_p = threading.Thread(target=uploader), threading.Thread(target=protocol)
+    th_u, th_p = threading.Thread(target=uploader, daemon=True), threading.Thread(target=protocol, daemon=True)   # (daemon: a failure on the main thread must not leave the process waiting for them)
     t0 = time.perf_counter()
     th_u.start()
     th_p.start()

@@ -320,9 +320,7 @@ int run_tail(nfc_ctx *c, uint32_t n, uint32_t skip, uint64_t g0) {
             const uint32_t need = (P.cap_bits[t] + 31u) / 32u + 1u;
             if (c->bits_clean[t] < need) HIPCHK(c, hipMemsetAsync(P.bits[t], 0, (size_t)need * 4, c->st));
             c->bits_clean[t] = 0;   // (used from here on)
-            const size_t before = c->d_bits_alt[t].cap;
             HIPCHK(c, c->d_bits_alt[t].ensure(c->d_bits[t].cap));
-            (void)before;
             A.Znext.p[t] = c->d_bits_alt[t].as<uint32_t>();
             A.Znext.n[t] = (uint32_t)std::min<size_t>(need + 4096, c->d_bits_alt[t].cap / 4);   // (room for a next batch that needs a little more)
             c->alt_clean[t] = A.Znext.n[t];
