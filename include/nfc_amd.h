@@ -31,7 +31,7 @@ extern "C" {
 
 /* 2: nfc_stats grew (ran_ahead, redone_total, ring_slots_carried); i16_scale == 0 means sample / 32767 (GNU Radio's wavfile_source), not / 32768 */
 /* 3: nfc_stats.reserved0 became decode_respeculated (same layout); the raw float32 envelope takes the fast threshold kernels */
-/* 4: nfc_stats grew (device_allocs, tail_fused) */
+/* 4: nfc_stats grew (device_allocs, tail_fused, chunks_rerun_in_place) */
 #define NFC_AMD_ABI_VERSION 4
 
 typedef enum {
@@ -129,6 +129,8 @@ typedef struct {
                                * of a stream -- the buffers are sized when a stream's first batch of a length is seen, with room for four
                                * times the transition density of a clean capture, so a stream that turns dense does not pay hipMalloc */
     uint32_t tail_fused;      /* 1: the last batch's edge, decode and framing stages ran as ONE launch (test build, NFC_TAIL=1); the product build: 0 */
+    uint32_t chunks_rerun_in_place; /* ... of chunks_rerun: re-runs by the workgroup kernel in the form that evaluates a failed round in place
+                                     * (up to a machine-full of failing chunks per round), the rest by the one-wave exact kernel */
 } nfc_stats;
 
 /* Everything a successor time chunk needs from its predecessor:

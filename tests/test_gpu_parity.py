@@ -130,6 +130,9 @@ def test_nonfinite_iq_input(case):
 
 def oracle_run(x, params, kind):
     o = co.COracle(trace=True, **params)
+    if kind == api.NFC_IN_I16_SQ:   # (16-bit PCM: sample / 32767 as a float32, then squared -- the WAV branch)
+        o.push_real_sq((np.asarray(x).astype(np.float32) / np.float32(32767.0)).astype(np.float32))
+        return o
     {api.NFC_IN_ENV_F32: o.push_env, api.NFC_IN_IQ_F32: o.push_iq, api.NFC_IN_REAL_F32_SQ: o.push_real_sq}[kind](x)
     return o
 
@@ -1052,6 +1055,48 @@ def test_no_device_allocation_in_the_middle_of_a_stream():
     assert allocs[5] == 0, allocs
 
 
+@pytest.mark.parametrize('kind', ['iq', 'env', 'real', 'i16'])
+def test_failed_rounds_are_evaluated_in_place(monkeypatch, kind):
+    # Level steps behind losses of signal: the chunk with the step gives up in pass 0 (the window is being overwritten with a new level:
+    # no drift allowance covers that), the ones behind it cannot be certified.  Up to a machine-full of failing chunks are re-run by
+    # k_threshold_wg<KIND, 4, true> (round 6): a round that fails its check is taken back and evaluated by the four waves the way
+    # k_threshold evaluates a step, and the chunk goes on -- the same transitions, symbols and packets, bit for bit, as the oracle's and
+    # as with k_threshold re-running everything (NFC_WG_EX=0), whatever the input kind and wherever the pushes cut the stream.
+    n = 3_000_000
+    iq = synth.stress_workload(n, depth=0.08, sigma=0.002, every=250_000)
+    params = dict(hi_val=1.1)
+    if kind == 'iq':
+        x, k = iq, api.NFC_IN_IQ_F32
+    elif kind == 'env':
+        x, k = synth.envelope_f32(iq), api.NFC_IN_ENV_F32
+    elif kind == 'real':
+        x, k = np.sqrt(synth.envelope_f32(iq).astype(np.float64)).astype(np.float32), api.NFC_IN_REAL_F32_SQ
+    else:
+        x, k = np.clip(np.round(np.sqrt(synth.envelope_f32(iq).astype(np.float64)) * 20000.0), -32768, 32767).astype(np.int16), api.NFC_IN_I16_SQ
+    r = check_vs_oracle(x, params, kind=k)
+    st = r['stats']
+    assert st.used_sequential == 0 and st.chunks_rerun_in_place > 0 and st.chunks_rerun_in_place >= st.chunks_rerun - 2, (st.chunks_rerun, st.chunks_rerun_in_place)
+    r1 = check_vs_oracle(x, params, kind=k, pushes=[0, 249_900, 250_200, 251_500, 1_000_001, 2_750_300, n])
+    monkeypatch.setenv('NFC_WG_EX', '0')
+    r0 = check_vs_oracle(x, params, kind=k)
+    assert r0['stats'].chunks_rerun_in_place == 0 and r0['stats'].chunks_rerun > 0
+    assert r0['transitions'] == r['transitions'] == r1['transitions'] and r0['packets'] == r['packets'] == r1['packets']
+
+
+def test_in_place_reruns_with_a_long_window_and_hovering_samples(monkeypatch):
+    # ... with the window of a 10 MS/s capture (pass 0 runs eight rows per step there, the re-runs four), and on the capture whose loaded
+    # half bits hover AT the HIGH threshold (every other round fails its check)
+    n = 1_500_000
+    iq = synth.stress_workload(n, depth=0.08, sigma=0.002, every=200_000)
+    # (chunks of whole eight-row rounds: a batch of a test's size would otherwise be cut into the window's smallest chunk, which is not)
+    r = check_vs_oracle(iq, dict(hi_val=1.1, samp_rate=1e7, av_window=10000, max_len=250), kind=api.NFC_IN_IQ_F32, chunk_samples=22528)
+    assert r['stats'].chunks_rerun_in_place > 0
+    hov = synth.stress_workload(1_000_000)
+    monkeypatch.setenv('NFC_WG_EX', '100000')   # (the product sends a batch where EVERY chunk fails to k_threshold: here the in-place form takes them)
+    r = check_vs_oracle(hov, dict(hi_val=1.1), kind=api.NFC_IN_IQ_F32)
+    assert r['stats'].chunks_rerun_in_place > 0
+
+
 @pytest.mark.parametrize('where', [1_500_000, 1_500_000 + 2048, 2_000_001])
 def test_a_lone_failure_is_rerun_by_the_workgroup_kernel(monkeypatch, where):
     # One level step of +15 % in an otherwise clean stream: the chunk that holds it gives up, the one behind it cannot be certified
@@ -1065,6 +1110,7 @@ def test_a_lone_failure_is_rerun_by_the_workgroup_kernel(monkeypatch, where):
     st = r['stats']
     assert st.used_sequential == 0 and 1 <= st.chunks_rerun <= 6 and st.threshold_passes <= 4, (st.chunks_rerun, st.threshold_passes)
     monkeypatch.setenv('NFC_WG_RERUN', '0')
+    monkeypatch.setenv('NFC_WG_EX', '0')
     r0 = check_vs_oracle(iq, params, kind=api.NFC_IN_IQ_F32)
     assert r0['transitions'] == r['transitions'] and r0['packets'] == r['packets']
     # ... and across pushes that put the step on a batch's first chunk

@@ -18,5 +18,5 @@ def test_lean_kernel_isa_audit(tmp_path):
     lines = [l for l in r.stdout.splitlines() if 'k_threshold_lean' in l]
     assert len(lines) >= 6 and all(l.endswith('0 findings') for l in lines), r.stdout   # every instantiation was looked at
     wg = [l for l in r.stdout.splitlines() if 'k_threshold_wg' in l]
-    assert len(wg) == 6 and all(l.endswith('0 findings') for l in wg), r.stdout        # four rows per step for the four input kinds, eight for IQ and the envelope
+    assert len(wg) == 10 and all(l.endswith('0 findings') for l in wg), r.stdout        # four rows per step for the four input kinds, eight for IQ and the envelope, the four re-run forms
     assert len(lines) == 8, r.stdout                                                    # the lean kernel: four kinds x two block widths

@@ -34,7 +34,7 @@ class Stats(C.Structure):
                 ('used_sequential', C.c_uint32), ('n_chunks', C.c_uint32), ('bytes_in', C.c_uint64),
                 ('ms_threshold_kernel', C.c_double * 6), ('n_threshold_timed', C.c_uint32), ('chunk_samples', C.c_uint32),
                 ('ran_ahead', C.c_uint32), ('redone_total', C.c_uint32), ('ring_slots_carried', C.c_uint32), ('decode_respeculated', C.c_uint32),
-                ('device_allocs', C.c_uint32), ('tail_fused', C.c_uint32)]
+                ('device_allocs', C.c_uint32), ('tail_fused', C.c_uint32), ('chunks_rerun_in_place', C.c_uint32)]
 
 
 class Frame(C.Structure):   # nfc_frame

@@ -128,6 +128,11 @@ struct nfc_ctx {
     bool wg_bulk = true, wg_bulk_now = false;                  // a chunk's plane words leave when the chunk is done (NFC_WG_BULK=0: always the ring); this launch may
     int wg_lone_max = 4, wg_lone_div = 64;   // ... how many failing chunks still count as lone: at most this many, and at most one in wg_lone_div
     int wg_rerun_lone = 1;   // a lone failing chunk of a clean batch is re-run by k_threshold_wg, gave up or not (host_threshold.h; NFC_WG_RERUN=0 in the test build: never)
+    // re-runs by k_threshold_wg<KIND, 4, true> (failed rounds evaluated in place): where it applies, its LDS, up to how many failing chunks
+    // of a round take it (more: k_threshold, whose one wave per chunk fills the machine where every chunk fails), the launch in progress
+    int wg_ex_ok = 0, wg_ex_max = 0;
+    size_t wg_ex_lds = 0;
+    bool wg_ex_launch = false;
     int wg_rerun = 0;   // certification-only failures re-run by k_threshold_wg in mode 1 (NFC_WG_RERUN=1; see host_threshold.h)
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
@@ -398,11 +403,16 @@ void launch_wg(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipE
             lds = need;
         }
     }
+    if (c->wg_ex_launch) {   // (re-runs that evaluate failed rounds in place: four rows per step whatever pass 0 ran with)
+        B.wg_stage_rounds = 2 * wg_flush_rounds(4);
+        lds = c->wg_ex_lds;
+    }
     if (c->dbg_bad_launch) lds += (size_t)1 << 20;
     auto go = [&](auto kern) {
         if (e0) NFC_LAUNCH_EXT(kern, dim3(nwork), dim3(256), lds, c->st, e0, e1, 0, B);
         else NFC_LAUNCH(kern, dim3(nwork), dim3(256), lds, c->st, B);
     };
+    if (c->wg_ex_launch) return go(k_threshold_wg<KIND, 4, true>);
     if constexpr (KIND == IN_IQ_F32 || KIND == IN_ENV_F32) {   // (the kinds eight rows per step are instantiated for: nfc_create chooses wg_nr)
         if (c->wg_nr == 8) return go(k_threshold_wg<KIND, 8>);
     }

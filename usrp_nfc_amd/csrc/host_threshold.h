@@ -383,7 +383,8 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
         const bool dbg = c->dbg_any;
         bool first_round = true;
         c->h_list.clear();
-        std::vector<uint8_t> tried_wg;   // chunks the workgroup kernel has re-run once
+        std::vector<uint8_t> tried_wg;   // 1: the workgroup kernel ran the chunk's latest re-run; 2: it has given up on it (or k_threshold has taken it since)
+        bool ex_off = false;             // the in-place form is not used for the rest of this batch
         std::vector<uint8_t> ever_rerun; // chunks re-run at least once in this batch
         for (uint32_t k = 1; k < nch; k++) c->h_list.push_back(k);
         int rounds = 0;
@@ -465,7 +466,11 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 if (!h_cert[k]) failing.push_back(k);
             if (c->dbg_trace) {
                 fprintf(stderr, "[nfc] round %d: n_fail %u, %zu failing of %u pending (cert[0] %d):", rounds, summary.n_fail, failing.size(), np, (int)h_cert[0]);
-                for (size_t i = 0; i < failing.size() && i < 12; i++) fprintf(stderr, " %u", failing[i]);
+                for (size_t i = 0; i < failing.size() && i < 12; i++) fprintf(stderr, " %u(%x)", failing[i], (unsigned)h_gflags[failing[i]]);
+                int why[8] = {0};
+                for (uint32_t k : failing) why[(h_gflags[k] >> 4) & 7]++;
+                fprintf(stderr, "; gave up by code:");
+                for (int i = 0; i < 8; i++) fprintf(stderr, " %d", why[i]);
                 fprintf(stderr, "\n");
             }
             if (dbg) {
@@ -525,16 +530,31 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             // where the general kernel's one wave takes 670 (measured on configs[2] with the margin set to make a chunk give up: the step
             // 0.927 -> 0.526 ms, same call).  If it gives up again the general kernel takes it in the next round (tried_wg).
             const bool lone = c->wg_rerun_lone && failing.size() <= (size_t)c->wg_lone_max && (uint64_t)failing.size() * (uint64_t)c->wg_lone_div <= (uint64_t)nch;
+            // Up to a machine-full of failing chunks (round 6): the workgroup kernel in the form that evaluates a failed round IN PLACE
+            // (k_threshold_wg<KIND, 4, true>) -- it gives up only where a round is not four whole steps or a LOW run is out of sight.
             if (tried_wg.empty()) tried_wg.assign(nch, 0);
+            {   // (a stream it keeps giving up on -- values out of range, a stream's first chunk: k_threshold alone for the rest of the batch)
+                size_t ran = 0, gave = 0;
+                for (uint32_t k : failing)
+                    if (tried_wg[k] == 1) ran++, gave += (h_gflags[k] & 4) ? 1 : 0;
+                if (gave * 4 > ran) ex_off = true;
+            }
+            const bool ex = c->wg_now && c->wg_ex_ok && !ex_off && failing.size() <= (size_t)c->wg_ex_max;
             std::vector<uint32_t> by_wg, by_general;
             for (uint32_t k : failing) {
-                if (c->wg_now && !tried_wg[k] && ((c->wg_rerun && !(h_gflags[k] & 4)) || lone)) {   // (a chunk that GAVE UP needs decisions made in place: the general kernel -- unless it stands alone)
+                // (a chunk the in-place form has re-run and that did NOT give up may take it again -- what failed is its incoming state;
+                // one it gave up on is k_threshold's for the rest of the batch: that kernel never gives up, so the rounds converge)
+                if (tried_wg[k] == 1 && (h_gflags[k] & 4)) tried_wg[k] = 2;
+                const bool ex_again = ex && tried_wg[k] == 1;
+                if (c->wg_now && (!tried_wg[k] || ex_again) && (ex || (c->wg_rerun && !(h_gflags[k] & 4)) || lone)) {   // (a chunk that GAVE UP needs decisions made in place: the general kernel -- unless it stands alone)
                     by_wg.push_back(k);
                     tried_wg[k] = 1;
                 } else {
                     by_general.push_back(k);
+                    if (tried_wg[k]) tried_wg[k] = 2;
                 }
             }
+            if (c->dbg_trace) fprintf(stderr, "[nfc]   re-run: %zu by the workgroup kernel%s, %zu by k_threshold\n", by_wg.size(), ex ? " (in-place form)" : "", by_general.size());
             A.mode = 1;
             // One host turn per round (round 4: two before -- the re-runs were waited for before their certification was enqueued,
             // and every small copy came out of pageable memory): the lists travel from pinned staging, the version bytes of the
@@ -552,7 +572,9 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 A.list = c->d_list.as<uint32_t>();
                 A.nlist = (uint32_t)by_wg.size();
                 A.ksteps = 2;
+                c->wg_ex_launch = ex;
                 launch_threshold_kind(c, A, A.nlist, true);
+                c->wg_ex_launch = false;
                 A.ksteps = c->wg_rounds;
             }
             if (!by_general.empty()) {
@@ -564,6 +586,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
             c->stats.threshold_passes++;
             passes++;
             c->stats.chunks_rerun += A.nlist;
+            if (ex) c->stats.chunks_rerun_in_place += (uint32_t)by_wg.size();
             std::vector<uint8_t> ran(nch, 0);
             for (uint32_t k : failing) {
                 ran[k] = 1;
@@ -580,7 +603,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 const bool full = !ran[k] && !(h_gflags[k] & 2);   // (a re-run chunk: not known yet -- taken as not full)
                 vis = ran[k] || (vis && !full);
             }
-            if (++rounds > (int)nch + 2) return fail(c, NFC_ERR_INTERNAL, "threshold passes did not converge");
+            if (++rounds > 2 * (int)nch + 2) return fail(c, NFC_ERR_INTERNAL, "threshold passes did not converge");
         }
 
         // can every fp64 sum of this batch be proven exact?  (otherwise the summation order matters)
@@ -674,6 +697,7 @@ int run_threshold(nfc_ctx *c, const void *d_in, uint32_t n, uint32_t skip, const
     *clean = false;
     c->stats.threshold_passes = 0;
     c->stats.chunks_rerun = 0;
+    c->stats.chunks_rerun_in_place = 0;
     c->stats.used_sequential = 0;
     const uint32_t span = (uint32_t)std::min<uint64_t>(((uint64_t)8 * c->L + STEP - 1) / STEP * STEP, 1u << 30);   // prefix per round
     EdgeCarry ec = c->h_ecarry;

@@ -65,6 +65,14 @@ using namespace nfc;
 // ===========================================================================
 namespace {
 // the instantiation of k_threshold_wg a context launches (for the occupancy query and the LDS attribute)
+const void *wg_ex_kernel_of(int kind) {
+    switch (kind) {
+    case NFC_IN_IQ_F32: return (const void *)k_threshold_wg<IN_IQ_F32, 4, true>;
+    case NFC_IN_ENV_F32: return (const void *)k_threshold_wg<IN_ENV_F32, 4, true>;
+    case NFC_IN_REAL_F32_SQ: return (const void *)k_threshold_wg<IN_REAL_F32_SQ, 4, true>;
+    default: return (const void *)k_threshold_wg<IN_I16_SQ, 4, true>;
+    }
+}
 const void *wg_kernel_of(int kind, int nr) {
     // (six instantiations: four rows per step for every input kind, eight for the two kinds a long-window capture arrives in)
     switch (kind) {
@@ -308,6 +316,23 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
             c->wg_slots_ahead = prop.multiProcessorCount * per_cu_ahead;
             // (what a batch submitted ahead holds of a CU's LDS is this kernel's, not the lean kernel's: host_submit.h, submit_fast_ok)
             if (c->wg_ok && c->wg && c->lean) c->ahead_lds_per_cu = c->wg_lds * (size_t)per_cu_ahead;
+            // re-runs with failed rounds evaluated in place (k_threshold_wg<KIND, 4, true>): max_len within one four-row step, a round of
+            // four of them within the window; up to a machine-full of failing chunks per round
+            c->wg_ex_lds = c->wg_lds_base + wg_stage_bytes(4, 2 * wg_flush_rounds(4));
+            c->wg_ex_ok = c->wg_ok && c->mx <= 64 * 4 - 2 && c->L >= wg_round_samples(4) && c->wg_ex_lds <= 160 * 1024;
+            if (c->wg_ex_ok) {
+                const void *kx = wg_ex_kernel_of(p->input_kind);
+                if (c->wg_ex_lds > 64 * 1024) CRT(hipFuncSetAttribute(kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->wg_ex_lds));
+                int fit = 0;
+                CRT(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kx, 256, c->wg_ex_lds));
+                if (fit < 1) c->wg_ex_ok = 0;
+                c->wg_ex_max = prop.multiProcessorCount * std::max(1, std::min(4, fit));
+            }
+            if (const char *e = NFC_ENV("NFC_WG_EX")) {   // 0: never; N: up to N failing chunks per round
+                const int v = atoi(e);
+                if (v <= 0) c->wg_ex_ok = 0;
+                else c->wg_ex_max = v;
+            }
             // the longest superstep (rounds): the kernel lengthens and shortens its supersteps by the head-room it sees between the
             // samples and the thresholds; this caps them
             if (!c->wg_rounds) c->wg_rounds = 8;

@@ -198,8 +198,14 @@ __device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (
     }
 }
 
-template <int KIND, int NR>
+// EX (re-runs from the exact state, mode 1): a round that fails its check is not the chunk's end -- every wave puts the ring slots
+// of its step back, wave 0 evaluates the round's rows the way k_threshold does (row_exact of threshold.hip.h: the accept mask
+// iterated to its fixed point on fp64 sums), leaves the masks and plane words where the round's waves would have, and the chunk goes
+// on in the tracked form from the exact sum.  One-round supersteps; rounds of whole steps only (a ragged end, the stream's first
+// stable sample: the chunk gives up as before and k_threshold takes it).
+template <int KIND, int NR, bool EX = false>
 __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
+    static_assert(!EX || NR == 4, "the samples of an exact round travel through sh->acc: sixteen rows");
     constexpr uint32_t STEPN = 64u * NR;
     constexpr int WG_ROUND = wg_round_samples(NR);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -446,6 +452,18 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     uint32_t xlo_acc = 0x7F7FFFFFu, xhi_acc = 0u;   // (raw bits: envelopes are >= 0)
     int lz_base = LL_NONE;                  // base of this wave's latest step with LOW samples
     int rounds_since_sync = 0;
+    // EX: what a round needs to be taken back and evaluated again -- this wave's samples, the raw ring values of its slots, the
+    // bookkeeping a step in the general form may have moved; wave 0: the exact state behind a round it evaluated itself
+    float xkeep[NR], snap[NR];
+    uint32_t snap_slot = 0u, st_off_round = 0u, c_snap[4] = {0u, 0u, 0u, 0u};
+    int lz_snap = LL_NONE;
+    double ex_ss = 0;
+    bool ex_valid = false;
+#ifdef NFC_EX_PRINTF
+    int ex_count = 0, ex_codes = 0, ex_first = -1, ex_last = -1, n_rounds = 0, ex_trips = 0;
+#endif
+#pragma unroll
+    for (int j = 0; j < NR; j++) xkeep[j] = snap[j] = 0.f;
 
     auto open_round = [&]() __attribute__((always_inline)) -> bool {
         tlo = rfl(ssf * loLf);
@@ -630,7 +648,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     // A SUPERSTEP is `sup` regular rounds classified against one set of thresholds (A.ksteps), or ONE round that is not four whole
     // steps of stable samples (the stream's first stable sample, a batch's ragged end): its
     // rounds are separated by the first barrier only, the second one and the exchange behind it close the superstep.
-    const int sup = max(1, A.ksteps);   // the longest superstep
+    const int sup = EX ? 1 : max(1, A.ksteps);   // the longest superstep
     int cur_sup = 1;                    // rounds of the next one (it adapts: see the close)
     bool need_open = true;
     uint32_t rbase = m_chunk;   // base of the round
@@ -810,6 +828,22 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             WG_PF_BEGIN();
             wg_barrier();
             WG_PF_END(pf_b1);
+            if constexpr (EX && REG) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    uint32_t s = slot_step + 64u * j + lane;
+                    s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
+                    xkeep[j] = x[j];
+                    snap[j] = ring[s];
+                }
+                snap_slot = slot_step;
+                st_off_round = st_off;
+                lz_snap = lz_base;
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) c_snap[i] = sh->cold[wave][i];
+                }
+            }
 
             // ---- phase B: the ring, the drift accumulators, the HIGH plane ----
             // which form: nothing classifies / only LOW / only HIGH with no LOW sample in reach / the general step.
@@ -987,6 +1021,20 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 const float M = (B + (eps + RND_SUM) * ssf) * slU + ssf * 7.62939453125e-06f;   // (+ 2^-17 of the sum: the f32 thresholds)
                 const float need_lo = M * loLf, need_hi = M * hiLf;
                 if (!f && !(dlmin > need_lo && dhmin > need_hi && M < 0.25f * ssf)) f = (dlmin > need_lo && dhmin > need_hi) ? 4u : 2u;
+                if constexpr (EX) {
+                    // a round of whole steps that drifted too far, came too close or met a LOW run it could not measure: evaluated again below
+#ifdef NFC_EX_PRINTF
+                    n_rounds++;
+                    if (regular && (f == 2u || f == 3u || f == 4u)) {
+                        ex_count++;
+                        ex_codes |= 1 << f;
+                        if (ex_first < 0) ex_first = n_rounds - 1;
+                        ex_last = n_rounds - 1;
+                    }
+#endif
+                    if (regular && (f == 2u || f == 3u || f == 4u)) f = 0x40u;
+                    if (lane == 0) sh->bc[4] = Dt;   // (what the round added to the sum as it was tried: the first guess below leans on it)
+                }
                 int next_sup = cur_sup;
                 if (!f) {
                     // every window sum of the superstep lay below ssf + M, and what it accepted between the thresholds
@@ -1011,9 +1059,228 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 if (lane == 0) *(float4 *)&sh->bc[0] = make_float4(tlo, thi, ssf, __uint_as_float(f | ((uint32_t)next_sup << 8)));
             }
             wg_barrier();
-            const float4 t4 = *(const float4 *)&sh->bc[0];
-            const uint32_t fw = rfl(__float_as_uint(t4.w));
-            const uint32_t f = fw & 0xFFu;
+            float4 t4 = *(const float4 *)&sh->bc[0];
+            uint32_t fw = rfl(__float_as_uint(t4.w));
+            uint32_t f = fw & 0xFFu;
+            bool was_exact = false;
+            if constexpr (EX) {
+                if (f == 0x40u) {
+                    // The round is taken back and evaluated the way k_threshold evaluates a step (row_exact: the accept mask of a row
+                    // iterated to its fixed point on fp64 sums) -- by all four waves at once.  A step's rows need the window sum and the LOW
+                    // bookkeeping at its first sample, which the steps before it decide: every wave GUESSES its step's masks (from the
+                    // thresholds the round was tried with), hands in what its step would add to the sum under the guess and its LOW masks,
+                    // evaluates its rows from what the waves before it handed in, and takes the outcome as its next guess.  When no wave's
+                    // masks moved, every step was evaluated from the state its predecessors really leave (by induction from step 0, which
+                    // starts from the exact sum): at most five trips, one when the guess was right.
+                    was_exact = true;
+                    const int rb0 = (int)rbase - WG_ROUND;   // the round's first sample (rbase has moved on)
+                    const int sb = rb0 + (int)STEPN * wave;  // this wave's
+                    constexpr uint32_t MB = (uint32_t)sizeof(sh->msk[0]);
+                    const uint32_t cur = mo_prev, p1 = (cur == 0u) ? 2u * MB : cur - MB, p2 = mo;   // the mask buffers of this round, the one before, the one before that
+                    uint32_t slot[NR];
+                    float pv[NR];
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
+                        uint32_t s = snap_slot + 64u * j + lane;
+                        s = (s >= (uint32_t)L) ? s - (uint32_t)L : s;
+                        slot[j] = s;
+                        ring[s] = snap[j];
+                        pv[j] = fabsf(snap[j]);
+                    }
+                    lz_base = lz_snap;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) sh->cold[wave][i] = c_snap[i];
+                    }
+                    fail = 0u;
+                    rounds_since_sync = 0;
+                    // the exact sum at the round's first sample: the one the round before left if it was evaluated here, else the ring's
+                    double ss0 = ex_ss;
+                    if (!ex_valid) {
+                        wg_barrier();   // (every slot is back)
+                        double part = 0;
+                        for (int s2 = tid; s2 < L; s2 += 256) part += (double)fabsf(ring[s2]);
+                        const double ps = wave_sum_f64(part);
+                        uint32_t v[8], g[WG_WAVES][8];
+                        v[0] = (uint32_t)__double2loint(ps);
+                        v[1] = (uint32_t)__double2hiint(ps);
+                        wg_gather(v, 2, g);
+                        double tot = 0;
+                        for (int w = 0; w < WG_WAVES; w++) tot += __hiloint2double((int)g[w][1], (int)g[w][0]);
+                        ss0 = tot + cr.delta;
+                    }
+                    double *const exd = (double *)&sh->acc[0][0];        // (sh->acc: read and done with when the verdict was given)
+                    uint32_t *const exf = (uint32_t *)&sh->acc[1][0];
+                    unsigned long long accG[NR], lowG[NR], posG[NR];
+                    // (the first guess: thresholds of a sum that moves evenly through the round by what the round added to it as it was
+                    // tried -- a window that is being overwritten with a new level drifts like that, and a guess that is nearly right
+                    // saves trips: measured on the level-step capture, 3.7 trips per round with the round's own thresholds)
+                    const float dt_round = rfl(sh->bc[4]);
+#pragma unroll
+                    for (int j = 0; j < NR; j++) {
+                        const float sg = ssf + dt_round * (((float)(wave * NR + j) + 0.5f) / (float)(4 * NR));
+                        lowG[j] = __ballot(xkeep[j] < sg * loLf);
+                        accG[j] = ~lowG[j] & ~__ballot(xkeep[j] > sg * hiLf);
+                        posG[j] = 0ull;
+                    }
+                    uint32_t fx = 0u, flx = 0u;
+                    double S = ss0;
+                    float bsum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NR; j++) bsum += fabsf(xkeep[j] - pv[j]);
+                    bsum = wave_sum_f32(bsum);
+                    int trips = 0;
+                    (void)trips;
+                    for (int trip = 0;; trip++) {
+                        trips = trip + 1;
+                        // what this step adds to the sum under the guess; its LOW masks where the rounds' steps publish theirs
+                        double d = 0;
+#pragma unroll
+                        for (int j = 0; j < NR; j++) d += ((accG[j] >> lane) & 1ull) ? ((double)xkeep[j] - (double)pv[j]) : 0.0;
+                        d = wave_sum_f64(d);
+                        if (lane == 0) {
+                            exd[wave] = d;
+                            uint32_t *mp = (uint32_t *)((char *)&sh->msk[0][wave][0] + cur);
+                            unsigned long long any = 0ull;
+#pragma unroll
+                            for (int j = 0; j < NR; j++) {
+                                mp[2 * j] = (uint32_t)lowG[j];
+                                mp[2 * j + 1] = (uint32_t)(lowG[j] >> 32);
+                                any |= lowG[j];
+                            }
+                            mp[4 * NR] = any ? 1u : 0u;
+                        }
+                        wg_barrier();
+                        S = ss0;
+                        for (int w = 0; w < wave; w++) S += exd[w];
+                        S = rfl(S);
+                        // The LOW bookkeeping at the step's first sample, off the LOW masks of the two rounds' worth of steps before it
+                        // (lane i: word i of their 8 NR words; the steps of rounds before this one stood their check or were evaluated
+                        // here, the steps before it in this round are guesses like its own).  Before the chunk's first sample: what the
+                        // chunk started from.
+                        int nl, kl = KEY_NONE;
+                        {
+                            const int W0 = sb - 2 * WG_ROUND;
+                            const bool reaches = W0 <= (int)m_chunk;   // the words reach back to the chunk's first sample
+                            if (m_start > m_chunk && W0 < (int)m_start) fx = 5u;   // (masked lanes among them: the stream's first chunk)
+                            const int Wb = W0 + 64 * lane;
+                            const bool valid = lane < 8 * NR && Wb >= (int)m_chunk;
+                            unsigned long long lw = 0ull;
+                            if (lane < 8 * NR) {
+                                const int rel = Wb - (rb0 - 2 * WG_ROUND);   // from the first sample of the round two before this one
+                                const int q = rel / WG_ROUND, in_r = (rel - q * WG_ROUND) >> 6;
+                                const uint32_t bo = (q == 0) ? p2 : (q == 1 ? p1 : cur);
+                                const int wv = in_r / NR, j = in_r & (NR - 1);
+                                const uint32_t *wp = (const uint32_t *)((const char *)&sh->msk[0][wv][0] + bo) + 2 * j;
+                                lw = (unsigned long long)wp[0] | ((unsigned long long)wp[1] << 32);
+                            }
+                            const unsigned long long lowv = valid ? lw : 0ull, nonlow = valid ? ~lw : 0ull;
+                            nl = wave_max_i32(nonlow ? Wb + last_set(nonlow) : LL_NONE);
+                            const int ll = wave_max_i32(lowv ? Wb + last_set(lowv) : LL_NONE);
+                            if (nl == LL_NONE) {
+                                if (reaches) nl = nl_in;
+                                else fx = 3u;   // (two rounds of LOW samples: where the run began is out of sight)
+                            }
+                            if (ll == LL_NONE) {
+                                kl = reaches ? kl_in : KEY_NONE;   // (a LOW sample further back is out of every HIGH sample's reach)
+                            } else {
+                                // did its run end on a time-out?  The last sample before it that is not LOW says it.
+                                unsigned long long below = nonlow;
+                                if (Wb > ll) below = 0ull;
+                                else if (Wb + 63 >= ll) below &= (1ull << (ll - Wb)) - 1ull;
+                                int s1 = wave_max_i32(below ? Wb + last_set(below) : LL_NONE);
+                                bool known = true;
+                                if (s1 == LL_NONE) {
+                                    if (reaches) s1 = nl_in;
+                                    else known = false;
+                                }
+                                const int koff = ll - (s1 + 1);
+                                const bool bad = known && koff > 0 && (koff % mx) == 0;
+                                kl = 2 * ll + (bad ? 0 : 1);
+                                if (!known && sb - ll <= mx + 1) fx = 3u;
+                            }
+                            nl = rfl(nl);
+                            kl = rfl(kl);
+                        }
+                        // the step's rows from that state
+                        bool moved = false;
+                        double ss = S;
+#pragma unroll 1
+                        for (int j = 0; j < NR; j++) {
+                            float xj = xkeep[0], pj = pv[0];
+                            unsigned long long aG = accG[0], lG = lowG[0];
+#pragma unroll
+                            for (int k = 1; k < NR; k++) {
+                                xj = (j == k) ? xkeep[k] : xj;
+                                pj = (j == k) ? pv[k] : pj;
+                                aG = (j == k) ? accG[k] : aG;
+                                lG = (j == k) ? lowG[k] : lG;
+                            }
+                            unsigned long long lm, pm;
+                            uint32_t e0 = 255u, e1 = 0u;
+                            const bool a = row_exact(A, lane, sb + 64 * j + lane, true, xj, pj, ss, nl, kl, e0, e1, flx, lm, pm);
+                            const unsigned long long am = __ballot(a);
+                            moved = moved || am != aG || lm != lG;
+#pragma unroll
+                            for (int k = 0; k < NR; k++) {
+                                accG[k] = (j == k) ? am : accG[k];
+                                lowG[k] = (j == k) ? lm : lowG[k];
+                                posG[k] = (j == k) ? pm : posG[k];
+                            }
+                        }
+                        if (lane == 0) exf[wave] = (moved ? 1u : 0u) | ((flx & 1u) << 1) | (fx << 8);
+                        wg_barrier();
+                        const uint4 xf = *(const uint4 *)&exf[0];
+                        const uint32_t all = rfl(xf.x | xf.y | xf.z | xf.w);
+                        if (all >> 8) fx = (all >> 8) > 5u ? 3u : (all >> 8);   // (a LOW run out of some wave's sight)
+                        else if (all & 2u) fx = 2u;                             // (a row whose accept mask found no fixed point: k_threshold flags it)
+                        if (fx || !(all & 1u)) break;
+                        if (trip >= 6) {   // (cannot happen: trip k leaves step k - 1 final)
+                            fx = 2u;
+                            break;
+                        }
+                    }
+                    if (!fx) {
+                        // the round as evaluated: the ring, the plane words, the bookkeeping of a step in the general form
+                        vmax = max(vmax, __float_as_uint((float)S * slU + bsum * 1.001f));   // (no sum inside the step can exceed this)
+                        int step_ll = LL_NONE, step_nl = LL_NONE;
+                        int pk = 0;
+#pragma unroll
+                        for (int j = 0; j < NR; j++) {
+                            if ((accG[j] >> lane) & 1ull) {
+                                ring[slot[j]] = xkeep[j];
+                                const uint32_t xb = __float_as_uint(xkeep[j]);
+                                vmax = max(vmax, xb);
+                                vmin = min(vmin, xb ? xb : 0xFFFFFFFFu);
+                            }
+                            const int rb = sb + 64 * j;
+                            step_ll = lowG[j] ? rb + last_set(lowG[j]) : step_ll;
+                            step_nl = ~lowG[j] ? rb + last_set(~lowG[j]) : step_nl;
+                            PLANE_PUT(pk, lowG[j], 2 * j);
+                            PLANE_PUT(pk, (lowG[j] >> 32), 2 * j + 1);
+                            PLANE_PUT(pk, posG[j], 2 * NR + 2 * j);
+                            PLANE_PUT(pk, (posG[j] >> 32), 2 * NR + 2 * j + 1);
+                        }
+                        if (lane < 4 * NR) pst[st_lane + st_off_round] = (uint32_t)pk;
+                        if (lane == 0) {
+                            if (step_ll != LL_NONE) sh->cold[wave][0] = (uint32_t)step_ll;
+                            if (step_nl != LL_NONE) sh->cold[wave][1] = (uint32_t)step_nl;
+                        }
+                        double se = ss0;
+                        for (int w = 0; w < WG_WAVES; w++) se += exd[w];
+                        ex_ss = rfl(se);
+                        ex_valid = true;
+                        ssf = rfl((float)ex_ss);
+                        if (!open_round()) fx = 1u;
+                    }
+                    f = fx;
+                    fw = fx | (1u << 8);
+                    t4 = make_float4(tlo, thi, ssf, 0.f);
+#ifdef NFC_EX_PRINTF
+                    if (tid == 0) ex_trips += trips;
+#endif
+                }
+            }
             if (f) {
                 why = (f > 5u) ? 2u : f;   // (codes of several waves may be or-ed together: the aid names one at most)
                 good_run = false;
@@ -1022,6 +1289,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                 thi = rfl(t4.y);
                 ssf = rfl(t4.z);
                 cur_sup = (int)(fw >> 8);
+                if (!was_exact) ex_valid = false;   // (the round stands by its check: the exact state of the round before is history)
             }
         }
     }
@@ -1136,6 +1404,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
         }
     }
 
+#ifdef NFC_EX_PRINTF
+    if (EX && tid == 0) printf("chunk %u: %d of %d rounds exact (codes %x, first %d last %d, %d trips) good %d why %u\n", c, ex_count, n_rounds, ex_codes, ex_first, ex_last, ex_trips, (int)good_run, why);
+#endif
     if (A.dbg_clk) clk2 = clock64();
     const uint32_t all_robust = good_run ? 1u : 0u;
     if (c == 0 && tid == 0 && A.mode == 0) {   // chunk 0 has no certification of its own: its verdict travels here
