@@ -38,6 +38,10 @@ fi
 { echo "# python tools/ab.py env miller --rounds 3 NFC_TAIL=0 NFC_TAIL=1"; python3 tools/ab.py env miller --rounds 3 "NFC_TAIL=0" "NFC_TAIL=1";
   echo "# per kernel under rocprofv3, NFC_TAIL=1 (test build)"; NFC_TAIL=1 NFC_AMD_LIB=usrp_nfc_amd/libnfc_amd_hooks.so bash tools/kstats.sh miller tail1 | grep -v "^$";
   echo "# chunks cut by dispatch row against the equal cut, same call, alternating"; python3 tools/ab.py env miller --rounds 4 "NFC_WG_ROWBAL=0" "NFC_WG_ROWBAL=1"; } > $out/${tag}_tail_fused_ab.txt 2>&1
+# the re-runs that evaluate failed rounds in place (k_threshold_wg<KIND, 4, true>) against k_threshold re-running everything: same call, alternating
+{ echo "# python tools/ab.py stress stress_dropouts_steps NFC_WG_EX=0 NFC_WG_EX=1024 NFC_WG_EX=0 NFC_WG_EX=1024   (ms per batch, threshold launches, chunks re-run)"; python3 tools/ab.py stress stress_dropouts_steps "NFC_WG_EX=0" "NFC_WG_EX=1024" "NFC_WG_EX=0" "NFC_WG_EX=1024";
+  echo "# ... the capture where EVERY chunk fails, with the limit of a machine-full lifted: python tools/ab.py stress stress_hover NFC_WG_EX=1024 NFC_WG_EX=100000"; python3 tools/ab.py stress stress_hover "NFC_WG_EX=1024" "NFC_WG_EX=100000";
+  if [ -f scratch/r6/exprintf.so ]; then echo "# NFC_AMD_LIB=<-DNFC_TEST_HOOKS -DNFC_EX_PRINTF build> python tools/stress_step.py stress_dropouts_steps | python tools/exrounds_summary.py"; NFC_AMD_LIB=scratch/r6/exprintf.so python3 tools/stress_step.py stress_dropouts_steps 2>&1 | python3 tools/exrounds_summary.py; fi; } > $out/${tag}_rerun_in_place_ab.txt 2>&1
 for nm in stress_dropouts_steps stress_hover; do tools/stress_timeline.sh $nm > $out/${tag}_timeline_$nm.txt 2>&1; done
 timeout 600 python3 bench.py > $out/${tag}_bench.json 2> $out/bench.log
 python3 - <<PY
