@@ -538,7 +538,7 @@ def stress_config(a, name, n, steps=6):
         # fine cut for as long as batches need re-runs, fine_left -- which is what the median shows)
         out.update({'ms_per_step': float(np.median(ts[1:])) * 1e3, 'steps': steps - 1, 'first_step_ms': ts[0] * 1e3, 'steps_ms': [round(t * 1e3, 4) for t in ts],
                     'device_allocs': allocs, 'worst_over_median': float(max(ts[1:]) / np.median(ts[1:])),
-                    'threshold_passes': int(st.threshold_passes), 'chunks_rerun': int(st.chunks_rerun), 'n_chunks': int(st.n_chunks),
+                    'threshold_passes': int(st.threshold_passes), 'chunks_rerun': int(st.chunks_rerun), 'chunks_rerun_in_place': int(st.chunks_rerun_in_place), 'n_chunks': int(st.n_chunks),
                     'chunk_samples': int(st.chunk_samples), 'used_sequential': int(st.used_sequential)})
         if not a.no_parity:
             o = co.COracle(**stream_params('all'), **decoder_flags('all'))

@@ -1091,6 +1091,15 @@ def test_in_place_reruns_with_a_long_window_and_hovering_samples(monkeypatch):
     # (chunks of whole eight-row rounds: a batch of a test's size would otherwise be cut into the window's smallest chunk, which is not)
     r = check_vs_oracle(iq, dict(hi_val=1.1, samp_rate=1e7, av_window=10000, max_len=250), kind=api.NFC_IN_IQ_F32, chunk_samples=22528)
     assert r['stats'].chunks_rerun_in_place > 0
+    # ... a window that holds exactly one round (the steps' ring slots just stay disjoint), one that does not divide by anything; losses of
+    # signal longer than the two rounds the in-place form looks back for where a LOW run began (it gives the chunk up: k_threshold's)
+    short = synth.stress_workload(1_200_000, depth=0.08, sigma=0.002, every=150_000)
+    for L in (1024, 1500):
+        r = check_vs_oracle(short, dict(hi_val=1.1, av_window=L), kind=api.NFC_IN_IQ_F32)
+        assert r['stats'].chunks_rerun_in_place > 0, L
+    gone = synth.stress_workload(2_000_000, depth=0.08, sigma=0.002, every=250_000, dropout=5000)
+    r = check_vs_oracle(gone, dict(hi_val=1.1), kind=api.NFC_IN_IQ_F32)
+    assert r['stats'].chunks_rerun_in_place > 0
     hov = synth.stress_workload(1_000_000)
     monkeypatch.setenv('NFC_WG_EX', '100000')   # (the product sends a batch where EVERY chunk fails to k_threshold: here the in-place form takes them)
     r = check_vs_oracle(hov, dict(hi_val=1.1), kind=api.NFC_IN_IQ_F32)

@@ -23,10 +23,13 @@ with api.NfcContext(samp_rate=2e6, hi_val=1.1, input_kind=api.NFC_IN_IQ_F32) as 
     ctx.reset(); ctx.push_device(buf, n)
     L.nfc_debug_gen_prof(out, 0)
     st = ctx.stats()
-    print('passes %d rerun %d of %d chunks' % (st.threshold_passes, st.chunks_rerun, st.n_chunks))
+    print('passes %d rerun %d of %d chunks (%d with failed rounds evaluated in place)' % (st.threshold_passes, st.chunks_rerun, st.n_chunks, st.chunks_rerun_in_place))
 a = np.frombuffer(out, np.uint64).reshape(8192, 8).astype(np.int64)
 v = a[a[:, 7] != 0]
 print('chunks that ran the general kernel (last evaluation): %d' % len(v))
+if not len(v):   # (round 6: up to a machine-full of failing chunks take k_threshold_wg<KIND, 4, true> -- k_threshold did not run)
+    print('k_threshold ran no chunk of this batch (%d of its re-runs took the workgroup kernel with failed rounds evaluated in place)' % st.chunks_rerun_in_place)
+    sys.exit(0)
 print('mean ticks: incoming %.0f  loop %.0f (exact steps %.0f, of which the sum %.0f)  summary %.0f ; exact steps %.1f of %.0f' % (
     v[:, 0].mean(), v[:, 1].mean(), v[:, 2].mean(), v[:, 3].mean(), v[:, 5].mean(), v[:, 4].mean(), v[:, 6].mean()))
 tot = v[:, 0] + v[:, 1] + v[:, 5]

@@ -74,7 +74,8 @@ const void *wg_ex_kernel_of(int kind) {
     }
 }
 const void *wg_kernel_of(int kind, int nr) {
-    // (six instantiations: four rows per step for every input kind, eight for the two kinds a long-window capture arrives in)
+    // (six instantiations for pass 0: four rows per step for every input kind, eight for the two kinds a long-window capture arrives in;
+    // wg_ex_kernel_of above: the four that re-run chunks with failed rounds evaluated in place)
     switch (kind) {
     case NFC_IN_IQ_F32: return nr == 8 ? (const void *)k_threshold_wg<IN_IQ_F32, 8> : (const void *)k_threshold_wg<IN_IQ_F32, 4>;
     case NFC_IN_ENV_F32: return nr == 8 ? (const void *)k_threshold_wg<IN_ENV_F32, 8> : (const void *)k_threshold_wg<IN_ENV_F32, 4>;

@@ -25,9 +25,11 @@
 //     masked general form in every wave, on synchronously loaded samples;
 //   * speculation, the saved incoming ring and the summary are spread over the 256 threads.
 //
-// Everything else is as in k_threshold_lean: nothing is repaired in place -- a failed check makes the whole workgroup give up
-// its chunk, which the host re-runs with k_threshold from the exact state.  Same summaries (ChunkInfo, RunMeta, ring_in,
-// ring_out, touched), so certification and re-runs do not know which kernel ran.
+// Everything else is as in k_threshold_lean.  In pass 0 nothing is repaired in place -- a failed check makes the whole workgroup
+// give up its chunk, which the host re-runs from the exact state: with the EX instantiations of this kernel (round 6: a round that
+// fails its check is taken back and evaluated exactly by the four waves, see the template's comment) where few enough chunks
+// failed, with k_threshold otherwise.  Same summaries (ChunkInfo, RunMeta, ring_in, ring_out, touched), so certification and
+// re-runs do not know which kernel ran.
 #pragma once
 #include "edges.hip.h"
 #include "threshold_lean.hip.h"
