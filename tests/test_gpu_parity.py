@@ -826,14 +826,17 @@ def _wg_torture(seed, n=1_500_000):
     return synth.iq_from_profile(m, seed=seed, sigma=0.0015)
 
 
+@pytest.mark.parametrize('flags', ['0', '1'])
 @pytest.mark.parametrize('nr', ['4', '8'])
 @pytest.mark.parametrize('chunk', [0, 4096 * 3])
-def test_workgroup_kernel_low_runs_time_outs_and_seams(monkeypatch, nr, chunk):
+def test_workgroup_kernel_low_runs_time_outs_and_seams(monkeypatch, nr, chunk, flags):
     # k_threshold_wg against the C oracle where its reasoning is thinnest (threshold_wg.hip.h): LOW runs longer than max_len whose
     # last sample may have ended on a time-out with HIGH samples in reach of it, runs and HIGH bursts across the seams of steps,
     # rounds and chunks, level steps between supersteps; every step height, the library's chunk length and a short one (many
     # chunk seams: speculation, certification, chunks that start inside a run).  Per-sample val, edges, symbols, packets.
+    # flags = 1 (test build, round 6): the form whose waves wait for each other's counters instead of at a round's first barrier.
     monkeypatch.setenv('NFC_WG_NR', nr)
+    monkeypatch.setenv('NFC_WG_FLAGS', flags)
     L = {'4': 2000, '6': 2000, '8': 2560}[nr]
     iq = _wg_torture(int(nr) * 10 + (1 if chunk else 0))
     params = dict(hi_val=1.1, av_window=L)
@@ -847,16 +850,19 @@ def test_workgroup_kernel_low_runs_time_outs_and_seams(monkeypatch, nr, chunk):
     assert r['stats'].used_sequential == 0 and len(o.transitions()) > 30000
 
 
+@pytest.mark.parametrize('flags', ['0', '1'])
 @pytest.mark.parametrize('bulk', ['1', '0'])
 @pytest.mark.parametrize('nr', ['4', '8'])
-def test_workgroup_kernel_plane_staging(monkeypatch, bulk, nr):
+def test_workgroup_kernel_plane_staging(monkeypatch, bulk, nr, flags):
     # k_threshold_wg keeps the plane words of its regular rounds in LDS (threshold_wg.hip.h): a whole chunk's, stored when the chunk
     # is done (bulk), or a ring of 2 FR rounds stored FR at a time by one wave as whole lines (NFC_WG_BULK=0; batches submitted ahead
     # always).  Chunks of many rounds -- the ring wraps several times, its last flush is a partial one --, a ragged batch end, a
     # stream that becomes stable in the middle of a chunk (rounds that are not regular store directly, between two flushes), and
     # the same stream submitted ahead.  Per-sample val, edges, symbols, packets against the C oracle.
+    # (flags = 1: the waves of the counter form may be a round apart -- the ring's flush waits a round longer)
     monkeypatch.setenv('NFC_WG_BULK', bulk)
     monkeypatch.setenv('NFC_WG_NR', nr)
+    monkeypatch.setenv('NFC_WG_FLAGS', flags)
     L = {'4': 2000, '8': 2560}[nr]
     rnd = 256 * int(nr)
     iq = _wg_torture(500 + int(nr), 1_000_000 + 12_345)

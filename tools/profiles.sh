@@ -38,6 +38,10 @@ fi
 { echo "# python tools/ab.py env miller --rounds 3 NFC_TAIL=0 NFC_TAIL=1"; python3 tools/ab.py env miller --rounds 3 "NFC_TAIL=0" "NFC_TAIL=1";
   echo "# per kernel under rocprofv3, NFC_TAIL=1 (test build)"; NFC_TAIL=1 NFC_AMD_LIB=usrp_nfc_amd/libnfc_amd_hooks.so bash tools/kstats.sh miller tail1 | grep -v "^$";
   echo "# chunks cut by dispatch row against the equal cut, same call, alternating"; python3 tools/ab.py env miller --rounds 4 "NFC_WG_ROWBAL=0" "NFC_WG_ROWBAL=1"; } > $out/${tag}_tail_fused_ab.txt 2>&1
+# per-wave counters instead of the first barrier of a round (k_threshold_wg<KIND, NR, false, true>, test build): same call, alternating
+{ echo "# python tools/ab.py env miller --rounds 4 NFC_WG_FLAGS=0 NFC_WG_FLAGS=1"; python3 tools/ab.py env miller --rounds 4 "NFC_WG_FLAGS=0" "NFC_WG_FLAGS=1";
+  echo "# python tools/ab.py env manchester --rounds 2 NFC_WG_FLAGS=0 NFC_WG_FLAGS=1"; python3 tools/ab.py env manchester --rounds 2 "NFC_WG_FLAGS=0" "NFC_WG_FLAGS=1";
+  echo "# python tools/ab.py env classic1k --rounds 2 --bench '--samples 1e9 --steps 10 --warmup 2' NFC_WG_FLAGS=0 NFC_WG_FLAGS=1   (eight rows per step, the staging ring)"; python3 tools/ab.py env classic1k --rounds 2 --bench "--samples 1e9 --steps 10 --warmup 2" "NFC_WG_FLAGS=0" "NFC_WG_FLAGS=1"; } > $out/${tag}_wg_flags_ab.txt 2>&1
 # the re-runs that evaluate failed rounds in place (k_threshold_wg<KIND, 4, true>) against k_threshold re-running everything: same call, alternating
 { echo "# python tools/ab.py stress stress_dropouts_steps NFC_WG_EX=0 NFC_WG_EX=1024 NFC_WG_EX=0 NFC_WG_EX=1024   (ms per batch, threshold launches, chunks re-run)"; python3 tools/ab.py stress stress_dropouts_steps "NFC_WG_EX=0" "NFC_WG_EX=1024" "NFC_WG_EX=0" "NFC_WG_EX=1024";
   echo "# ... the capture where EVERY chunk fails, with the limit of a machine-full lifted: python tools/ab.py stress stress_hover NFC_WG_EX=1024 NFC_WG_EX=100000"; python3 tools/ab.py stress stress_hover "NFC_WG_EX=1024" "NFC_WG_EX=100000";

@@ -133,6 +133,7 @@ struct nfc_ctx {
     int wg_ex_ok = 0, wg_ex_max = 0;
     size_t wg_ex_lds = 0;
     bool wg_ex_launch = false;
+    bool wg_flags = false;   // test build: pass 0 by the instantiations with per-wave counters instead of a round's first barrier
     int wg_rerun = 0;   // certification-only failures re-run by k_threshold_wg in mode 1 (NFC_WG_RERUN=1; see host_threshold.h)
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
@@ -413,6 +414,14 @@ void launch_wg(nfc_ctx *c, const ThrArgs &A, uint32_t nwork, hipEvent_t e0, hipE
         else NFC_LAUNCH(kern, dim3(nwork), dim3(256), lds, c->st, B);
     };
     if (c->wg_ex_launch) return go(k_threshold_wg<KIND, 4, true>);
+#ifdef NFC_TEST_HOOKS
+    if (c->wg_flags) {   // (NFC_WG_FLAGS=1: per-wave counters instead of a round's first barrier -- built and measured, threshold_wg.hip.h)
+        if constexpr (KIND == IN_IQ_F32 || KIND == IN_ENV_F32) {
+            if (c->wg_nr == 8) return go(k_threshold_wg<KIND, 8, false, true>);
+        }
+        return go(k_threshold_wg<KIND, 4, false, true>);
+    }
+#endif
     if constexpr (KIND == IN_IQ_F32 || KIND == IN_ENV_F32) {   // (the kinds eight rows per step are instantiated for: nfc_create chooses wg_nr)
         if (c->wg_nr == 8) return go(k_threshold_wg<KIND, 8>);
     }

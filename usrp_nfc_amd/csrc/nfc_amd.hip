@@ -73,6 +73,16 @@ const void *wg_ex_kernel_of(int kind) {
     default: return (const void *)k_threshold_wg<IN_I16_SQ, 4, true>;
     }
 }
+#ifdef NFC_TEST_HOOKS
+const void *wg_flags_kernel_of(int kind, int nr) {
+    switch (kind) {
+    case NFC_IN_IQ_F32: return nr == 8 ? (const void *)k_threshold_wg<IN_IQ_F32, 8, false, true> : (const void *)k_threshold_wg<IN_IQ_F32, 4, false, true>;
+    case NFC_IN_ENV_F32: return nr == 8 ? (const void *)k_threshold_wg<IN_ENV_F32, 8, false, true> : (const void *)k_threshold_wg<IN_ENV_F32, 4, false, true>;
+    case NFC_IN_REAL_F32_SQ: return (const void *)k_threshold_wg<IN_REAL_F32_SQ, 4, false, true>;
+    default: return (const void *)k_threshold_wg<IN_I16_SQ, 4, false, true>;
+    }
+}
+#endif
 const void *wg_kernel_of(int kind, int nr) {
     // (six instantiations for pass 0: four rows per step for every input kind, eight for the two kinds a long-window capture arrives in;
     // wg_ex_kernel_of above: the four that re-run chunks with failed rounds evaluated in place)
@@ -281,6 +291,10 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
         c->wg_ok = c->mx <= 64 * c->wg_nr - 2 && c->L >= wg_round_samples(c->wg_nr) && c->wg_lds <= 160 * 1024;
         if (c->wg_ok) {
             const void *kern = wg_kernel_of(p->input_kind, c->wg_nr);
+#ifdef NFC_TEST_HOOKS
+            if (const char *e = getenv("NFC_WG_FLAGS")) c->wg_flags = atoi(e) != 0;
+            if (c->wg_flags) kern = wg_flags_kernel_of(p->input_kind, c->wg_nr);
+#endif
             if (c->wg_lds > 64 * 1024) CRT(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->wg_lds));
             int per_cu_wg = 0;
             CRT(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wg, kern, 256, c->wg_lds));
