@@ -1275,7 +1275,11 @@ __device__ __forceinline__ void certify_block(const ThrArgs &A, uint8_t *cert, C
     if (mt.eps > 0.f) ok = mt.all_robust && (d <= mt.eps * mt.min_ss * 0.999f) && low_ok;
     else ok = !any_differ && (nl == mt.nl_in) && (kl == mt.kl_in) && !(A.gflags[c] & 4u);   // (flag 4: a re-run by k_threshold_wg that gave up)
     // (how much of the margin the speculation used: a diagnostic -- non-negative floats order like their bits)
-    if (sum && mt.eps > 0.f && mt.all_robust && mt.min_ss > 0.f) atomicMax(&sum->worst, __float_as_uint(d / mt.min_ss));
+    // (looked at first: four thousand chunks of a finely cut batch would otherwise queue at one address)
+    if (sum && mt.eps > 0.f && mt.all_robust && mt.min_ss > 0.f) {
+        const uint32_t wv = __float_as_uint(d / mt.min_ss);
+        if (wv > __hip_atomic_load(&sum->worst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&sum->worst, wv);
+    }
     cert[c] = ok ? 1 : 0;
     if (!ok && sum) atomicAdd(&sum->n_fail, 1u);
     if (dbg) dbg[c] = CertInfo{d, mt.eps * mt.min_ss, mt.all_robust, (uint32_t)low_ok};
@@ -1295,7 +1299,9 @@ struct CertLaunch {
 inline uint32_t cert_grid(uint32_t pending) { return pending + 1u; }
 __global__ __launch_bounds__(256) void k_certify(ThrArgs A, uint8_t *cert, CertInfo *dbg, float *ring_next, Carry *carry,
                                                  CertSummary *sum) {
-    certify_block(A, cert, dbg, ring_next, carry, sum, blockIdx.x, gridDim.x);
+    // (the workgroup that resolves the end-of-batch state -- one chain of look-backs, as long as the rest of the launch is wide -- goes first)
+    const uint32_t nb = gridDim.x, bid = ring_next ? (blockIdx.x == 0 ? nb - 1u : blockIdx.x - 1u) : blockIdx.x;
+    certify_block(A, cert, dbg, ring_next, carry, sum, bid, nb);
 }
 
 // Lowest / highest set bit of a double on the f32 exponent-field scale (bit value 2^(field-127)).
