@@ -412,6 +412,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                                    first_round ? d_sum : (CertSummary *)nullptr);
             };
             bool stamped_last = false;   // the round's last launch is the one that stamps the mirror (k_pkt_finish behind the writer)
+            bool flags_with_verdict = false;
             if (first_round && ahead && !dbg) {
                 // the stages that follow are enqueued now; their first full-width kernel takes the certification along
                 c->cert = CertLaunch{A, d_cert, c->d_ring[(c->ring_cur + 1) % NRING].as<float>(), dC(c), d_sum, cert_grid(np)};
@@ -428,7 +429,9 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 ran_ahead = true;
             } else {
                 launch_certify();
-                if (!first_round) {   // (the flags, and the chunks' sum bounds for the exactness guard: all in the round's one host turn)
+                // (a stream whose batches have needed re-runs: the first round's flags travel with its verdict too -- one host turn less)
+                flags_with_verdict = first_round && c->fine_left > 0;
+                if (!first_round || flags_with_verdict) {   // (the flags, and the chunks' sum bounds for the exactness guard: all in the round's one host turn)
                     HIPCHK(c, hipMemcpyAsync(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost, c->st));
                     HIPCHK(c, hipMemcpyAsync(P.h_gvtop, c->d_gvtop.p, (size_t)nch * 4, hipMemcpyDeviceToHost, c->st));
                 }
@@ -459,7 +462,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                     A.ver_zero = 0;
                     return NFC_OK;
                 }
-                HIPCHK(c, hipMemcpy(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost));
+                if (!flags_with_verdict) HIPCHK(c, hipMemcpy(c->h_cflags, c->d_cflags.p, (size_t)4 * nch, hipMemcpyDeviceToHost));
             }
             if (first_round && lean && !h_cert[0]) failing.push_back(0);   // chunk 0 gave up: re-run from the carried state
             for (uint32_t k : c->h_list)
