@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                             }
                             unsigned long long lm, pm;
                             uint32_t e0 = 255u, e1 = 0u;
-                            const bool a = row_exact(A, lane, sb + 64 * j + lane, true, xj, pj, ss, nl, kl, e0, e1, flx, lm, pm);
+                            const bool a = row_exact<true>(A, lane, sb + 64 * j + lane, true, xj, pj, ss, nl, kl, e0, e1, flx, lm, pm, ((aG >> lane) & 1ull) != 0ull);
                             const unsigned long long am = __ballot(a);
                             moved = moved || am != aG || lm != lG;
 #pragma unroll
