@@ -41,7 +41,10 @@ fi
 # per-wave counters instead of the first barrier of a round (k_threshold_wg<KIND, NR, false, true>, test build): same call, alternating
 { echo "# python tools/ab.py env miller --rounds 4 NFC_WG_FLAGS=0 NFC_WG_FLAGS=1"; python3 tools/ab.py env miller --rounds 4 "NFC_WG_FLAGS=0" "NFC_WG_FLAGS=1";
   echo "# python tools/ab.py env manchester --rounds 2 NFC_WG_FLAGS=0 NFC_WG_FLAGS=1"; python3 tools/ab.py env manchester --rounds 2 "NFC_WG_FLAGS=0" "NFC_WG_FLAGS=1";
-  echo "# python tools/ab.py env classic1k --rounds 2 --bench '--samples 1e9 --steps 10 --warmup 2' NFC_WG_FLAGS=0 NFC_WG_FLAGS=1   (eight rows per step, the staging ring)"; python3 tools/ab.py env classic1k --rounds 2 --bench "--samples 1e9 --steps 10 --warmup 2" "NFC_WG_FLAGS=0" "NFC_WG_FLAGS=1"; } > $out/${tag}_wg_flags_ab.txt 2>&1
+  echo "# python tools/ab.py env classic1k --rounds 2 --bench '--samples 1e9 --steps 10 --warmup 2' NFC_WG_FLAGS=0 NFC_WG_FLAGS=1   (eight rows per step, the staging ring)"; python3 tools/ab.py env classic1k --rounds 2 --bench "--samples 1e9 --steps 10 --warmup 2" "NFC_WG_FLAGS=0" "NFC_WG_FLAGS=1";
+  if [ -f scratch/r6/wgprof.so ]; then echo "# where a wave waits (a -DNFC_WG_PROF -DNFC_TEST_HOOKS build, NFC_DEBUG_CLK=1: s_memtime ticks per wave of a chunk): the barrier form, then NFC_WG_FLAGS=1";
+    NFC_DEBUG_CLK=1 NFC_AMD_LIB=scratch/r6/wgprof.so python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-extras --sync-steps 2>&1 | grep "wg kernel" | tail -1;
+    NFC_WG_FLAGS=1 NFC_DEBUG_CLK=1 NFC_AMD_LIB=scratch/r6/wgprof.so python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-extras --sync-steps 2>&1 | grep "wg kernel" | tail -1; fi; } > $out/${tag}_wg_flags_ab.txt 2>&1
 # the re-runs that evaluate failed rounds in place (k_threshold_wg<KIND, 4, true>) against k_threshold re-running everything: same call, alternating
 { echo "# python tools/ab.py stress stress_dropouts_steps NFC_WG_EX=0 NFC_WG_EX=1024 NFC_WG_EX=0 NFC_WG_EX=1024   (ms per batch, threshold launches, chunks re-run)"; python3 tools/ab.py stress stress_dropouts_steps "NFC_WG_EX=0" "NFC_WG_EX=1024" "NFC_WG_EX=0" "NFC_WG_EX=1024";
   echo "# ... the capture where EVERY chunk fails, with the limit of a machine-full lifted: python tools/ab.py stress stress_hover NFC_WG_EX=1024 NFC_WG_EX=100000"; python3 tools/ab.py stress stress_hover "NFC_WG_EX=1024" "NFC_WG_EX=100000";
