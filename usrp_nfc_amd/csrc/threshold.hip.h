@@ -388,12 +388,9 @@ __device__ unsigned long long g_row_iters[2];   // (a profiling build: rows walk
 #endif
 // One 64-sample row (lane l = sample m), exact: iterate the accept mask to its fixed point.
 // Updates ss0, w_nl, w_kl; returns the classification through low/pos ballots.
-// SEEDED (k_threshold_wg's in-place form, which arrives with a guess of the row's accept mask): the iteration starts from the sums
-// under `seed` instead of from the row's first sum -- a guess that is right is confirmed by ONE classification.
-template <bool SEEDED = false>
 __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, bool act, float x, float prev, double &ss0,
                                           int &w_nl, int &w_kl, uint32_t &emin, uint32_t &emax, uint32_t &flags,
-                                          unsigned long long &lowm, unsigned long long &posm, bool seed = false) {
+                                          unsigned long long &lowm, unsigned long long &posm) {
     const int mx = A.mx;
     const double x64 = (double)x;
     const int rb = m - lane;   // the row's first sample
@@ -405,13 +402,7 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
     bool st2 = false;
     int row_iters = 0;
     (void)row_iters;
-    constexpr int ITER0 = SEEDED ? 1 : 0;
-    if constexpr (SEEDED) {
-        acc = act && seed;
-        incs = wave_scan_sum_f64(acc ? (x64 - (double)prev) : 0.0);
-        ss = ss0 + wave_below_f64(incs);
-    }
-    for (int iter = ITER0;; iter++) {
+    for (int iter = 0;; iter++) {
         bool lw = false, hg = false;
         if (act) classify_one(A, x64, ss, lw, hg);
         low = lw;
@@ -420,7 +411,7 @@ __device__ __forceinline__ bool row_exact(const ThrArgs &A, int lane, int m, boo
         // (round 4: two six-step DPP scans of dependent moves per iteration before -- a lone wave pays every one of their
         // latencies): the last sample before a lane that is not LOW / that is LOW is the highest bit below the lane.
         const unsigned long long low_now = __ballot(lw);
-        if (iter == ITER0 || low_now != low_seen) {
+        if (iter == 0 || low_now != low_seen) {
             low_seen = low_now;
             const unsigned long long bn = actm & ~low_now & lane_lt;
             const int nl = bn ? rb + last_set(bn) : w_nl;   // (a sample of the row lies behind everything carried into it)

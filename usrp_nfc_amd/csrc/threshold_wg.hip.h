@@ -204,6 +204,40 @@ __device__ __forceinline__ void wg_put_masks(int &pk, const unsigned long long (
     }
 }
 
+// One row of 64 samples (lane l = sample m) classified ONCE against the window sums handed in -- one iteration of row_exact
+// (threshold.hip.h) without its loop: the in-place form below iterates over the whole round instead, every row's sums taken from the
+// accept masks guessed for the samples before it.  Updates the LOW bookkeeping (w_nl, w_kl) past the row.
+__device__ __forceinline__ void wg_row_once(const ThrArgs &A, int lane, int m, float x, double ss_before, int &w_nl, int &w_kl,
+                                            unsigned long long &accm, unsigned long long &lowm, unsigned long long &posm) {
+    const int mx = A.mx;
+    const int rb = m - lane;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    bool lw = false, hg = false;
+    classify_one(A, (double)x, ss_before, lw, hg);
+    const unsigned long long low_now = __ballot(lw);
+    const unsigned long long bn = ~low_now & lane_lt;
+    const int nl = bn ? rb + last_set(bn) : w_nl;   // the last sample before this one that is not LOW
+    int key = KEY_NONE;
+    if (lw) {
+        const int p = m - nl;   // 1-based position in the LOW run
+        const bool bad = (p > mx) && ((p - 1) % mx == 0);   // (its run ends on a time-out here: transition_sink.py:95-99)
+        key = 2 * m + (bad ? 0 : 1);
+    }
+    const unsigned long long bl = low_now & lane_lt;
+    const int kq = __shfl(key, bl ? last_set(bl) : 0, 64);   // the key of the last LOW sample below this lane
+    const int kl = bl ? max(kq, w_kl) : w_kl;
+    const bool st2 = (kl & 1) && (m - (kl >> 1)) <= mx + 1;   // HIGH is ignored within max_len + 1 of a LOW sample whose key is good
+    int v = 0;
+    if (lw) v = -1;
+    else if (hg && !st2) v = 1;
+    accm = __ballot(v == 0);
+    lowm = low_now;
+    posm = __ballot(v == 1);
+    const unsigned long long nonlowf = ~low_now;
+    w_nl = nonlowf ? rb + last_set(nonlowf) : w_nl;
+    if (low_now) w_kl = max(w_kl, __builtin_amdgcn_readlane(key, last_set(low_now)));
+}
+
 // EX (re-runs from the exact state, mode 1): a round that fails its check is not the chunk's end -- every wave puts the ring slots
 // of its step back, wave 0 evaluates the round's rows the way k_threshold does (row_exact of threshold.hip.h: the accept mask
 // iterated to its fixed point on fp64 sums), leaves the masks and plane words where the round's waves would have, and the chunk goes
@@ -482,6 +516,8 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     bool ex_valid = false;
 #ifdef NFC_EX_PRINTF
     int ex_count = 0, ex_codes = 0, ex_first = -1, ex_last = -1, n_rounds = 0, ex_trips = 0;
+    const unsigned long long ex_t0 = clock64();
+    unsigned long long ex_t1 = 0, ex_tx = 0, ex_ta = 0;   // the rounds' start; cycles spent evaluating rounds in place
 #endif
 #pragma unroll
     for (int j = 0; j < NR; j++) xkeep[j] = snap[j] = 0.f;
@@ -759,6 +795,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             st_off = 0u;   // (the next regular round stages behind a round's barrier: wave 0 is through by then)
         }
     };
+#ifdef NFC_EX_PRINTF
+    ex_t1 = clock64();
+#endif
     while (good_run && rbase < n1) {
         const bool regular = rbase >= m_start && rbase + (uint32_t)WG_ROUND <= n1;
         int nr = 1;
@@ -1107,14 +1146,18 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             bool was_exact = false;
             if constexpr (EX) {
                 if (f == 0x40u) {
-                    // The round is taken back and evaluated the way k_threshold evaluates a step (row_exact: the accept mask of a row
-                    // iterated to its fixed point on fp64 sums) -- by all four waves at once.  A step's rows need the window sum and the LOW
+                    // The round is taken back and evaluated the way k_threshold evaluates a step (row_exact of threshold.hip.h: every sample
+                    // against the thresholds of the exact fp64 window sum before it, the accept masks iterated to their fixed point) -- by
+                    // all four waves at once, and over the whole round at once.  A step's rows need the window sum and the LOW
                     // bookkeeping at its first sample, which the steps before it decide: every wave GUESSES its step's masks (from the
                     // thresholds the round was tried with), hands in what its step would add to the sum under the guess and its LOW masks,
                     // evaluates its rows from what the waves before it handed in, and takes the outcome as its next guess.  When no wave's
                     // masks moved, every step was evaluated from the state its predecessors really leave (by induction from step 0, which
                     // starts from the exact sum): at most five trips, one when the guess was right.
                     was_exact = true;
+#ifdef NFC_EX_PRINTF
+                    const unsigned long long ex_tb = clock64();
+#endif
                     const int rb0 = (int)rbase - WG_ROUND;   // the round's first sample (rbase has moved on)
                     const int sb = rb0 + (int)STEPN * wave;  // this wave's
                     constexpr uint32_t MB = (uint32_t)sizeof(sh->msk[0]);
@@ -1176,10 +1219,16 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                     for (int trip = 0;; trip++) {
                         trips = trip + 1;
                         // what this step adds to the sum under the guess; its LOW masks where the rounds' steps publish theirs
+                        // (per row: the sum before every sample of it under the guess, relative to the row's first; the row's total)
+                        double bel[NR], tot[NR];
                         double d = 0;
 #pragma unroll
-                        for (int j = 0; j < NR; j++) d += ((accG[j] >> lane) & 1ull) ? ((double)xkeep[j] - (double)pv[j]) : 0.0;
-                        d = wave_sum_f64(d);
+                        for (int j = 0; j < NR; j++) {
+                            const double incs = wave_scan_sum_f64(((accG[j] >> lane) & 1ull) ? ((double)xkeep[j] - (double)pv[j]) : 0.0);
+                            bel[j] = wave_below_f64(incs);
+                            tot[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(incs), 63), __builtin_amdgcn_readlane(__double2loint(incs), 63));
+                            d += tot[j];
+                        }
                         if (lane == 0) {
                             exd[wave] = d;
                             uint32_t *mp = (uint32_t *)((char *)&sh->msk[0][wave][0] + cur);
@@ -1244,31 +1293,20 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                             nl = rfl(nl);
                             kl = rfl(kl);
                         }
-                        // the step's rows from that state
+                        // the step's rows from that state: every sample classified once against the sum the guess implies before it
+                        // (no row iterates on its own any more: the trips do, over the whole round -- a fixed point of all the masks is the
+                        // sequential evaluation, by induction over the samples)
                         bool moved = false;
                         double ss = S;
-#pragma unroll 1
+#pragma unroll
                         for (int j = 0; j < NR; j++) {
-                            float xj = xkeep[0], pj = pv[0];
-                            unsigned long long aG = accG[0], lG = lowG[0];
-#pragma unroll
-                            for (int k = 1; k < NR; k++) {
-                                xj = (j == k) ? xkeep[k] : xj;
-                                pj = (j == k) ? pv[k] : pj;
-                                aG = (j == k) ? accG[k] : aG;
-                                lG = (j == k) ? lowG[k] : lG;
-                            }
-                            unsigned long long lm, pm;
-                            uint32_t e0 = 255u, e1 = 0u;
-                            const bool a = row_exact<true>(A, lane, sb + 64 * j + lane, true, xj, pj, ss, nl, kl, e0, e1, flx, lm, pm, ((aG >> lane) & 1ull) != 0ull);
-                            const unsigned long long am = __ballot(a);
-                            moved = moved || am != aG || lm != lG;
-#pragma unroll
-                            for (int k = 0; k < NR; k++) {
-                                accG[k] = (j == k) ? am : accG[k];
-                                lowG[k] = (j == k) ? lm : lowG[k];
-                                posG[k] = (j == k) ? pm : posG[k];
-                            }
+                            unsigned long long am, lm, pm;
+                            wg_row_once(A, lane, sb + 64 * j + lane, xkeep[j], ss + bel[j], nl, kl, am, lm, pm);
+                            moved = moved || am != accG[j] || lm != lowG[j];
+                            accG[j] = am;
+                            lowG[j] = lm;
+                            posG[j] = pm;
+                            ss = rfl(ss + tot[j]);
                         }
                         if (lane == 0) exf[wave] = (moved ? 1u : 0u) | ((flx & 1u) << 1) | (fx << 8);
                         wg_barrier();
@@ -1277,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                         if (all >> 8) fx = (all >> 8) > 5u ? 3u : (all >> 8);   // (a LOW run out of some wave's sight)
                         else if (all & 2u) fx = 2u;                             // (a row whose accept mask found no fixed point: k_threshold flags it)
                         if (fx || !(all & 1u)) break;
-                        if (trip >= 6) {   // (cannot happen: trip k leaves step k - 1 final)
+                        if (trip >= 24) {   // (a cascade -- every sample's outcome moving the next one's: a trip settles one more of them; k_threshold's)
                             fx = 2u;
                             break;
                         }
@@ -1320,6 +1358,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                     t4 = make_float4(tlo, thi, ssf, 0.f);
 #ifdef NFC_EX_PRINTF
                     if (tid == 0) ex_trips += trips;
+                    ex_tx += clock64() - ex_tb;
 #endif
                 }
             }
@@ -1335,6 +1374,9 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
             }
         }
     }
+#ifdef NFC_EX_PRINTF
+    ex_ta = clock64();
+#endif
     // (the whole chunk's plane words are in the LDS staging -- every round regular, nothing flushed yet)
     const bool staged_all = bulk && st_cnt > 0 && st_base == m_chunk && (uint32_t)st_cnt * (uint32_t)WG_ROUND == n1 - m_chunk;
     flush_planes();
@@ -1447,7 +1489,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
     }
 
 #ifdef NFC_EX_PRINTF
-    if (EX && tid == 0) printf("chunk %u: %d of %d rounds exact (codes %x, first %d last %d, %d trips) good %d why %u\n", c, ex_count, n_rounds, ex_codes, ex_first, ex_last, ex_trips, (int)good_run, why);
+    if (EX && tid == 0) printf("chunk %u: %d of %d rounds exact (codes %x, first %d last %d, %d trips) good %d why %u; cycles: prologue %llu rounds %llu (in place %llu) summary-so-far %llu\n", c, ex_count, n_rounds, ex_codes, ex_first, ex_last, ex_trips, (int)good_run, why, ex_t1 - ex_t0, ex_ta - ex_t1, ex_tx, clock64() - ex_ta);
 #endif
     if (A.dbg_clk) clk2 = clock64();
     const uint32_t all_robust = good_run ? 1u : 0u;
