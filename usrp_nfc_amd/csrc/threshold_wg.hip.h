@@ -239,9 +239,10 @@ __device__ __forceinline__ void wg_row_once(const ThrArgs &A, int lane, int m, f
 }
 
 // EX (re-runs from the exact state, mode 1): a round that fails its check is not the chunk's end -- every wave puts the ring slots
-// of its step back, wave 0 evaluates the round's rows the way k_threshold does (row_exact of threshold.hip.h: the accept mask
-// iterated to its fixed point on fp64 sums), leaves the masks and plane words where the round's waves would have, and the chunk goes
-// on in the tracked form from the exact sum.  One-round supersteps; rounds of whole steps only (a ragged end, the stream's first
+// of its step back, the four waves evaluate the round the way k_threshold evaluates a step (row_exact of threshold.hip.h: every sample
+// against the thresholds of the exact fp64 window sum before it, the accept masks iterated to their fixed point -- here over the whole
+// round at once, see the block behind the close), leave the masks and plane words where the round's waves would have, and the chunk
+// goes on in the tracked form from the exact sum.  One-round supersteps; rounds of whole steps only (a ragged end, the stream's first
 // stable sample: the chunk gives up as before and k_threshold takes it).
 // FLG (round 6, VERDICT r5 item 3: built and measured): the first barrier of a round of whole steps is replaced by
 // per-wave counters -- a wave publishes its step's LOW masks, bumps its counter and goes on as soon as the waves BEFORE it in the round
@@ -1208,7 +1209,7 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                         accG[j] = ~lowG[j] & ~__ballot(xkeep[j] > sg * hiLf);
                         posG[j] = 0ull;
                     }
-                    uint32_t fx = 0u, flx = 0u;
+                    uint32_t fx = 0u;
                     double S = ss0;
                     float bsum = 0.f;
 #pragma unroll
@@ -1308,12 +1309,11 @@ __global__ __launch_bounds__(256) void k_threshold_wg(ThrArgs A) {
                             posG[j] = pm;
                             ss = rfl(ss + tot[j]);
                         }
-                        if (lane == 0) exf[wave] = (moved ? 1u : 0u) | ((flx & 1u) << 1) | (fx << 8);
+                        if (lane == 0) exf[wave] = (moved ? 1u : 0u) | (fx << 8);
                         wg_barrier();
                         const uint4 xf = *(const uint4 *)&exf[0];
                         const uint32_t all = rfl(xf.x | xf.y | xf.z | xf.w);
                         if (all >> 8) fx = (all >> 8) > 5u ? 3u : (all >> 8);   // (a LOW run out of some wave's sight)
-                        else if (all & 2u) fx = 2u;                             // (a row whose accept mask found no fixed point: k_threshold flags it)
                         if (fx || !(all & 1u)) break;
                         if (trip >= 24) {   // (a cascade -- every sample's outcome moving the next one's: a trip settles one more of them; k_threshold's)
                             fx = 2u;
