@@ -134,7 +134,6 @@ struct nfc_ctx {
     size_t wg_ex_lds = 0;
     bool wg_ex_launch = false;
     bool wg_flags = false;   // test build: pass 0 by the instantiations with per-wave counters instead of a round's first barrier
-    int wg_rerun = 0;   // certification-only failures re-run by k_threshold_wg in mode 1 (NFC_WG_RERUN=1; see host_threshold.h)
     float lean_gfac = 1.3f, lean_gmin = 9.765625e-4f;   // drift allowance of the next superstep: max(gfac * B, gmin * ss)
     int gring = 0;   // this batch: the ring of a chunk in global memory instead of LDS
     int gring_ok = 0, gring_force = 0, wave_slots_g = 0;   // long windows qualify (NFC_RING=lds|global overrides the choice)

@@ -520,13 +520,10 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 for (uint32_t k : now) ever_rerun[k] = 1;
                 failing.swap(now);
             }
-            // Re-runs from the exact state.  A chunk whose speculation could not be certified -- its own pass was sound, only its
-            // incoming state was not what it assumed -- is re-run by the workgroup kernel where that kernel ran pass 0 (mode 1: four
-            // waves on the chunk take a tenth of what one does); a chunk that gave up, in pass 0 or in such a re-run, takes the
-            // general kernel, which decides everything in place and never gives up (so the rounds converge).
-            // (Off unless NFC_WG_RERUN=1: measured on the stress captures -- level steps, drop-outs -- the chunks behind a chunk that
-            // gave up mostly give up themselves when re-run this way, and the rounds take longer to converge: 6 passes / 4.7 ms
-            // against 3 passes / 2.1 ms with the general kernel alone.)
+            // Re-runs from the exact state: by the workgroup kernel's in-place form where it applies and the round's failures fit the
+            // machine (below), else by k_threshold, which decides everything in place and never gives up (so the rounds converge).
+            // (The pass-0 form of the workgroup kernel re-running whatever did not give up was measured on the stress captures in rounds 4-6 --
+            // the chunks behind a chunk that gave up mostly give up themselves, 6 passes / 4.7 ms against 3 / 2.1 -- and went in round 6.)
             // A LONE failure on an otherwise clean batch (round 6) -- a superstep that grew on the head-room it saw and met the next frame:
             // one chunk in a thousand -- takes the workgroup kernel too, gave up or not: from the exact state (no margin for a speculated
             // window) and with supersteps of at most two rounds it mostly gets through, and four waves walk a 98 304-sample chunk in 70 us
@@ -549,7 +546,7 @@ static int threshold_span(nfc_ctx *c, const void *d_in_all, uint32_t n_all, uint
                 // one it gave up on is k_threshold's for the rest of the batch: that kernel never gives up, so the rounds converge)
                 if (tried_wg[k] == 1 && (h_gflags[k] & 4)) tried_wg[k] = 2;
                 const bool ex_again = ex && tried_wg[k] == 1;
-                if (c->wg_now && (!tried_wg[k] || ex_again) && (ex || (c->wg_rerun && !(h_gflags[k] & 4)) || lone)) {   // (a chunk that GAVE UP needs decisions made in place: the general kernel -- unless it stands alone)
+                if (c->wg_now && (!tried_wg[k] || ex_again) && (ex || lone)) {
                     by_wg.push_back(k);
                     tried_wg[k] = 1;
                 } else {

@@ -169,7 +169,7 @@ int nfc_create(const nfc_params *p, nfc_ctx **out) {
     if (const char *e = NFC_ENV("NFC_WG")) c->wg = atoi(e) != 0;
     if (const char *e = NFC_ENV("NFC_WG_ROUNDS")) c->wg_rounds = std::max(1, atoi(e));
     if (const char *e = NFC_ENV("NFC_WG_BULK")) c->wg_bulk = atoi(e) != 0;
-    if (const char *e = NFC_ENV("NFC_WG_RERUN")) c->wg_rerun = atoi(e) == 1, c->wg_rerun_lone = atoi(e) != 0;   // 0: the general kernel re-runs everything; 1: the workgroup kernel whatever did not give up; default: lone failures only
+    if (const char *e = NFC_ENV("NFC_WG_RERUN")) c->wg_rerun_lone = atoi(e) != 0;   // 0: lone failures are k_threshold's too (with NFC_WG_EX=0: it re-runs everything)
     if (const char *e = NFC_ENV("NFC_WG_LONE")) {   // max,div
         int a = 4, b = 64;
         if (sscanf(e, "%d,%d", &a, &b) >= 1) c->wg_lone_max = std::max(0, a), c->wg_lone_div = std::max(1, b);
